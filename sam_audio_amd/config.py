@@ -1,0 +1,218 @@
+"""Configuration objects for the MI355X-native SAM-Audio separate() path.
+
+Same field names / defaults as the reference's plain-Python config classes
+(/root/reference/sam_audio/model/config.py:10-41 DACVAEConfig, :49-60 T5EncoderConfig,
+:69-83 PerceptionEncoderConfig, :86-135 TransformerConfig, :204-231 SAMAudioConfig) so a
+reference ``config.json`` parses unchanged.  Re-expressed as dataclasses and without the
+``core`` (perception_models) import the reference needs only as a type annotation.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, fields
+from typing import Any, Dict, List, Optional
+
+
+def _build(cls, raw):
+    if raw is None:
+        return cls()
+    if isinstance(raw, cls):
+        return raw
+    known = {f.name for f in fields(cls)}
+    unknown = set(raw) - known
+    if unknown:
+        # the reference would raise TypeError from cls(**raw) as well
+        raise TypeError(f"{cls.__name__}: unexpected config keys {sorted(unknown)}")
+    return cls(**raw)
+
+
+@dataclass
+class DACVAEConfig:
+    encoder_dim: int = 64
+    encoder_rates: List[int] = field(default_factory=lambda: [2, 8, 10, 12])
+    latent_dim: int = 1024
+    decoder_dim: int = 1536
+    decoder_rates: List[int] = field(default_factory=lambda: [12, 10, 8, 2])
+    n_codebooks: int = 16
+    codebook_size: int = 1024
+    codebook_dim: int = 128
+    quantizer_dropout: bool = False
+    sample_rate: int = 48_000
+    mean: float = 0.0
+    std: float = 1.0
+
+    @property
+    def hop_length(self) -> int:
+        return int(math.prod(self.encoder_rates))
+
+
+@dataclass
+class T5EncoderConfig:
+    name: str = "t5-base"
+    max_length: Optional[int] = 512
+    pad_mode: str = "longest"
+    dim: int = 768
+
+
+@dataclass
+class PerceptionEncoderConfig:
+    dim: int = 1024
+    batch_size: int = 300
+    name: str = "PE-Core-L14-336"
+    normalize_feature: bool = True
+    interpolation_mode: str = "BICUBIC"
+    image_size: int = 336
+
+
+@dataclass
+class TransformerConfig:
+    dim: int = 2048
+    n_heads: int = 16
+    n_layers: int = 16
+    dropout: float = 0.1
+    norm_eps: float = 1.0e-05
+    qk_norm: bool = True
+    fc_bias: bool = False
+    ffn_exp: int = 4
+    ffn_dim_multiplier: int = 1
+    multiple_of: int = 64
+    non_linearity: str = "swiglu"
+    use_rope: bool = True
+    max_positions: int = 10000
+    frequency_embedding_dim: int = 256
+    timestep_non_linearity: str = "swiglu"
+    t_block_non_linearity: str = "silu"
+    t_block_bias: bool = True
+    context_dim: int = 2048
+    context_non_linearity: str = "swiglu"
+    context_embedder_dropout: float = 0.0
+    context_norm: bool = False
+    out_channels: int = 256
+    in_channels: Optional[int] = None
+
+    @property
+    def head_dim(self) -> int:
+        return self.dim // self.n_heads
+
+    @property
+    def ffn_hidden(self) -> int:
+        """SwiGLU hidden width, rule of reference transformer.py:176-185."""
+        hidden = int(self.ffn_exp * self.dim)
+        if self.non_linearity == "swiglu":
+            hidden = int(2 * hidden / 3)
+        hidden = int(self.ffn_dim_multiplier * hidden)
+        return self.multiple_of * ((hidden + self.multiple_of - 1) // self.multiple_of)
+
+    @property
+    def rope_theta(self) -> float:
+        # reference transformer.py:405-409
+        return float(max(10000, 2 * self.max_positions))
+
+    def check_supported(self) -> None:
+        """The HIP path implements the configuration family the reference ships."""
+        problems = []
+        if self.head_dim != 128:
+            problems.append(f"head_dim must be 128 (got {self.head_dim})")
+        if self.dim % self.n_heads:
+            problems.append("dim must be divisible by n_heads")
+        if not self.qk_norm:
+            problems.append("qk_norm=False")
+        if self.fc_bias:
+            problems.append("fc_bias=True")
+        if not self.use_rope:
+            problems.append("use_rope=False")
+        if not self.t_block_bias:
+            problems.append("t_block_bias=False")
+        if self.context_norm:
+            problems.append("context_norm=True")
+        if self.context_dim != self.dim:
+            problems.append("context_dim != dim")
+        if self.in_channels is not None:
+            problems.append("in_channels (data_proj) is not used by SAMAudio")
+        for name in ("non_linearity", "timestep_non_linearity", "context_non_linearity"):
+            if getattr(self, name) != "swiglu":
+                problems.append(f"{name} must be 'swiglu'")
+        if self.t_block_non_linearity != "silu":
+            problems.append("t_block_non_linearity must be 'silu'")
+        if self.frequency_embedding_dim % 64:
+            problems.append("frequency_embedding_dim must be a multiple of 64")
+        if problems:
+            raise NotImplementedError(
+                "TransformerConfig outside the HIP path's supported family: " + "; ".join(problems)
+            )
+
+
+@dataclass
+class JudgeRankerConfig:
+    checkpoint_or_model_id: str = "facebook/sam-audio-judge"
+    kind: str = "judge"
+
+
+def parse_ranker_config(raw: Optional[Dict[str, Any]]):
+    """Only the Judge ranker is on this build's roadmap; CLAP / ImageBind are
+    third-party models that are out of scope, so their configs are kept as opaque dicts."""
+    if raw is None:
+        return None
+    raw = dict(raw)
+    if raw.get("kind") == "judge":
+        raw.pop("kind")
+        return JudgeRankerConfig(**raw)
+    return raw
+
+
+class SAMAudioConfig:
+    def __init__(
+        self,
+        in_channels: int = 768,
+        audio_codec=None,
+        text_encoder=None,
+        vision_encoder=None,
+        transformer=None,
+        num_anchors: int = 3,
+        anchor_embedding_dim: int = 128,
+        visual_ranker=None,
+        text_ranker=None,
+        span_predictor: Optional[str] = "pe-a-frame-large",
+    ):
+        self.in_channels = in_channels
+        self.audio_codec = _build(DACVAEConfig, audio_codec)
+        self.text_encoder = _build(T5EncoderConfig, text_encoder)
+        self.vision_encoder = _build(PerceptionEncoderConfig, vision_encoder)
+        self.transformer = _build(TransformerConfig, transformer)
+        self.num_anchors = num_anchors
+        self.anchor_embedding_dim = anchor_embedding_dim
+        self.visual_ranker = parse_ranker_config(visual_ranker)
+        self.text_ranker = parse_ranker_config(text_ranker)
+        self.span_predictor = span_predictor
+
+    def check_supported(self) -> None:
+        self.transformer.check_supported()
+        c = self.audio_codec
+        if self.in_channels != 6 * c.codebook_dim:
+            raise NotImplementedError("in_channels must be 6*codebook_dim (noisy|zeros|features)")
+        if self.transformer.out_channels != 2 * c.codebook_dim:
+            raise NotImplementedError("transformer.out_channels must be 2*codebook_dim")
+        if len(c.encoder_rates) != 4 or len(c.decoder_rates) != 4:
+            raise NotImplementedError("codec must have 4 down/up-sampling stages")
+        if any(r % 2 for r in list(c.encoder_rates) + list(c.decoder_rates)):
+            raise NotImplementedError("codec strides must be even")
+        if self.anchor_embedding_dim % 64 or c.codebook_dim % 64:
+            raise NotImplementedError("anchor_embedding_dim / codebook_dim must be multiples of 64")
+
+
+# Labelled stand-ins for the checkpoint sizes whose real config.json is not reachable offline
+# (SURVEY.md §0, §8d).  head_dim 128 and the reference FFN rule are kept.
+SIZE_PRESETS: Dict[str, Dict[str, int]] = {
+    "tiny": dict(dim=256, n_heads=2, n_layers=2),        # test-only
+    "mini": dict(dim=512, n_heads=4, n_layers=3),        # test-only
+    "small*": dict(dim=1536, n_heads=12, n_layers=12),   # ASSUMED stand-in for sam-audio-small
+    "default": dict(dim=2048, n_heads=16, n_layers=16),  # reference config.py defaults
+    "large*": dict(dim=2816, n_heads=22, n_layers=22),   # ASSUMED stand-in for sam-audio-large
+}
+
+
+def preset_config(size: str, **overrides) -> SAMAudioConfig:
+    dims = dict(SIZE_PRESETS[size])
+    dims["context_dim"] = dims["dim"]
+    dims.update(overrides.pop("transformer", {}))
+    return SAMAudioConfig(transformer=dims, **overrides)

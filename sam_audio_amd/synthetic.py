@@ -1,0 +1,181 @@
+"""Seeded synthetic checkpoints and inputs.
+
+There are no SAM-Audio weights, config.json files or datasets reachable offline (SURVEY.md §0,
+§8c/d), so tests, smoke() and bench.py run on random-init weights of the reference architecture
+and on synthetic clips.  Key names follow the reference state_dict (SURVEY.md §8b "Ownership");
+the ``audio_codec.*`` names follow descript-audio-codec's Sequential numbering, which is what the
+un-vendored ``dacvae`` package derives from (documented assumption - see DESIGN.md).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+
+from .config import SAMAudioConfig
+
+
+def _uniform(gen, shape, bound, device):
+    return (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) * 2 - 1) * bound
+
+
+def _normal(gen, shape, std, device):
+    return torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std
+
+
+def init_state_dict(cfg: SAMAudioConfig, seed: int = 0, device="cpu",
+                    with_codec: bool = True) -> Dict[str, torch.Tensor]:
+    """Random weights with the reference's init scales (Linear/Conv: U(+-1/sqrt(fan_in));
+    scale_shift tables: randn/sqrt(D), reference transformer.py:350-352,469-471).  Gates are set
+    to 0.5 (the reference initialises them to 0, align.py:26 / model.py:51, which would switch
+    the video / anchor terms off and leave them untested)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    t = cfg.transformer
+    D, F, hd = t.dim, t.ffn_hidden, t.head_dim
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out_f, in_f, bias=False, gain=1.0):
+        b = gain / math.sqrt(in_f)
+        sd[name + ".weight"] = _uniform(gen, (out_f, in_f), b, dev)
+        if bias:
+            sd[name + ".bias"] = _uniform(gen, (out_f,), b, dev)
+
+    def norm_w(name, n):
+        sd[name] = 1.0 + _normal(gen, (n,), 0.1, dev)
+
+    P = "transformer."
+    sd[P + "final_layer_scale_shift_table"] = _normal(gen, (2, D), 1 / math.sqrt(D), dev)
+    for i in range(t.n_layers):
+        L = f"{P}layers.{i}."
+        sd[L + "scale_shift_table"] = _normal(gen, (6, D), 1 / math.sqrt(D), dev)
+        for att in ("attention", "cross_attention"):
+            for w in ("wq", "wk", "wv", "wo"):
+                lin(f"{L}{att}.{w}", D, D)
+            norm_w(f"{L}{att}.q_norm.weight", hd)
+            norm_w(f"{L}{att}.k_norm.weight", hd)
+        lin(L + "feed_forward.w1", F, D)
+        lin(L + "feed_forward.w2", D, F)
+        lin(L + "feed_forward.w3", F, D)
+        norm_w(L + "attention_norm.weight", D)
+        norm_w(L + "ffn_norm.weight", D)
+    norm_w(P + "norm.weight", D)
+    lin(P + "output", t.out_channels, D)
+    for blk in ("block1", "block2"):
+        B = f"{P}x_embedder.block.{blk}."
+        norm_w(B + "groupnorm.weight", D)
+        sd[B + "groupnorm.bias"] = _normal(gen, (D,), 0.1, dev)
+        b = 1 / math.sqrt(3 * D)
+        sd[B + "project.weight"] = _uniform(gen, (D, D, 3), b, dev)
+        sd[B + "project.bias"] = _uniform(gen, (D,), b, dev)
+    for w, (o, i) in dict(w1=(D, t.context_dim), w2=(D, D), w3=(D, t.context_dim)).items():
+        lin(f"{P}y_embedder.projection.{w}", o, i)
+    fd = t.frequency_embedding_dim
+    for w, (o, i) in dict(w1=(D, fd), w2=(D, D), w3=(D, fd)).items():
+        lin(f"{P}t_embedder.projection.{w}", o, i)
+    lin(P + "t_block", 6 * D, D, bias=True)
+
+    lin("proj", D, cfg.in_channels, bias=True)
+    lin("memory_proj", D, cfg.text_encoder.dim, bias=True)
+    vb = 1 / math.sqrt(cfg.vision_encoder.dim)
+    sd["align_masked_video.conv.weight"] = _uniform(gen, (D, cfg.vision_encoder.dim, 1), vb, dev)
+    sd["align_masked_video.conv.bias"] = _uniform(gen, (D,), 1.0, dev)
+    norm_w("align_masked_video.layer_norm.weight", D)
+    sd["align_masked_video.layer_norm.bias"] = _normal(gen, (D,), 0.1, dev)
+    sd["align_masked_video.gate"] = torch.tensor([0.5], device=dev)
+    emb = _normal(gen, (cfg.num_anchors + 1, cfg.anchor_embedding_dim), 1.0, dev)
+    sd["embed_anchors.embed.weight"] = emb
+    sd["embed_anchors.gate"] = torch.tensor([0.5], device=dev)
+    lin("embed_anchors.proj", D, cfg.anchor_embedding_dim)
+
+    if with_codec:
+        sd.update(init_codec_state_dict(cfg, gen, dev))
+    return sd
+
+
+def codec_layout(cfg: SAMAudioConfig):
+    """Channel plan of the DAC-VAE (HF `dac` topology, transformers/models/dac/modeling_dac.py
+    :175-264,407-474; constructor arguments at reference config.py:11-37)."""
+    c = cfg.audio_codec
+    enc_ch = [c.encoder_dim * (2 ** i) for i in range(len(c.encoder_rates) + 1)]  # 64..1024
+    dec_ch = [c.decoder_dim // (2 ** i) for i in range(len(c.decoder_rates) + 1)]  # 1536..96
+    return enc_ch, dec_ch
+
+
+def init_codec_state_dict(cfg: SAMAudioConfig, gen, dev) -> Dict[str, torch.Tensor]:
+    c = cfg.audio_codec
+    enc_ch, dec_ch = codec_layout(cfg)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def conv(name, co, ci, k, gain=1.0):
+        b = gain / math.sqrt(ci * k)
+        sd[name + ".weight"] = _uniform(gen, (co, ci, k), b, dev)
+        sd[name + ".bias"] = _uniform(gen, (co,), b, dev)
+
+    def snake(name, ch):
+        sd[name + ".alpha"] = (1.0 + _normal(gen, (1, ch, 1), 0.25, dev)).clamp_(0.3, 2.0)
+
+    def res_unit(name, ch):
+        snake(name + ".block.0", ch)
+        conv(name + ".block.1", ch, ch, 7)
+        snake(name + ".block.2", ch)
+        conv(name + ".block.3", ch, ch, 1, gain=0.5)
+
+    E = "audio_codec.encoder.block."
+    conv(E + "0", enc_ch[0], 1, 7, gain=2.0)
+    for i, s in enumerate(c.encoder_rates):
+        B = f"{E}{i + 1}.block."
+        for j in range(3):
+            res_unit(f"{B}{j}", enc_ch[i])
+        snake(B + "3", enc_ch[i])
+        conv(B + "4", enc_ch[i + 1], enc_ch[i], 2 * s)
+    snake(E + "5", enc_ch[-1])
+    conv(E + "6", c.latent_dim, enc_ch[-1], 3)
+    conv("audio_codec.quantizer.in_proj", 2 * c.codebook_dim, c.latent_dim, 1, gain=2.0)
+    conv("audio_codec.quantizer.out_proj", c.latent_dim, c.codebook_dim, 1)
+
+    Dm = "audio_codec.decoder.model."
+    conv(Dm + "0", dec_ch[0], c.latent_dim, 7)
+    for i, s in enumerate(c.decoder_rates):
+        B = f"{Dm}{i + 1}.block."
+        snake(B + "0", dec_ch[i])
+        b = 1 / math.sqrt(dec_ch[i] * 2)
+        sd[B + "1.weight"] = _uniform(gen, (dec_ch[i], dec_ch[i + 1], 2 * s), b, dev)  # ConvTranspose1d
+        sd[B + "1.bias"] = _uniform(gen, (dec_ch[i + 1],), b, dev)
+        for j in range(3):
+            res_unit(f"{B}{j + 2}", dec_ch[i + 1])
+    snake(Dm + "5", dec_ch[-1])
+    conv(Dm + "6", 1, dec_ch[-1], 7)
+    return sd
+
+
+def synthetic_clip(index: int, n_samples: int = 480_000, sample_rate: int = 48_000) -> torch.Tensor:
+    """Clip `index` of the synthetic benchmark set: 0.1*noise + two sines,
+    mono fp32 [1, n_samples] in [-1, 1]."""
+    g = torch.Generator().manual_seed(1234 + index)
+    t = torch.arange(n_samples, dtype=torch.float32) / sample_rate
+    wav = 0.1 * torch.randn(n_samples, generator=g)
+    wav += 0.2 * torch.sin(2 * math.pi * (220.0 + 10 * index) * t)
+    wav += 0.2 * torch.sin(2 * math.pi * 1300.0 * t)
+    return wav.clamp_(-1, 1).unsqueeze(0)
+
+
+def synthetic_text_features(batch: int, text_len: int = 8, dim: int = 768, seed: int = 7,
+                            ragged: bool = False):
+    """Stand-in for the T5 encoder output (the t5-base tokenizer file is not available offline):
+    (features [B, Lt, dim] fp32, mask [B, Lt] bool)."""
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(batch, text_len, dim, generator=g)
+    mask = torch.ones(batch, text_len, dtype=torch.bool)
+    if ragged:
+        for b in range(batch):
+            mask[b, max(1, text_len - (b % text_len)):] = False
+    return feats, mask
+
+
+def synthetic_noise(batch: int, frames: int, channels: int = 256, seed: int = 99) -> torch.Tensor:
+    """ODE start state, generated on the CPU so CPU-oracle and GPU runs share it (quirk Q12)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(batch, frames, channels, generator=g)
