@@ -1,1 +1,19 @@
-"""MI355X-native implementation of the SAMAudio.separate() hot path."""
+"""MI355X-native implementation of the SAMAudio.separate() hot path.
+
+Public surface mirrors `sam_audio` (reference sam_audio/__init__.py:3-4) for that path:
+SAMAudio, SAMAudioProcessor, Batch, SeparationResult.
+"""
+from .config import SAMAudioConfig, preset_config  # noqa: F401
+from .processor import Batch, SAMAudioProcessor  # noqa: F401
+
+
+def __getattr__(name):
+    # model.py loads libsamaudio_hip.so on construction; import it lazily so that host-only users
+    # (processor, configs) work on machines without the built library.
+    if name in ("SAMAudio", "SeparationResult", "DFLT_ODE_OPT"):
+        from . import model
+        return getattr(model, name)
+    raise AttributeError(name)
+
+
+__all__ = ["SAMAudio", "SAMAudioProcessor", "Batch", "SeparationResult", "SAMAudioConfig", "preset_config"]

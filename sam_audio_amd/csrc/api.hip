@@ -1,0 +1,164 @@
+// extern "C" surface of libsamaudio_hip.so (declared in include/samaudio.h).
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+
+struct samaudio_ctx {
+  sa::Engine* engine;
+};
+
+namespace {
+thread_local std::string g_err;
+int ret(const sa::Status& s) {
+  if (!s.ok()) g_err = s.msg;
+  return s.code;
+}
+int hip_ret(hipError_t e, const char* what) {
+  if (e == hipSuccess) return SAMAUDIO_OK;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return SAMAUDIO_ERR_HIP;
+}
+int bad(const char* msg) {
+  g_err = msg;
+  return SAMAUDIO_ERR_ARG;
+}
+}  // namespace
+
+extern "C" {
+
+const char* samaudio_last_error(void) { return g_err.c_str(); }
+const char* samaudio_version(void) { return "samaudio-hip 0.1 (gfx950)"; }
+
+int samaudio_create(const samaudio_config* cfg, samaudio_ctx** out) {
+  if (!cfg || !out) return bad("samaudio_create: null argument");
+  if (cfg->precision != SAMAUDIO_F32 && cfg->precision != SAMAUDIO_BF16) return bad("samaudio_create: precision");
+  if (cfg->dim <= 0 || cfg->n_heads <= 0 || cfg->n_layers < 0 || cfg->ffn_hidden <= 0) return bad("samaudio_create: dims");
+  samaudio_ctx* c = new samaudio_ctx;
+  c->engine = new sa::Engine(*cfg);
+  *out = c;
+  return SAMAUDIO_OK;
+}
+
+void samaudio_destroy(samaudio_ctx* ctx) {
+  if (!ctx) return;
+  delete ctx->engine;
+  delete ctx;
+}
+
+int samaudio_set_tensor(samaudio_ctx* ctx, const char* name, const void* data, int dtype, int ndim,
+                        const int64_t* shape) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->set_tensor(name, data, dtype, ndim, shape));
+}
+
+int samaudio_finalize(samaudio_ctx* ctx, int what) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->finalize(what));
+}
+
+size_t samaudio_workspace_bytes(samaudio_ctx* ctx, int rows, int frames, int text_len, int codec_items,
+                                int64_t samples) {
+  if (!ctx) return 0;
+  return ctx->engine->workspace_bytes(rows, frames, text_len, codec_items, samples);
+}
+
+int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->set_workspace(workspace, bytes));
+}
+
+int samaudio_prepare(samaudio_ctx* ctx, int rows, int frames, int text_len, const float* audio_features,
+                     const float* text, const uint8_t* text_mask, const float* video, const int64_t* anchor_ids,
+                     int n_ids, const int64_t* anchor_alignment, const uint8_t* audio_pad_mask,
+                     samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->prepare(rows, frames, text_len, audio_features, text, text_mask, video, anchor_ids, n_ids,
+                                  anchor_alignment, audio_pad_mask, (hipStream_t)stream));
+}
+
+int samaudio_forward(samaudio_ctx* ctx, const float* noisy, const float* time, int n_time, float* out,
+                     samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->forward(noisy, time, n_time, out, (hipStream_t)stream));
+}
+
+int samaudio_ode_solve(samaudio_ctx* ctx, float* state, int method, const float* grid_host, int n_grid,
+                       samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->ode_solve(state, method, grid_host, n_grid, (hipStream_t)stream));
+}
+
+int samaudio_codec_encode(samaudio_ctx* ctx, const float* wav, int items, int64_t samples, float* latent,
+                          samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->codec_encode(wav, items, samples, latent, (hipStream_t)stream));
+}
+
+int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int frames, float* wav,
+                          samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->codec_decode(latent, items, frames, wav, (hipStream_t)stream));
+}
+
+// ---- per-kernel hooks ------------------------------------------------------------------------------
+int samaudio_op_gemm(const void* params_host, size_t params_bytes, int precision, samaudio_stream stream) {
+  if (!params_host || params_bytes != sizeof(sa::GemmParams)) return bad("samaudio_op_gemm: GemmParams size mismatch");
+  sa::GemmParams p;
+  std::memcpy(&p, params_host, sizeof(p));
+  const bool bf16 = precision == SAMAUDIO_BF16;
+  if (const char* why = sa::gemm_check(p, bf16)) return bad(why);
+  return hip_ret(sa::launch_gemm(p, bf16, (hipStream_t)stream), "gemm");
+}
+
+int samaudio_op_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
+                            const float* tvec, int64_t tvec_ld, int shift_off, int scale_off, void* out,
+                            int precision, int rows, int dim, int rows_per_batch, float eps, samaudio_stream stream) {
+  if (dim % 4) return bad("rmsnorm_mod: dim % 4");
+  return hip_ret(sa::launch_rmsnorm_mod(x, w, shift_tab, scale_tab, tvec, tvec_ld, shift_off, scale_off, out,
+                                        precision == SAMAUDIO_BF16, rows, dim, rows_per_batch, eps,
+                                        (hipStream_t)stream), "rmsnorm_mod");
+}
+
+int samaudio_op_groupnorm_silu(const float* x, const float* w, const float* b, void* partials_f64, void* out,
+                               int precision, int batch, int frames, int channels, int halo, float eps,
+                               samaudio_stream stream) {
+  if (channels % 4) return bad("groupnorm: channels % 4");
+  return hip_ret(sa::launch_groupnorm_silu(x, w, b, (double*)partials_f64, out, precision == SAMAUDIO_BF16, batch,
+                                           frames, channels, halo, eps, (hipStream_t)stream), "groupnorm_silu");
+}
+
+int samaudio_op_qkv_prep(const void* qkv, const float* q_w, const float* k_w, const float* rope_cos,
+                         const float* rope_sin, void* q, void* k, void* vt, int precision, int batch, int frames,
+                         int frames_padded, int heads, float eps, samaudio_stream stream) {
+  if (frames_padded % 64 || frames_padded < frames) return bad("qkv_prep: frames_padded");
+  return hip_ret(sa::launch_qkv_prep(qkv, q_w, k_w, rope_cos, rope_sin, q, k, vt, precision == SAMAUDIO_BF16, batch,
+                                     frames, frames_padded, heads, eps, (hipStream_t)stream), "qkv_prep");
+}
+
+int samaudio_op_self_attention(const void* q, const void* k, const void* vt, const uint8_t* key_mask, void* out,
+                               int precision, int batch, int frames, int frames_padded, int heads,
+                               samaudio_stream stream) {
+  if (frames_padded % 64 || frames_padded < frames) return bad("self_attention: frames_padded");
+  return hip_ret(sa::launch_self_attention(q, k, vt, key_mask, out, precision == SAMAUDIO_BF16, batch, frames,
+                                           frames_padded, heads, (hipStream_t)stream), "self_attention");
+}
+
+int samaudio_op_cross_attention(const void* q, const float* q_w, void* kv, const float* k_w, const uint8_t* mask,
+                                void* out, int precision, int batch, int frames, int text_len, int heads, float eps,
+                                samaudio_stream stream) {
+  const bool bf16 = precision == SAMAUDIO_BF16;
+  hipError_t e = sa::launch_headnorm(kv, k_w, bf16, batch * text_len, 2L * heads * 128, 0, heads, eps,
+                                     (hipStream_t)stream);
+  if (e != hipSuccess) return hip_ret(e, "headnorm");
+  return hip_ret(sa::launch_cross_attention(q, q_w, kv, mask, out, bf16, batch, frames, text_len, heads, eps,
+                                            (hipStream_t)stream), "cross_attention");
+}
+
+int samaudio_op_layernorm_accum(const float* x, const float* w, const float* b, const float* gate, float* acc,
+                                int rows, int dim, float eps, samaudio_stream stream) {
+  return hip_ret(sa::launch_layernorm_accum(x, w, b, gate, acc, rows, dim, eps, (hipStream_t)stream),
+                 "layernorm_accum");
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// Attention kernels of the DiT block (reference transformer.py:153-160: non-causal SDPA, bool key-padding
+// mask, scale 1/sqrt(128)).  Sequence lengths on this path are short (T = 250 latent frames for a 10 s clip),
+// so one workgroup owns 64 query rows of one (batch, head) and streams the keys through LDS in tiles of 64.
+//
+//   * bf16 mode: flash-style, both contractions on v_mfma_f32_16x16x32_bf16.  S = Q K^T with Q fragments
+//     held in registers; the softmax runs in the accumulator layout (row statistics by 16-lane shuffles);
+//     P is re-laid as an A operand through a per-wave LDS tile; V arrives pre-transposed ([d][key]) so that
+//     P@V is again a K-contiguous contraction.  LDS tiles are XOR-swizzled against ds_read_b128 conflicts.
+//   * fp32 mode (parity path): same tiling on the vector ALU, exact fp32 with expf.
+//   * cross-attention (Lt ~ a handful of T5 tokens): one wave per (row, head), q-norm fused, online softmax.
+#include "kernels.h"
+
+namespace sa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---------------------------------------------------------------------------------------------------
+// bf16 MFMA self-attention.  grid (Tp/64, H, B), 256 threads (4 waves x 16 query rows).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                             const bf16_t* __restrict__ Vt,
+                                                             const unsigned char* __restrict__ key_mask,
+                                                             bf16_t* __restrict__ out, int T, int Tp, int H) {
+  __shared__ __attribute__((aligned(16))) char Ks[64 * 256];   // [key][128 d] bf16, chunk ^= key & 15
+  __shared__ __attribute__((aligned(16))) char Vs[128 * 128];  // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
+  __shared__ __attribute__((aligned(16))) char Ps[4 * 16 * 128];  // per wave [16 q][64 keys] bf16
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const long bh = (long)b * H + h;
+  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+
+  bf16x8_t qf[4];
+  {
+    const bf16_t* qrow = Q + (bh * Tp + q0 + wave * 16 + lr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
+  }
+  float m_i[4], l_i[4];
+  f32x4_t o[8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_i[r] = -INFINITY; l_i[r] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < 8; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  char* Pw = Ps + wave * 2048;
+
+  for (int kt = 0; kt < Tp; kt += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 256 * it;
+      {
+        const int row = idx >> 4, c = idx & 15;
+        const uint4 v = *(const uint4*)(K + (bh * Tp + kt + row) * 128 + c * 8);
+        *(uint4*)(Ks + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+      }
+      {
+        const int d = idx >> 3, c = idx & 7;
+        const uint4 v = *(const uint4*)(Vt + (bh * 128 + d) * Tp + kt + c * 8);
+        *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = v;
+      }
+    }
+    __syncthreads();
+    // S = Q K^T : s[nb][r] = S[q = lg*4 + r][key = nb*16 + lr]
+    f32x4_t s[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      s[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = nb * 16 + lr;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + row * 256 + (((ks * 4 + lg) ^ (row & 15)) << 4));
+        s[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[nb], 0, 0, 0);
+      }
+    }
+    bool valid[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int key = kt + nb * 16 + lr;
+      valid[nb] = key < T && key_mask[(long)b * T + key] != 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        s[nb][r] = valid[nb] ? s[nb][r] * scale : -INFINITY;
+        mx = fmaxf(mx, s[nb][r]);
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float m_new = fmaxf(m_i[r], mx);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = __expf(m_i[r] - m_safe);
+      float rs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float pv = __expf(s[nb][r] - m_safe);
+        s[nb][r] = pv;
+        rs += pv;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+      l_i[r] = l_i[r] * alpha + rs;
+      m_i[r] = m_new;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) o[n][r] *= alpha;
+      // P -> LDS as an A operand image: row q = lg*4 + r, key = nb*16 + lr
+      const int q = lg * 4 + r;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int c = nb * 2 + (lr >> 3);
+        *(unsigned short*)(Pw + q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + (lr & 7) * 2) = f2bf(s[nb][r]);
+      }
+    }
+    __syncthreads();
+    // O += P V : A = P[q = lr][key chunk], B = Vt[d = n*16 + lr][key chunk]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + lg;
+      const bf16x8_t pf = *(const bf16x8_t*)(Pw + lr * 128 + ((c ^ ((lr >> 1) & 7)) << 4));
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int d = n * 16 + lr;
+        const bf16x8_t vf = *(const bf16x8_t*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
+        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
+      }
+    }
+  }
+  const int D = H * 128;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int q = q0 + wave * 16 + lg * 4 + r;
+    if (q >= T) continue;
+    const float inv = 1.f / l_i[r];
+    bf16_t* orow = out + ((long)b * T + q) * D + h * 128;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) orow[n * 16 + lr].v = f2bf(o[n][r] * inv);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fp32 self-attention (parity path).  grid (ceil(T/32), H, B), 256 threads: thread = (query qi, lane-in-8 sub).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ Vt,
+                                                            const unsigned char* __restrict__ key_mask,
+                                                            float* __restrict__ out, int T, int Tp, int H) {
+  __shared__ float Qs[32][129];
+  __shared__ float KV[128 * 65];  // K tile as [64][129] (8256 floats) or V^T tile as [128][65] (8320 floats)
+  __shared__ float Ss[32][65];
+  const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, qi = tid >> 3, sub = tid & 7;
+  const long bh = (long)b * H + h;
+  const float scale = 0.08838834764831845f;
+  for (int idx = tid; idx < 32 * 128; idx += 256) {
+    const int r = idx >> 7, d = idx & 127;
+    const int q = q0 + r;
+    Qs[r][d] = q < Tp ? Q[(bh * Tp + q) * 128 + d] : 0.f;
+  }
+  float m_i = -INFINITY, l_i = 0.f, o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = 0.f;
+  for (int kt = 0; kt < Tp; kt += 64) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * 128; idx += 256) {
+      const int r = idx >> 7, d = idx & 127;
+      KV[r * 129 + d] = K[(bh * Tp + kt + r) * 128 + d];
+    }
+    __syncthreads();
+    float sc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sc[u] = 0.f;
+    for (int d = 0; d < 128; ++d) {
+      const float qv = Qs[qi][d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sc[u] = fmaf(qv, KV[(sub + 8 * u) * 129 + d], sc[u]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int key = kt + sub + 8 * u;
+      const bool valid = key < T && key_mask[(long)b * T + key] != 0;
+      sc[u] = valid ? sc[u] * scale : -INFINITY;
+      mx = fmaxf(mx, sc[u]);
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = expf(m_i - m_safe);
+    float rs = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float pv = expf(sc[u] - m_safe);
+      Ss[qi][sub + 8 * u] = pv;
+      rs += pv;
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] *= alpha;
+    __syncthreads();  // scores written, K tile no longer needed
+    for (int idx = tid; idx < 128 * 64; idx += 256) {
+      const int d = idx >> 6, kk = idx & 63;
+      KV[d * 65 + kk] = Vt[(bh * 128 + d) * Tp + kt + kk];
+    }
+    __syncthreads();
+    for (int kk = 0; kk < 64; ++kk) {
+      const float pv = Ss[qi][kk];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = fmaf(pv, KV[(sub + 8 * i) * 65 + kk], o[i]);
+    }
+  }
+  const int q = q0 + qi;
+  if (q < T) {
+    const float inv = 1.f / l_i;
+    float* orow = out + ((long)b * T + q) * (H * 128) + h * 128;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) orow[sub + 8 * i] = o[i] * inv;
+  }
+}
+
+hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
+                                 void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
+  if (bf16)
+    hipLaunchKernelGGL(self_attn_bf16_kernel, dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else
+    hipLaunchKernelGGL(self_attn_f32_kernel, dim3((T + 31) / 32, H, B), dim3(256), 0, st, (const float*)Q,
+                       (const float*)K, (const float*)Vt, key_mask, (float*)out, T, Tp, H);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cross-attention onto the text memory (reference transformer.py:382-388 via :128-161: qk-norm on, no RoPE,
+// no gate).  One wave per (row, head); lane holds elements (2*lane, 2*lane+1) of the 128-wide head.
+// ---------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ q, const float* __restrict__ qw,
+                                                         const TA* __restrict__ kv,
+                                                         const unsigned char* __restrict__ mask, TA* __restrict__ out,
+                                                         long M, int T, int Lt, int H, float eps) {
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= M * H) return;
+  const int lane = threadIdx.x & 63;
+  const long m = item / H;
+  const int h = (int)(item % H);
+  const long b = m / T;
+  const int D = H * 128;
+  float q0, q1;
+  load2<TA>(q + m * D + h * 128 + 2 * lane, q0, q1);
+  const float inv = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / 128.f + eps);
+  q0 *= inv * qw[2 * lane];
+  q1 *= inv * qw[2 * lane + 1];
+  const float scale = 0.08838834764831845f;
+  float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+  for (int j = 0; j < Lt; ++j) {
+    if (!mask[b * Lt + j]) continue;  // wave-uniform
+    const TA* krow = kv + (b * Lt + j) * (2L * D) + h * 128 + 2 * lane;
+    float k0, k1, v0, v1;
+    load2<TA>(krow, k0, k1);
+    load2<TA>(krow + D, v0, v1);
+    const float s = wave_sum(q0 * k0 + q1 * k1) * scale;
+    const float m_new = fmaxf(mx, s);
+    const float a = expf(mx - m_new), p = expf(s - m_new);
+    l = l * a + p;
+    o0 = o0 * a + p * v0;
+    o1 = o1 * a + p * v1;
+    mx = m_new;
+  }
+  const float il = 1.f / l;
+  store2<TA>(out + m * D + h * 128 + 2 * lane, o0 * il, o1 * il);
+}
+
+hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, const unsigned char* mask,
+                                  void* out, bool bf16, int B, int T, int Lt, int H, float eps, hipStream_t st) {
+  const long M = (long)B * T;
+  dim3 grid((unsigned)((M * H + 3) / 4)), block(256);
+  if (bf16)
+    hipLaunchKernelGGL(cross_attn_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, qw, (const bf16_t*)kv, mask,
+                       (bf16_t*)out, M, T, Lt, H, eps);
+  else
+    hipLaunchKernelGGL(cross_attn_kernel<float>, grid, block, 0, st, (const float*)q, qw, (const float*)kv, mask,
+                       (float*)out, M, T, Lt, H, eps);
+  return hipGetLastError();
+}
+
+}  // namespace sa

@@ -1,0 +1,111 @@
+// Shared device/host helpers for libsamaudio_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sa {
+
+// ---- activation element types -------------------------------------------------------------
+// bf16 is stored as raw 16-bit words (bit-compatible with torch.bfloat16); all arithmetic is fp32.
+struct bf16_t {
+  unsigned short v;
+};
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf2f(p->v); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { p->v = f2bf(v); }
+};
+
+template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  ushort4 v;
+  v.x = f2bf(a); v.y = f2bf(b); v.z = f2bf(c); v.w = f2bf(d);
+  *(ushort4*)p = v;
+}
+template <typename T> __device__ __forceinline__ void load2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b) {
+  float2 v = *(const float2*)p; a = v.x; b = v.y;
+}
+template <> __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float& a, float& b) {
+  ushort2 v = *(const ushort2*)p; a = bf2f(v.x); b = bf2f(v.y);
+}
+template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b);
+template <> __device__ __forceinline__ void store2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
+  ushort2 v; v.x = f2bf(a); v.y = f2bf(b); *(ushort2*)p = v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float snake_f(float x, float a) {
+  float s = sinf(a * x);
+  return x + s * s / (a + 1e-9f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- epilogue activation codes --------------------------------------------------------------
+enum : int { ACT_NONE = 0, ACT_SNAKE = 1, ACT_TANH = 2, ACT_SILU = 3 };
+
+// ---- generalised (implicit-convolution) GEMM ---------------------------------------------------
+// C[b][m][n] = sum_k A(b, m, k) * W[n][k]
+//   A(b,m,k): k is split into `ntaps` segments of `kc` contiguous elements;
+//             element address = A + a_off + b*a_bstride + m*lda + (k / kc)*tap_stride + (k % kc).
+//   plain GEMM: ntaps=1, kc=K.  dilated conv: ntaps=taps, kc=C_in, tap_stride=dil*C_in.
+//   strided conv / transposed conv: a single contiguous window per row with lda < kc (overlapping).
+// Rows are clamped to M-1 on load (halo rows make shifted reads legal) and masked on store.
+struct GemmParams {
+  const void* A;
+  const void* W;  // [N][K] row-major, K contiguous; same element type as A
+  long a_off, a_bstride, lda, tap_stride;
+  int kc;
+  int M, N, K, nbatch;
+  // epilogue:  v = acc (+ bias[n % chan_mod]);  swiglu: v = silu(v_even_blk) * v_odd_blk
+  //            v *= gate_tab[n] + gate[gate_row*gate_ld + n]   (if gate)   ; v *= alpha
+  //            v += res[...]                                    (if res)
+  //            out_f32[...] = v ; out_act[...] = act(v)
+  const float* bias;
+  int chan_mod;
+  int swiglu;
+  const float* gate_tab;
+  const float* gate;
+  long gate_ld;
+  int rows_per_gate;
+  float alpha;
+  const float* res;
+  long res_bstride, res_ld, res_off;
+  float* out_f32;
+  long f32_bstride, f32_ld, f32_off;
+  void* out_act;
+  long act_bstride, act_ld, act_off;
+  int act;
+  int f32_act;             // 1: out_f32 receives act(v) instead of v
+  const float* act_alpha;  // snake alpha per channel (n % chan_mod)
+  long c_lo, c_hi;         // valid range of (m*c_ld_rel + n); c_ld_rel = f32_ld or act_ld
+  long c_ld_rel;
+};
+
+}  // namespace sa

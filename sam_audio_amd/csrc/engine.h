@@ -1,0 +1,123 @@
+// Host-side orchestration of the separate() hot path: owns no device memory, sequences the kernels.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/samaudio.h"
+#include "kernels.h"
+
+namespace sa {
+
+struct TensorRef {
+  const void* p = nullptr;
+  int dtype = 0;
+  std::vector<int64_t> shape;
+};
+
+struct Status {
+  int code = 0;
+  std::string msg;
+  bool ok() const { return code == 0; }
+};
+
+constexpr int HALO = 40;  // zero rows either side of codec activations (>= 4 * max dilation 9)
+
+class Bump {  // workspace carving (also used dry to size the workspace)
+ public:
+  explicit Bump(char* base = nullptr, size_t cap = 0) : base_(base), cap_(cap) {}
+  void* take(size_t bytes) {
+    size_t off = (used_ + 255) & ~size_t(255);
+    used_ = off + bytes;
+    return base_ ? base_ + off : nullptr;
+  }
+  size_t used() const { return (used_ + 255) & ~size_t(255); }
+  bool fits() const { return used() <= cap_; }
+  void reset_to(size_t mark) { used_ = mark; }
+  size_t mark() const { return used_; }
+
+ private:
+  char* base_;
+  size_t cap_;
+  size_t used_ = 0;
+};
+
+class Engine {
+ public:
+  explicit Engine(const samaudio_config& c);
+  Status set_tensor(const char* name, const void* p, int dtype, int ndim, const int64_t* shape);
+  Status finalize(int what);
+  size_t workspace_bytes(int rows, int frames, int text_len, int codec_items, int64_t samples);
+  Status set_workspace(void* p, size_t bytes);
+
+  Status prepare(int rows, int frames, int text_len, const float* feats, const float* text, const uint8_t* text_mask,
+                 const float* video, const int64_t* anchor_ids, int n_ids, const int64_t* anchor_alignment,
+                 const uint8_t* pad_mask, hipStream_t st);
+  Status forward(const float* noisy, const float* time, int n_time, float* out, hipStream_t st);
+  Status ode_solve(float* state, int method, const float* grid_host, int n_grid, hipStream_t st);
+  Status codec_encode(const float* wav, int items, int64_t samples, float* latent, hipStream_t st);
+  Status codec_decode(const float* latent, int items, int frames, float* wav, hipStream_t st);
+
+ private:
+  struct DitBuffers;
+  struct DitW;
+  struct CodecW;
+  // one field evaluation; out = res + alpha * v(noisy, t) (res may be null)
+  Status eval_field(const float* noisy, const float* time, int n_time, float* out, const float* res, float alpha,
+                    hipStream_t st);
+  Status plan_dit(Bump& b, int rows, int frames, int text_len, bool assign);
+  size_t codec_bytes(int items, int64_t samples) const;
+  Status gemm(const GemmParams& p, hipStream_t st);
+  const TensorRef* find(const std::string& name) const;
+  Status need(const std::string& name, int dtype, std::vector<int64_t> shape, const void** out);
+
+  samaudio_config cfg_;
+  bool bf16_;
+  size_t esz_;  // bytes per activation / GEMM-operand element
+  int at_dtype_;
+  std::map<std::string, TensorRef> tensors_;
+  bool dit_ready_ = false, codec_ready_ = false, prepared_ = false;
+  char* ws_ = nullptr;
+  size_t ws_bytes_ = 0;
+  int rows_ = 0, frames_ = 0, text_len_ = 0, frames_pad_ = 0;
+  bool has_anchor_ = false;
+
+  // resolved weights (pointers into caller memory)
+  struct LayerW {
+    const float *attn_norm, *ffn_norm, *mod_table, *q_norm, *k_norm, *c_q_norm, *c_k_norm;
+    const void *wqkv, *wo, *c_wq, *c_wkv, *c_wo, *w13, *w2;
+  };
+  std::vector<LayerW> layers_;
+  struct {
+    const float *final_table, *final_norm, *gn1_w, *gn1_b, *gn2_w, *gn2_b, *pb1, *pb2, *tb_b, *t_freqs, *mem_inv_freq,
+        *rope_cos, *rope_sin, *proj_b, *mem_b, *vid_b, *vid_ln_w, *vid_ln_b, *vid_gate, *anc_emb;
+    const void *w_out, *pw1, *pw2, *y_w13, *y_w2, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w;
+  } g_;
+  struct ResUnitW {
+    const float *a1, *b1, *a2, *b2;
+    const void *w1, *w2;
+    int k1pad, k2pad;
+  };
+  struct StageW {
+    ResUnitW r[3];
+    const float *a, *b;   // snake before the resampling conv, its bias
+    const void* w;        // down conv [2C, 2s*C] (encoder)  /  up conv [s*Cout, 2*Cin] (decoder)
+  };
+  struct {
+    const void *in_w, *out_w, *proj_w;
+    const float *in_b, *out_a, *out_b, *proj_b;
+    int out_kpad;
+    StageW s[4];
+  } enc_, dec_;
+
+  // DiT workspace (assigned by plan_dit)
+  struct {
+    float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *tsin, *vtmp, *times;
+    void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
+        *feats, *text, *video, *anch;
+    unsigned char *pad_mask, *text_mask;
+    double* gn_part;
+  } d_;
+};
+
+}  // namespace sa

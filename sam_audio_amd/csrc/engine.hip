@@ -1,0 +1,722 @@
+// Engine: sequences the HIP kernels of SAMAudio.separate() (reference sam_audio/model/model.py:247-338).
+// Host code only - every arithmetic step is a kernel from gemm.hip / kernels.hip / attention.hip.
+#include "engine.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace sa {
+
+#define SA_TRY(expr)                     \
+  do {                                   \
+    Status _s = (expr);                  \
+    if (!_s.ok()) return _s;             \
+  } while (0)
+#define SA_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess)                                                             \
+      return Status{SAMAUDIO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
+  } while (0)
+
+static Status fail(int code, const std::string& m) { return Status{code, m}; }
+static long round_up(long v, long m) { return (v + m - 1) / m * m; }
+
+Engine::Engine(const samaudio_config& c) : cfg_(c) {
+  bf16_ = c.precision == SAMAUDIO_BF16;
+  esz_ = bf16_ ? 2 : 4;
+  at_dtype_ = bf16_ ? SAMAUDIO_DT_BF16 : SAMAUDIO_DT_F32;
+  std::memset(&g_, 0, sizeof(g_));
+  std::memset(&enc_, 0, sizeof(enc_));
+  std::memset(&dec_, 0, sizeof(dec_));
+  std::memset(&d_, 0, sizeof(d_));
+}
+
+Status Engine::set_tensor(const char* name, const void* p, int dtype, int ndim, const int64_t* shape) {
+  if (!name || !p || ndim < 0 || ndim > 4) return fail(SAMAUDIO_ERR_ARG, "set_tensor: bad argument");
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0)
+    return fail(SAMAUDIO_ERR_ARG, std::string("set_tensor: ") + name + " is not 16-byte aligned");
+  TensorRef t;
+  t.p = p;
+  t.dtype = dtype;
+  t.shape.assign(shape, shape + ndim);
+  tensors_[name] = t;
+  dit_ready_ = codec_ready_ = false;
+  return Status{};
+}
+
+const TensorRef* Engine::find(const std::string& name) const {
+  auto it = tensors_.find(name);
+  return it == tensors_.end() ? nullptr : &it->second;
+}
+
+Status Engine::need(const std::string& name, int dtype, std::vector<int64_t> shape, const void** out) {
+  const TensorRef* t = find(name);
+  if (!t) return fail(SAMAUDIO_ERR_WEIGHT, "missing weight tensor '" + name + "'");
+  if (t->dtype != dtype) return fail(SAMAUDIO_ERR_WEIGHT, "weight '" + name + "' has the wrong dtype");
+  if (t->shape != shape) {
+    std::string s = "weight '" + name + "' has shape [";
+    for (auto v : t->shape) s += std::to_string(v) + ",";
+    s += "] expected [";
+    for (auto v : shape) s += std::to_string(v) + ",";
+    return fail(SAMAUDIO_ERR_WEIGHT, s + "]");
+  }
+  *out = t->p;
+  return Status{};
+}
+
+static int kpad(int k, bool bf16) { return (int)round_up(k, bf16 ? 64 : 32); }
+
+Status Engine::finalize(int what) {
+  const int D = cfg_.dim, F = cfg_.ffn_hidden, L = cfg_.n_layers, C2 = cfg_.latent_channels;
+  const int F32 = SAMAUDIO_DT_F32, AT = at_dtype_;
+#define NEEDF(field, name, ...) SA_TRY(need(name, F32, {__VA_ARGS__}, (const void**)&(field)))
+#define NEEDW(field, name, ...) SA_TRY(need(name, AT, {__VA_ARGS__}, (const void**)&(field)))
+  if (what == 0) {
+    if (D % 256 || cfg_.n_heads * 128 != D) return fail(SAMAUDIO_ERR_ARG, "dim must be n_heads*128 and a multiple of 256");
+    if (F % 64 || C2 % 64 || cfg_.text_dim % 64 || cfg_.video_dim % 64 || cfg_.freq_dim % 64 || cfg_.anchor_dim % 64)
+      return fail(SAMAUDIO_ERR_ARG, "channel widths must be multiples of 64");
+    layers_.assign(L, LayerW{});
+    for (int i = 0; i < L; ++i) {
+      const std::string P = "L" + std::to_string(i) + ".";
+      LayerW& w = layers_[i];
+      NEEDF(w.attn_norm, P + "attn_norm", D);
+      NEEDF(w.ffn_norm, P + "ffn_norm", D);
+      NEEDF(w.mod_table, P + "mod_table", 6, D);
+      NEEDF(w.q_norm, P + "q_norm", 128);
+      NEEDF(w.k_norm, P + "k_norm", 128);
+      NEEDF(w.c_q_norm, P + "c_q_norm", 128);
+      NEEDF(w.c_k_norm, P + "c_k_norm", 128);
+      NEEDW(w.wqkv, P + "wqkv", 3 * D, D);
+      NEEDW(w.wo, P + "wo", D, D);
+      NEEDW(w.c_wq, P + "c_wq", D, D);
+      NEEDW(w.c_wkv, P + "c_wkv", 2 * D, D);
+      NEEDW(w.c_wo, P + "c_wo", D, D);
+      NEEDW(w.w13, P + "w13", 2 * F, D);
+      NEEDW(w.w2, P + "w2", D, F);
+    }
+    NEEDF(g_.final_table, "final_table", 2, D);
+    NEEDF(g_.final_norm, "final_norm", D);
+    NEEDW(g_.w_out, "w_out", C2, D);
+    NEEDF(g_.gn1_w, "patch1.gn_w", D);
+    NEEDF(g_.gn1_b, "patch1.gn_b", D);
+    NEEDW(g_.pw1, "patch1.w", D, 3 * D);
+    NEEDF(g_.pb1, "patch1.b", D);
+    NEEDF(g_.gn2_w, "patch2.gn_w", D);
+    NEEDF(g_.gn2_b, "patch2.gn_b", D);
+    NEEDW(g_.pw2, "patch2.w", D, 3 * D);
+    NEEDF(g_.pb2, "patch2.b", D);
+    NEEDW(g_.y_w13, "y_w13", 2 * D, D);
+    NEEDW(g_.y_w2, "y_w2", D, D);
+    NEEDW(g_.t_w13, "t_w13", 2 * D, cfg_.freq_dim);
+    NEEDW(g_.t_w2, "t_w2", D, D);
+    NEEDW(g_.tb_w, "tb_w", 6 * D, D);
+    NEEDF(g_.tb_b, "tb_b", 6 * D);
+    NEEDF(g_.t_freqs, "t_freqs", cfg_.freq_dim / 2);
+    NEEDF(g_.mem_inv_freq, "mem_inv_freq", D / 2);
+    NEEDF(g_.rope_cos, "rope_cos", cfg_.max_positions, 64);
+    NEEDF(g_.rope_sin, "rope_sin", cfg_.max_positions, 64);
+    NEEDW(g_.proj_wy, "proj_wy", D, C2);
+    NEEDW(g_.proj_wf, "proj_wf", D, C2);
+    NEEDF(g_.proj_b, "proj_b", D);
+    NEEDW(g_.mem_w, "mem_w", D, cfg_.text_dim);
+    NEEDF(g_.mem_b, "mem_b", D);
+    NEEDW(g_.vid_w, "vid_w", D, cfg_.video_dim);
+    NEEDF(g_.vid_b, "vid_b", D);
+    NEEDF(g_.vid_ln_w, "vid_ln_w", D);
+    NEEDF(g_.vid_ln_b, "vid_ln_b", D);
+    NEEDF(g_.vid_gate, "vid_gate", 1);
+    NEEDF(g_.anc_emb, "anc_emb", cfg_.anchor_vocab, cfg_.anchor_dim);
+    NEEDW(g_.anc_w, "anc_w", D, cfg_.anchor_dim);
+    dit_ready_ = true;
+  } else {
+    const int CD = cfg_.codec_dim, CL = cfg_.codec_latent;
+    auto res_units = [&](const std::string& P, StageW& s, int C) -> Status {
+      for (int j = 0; j < 3; ++j) {
+        const std::string R = P + "r" + std::to_string(j) + ".";
+        ResUnitW& r = s.r[j];
+        r.k1pad = kpad(7 * C, bf16_);
+        r.k2pad = kpad(C, bf16_);
+        NEEDF(r.a1, R + "a1", C);
+        NEEDW(r.w1, R + "w1", C, r.k1pad);
+        NEEDF(r.b1, R + "b1", C);
+        NEEDF(r.a2, R + "a2", C);
+        NEEDW(r.w2, R + "w2", C, r.k2pad);
+        NEEDF(r.b2, R + "b2", C);
+      }
+      return Status{};
+    };
+    // encoder
+    NEEDW(enc_.in_w, "enc.in.w", cfg_.enc_dim, 64);
+    NEEDF(enc_.in_b, "enc.in.b", cfg_.enc_dim);
+    int C = cfg_.enc_dim;
+    for (int i = 0; i < 4; ++i) {
+      const std::string P = "enc.s" + std::to_string(i) + ".";
+      const int s = cfg_.enc_rates[i];
+      if (s % 2) return fail(SAMAUDIO_ERR_ARG, "codec strides must be even");
+      SA_TRY(res_units(P, enc_.s[i], C));
+      NEEDF(enc_.s[i].a, P + "a", C);
+      NEEDW(enc_.s[i].w, P + "down.w", 2 * C, 2 * s * C);
+      NEEDF(enc_.s[i].b, P + "down.b", 2 * C);
+      C *= 2;
+    }
+    NEEDF(enc_.out_a, "enc.out.a", C);
+    NEEDW(enc_.out_w, "enc.out.w", CL, 3 * C);
+    NEEDF(enc_.out_b, "enc.out.b", CL);
+    NEEDW(enc_.proj_w, "enc.proj.w", CD, CL);
+    NEEDF(enc_.proj_b, "enc.proj.b", CD);
+    // decoder
+    NEEDW(dec_.proj_w, "dec.proj.w", CL, CD);
+    NEEDF(dec_.proj_b, "dec.proj.b", CL);
+    NEEDW(dec_.in_w, "dec.in.w", cfg_.dec_dim, 7 * CL);
+    NEEDF(dec_.in_b, "dec.in.b", cfg_.dec_dim);
+    C = cfg_.dec_dim;
+    for (int i = 0; i < 4; ++i) {
+      const std::string P = "dec.s" + std::to_string(i) + ".";
+      const int s = cfg_.dec_rates[i];
+      if (s % 2) return fail(SAMAUDIO_ERR_ARG, "codec strides must be even");
+      NEEDF(dec_.s[i].a, P + "a", C);
+      NEEDW(dec_.s[i].w, P + "up.w", s * (C / 2), 2 * C);
+      NEEDF(dec_.s[i].b, P + "up.b", C / 2);
+      C /= 2;
+      SA_TRY(res_units(P, dec_.s[i], C));
+    }
+    dec_.out_kpad = kpad(7 * C, bf16_);
+    NEEDF(dec_.out_a, "dec.out.a", C);
+    NEEDW(dec_.out_w, "dec.out.w", 1, dec_.out_kpad);
+    NEEDF(dec_.out_b, "dec.out.b", 1);
+    codec_ready_ = true;
+  }
+#undef NEEDF
+#undef NEEDW
+  return Status{};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
+  const long D = cfg_.dim, F = cfg_.ffn_hidden, C2 = cfg_.latent_channels, H = cfg_.n_heads;
+  const long M = (long)rows * T, Mt = (long)rows * Lt, Tp = round_up(T, 64);
+  const long nt = rows;  // worst case: one time value per row
+  auto f32 = [&](long n) { return (float*)b.take((size_t)n * 4); };
+  auto act = [&](long n) { return b.take((size_t)n * esz_); };
+  auto& d = d_;
+  float* ymid = f32(M * C2); float* aligned = f32(M * D); float* cond = f32(M * D); float* h = f32(M * D);
+  float* hp1 = f32(M * D); float* text_proj = f32(Mt * D); float* t_emb = f32(nt * D); float* t0 = f32(nt * 6 * D);
+  float* tsin = f32(nt * D); float* vtmp = f32(M * D); float* times = f32(4096);
+  void* ybf = act(M * C2); void* xn = act(M * D); void* qkv = act(M * 3 * D);
+  void* Q = act((long)rows * H * Tp * 128); void* K = act((long)rows * H * Tp * 128);
+  void* Vt = act((long)rows * H * 128 * Tp);
+  void* attn = act(M * D); void* hbf = act(M * D); void* qc = act(M * D); void* ca = act(M * D); void* u = act(M * F);
+  void* gnbuf = act((long)rows * (T + 2) * D); void* mem = act(Mt * D); void* yu = act(Mt * D); void* yemb = act(Mt * D);
+  void* kvc = act(Mt * 2 * D); void* temb = act(nt * cfg_.freq_dim); void* tu = act(nt * D); void* tsilu = act(nt * D);
+  void* feats = act(M * C2); void* text = act(Mt * cfg_.text_dim); void* video = act(M * cfg_.video_dim);
+  void* anch = act(M * cfg_.anchor_dim);
+  unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
+  unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
+  double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
+  if (assign) {
+    d.ymid = ymid; d.aligned = aligned; d.cond = cond; d.h = h; d.hp1 = hp1; d.text_proj = text_proj; d.t_emb = t_emb;
+    d.t0 = t0; d.tsin = tsin; d.vtmp = vtmp; d.times = times; d.ybf = ybf; d.xn = xn; d.qkv = qkv; d.Q = Q; d.K = K;
+    d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
+    d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
+    d.video = video; d.anch = anch; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
+  }
+  return Status{};
+}
+
+// per-item element counts of the codec stage buffers (see codec_encode / codec_decode)
+static void codec_stage_dims(const samaudio_config& c, int64_t samples, long encT[5], int encC[5], long decT[5],
+                             int decC[5]) {
+  long T = samples;
+  int C = c.enc_dim;
+  for (int i = 0; i < 5; ++i) {
+    encT[i] = T; encC[i] = C;
+    if (i < 4) { T /= c.enc_rates[i]; C *= 2; }
+  }
+  long hop = 1;
+  for (int i = 0; i < 4; ++i) hop *= c.enc_rates[i];
+  T = samples / hop;
+  C = c.dec_dim;
+  for (int i = 0; i < 5; ++i) {
+    decT[i] = T; decC[i] = C;
+    if (i < 4) { T *= c.dec_rates[i]; C /= 2; }
+  }
+}
+
+size_t Engine::codec_bytes(int items, int64_t samples) const {
+  if (items <= 0) return 0;
+  long encT[5], decT[5];
+  int encC[5], decC[5];
+  codec_stage_dims(cfg_, samples, encT, encC, decT, decC);
+  const size_t per_elem = 4 + 2 * esz_;  // raw f32 + act + tmp
+  size_t enc = (size_t)(samples + 2 * HALO) * 8 * esz_, dec = 0;
+  for (int i = 0; i < 5; ++i) enc += (size_t)(encT[i] + 2 * HALO) * encC[i] * per_elem + 1024;
+  enc += (size_t)(encT[4] + 2 * HALO) * cfg_.codec_latent * esz_;
+  dec += (size_t)(decT[0] + 2 * HALO) * (cfg_.codec_dim + cfg_.codec_latent) * esz_;
+  for (int i = 0; i < 5; ++i) dec += (size_t)(decT[i] + 2 * HALO) * decC[i] * per_elem + 1024;
+  return (size_t)items * (enc > dec ? enc : dec) + (1 << 16);
+}
+
+size_t Engine::workspace_bytes(int rows, int frames, int text_len, int codec_items, int64_t samples) {
+  size_t dit = 0;
+  if (rows > 0) {
+    Bump b;
+    plan_dit(b, rows, frames, text_len < 1 ? 1 : text_len, false);
+    dit = b.used() + 4096;
+  }
+  size_t codec = codec_bytes(codec_items, samples);
+  return dit > codec ? dit : codec;
+}
+
+Status Engine::set_workspace(void* p, size_t bytes) {
+  if (!p || (reinterpret_cast<uintptr_t>(p) & 255)) return fail(SAMAUDIO_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  ws_ = (char*)p;
+  ws_bytes_ = bytes;
+  prepared_ = false;
+  return Status{};
+}
+
+Status Engine::gemm(const GemmParams& p, hipStream_t st) {
+  if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
+  SA_HIP(launch_gemm(p, bf16_, st));
+  return Status{};
+}
+
+static GemmParams lin(const void* A, long lda, const void* W, long M, int N, int K) {
+  GemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.lda = lda; p.kc = K; p.tap_stride = 0;
+  p.M = (int)M; p.N = N; p.K = K; p.nbatch = 1; p.alpha = 1.f; p.rows_per_gate = 1;
+  return p;
+}
+static void out_f32(GemmParams& p, float* o, long ld) { p.out_f32 = o; p.f32_ld = ld; }
+static void out_act(GemmParams& p, void* o, long ld, int act = ACT_NONE) { p.out_act = o; p.act_ld = ld; p.act = act; }
+static void with_res(GemmParams& p, const float* r, long ld) { p.res = r; p.res_ld = ld; }
+
+// ---------------------------------------------------------------------------------------------------
+// conditioning that is constant over the ODE (hoisted out of the 32 evaluations)
+// ---------------------------------------------------------------------------------------------------
+Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float* text, const uint8_t* text_mask,
+                       const float* video, const int64_t* anchor_ids, int n_ids, const int64_t* anchor_alignment,
+                       const uint8_t* pad_mask, hipStream_t st) {
+  if (!dit_ready_) return fail(SAMAUDIO_ERR_STATE, "prepare: DiT weights not finalized");
+  if (rows <= 0 || T <= 0 || !feats) return fail(SAMAUDIO_ERR_ARG, "prepare: bad shape");
+  if (T > cfg_.max_positions) return fail(SAMAUDIO_ERR_ARG, "prepare: more frames than RoPE positions");
+  if (text && Lt <= 0) return fail(SAMAUDIO_ERR_ARG, "prepare: text_len must be positive");
+  if (!text) Lt = 1;
+  if (anchor_ids && (!anchor_alignment || n_ids <= 0)) return fail(SAMAUDIO_ERR_ARG, "prepare: anchors incomplete");
+  Bump b(ws_, ws_bytes_);
+  plan_dit(b, rows, T, Lt, true);
+  if (!ws_ || !b.fits())
+    return fail(SAMAUDIO_ERR_WORKSPACE, "prepare: workspace too small (" + std::to_string(b.used()) + " bytes needed)");
+  rows_ = rows; frames_ = T; text_len_ = Lt; frames_pad_ = (int)round_up(T, 64);
+  const int D = cfg_.dim, C2 = cfg_.latent_channels;
+  const long M = (long)rows * T, Mt = (long)rows * Lt;
+
+  if (pad_mask) SA_HIP(hipMemcpyAsync(d_.pad_mask, pad_mask, M, hipMemcpyDeviceToDevice, st));
+  else SA_HIP(hipMemsetAsync(d_.pad_mask, 1, M, st));
+  if (text && text_mask) SA_HIP(hipMemcpyAsync(d_.text_mask, text_mask, Mt, hipMemcpyDeviceToDevice, st));
+  else SA_HIP(hipMemsetAsync(d_.text_mask, 1, Mt, st));
+  // patcher conv input: halo rows stay zero for the whole solve
+  SA_HIP(hipMemsetAsync(d_.gnbuf, 0, (size_t)rows * (T + 2) * D * esz_, st));
+
+  // cond = proj_b + audio_features @ Wf^T                           (model.py:116-125, columns 512..767)
+  SA_HIP(launch_to_act(feats, 0, C2, 0, d_.feats, 0, bf16_, 1, M, C2, C2, 0, st));
+  {
+    GemmParams p = lin(d_.feats, C2, g_.proj_wf, M, D, C2);
+    p.bias = g_.proj_b;
+    out_f32(p, d_.cond, D);
+    SA_TRY(gemm(p, st));
+  }
+  // cond += tanh(g_v) * LayerNorm(conv1x1(video))                   (align.py:41-50; zeros if no video: Q8)
+  if (video) SA_HIP(launch_to_act(video, 0, cfg_.video_dim, 0, d_.video, 0, bf16_, 1, M, cfg_.video_dim, cfg_.video_dim, 0, st));
+  else SA_HIP(hipMemsetAsync(d_.video, 0, (size_t)M * cfg_.video_dim * esz_, st));
+  {
+    GemmParams p = lin(d_.video, cfg_.video_dim, g_.vid_w, M, D, cfg_.video_dim);
+    p.bias = g_.vid_b;
+    out_f32(p, d_.vtmp, D);
+    SA_TRY(gemm(p, st));
+    SA_HIP(launch_layernorm_accum(d_.vtmp, g_.vid_ln_w, g_.vid_ln_b, g_.vid_gate, d_.cond, (int)M, D, 1e-5f, st));
+  }
+  // cond += tanh(g_a) * proj(Emb[ids.gather(alignment)])            (model.py:54-65; tanh folded into anc_w)
+  has_anchor_ = anchor_ids != nullptr;
+  if (anchor_ids) {
+    SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment, d_.anch,
+                                bf16_, rows, T, cfg_.anchor_dim, st));
+    GemmParams p = lin(d_.anch, cfg_.anchor_dim, g_.anc_w, M, D, cfg_.anchor_dim);
+    with_res(p, d_.cond, D);
+    out_f32(p, d_.cond, D);
+    SA_TRY(gemm(p, st));
+  }
+  // text_proj = memory_proj(text)                                   (model.py:171)
+  if (text) {
+    SA_HIP(launch_to_act(text, 0, cfg_.text_dim, 0, d_.text, 0, bf16_, 1, Mt, cfg_.text_dim, cfg_.text_dim, 0, st));
+    GemmParams p = lin(d_.text, cfg_.text_dim, g_.mem_w, Mt, D, cfg_.text_dim);
+    p.bias = g_.mem_b;
+    out_f32(p, d_.text_proj, D);
+    SA_TRY(gemm(p, st));
+  } else {
+    SA_HIP(hipMemsetAsync(d_.text_proj, 0, (size_t)Mt * D * 4, st));
+  }
+  prepared_ = true;
+  return Status{};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one evaluation of the vector field: out = res + alpha * DiT(align(noisy), t)
+// ---------------------------------------------------------------------------------------------------
+Status Engine::eval_field(const float* noisy, const float* time, int nt, float* out, const float* res, float alpha,
+                          hipStream_t st) {
+  if (!prepared_) return fail(SAMAUDIO_ERR_STATE, "forward: call samaudio_prepare first");
+  if (nt != 1 && nt != rows_) return fail(SAMAUDIO_ERR_ARG, "forward: n_time must be 1 or rows");
+  const int D = cfg_.dim, F = cfg_.ffn_hidden, C2 = cfg_.latent_channels, H = cfg_.n_heads, T = frames_,
+            Lt = text_len_, Tp = frames_pad_, rows = rows_;
+  const long M = (long)rows * T, Mt = (long)rows * Lt;
+  const float eps = cfg_.norm_eps;
+  const long t6 = nt == 1 ? 0 : 6L * D, t1 = nt == 1 ? 0 : (long)D;
+
+  // aligned = noisy @ Wy^T + cond                                   (model.py:116-125, columns 0..255)
+  SA_HIP(launch_to_act(noisy, 0, C2, 0, d_.ybf, 0, bf16_, 1, M, C2, C2, 0, st));
+  {
+    GemmParams p = lin(d_.ybf, C2, g_.proj_wy, M, D, C2);
+    with_res(p, d_.cond, D);
+    out_f32(p, d_.aligned, D);
+    SA_TRY(gemm(p, st));
+  }
+  // patcher: (GroupNorm(1) -> SiLU -> conv k3) x 2 + skip           (patcher.py:138-141)
+  auto patch_conv = [&](const void* W, const float* bias, const float* skip, float* dst) -> Status {
+    GemmParams p = lin(d_.gnbuf, D, W, T, D, 3 * D);
+    p.kc = D; p.tap_stride = D; p.a_off = 0; p.a_bstride = (long)(T + 2) * D; p.nbatch = rows;
+    p.bias = bias;
+    if (skip) { with_res(p, skip, D); p.res_bstride = (long)T * D; }
+    out_f32(p, dst, D);
+    p.f32_bstride = (long)T * D;
+    return gemm(p, st);
+  };
+  SA_HIP(launch_groupnorm_silu(d_.aligned, g_.gn1_w, g_.gn1_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st));
+  SA_TRY(patch_conv(g_.pw1, g_.pb1, nullptr, d_.hp1));
+  SA_HIP(launch_groupnorm_silu(d_.hp1, g_.gn2_w, g_.gn2_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st));
+  SA_TRY(patch_conv(g_.pw2, g_.pb2, d_.aligned, d_.h));
+
+  // timestep embeddings                                             (transformer.py:490-493, model.py:170)
+  SA_HIP(launch_time_features(time, nt, g_.t_freqs, cfg_.freq_dim, g_.mem_inv_freq, D, d_.temb, d_.tsin, bf16_, st));
+  {
+    GemmParams p = lin(d_.temb, cfg_.freq_dim, g_.t_w13, nt, 2 * D, cfg_.freq_dim);
+    p.swiglu = 1;
+    out_act(p, d_.tu, D);
+    SA_TRY(gemm(p, st));
+    p = lin(d_.tu, D, g_.t_w2, nt, D, D);
+    out_f32(p, d_.t_emb, D);
+    out_act(p, d_.tsilu, D, ACT_SILU);
+    SA_TRY(gemm(p, st));
+    p = lin(d_.tsilu, D, g_.tb_w, nt, 6 * D, D);
+    p.bias = g_.tb_b;
+    out_f32(p, d_.t0, 6L * D);
+    SA_TRY(gemm(p, st));
+  }
+  // memory = memory_proj(text) + sincos(t); y = y_embedder(memory)  (model.py:170-172, transformer.py:495)
+  SA_HIP(launch_add_rowvec(d_.text_proj, d_.tsin, t1, d_.mem, bf16_, (int)Mt, D, Lt, st));
+  {
+    GemmParams p = lin(d_.mem, D, g_.y_w13, Mt, 2 * D, D);
+    p.swiglu = 1;
+    out_act(p, d_.yu, D);
+    SA_TRY(gemm(p, st));
+    p = lin(d_.yu, D, g_.y_w2, Mt, D, D);
+    out_act(p, d_.yemb, D);
+    SA_TRY(gemm(p, st));
+  }
+
+  for (int l = 0; l < cfg_.n_layers; ++l) {  // DiTBlock.forward, transformer.py:354-391
+    const LayerW& w = layers_[l];
+    const float* tab = w.mod_table;
+    // self-attention branch
+    SA_HIP(launch_rmsnorm_mod(d_.h, w.attn_norm, tab + 0 * D, tab + 1 * D, d_.t0, t6, 0 * D, 1 * D, d_.xn, bf16_,
+                              (int)M, D, T, eps, st));
+    {
+      GemmParams p = lin(d_.xn, D, w.wqkv, M, 3 * D, D);
+      out_act(p, d_.qkv, 3L * D);
+      SA_TRY(gemm(p, st));
+    }
+    SA_HIP(launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp,
+                           H, eps, st));
+    SA_HIP(launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st));
+    {
+      GemmParams p = lin(d_.attn, D, w.wo, M, D, D);  // h = x + gate_msa * attn
+      p.gate_tab = tab + 2 * D; p.gate = d_.t0 + 2 * D; p.gate_ld = t6; p.rows_per_gate = T;
+      with_res(p, d_.h, D);
+      out_f32(p, d_.h, D);
+      out_act(p, d_.hbf, D);
+      SA_TRY(gemm(p, st));
+    }
+    // cross-attention branch: h = h + CA(h, y)   (no norm, no gate: quirk Q4)
+    {
+      GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
+      out_act(p, d_.qc, D);
+      SA_TRY(gemm(p, st));
+      p = lin(d_.yemb, D, w.c_wkv, Mt, 2 * D, D);
+      out_act(p, d_.kvc, 2L * D);
+      SA_TRY(gemm(p, st));
+    }
+    SA_HIP(launch_headnorm(d_.kvc, w.c_k_norm, bf16_, (int)Mt, 2L * D, 0, H, eps, st));
+    SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, d_.kvc, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
+    {
+      GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
+      with_res(p, d_.h, D);
+      out_f32(p, d_.h, D);
+      SA_TRY(gemm(p, st));
+    }
+    // feed-forward branch
+    SA_HIP(launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_,
+                              (int)M, D, T, eps, st));
+    {
+      GemmParams p = lin(d_.xn, D, w.w13, M, 2 * F, D);
+      p.swiglu = 1;
+      out_act(p, d_.u, F);
+      SA_TRY(gemm(p, st));
+      p = lin(d_.u, F, w.w2, M, D, F);  // out = h + gate_mlp * ff
+      p.gate_tab = tab + 5 * D; p.gate = d_.t0 + 5 * D; p.gate_ld = t6; p.rows_per_gate = T;
+      with_res(p, d_.h, D);
+      out_f32(p, d_.h, D);
+      SA_TRY(gemm(p, st));
+    }
+  }
+  // final modulated norm + output projection                         (transformer.py:507-519)
+  SA_HIP(launch_rmsnorm_mod(d_.h, g_.final_norm, g_.final_table, g_.final_table + D, d_.t_emb, t1, 0, 0, d_.xn, bf16_,
+                            (int)M, D, T, eps, st));
+  {
+    GemmParams p = lin(d_.xn, D, g_.w_out, M, C2, D);
+    p.alpha = alpha;
+    if (res) with_res(p, res, C2);
+    out_f32(p, out, C2);
+    SA_TRY(gemm(p, st));
+  }
+  return Status{};
+}
+
+Status Engine::forward(const float* noisy, const float* time, int n_time, float* out, hipStream_t st) {
+  if (!noisy || !time || !out) return fail(SAMAUDIO_ERR_ARG, "forward: null pointer");
+  return eval_field(noisy, time, n_time, out, nullptr, 1.f, st);
+}
+
+Status Engine::ode_solve(float* y, int method, const float* grid, int n_grid, hipStream_t st) {
+  if (!prepared_) return fail(SAMAUDIO_ERR_STATE, "ode_solve: call samaudio_prepare first");
+  if (method != SAMAUDIO_ODE_EULER && method != SAMAUDIO_ODE_MIDPOINT)
+    return fail(SAMAUDIO_ERR_ARG, "ode_solve: unsupported method");
+  if (!y || !grid || n_grid < 2 || 2 * n_grid > 4096) return fail(SAMAUDIO_ERR_ARG, "ode_solve: bad grid");
+  std::vector<float> ev(2 * (size_t)n_grid);
+  for (int k = 0; k + 1 < n_grid; ++k) {
+    if (!(grid[k + 1] > grid[k])) return fail(SAMAUDIO_ERR_ARG, "ode_solve: grid must be increasing");
+    ev[2 * k] = grid[k];
+    ev[2 * k + 1] = (float)((double)grid[k] + 0.5 * ((double)grid[k + 1] - (double)grid[k]));
+  }
+  SA_HIP(hipMemcpyAsync(d_.times, ev.data(), ev.size() * 4, hipMemcpyHostToDevice, st));
+  SA_HIP(hipStreamSynchronize(st));  // `ev` is pageable host memory owned by this frame
+  for (int k = 0; k + 1 < n_grid; ++k) {
+    const float dt = (float)((double)grid[k + 1] - (double)grid[k]);
+    if (method == SAMAUDIO_ODE_EULER) {
+      SA_TRY(eval_field(y, d_.times + 2 * k, 1, y, y, dt, st));
+    } else {
+      SA_TRY(eval_field(y, d_.times + 2 * k, 1, d_.ymid, y, 0.5f * dt, st));
+      SA_TRY(eval_field(d_.ymid, d_.times + 2 * k + 1, 1, y, y, dt, st));
+    }
+  }
+  return Status{};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DAC-VAE: every Conv1d / ConvTranspose1d is one launch of the generalised GEMM over channels-last,
+// halo-padded activations; Snake is fused into the producer's epilogue (raw f32 stream for residuals,
+// activated copy as the next convolution's operand).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct SBuf {
+  float* raw; void* act; void* tmp;
+  long T; int C;
+};
+}  // namespace
+
+static GemmParams conv_same(const void* x, long T, int Cin, int taps, int dil, const void* W, int Kp, int Cout,
+                            int items) {
+  GemmParams p = lin(x, Cin, W, T, Cout, Kp);
+  p.kc = Cin;
+  p.tap_stride = taps == 1 ? (long)Cin : (long)dil * Cin;
+  p.a_off = (long)(HALO - (taps / 2) * dil) * Cin;
+  p.a_bstride = (T + 2L * HALO) * Cin;
+  p.nbatch = items;
+  return p;
+}
+static void halo_out(GemmParams& p, float* raw, void* act, long T, int C, int actfn, const float* alpha) {
+  if (raw) { p.out_f32 = raw; p.f32_bstride = (T + 2L * HALO) * C; p.f32_ld = C; p.f32_off = (long)HALO * C; }
+  if (act) { p.out_act = act; p.act_bstride = (T + 2L * HALO) * C; p.act_ld = C; p.act_off = (long)HALO * C; }
+  p.act = actfn;
+  p.act_alpha = alpha;
+}
+
+Status Engine::codec_encode(const float* wav, int items, int64_t S, float* latent, hipStream_t st) {
+  if (!codec_ready_) return fail(SAMAUDIO_ERR_STATE, "codec_encode: codec weights not finalized");
+  long hop = 1;
+  for (int i = 0; i < 4; ++i) hop *= cfg_.enc_rates[i];
+  if (!wav || !latent || items <= 0 || S <= 0 || S % hop) return fail(SAMAUDIO_ERR_ARG, "codec_encode: samples % hop != 0");
+  const size_t per_item = codec_bytes(1, S);
+  int chunk = (int)(ws_bytes_ / (per_item ? per_item : 1));
+  if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_encode: workspace too small");
+  if (chunk > items) chunk = items;
+  prepared_ = false;  // the codec scratch aliases the DiT scratch
+  long encT[5], decT[5];
+  int encC[5], decC[5];
+  codec_stage_dims(cfg_, S, encT, encC, decT, decC);
+  const int CL = cfg_.codec_latent, CD = cfg_.codec_dim;
+  for (int i0 = 0; i0 < items; i0 += chunk) {
+    const int n = items - i0 < chunk ? items - i0 : chunk;
+    Bump b(ws_, ws_bytes_);
+    void* in8 = b.take((size_t)n * (S + 2 * HALO) * 8 * esz_);
+    SBuf sb[5];
+    for (int i = 0; i < 5; ++i) {
+      const size_t e = (size_t)n * (encT[i] + 2 * HALO) * encC[i];
+      sb[i] = SBuf{(float*)b.take(e * 4), b.take(e * esz_), b.take(e * esz_), encT[i], encC[i]};
+    }
+    void* eout = b.take((size_t)n * (encT[4] + 2 * HALO) * CL * esz_);
+    if (!b.fits()) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_encode: workspace too small");
+    // waveform -> [n][HALO + S + HALO][8] (channel 0), zero halos
+    SA_HIP(hipMemsetAsync(in8, 0, (size_t)n * (S + 2 * HALO) * 8 * esz_, st));
+    SA_HIP(launch_to_act(wav + (long)i0 * S, S, 1, 0, in8, 0, bf16_, n, S, 1, 8, HALO, st));
+    for (int i = 0; i < 5; ++i) {
+      SA_HIP(launch_zero_halo(sb[i].act, bf16_, n, sb[i].T, sb[i].C, HALO, st));
+      SA_HIP(launch_zero_halo(sb[i].tmp, bf16_, n, sb[i].T, sb[i].C, HALO, st));
+    }
+    SA_HIP(launch_zero_halo(eout, bf16_, n, encT[4], CL, HALO, st));
+    {  // conv k7 (1 -> 64): window of 8 samples x 8 padded channels = one 64-wide row
+      GemmParams p = lin(in8, 8, enc_.in_w, S, encC[0], 64);
+      p.a_off = (long)(HALO - 3) * 8; p.a_bstride = (S + 2L * HALO) * 8; p.nbatch = n; p.bias = enc_.in_b;
+      halo_out(p, sb[0].raw, sb[0].act, S, encC[0], ACT_SNAKE, enc_.s[0].r[0].a1);
+      SA_TRY(gemm(p, st));
+    }
+    for (int i = 0; i < 4; ++i) {
+      const StageW& sw = enc_.s[i];
+      const long T = sb[i].T;
+      const int C = sb[i].C, s = cfg_.enc_rates[i];
+      const int dil[3] = {1, 3, 9};
+      for (int j = 0; j < 3; ++j) {
+        const ResUnitW& r = sw.r[j];
+        GemmParams p = conv_same(sb[i].act, T, C, 7, dil[j], r.w1, r.k1pad, C, n);
+        p.bias = r.b1;
+        halo_out(p, nullptr, sb[i].tmp, T, C, ACT_SNAKE, r.a2);
+        SA_TRY(gemm(p, st));
+        p = conv_same(sb[i].tmp, T, C, 1, 1, r.w2, r.k2pad, C, n);
+        p.bias = r.b2;
+        p.res = sb[i].raw; p.res_bstride = (T + 2L * HALO) * C; p.res_ld = C; p.res_off = (long)HALO * C;
+        halo_out(p, sb[i].raw, sb[i].act, T, C, ACT_SNAKE, j < 2 ? sw.r[j + 1].a1 : sw.a);
+        SA_TRY(gemm(p, st));
+      }
+      // strided conv k = 2s, stride s, pad s/2: the 2s input rows of one output are contiguous
+      const int pad = (s + 1) / 2;
+      GemmParams p = lin(sb[i].act, (long)s * C, sw.w, T / s, 2 * C, 2 * s * C);
+      p.a_off = (long)(HALO - pad) * C; p.a_bstride = (T + 2L * HALO) * C; p.nbatch = n; p.bias = sw.b;
+      halo_out(p, sb[i + 1].raw, sb[i + 1].act, T / s, 2 * C, ACT_SNAKE, i < 3 ? enc_.s[i + 1].r[0].a1 : enc_.out_a);
+      SA_TRY(gemm(p, st));
+    }
+    {
+      const long T = sb[4].T;
+      const int C = sb[4].C;
+      GemmParams p = conv_same(sb[4].act, T, C, 3, 1, enc_.out_w, 3 * C, CL, n);
+      p.bias = enc_.out_b;
+      halo_out(p, nullptr, eout, T, CL, ACT_NONE, nullptr);
+      SA_TRY(gemm(p, st));
+      p = conv_same(eout, T, CL, 1, 1, enc_.proj_w, CL, CD, n);  // quantizer.in_proj, mean half only
+      p.bias = enc_.proj_b;
+      p.out_f32 = latent + (long)i0 * T * CD; p.f32_bstride = T * CD; p.f32_ld = CD; p.f32_off = 0;
+      SA_TRY(gemm(p, st));
+    }
+  }
+  return Status{};
+}
+
+Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, hipStream_t st) {
+  if (!codec_ready_) return fail(SAMAUDIO_ERR_STATE, "codec_decode: codec weights not finalized");
+  if (!latent || !wav || items <= 0 || T0 <= 0) return fail(SAMAUDIO_ERR_ARG, "codec_decode: bad argument");
+  long hop = 1;
+  for (int i = 0; i < 4; ++i) hop *= cfg_.enc_rates[i];
+  const int64_t S = (int64_t)T0 * hop;
+  const size_t per_item = codec_bytes(1, S);
+  int chunk = (int)(ws_bytes_ / (per_item ? per_item : 1));
+  if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_decode: workspace too small");
+  if (chunk > items) chunk = items;
+  prepared_ = false;
+  long encT[5], decT[5];
+  int encC[5], decC[5];
+  codec_stage_dims(cfg_, S, encT, encC, decT, decC);
+  const int CL = cfg_.codec_latent, CD = cfg_.codec_dim;
+  for (int i0 = 0; i0 < items; i0 += chunk) {
+    const int n = items - i0 < chunk ? items - i0 : chunk;
+    Bump b(ws_, ws_bytes_);
+    void* lat = b.take((size_t)n * (T0 + 2 * HALO) * CD * esz_);
+    void* p0 = b.take((size_t)n * (T0 + 2 * HALO) * CL * esz_);
+    SBuf sb[5];
+    for (int i = 0; i < 5; ++i) {
+      const size_t e = (size_t)n * (decT[i] + 2 * HALO) * decC[i];
+      sb[i] = SBuf{(float*)b.take(e * 4), b.take(e * esz_), b.take(e * esz_), decT[i], decC[i]};
+    }
+    if (!b.fits()) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_decode: workspace too small");
+    SA_HIP(launch_zero_halo(lat, bf16_, n, T0, CD, HALO, st));
+    SA_HIP(launch_zero_halo(p0, bf16_, n, T0, CL, HALO, st));
+    for (int i = 0; i < 5; ++i) {
+      SA_HIP(launch_zero_halo(sb[i].act, bf16_, n, sb[i].T, sb[i].C, HALO, st));
+      SA_HIP(launch_zero_halo(sb[i].tmp, bf16_, n, sb[i].T, sb[i].C, HALO, st));
+    }
+    SA_HIP(launch_to_act(latent + (long)i0 * T0 * CD, (long)T0 * CD, CD, 0, lat, 0, bf16_, n, T0, CD, CD, HALO, st));
+    {
+      GemmParams p = conv_same(lat, T0, CD, 1, 1, dec_.proj_w, CD, CL, n);  // quantizer.out_proj
+      p.bias = dec_.proj_b;
+      halo_out(p, nullptr, p0, T0, CL, ACT_NONE, nullptr);
+      SA_TRY(gemm(p, st));
+      p = conv_same(p0, T0, CL, 7, 1, dec_.in_w, 7 * CL, decC[0], n);
+      p.bias = dec_.in_b;
+      halo_out(p, nullptr, sb[0].act, T0, decC[0], ACT_SNAKE, dec_.s[0].a);
+      SA_TRY(gemm(p, st));
+    }
+    for (int i = 0; i < 4; ++i) {
+      const StageW& sw = dec_.s[i];
+      const long Tin = sb[i].T, Tout = sb[i + 1].T;
+      const int Cin = sb[i].C, C = sb[i + 1].C, s = cfg_.dec_rates[i];
+      const int pad = (s + 1) / 2;
+      {  // ConvTranspose1d(k=2s, stride s, pad s/2): out rows q*s + r - pad = x[q-1] W[r+s] + x[q] W[r]
+        GemmParams p = lin(sb[i].act, Cin, sw.w, Tin + 1, s * C, 2 * Cin);
+        p.a_off = (long)(HALO - 1) * Cin; p.a_bstride = (Tin + 2L * HALO) * Cin; p.nbatch = n;
+        p.bias = sw.b; p.chan_mod = C;
+        halo_out(p, sb[i + 1].raw, sb[i + 1].act, Tout, C, ACT_SNAKE, sw.r[0].a1);
+        p.f32_ld = p.act_ld = (long)s * C;
+        p.f32_off = p.act_off = (long)(HALO - pad) * C;
+        p.c_ld_rel = (long)s * C; p.c_lo = (long)pad * C; p.c_hi = (Tout + pad) * (long)C;
+        SA_TRY(gemm(p, st));
+      }
+      const int dil[3] = {1, 3, 9};
+      for (int j = 0; j < 3; ++j) {
+        const ResUnitW& r = sw.r[j];
+        GemmParams p = conv_same(sb[i + 1].act, Tout, C, 7, dil[j], r.w1, r.k1pad, C, n);
+        p.bias = r.b1;
+        halo_out(p, nullptr, sb[i + 1].tmp, Tout, C, ACT_SNAKE, r.a2);
+        SA_TRY(gemm(p, st));
+        p = conv_same(sb[i + 1].tmp, Tout, C, 1, 1, r.w2, r.k2pad, C, n);
+        p.bias = r.b2;
+        p.res = sb[i + 1].raw; p.res_bstride = (Tout + 2L * HALO) * C; p.res_ld = C; p.res_off = (long)HALO * C;
+        const float* next_alpha = j < 2 ? sw.r[j + 1].a1 : (i < 3 ? dec_.s[i + 1].a : dec_.out_a);
+        halo_out(p, sb[i + 1].raw, sb[i + 1].act, Tout, C, ACT_SNAKE, next_alpha);
+        SA_TRY(gemm(p, st));
+      }
+    }
+    {  // conv k7 (C -> 1) + tanh
+      const long T = sb[4].T;
+      const int C = sb[4].C;
+      GemmParams p = conv_same(sb[4].act, T, C, 7, 1, dec_.out_w, dec_.out_kpad, 1, n);
+      p.bias = dec_.out_b;
+      p.act = ACT_TANH; p.f32_act = 1;
+      p.out_f32 = wav + (long)i0 * T; p.f32_bstride = T; p.f32_ld = 1; p.f32_off = 0;
+      SA_TRY(gemm(p, st));
+    }
+  }
+  return Status{};
+}
+
+}  // namespace sa

@@ -1,0 +1,235 @@
+// Generalised GEMM / implicit 1-D convolution on the CDNA4 matrix cores (gfx950).
+//
+// One kernel serves every dense contraction on the separate() path: the DiT linears
+// (reference transformer.py:102-114,186-189,426-428,462-467), the patcher k3 convolutions
+// (patcher.py:48-67), proj / memory_proj / align conv1x1 / anchor proj (model.py:90-95, align.py:17-19)
+// and every DAC-VAE Conv1d / ConvTranspose1d (codec.py:65-70,86-89) - see GemmParams in common.h
+// for how convolutions are expressed as overlapping-row GEMMs over channels-last, halo-padded
+// activations.
+//
+// Structure (per workgroup, 256 threads = 4 waves of 64):
+//   * BM x BN output tile, K consumed in 128-byte slabs per row (64 bf16 / 32 f32).
+//   * both operands are K-contiguous ("NT"), staged HBM -> LDS with direct-to-LDS loads
+//     (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip), double-buffered:
+//     slab k+1 streams in while slab k feeds the MFMAs; one barrier per slab.
+//   * LDS image = rows of 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 so that the
+//     16 lanes serviced together by ds_read_b128 hit 16 distinct 16-B slots (conflict-free).  As the
+//     DMA writes lane-linear, the swizzle is applied to the per-lane SOURCE address and to the read.
+//   * bf16: v_mfma_f32_16x16x32_bf16 (8 k per lane per chunk); f32: 4 x v_mfma_f32_16x16x4_f32 per
+//     chunk (exact fp32, k-ordered fma chain) - identical staging, identical fragment addressing.
+//   * accumulation order depends only on k => results are bitwise independent of M / batch sharding.
+#include "common.h"
+
+namespace sa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  typedef bf16x8_t frag_t;
+  static __device__ __forceinline__ f32x4_t run(const frag_t& a, const frag_t& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  typedef f32x4_t frag_t;
+  static __device__ __forceinline__ f32x4_t run(const frag_t& a, const frag_t& b, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    return c;
+  }
+};
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+  // lane i's 16 bytes land at lds_wave_base + 16*i  (wave-uniform base, lane-linear destination)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM_, int WN_>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int NW = WM_ * WN_;
+  static_assert(NW == 4, "4 waves per workgroup");
+  constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
+  constexpr int BK = 128 / (int)sizeof(T);  // elements per 128-byte row slab
+  constexpr int WTM = BM / WM_, WTN = BN / WN_;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave per slab
+  static_assert(BM % 32 == 0 && BN % 32 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
+  constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_, wn = wave % WN_;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int id = blockIdx.x;
+  const int tn = id % tiles_n;
+  id /= tiles_n;
+  const int tm = id % tiles_m;
+  const int b = id / tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane DMA source bookkeeping ---------------------------------------------------------
+  // wave-instruction j (j = wave + 4*i) fills tile rows 8j..8j+7; lane -> (row = 8j + lane/8,
+  // 16-byte slot = lane%8); slot s of row r holds source chunk  s ^ ((r>>1)&7).
+  const int r8 = lane >> 3;
+  const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
+  const T* a_rows[AI];
+  const T* w_rows[BI];
+  {
+    const T* A = (const T*)p.A + p.a_off + (long)b * p.a_bstride;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int m = m0 + (wave + 4 * i) * 8 + r8;
+      m = m < p.M ? m : p.M - 1;
+      a_rows[i] = A + (long)m * p.lda;
+    }
+    const T* W = (const T*)p.W;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int n = n0 + (wave + 4 * i) * 8 + r8;
+      n = n < p.N ? n : p.N - 1;
+      w_rows[i] = W + (long)n * p.K + chunk * CH;
+    }
+  }
+  // running position of this lane's chunk inside the (tap, offset) structure of A's k axis
+  int a_in = chunk * CH;   // offset inside the current tap segment
+  long a_tap = 0;          // element offset of the current tap
+  while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
+
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + TILE_A;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) dma16(a_rows[i] + a_tap + a_in, sA + (wave + 4 * i) * 1024);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (wave + 4 * i) * 1024);
+    // advance to the next slab
+    a_in += BK;
+    while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) w_rows[i] += BK;
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nslab = p.K / BK;
+  const int lr = lane & 15, lg = lane >> 4;
+  issue(0);
+  for (int s = 0; s < nslab; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // slab s landed for every wave; everyone is done reading the other stage
+    if (s + 1 < nslab) issue((s + 1) & 1);
+    const char* sA = smem + (s & 1) * STAGE;
+    const char* sB = sA + TILE_A;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      typename Mma<T>::frag_t af[FM], bfr[FN];
+      const int c = ks * 4 + lg;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + lr;
+        af[i] = *(const typename Mma<T>::frag_t*)(sA + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WTN + j * 16 + lr;
+        bfr[j] = *(const typename Mma<T>::frag_t*)(sB + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  const long bM = (long)b * p.M;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * WTM + i * 16 + lg * 4 + r;
+      if (m >= p.M) continue;
+      const float* grow = nullptr;
+      if (p.gate) grow = p.gate + ((bM + m) / p.rows_per_gate) * p.gate_ld;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        int n = n0 + wn * WTN + j * 16 + lr;
+        float v = acc[i][j][r];
+        if (p.swiglu) {
+          if (j & 1) continue;
+          if (n >= p.N) continue;
+          const float g = acc[i][j | 1][r];  // matching w3 column (weights interleaved in 16-row blocks)
+          v = silu_f(v) * g;
+          n = ((n0 + wn * WTN) >> 1) + (j >> 1) * 16 + lr;
+        } else {
+          if (n >= p.N) continue;
+        }
+        const int ch = p.chan_mod ? n % p.chan_mod : n;
+        if (p.bias) v += p.bias[ch];
+        if (grow) v *= (p.gate_tab ? p.gate_tab[n] : 0.f) + grow[n];
+        v *= p.alpha;
+        const long erel = (long)m * p.c_ld_rel + n;
+        if (p.c_ld_rel && (erel < p.c_lo || erel >= p.c_hi)) continue;
+        if (p.res) v += p.res[p.res_off + (long)b * p.res_bstride + (long)m * p.res_ld + n];
+        float a = v;
+        if (p.act == ACT_SNAKE) a = snake_f(v, p.act_alpha[ch]);
+        else if (p.act == ACT_TANH) a = tanhf(v);
+        else if (p.act == ACT_SILU) a = silu_f(v);
+        if (p.out_f32)
+          p.out_f32[p.f32_off + (long)b * p.f32_bstride + (long)m * p.f32_ld + n] = p.f32_act ? a : v;
+        if (p.out_act)
+          Elem<T>::store((T*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)m * p.act_ld + n, a);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM_, int WN_>
+static hipError_t launch_cfg(const GemmParams& p, hipStream_t st) {
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM_, WN_>), dim3((unsigned)tiles), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_t(const GemmParams& p, hipStream_t st) {
+  // narrow outputs (codec stages with 1 / 64 / 96 / 192 channels) use narrower N tiles
+  const int N = p.N;
+  if (p.swiglu) return launch_cfg<T, 128, 128, 2, 2>(p, st);
+  if (N <= 32 || N == 96) return launch_cfg<T, 128, 32, 4, 1>(p, st);
+  if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N <= 448)) return launch_cfg<T, 128, 64, 2, 2>(p, st);
+  return launch_cfg<T, 128, 128, 2, 2>(p, st);
+}
+
+// host entry used by the engine and by the C-ABI test hook; is_bf16 selects the element type
+hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st) {
+  return is_bf16 ? launch_t<bf16_t>(p, st) : launch_t<float>(p, st);
+}
+
+const char* gemm_check(const GemmParams& p, bool is_bf16) {
+  const int bk = is_bf16 ? 64 : 32, ch = is_bf16 ? 8 : 4;
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.nbatch <= 0) return "gemm: empty problem";
+  if (p.K % bk) return "gemm: K must be a multiple of 64 (bf16) / 32 (f32) - pad W with zeros";
+  if (p.kc % ch || p.kc <= 0) return "gemm: kc must be a positive multiple of the 16-byte chunk";
+  if ((p.lda % ch) || (p.tap_stride % ch) || (p.a_off % ch) || (p.a_bstride % ch))
+    return "gemm: A strides/offsets must be 16-byte aligned";
+  if (p.swiglu && (p.N % 32)) return "gemm: swiglu needs N % 32 == 0";
+  if (p.gate && p.rows_per_gate <= 0) return "gemm: rows_per_gate";
+  return nullptr;
+}
+
+}  // namespace sa

@@ -1,0 +1,64 @@
+// Launchers of the non-GEMM kernels (kernels.hip, attention.hip).  `bf16` selects the activation
+// element type AT: bf16_t (bf16 compute mode) or float (fp32 parity mode).
+#pragma once
+#include "common.h"
+
+namespace sa {
+
+hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
+const char* gemm_check(const GemmParams& p, bool is_bf16);
+
+// out[m,:] = AT( rmsnorm(x[m,:]) * w * (1 + scale) + shift ),  shift = shift_tab + tvec[b, shift_off:],
+// scale likewise; b = m / rows_per_b; tvec_ld = 0 shares one conditioning row.  tvec == nullptr: no modulation.
+hipError_t launch_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
+                              const float* tvec, long tvec_ld, int shift_off, int scale_off, void* out, bool bf16,
+                              int M, int D, int rows_per_b, float eps, hipStream_t st);
+
+// acc[m,:] += tanh(gate[0]) * (layernorm(x[m,:]) * w + b)
+hipError_t launch_layernorm_accum(const float* x, const float* w, const float* b, const float* gate, float* acc,
+                                  int M, int D, float eps, hipStream_t st);
+
+// GroupNorm(1 group) over (T x C) per sample: partial sums, then normalise+affine+SiLU into a halo-padded
+// channels-last buffer out[b][halo + t][c].
+hipError_t launch_groupnorm_silu(const float* x, const float* w, const float* b, double* partials, void* out,
+                                 bool bf16, int B, int T, int C, int halo, float eps, hipStream_t st);
+
+// q/k: per-head RMSNorm (shared weight) + RoPE (adjacent pairs) -> Q,K [B,H,Tp,128]; v -> Vt [B,H,128,Tp]
+hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
+                           const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
+                           float eps, hipStream_t st);
+
+// self-attention over the padded layout above; key_mask [B,T] bytes (1 = attend); out [B*T, H*128]
+hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
+                                 void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st);
+
+// in-place per-(row, head) RMSNorm of x[rows, ld] columns [col0, col0 + H*128)
+hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
+                           hipStream_t st);
+
+// cross attention: q [M, D] (raw, q-norm applied here), kv [B*Lt, 2D] (k already normalised | v),
+// mask [B, Lt] bytes; out [M, D]
+hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, const unsigned char* mask,
+                                  void* out, bool bf16, int B, int T, int Lt, int H, float eps, hipStream_t st);
+
+// timestep features: temb [nt, fdim] (AT) = cat(cos, sin)(t*freqs);  tsin [nt, D] fp32 likewise with inv_freq
+hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,
+                                void* temb, float* tsin, bool bf16, hipStream_t st);
+
+// out[r,:] = AT(x[r,:] + vec[(r / rows_per_b) * vec_ld + :])
+hipError_t launch_add_rowvec(const float* x, const float* vec, long vec_ld, void* out, bool bf16, int rows, int D,
+                             int rows_per_b, hipStream_t st);
+
+// out[r,:] = AT(emb[ids[b, align[b,t]], :])   (model.py:61: embed(anchor_ids.gather(1, anchor_alignment)))
+hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, const long* align, void* out, bool bf16,
+                                int B, int T, int E, hipStream_t st);
+
+// generic fp32 -> AT copy with optional halo layout: out[b][halo + t][c_out_pad] <- in[b][t][c_in] (extra channels 0)
+// out_bstride in elements (0 = dense (T + 2*halo) * C_out)
+hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_col0, void* out, long out_bstride,
+                         bool bf16, int B, long T, int C_in, int C_out, int halo, hipStream_t st);
+
+// zero the halo rows of a [B][halo + T + halo][C] buffer
+hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t st);
+
+}  // namespace sa

@@ -1,0 +1,423 @@
+// Bandwidth-bound kernels of the separate() path: norms, modulation, RoPE, layout changes.
+// All of them are one-pass (or read-twice-from-L2) streaming kernels with 16-byte accesses where
+// the layout allows; reductions are wave-shuffle based (64-lane wavefronts).
+#include "kernels.h"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm (+ adaLN modulate).  Reference transformer.py:36-47 (fp32 inside, eps in the rsqrt),
+// :21-22 modulate = x*(1+scale)+shift, :360-372 / :507-518 where shift/scale = table + t-vector.
+// One wave per row, 4 rows per workgroup.
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ shift_tab,
+                                                          const float* __restrict__ scale_tab,
+                                                          const float* __restrict__ tvec, long tvec_ld, int shift_off,
+                                                          int scale_off, TO* __restrict__ out, int M, int D,
+                                                          int rows_per_b, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + (long)row * D);
+  const int n4 = D >> 2;
+  float ss = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss / (float)D + eps);
+  const float* trow = tvec ? tvec + (long)(row / rows_per_b) * tvec_ld : nullptr;
+  TO* orow = out + (long)row * D;
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i];
+    float4 g = ((const float4*)w)[i];
+    float o0 = v.x * inv * g.x, o1 = v.y * inv * g.y, o2 = v.z * inv * g.z, o3 = v.w * inv * g.w;
+    if (trow) {
+      float4 st = ((const float4*)shift_tab)[i], ct = ((const float4*)scale_tab)[i];
+      float4 sv = *(const float4*)(trow + shift_off + 4 * i), cv = *(const float4*)(trow + scale_off + 4 * i);
+      o0 = o0 * (1.f + (ct.x + cv.x)) + (st.x + sv.x);
+      o1 = o1 * (1.f + (ct.y + cv.y)) + (st.y + sv.y);
+      o2 = o2 * (1.f + (ct.z + cv.z)) + (st.z + sv.z);
+      o3 = o3 * (1.f + (ct.w + cv.w)) + (st.w + sv.w);
+    }
+    store4<TO>(orow + 4 * i, o0, o1, o2, o3);
+  }
+}
+
+hipError_t launch_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
+                              const float* tvec, long tvec_ld, int shift_off, int scale_off, void* out, bool bf16,
+                              int M, int D, int rows_per_b, float eps, hipStream_t st) {
+  dim3 grid((M + 3) / 4), block(256);
+  if (bf16)
+    hipLaunchKernelGGL(rmsnorm_mod_kernel<bf16_t>, grid, block, 0, st, x, w, shift_tab, scale_tab, tvec, tvec_ld,
+                       shift_off, scale_off, (bf16_t*)out, M, D, rows_per_b, eps);
+  else
+    hipLaunchKernelGGL(rmsnorm_mod_kernel<float>, grid, block, 0, st, x, w, shift_tab, scale_tab, tvec, tvec_ld,
+                       shift_off, scale_off, (float*)out, M, D, rows_per_b, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// acc += tanh(gate) * LayerNorm(x)   (reference align.py:41-50; eps = torch default 1e-5)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_accum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, const float* __restrict__ gate,
+                                                              float* __restrict__ acc, int M, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + (long)row * D);
+  const int n4 = D >> 2;
+  float s = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i];
+    float a = v.x - mean, c = v.y - mean, d = v.z - mean, e = v.w - mean;
+    q += a * a + c * c + d * d + e * e;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float g = tanhf(gate[0]);
+  float4* ar = (float4*)(acc + (long)row * D);
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i], ww = ((const float4*)w)[i], bb = ((const float4*)b)[i], a = ar[i];
+    a.x += g * ((v.x - mean) * rstd * ww.x + bb.x);
+    a.y += g * ((v.y - mean) * rstd * ww.y + bb.y);
+    a.z += g * ((v.z - mean) * rstd * ww.z + bb.z);
+    a.w += g * ((v.w - mean) * rstd * ww.w + bb.w);
+    ar[i] = a;
+  }
+}
+
+hipError_t launch_layernorm_accum(const float* x, const float* w, const float* b, const float* gate, float* acc,
+                                  int M, int D, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_accum_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, w, b, gate, acc, M, D, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(num_groups=1) + SiLU, channels-last (reference patcher.py:83-101 with num_groups=1,
+// :155-159; statistics over C x T per sample, padded frames included - quirk Q5).
+// Pass 1: GN_CHUNKS partial (sum, sumsq) per sample in fp64, fixed order (deterministic);
+// pass 2: every workgroup folds the partials (same order everywhere) and streams its rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ partials,
+                                                         long per_sample) {
+  const int b = blockIdx.y, c = blockIdx.x;
+  const long n4 = per_sample >> 2;
+  const long per_chunk = (n4 + GN_CHUNKS - 1) / GN_CHUNKS;
+  const long lo = c * per_chunk, hi = (lo + per_chunk < n4) ? lo + per_chunk : n4;
+  const float4* xs = (const float4*)(x + (long)b * per_sample);
+  double s = 0.0, q = 0.0;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    float4 v = xs[i];
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partials[((long)b * GN_CHUNKS + c) * 2 + 0] = sh[0][0];
+    partials[((long)b * GN_CHUNKS + c) * 2 + 1] = sh[1][0];
+  }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       const double* __restrict__ partials, TO* __restrict__ out,
+                                                       int T, int C, int halo, float eps) {
+  const int b = blockIdx.y;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < GN_CHUNKS; ++c) {
+    s += partials[((long)b * GN_CHUNKS + c) * 2 + 0];
+    q += partials[((long)b * GN_CHUNKS + c) * 2 + 1];
+  }
+  const double n = (double)T * (double)C;
+  const double mean_d = s / n;
+  double var_d = q / n - mean_d * mean_d;
+  if (var_d < 0.0) var_d = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  const int n4 = C >> 2;
+  const long total4 = (long)T * n4;
+  const float4* xs = (const float4*)(x + (long)b * T * C);
+  TO* ob = out + ((long)b * (T + 2 * halo) + halo) * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % n4);
+    float4 v = xs[i], ww = ((const float4*)w)[c4], bb = ((const float4*)bias)[c4];
+    store4<TO>(ob + 4 * i, silu_f((v.x - mean) * rstd * ww.x + bb.x), silu_f((v.y - mean) * rstd * ww.y + bb.y),
+               silu_f((v.z - mean) * rstd * ww.z + bb.z), silu_f((v.w - mean) * rstd * ww.w + bb.w));
+  }
+}
+
+hipError_t launch_groupnorm_silu(const float* x, const float* w, const float* b, double* partials, void* out,
+                                 bool bf16, int B, int T, int C, int halo, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_CHUNKS, B), dim3(256), 0, st, x, partials, (long)T * C);
+  long total4 = (long)T * (C / 4);
+  int gx = (int)((total4 + 255) / 256);
+  if (gx > 512) gx = 512;
+  if (bf16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, st, x, w, b, partials, (bf16_t*)out, T, C,
+                       halo, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(gx, B), dim3(256), 0, st, x, w, b, partials, (float*)out, T, C,
+                       halo, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// QKV post-processing (reference transformer.py:139-151 + rope.py:145-155):
+//   q,k: per-head RMSNorm over 128 (weight shared by all heads) then RoPE on adjacent pairs (2i,2i+1),
+//        written as [B,H,Tp,128] (rows t >= T are zero);
+//   v  : transposed to [B,H,128,Tp] so that P@V is a K-contiguous ("NT") MFMA contraction.
+// The QKV GEMM already produces head-major columns (weights permuted at load, quirk Q1).
+// grid (Tp/64, H, B), 256 threads.
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void qkv_prep_kernel(const TA* __restrict__ qkv, const float* __restrict__ qw,
+                                                       const float* __restrict__ kw, const float* __restrict__ rc,
+                                                       const float* __restrict__ rs, TA* __restrict__ Q,
+                                                       TA* __restrict__ K, TA* __restrict__ Vt, int T, int Tp, int H,
+                                                       float eps) {
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * 128;
+  const long ld = 3L * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long bh = (long)b * H + h;
+  const float w0q = qw[2 * lane], w1q = qw[2 * lane + 1], w0k = kw[2 * lane], w1k = kw[2 * lane + 1];
+  for (int i = 0; i < 16; ++i) {
+    const int t = t0 + wave * 16 + i;
+    float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f;
+    if (t < T) {
+      const TA* row = qkv + ((long)b * T + t) * ld + h * 128 + 2 * lane;
+      load2<TA>(row, q0, q1);
+      load2<TA>(row + D, k0, k1);
+      const float iq = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / 128.f + eps);
+      const float ik = rsqrtf(wave_sum(k0 * k0 + k1 * k1) / 128.f + eps);
+      q0 *= iq * w0q; q1 *= iq * w1q; k0 *= ik * w0k; k1 *= ik * w1k;
+      const float c = rc[(long)t * 64 + lane], s = rs[(long)t * 64 + lane];
+      const float a0 = q0 * c - q1 * s, a1 = q0 * s + q1 * c;
+      const float b0 = k0 * c - k1 * s, b1 = k0 * s + k1 * c;
+      q0 = a0; q1 = a1; k0 = b0; k1 = b1;
+    }
+    store2<TA>(Q + (bh * Tp + t) * 128 + 2 * lane, q0, q1);
+    store2<TA>(K + (bh * Tp + t) * 128 + 2 * lane, k0, k1);
+  }
+  __shared__ float tile[64][129];
+  for (int idx = threadIdx.x; idx < 64 * 128; idx += 256) {
+    const int tt = idx >> 7, d = idx & 127;
+    const int t = t0 + tt;
+    tile[tt][d] = t < T ? Elem<TA>::load(qkv + ((long)b * T + t) * ld + 2L * D + h * 128 + d) : 0.f;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * 128; idx += 256) {
+    const int d = idx >> 6, tt = idx & 63;
+    Elem<TA>::store(Vt + (bh * 128 + d) * Tp + t0 + tt, tile[tt][d]);
+  }
+}
+
+hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
+                           const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
+                           float eps, hipStream_t st) {
+  dim3 grid(Tp / 64, H, B), block(256);
+  if (bf16)
+    hipLaunchKernelGGL(qkv_prep_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin,
+                       (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
+  else
+    hipLaunchKernelGGL(qkv_prep_kernel<float>, grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin,
+                       (float*)Q, (float*)K, (float*)Vt, T, Tp, H, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// in-place per-(row, head) RMSNorm (cross-attention k_norm, transformer.py:143-144); wave per (row, head)
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void headnorm_kernel(TA* __restrict__ x, const float* __restrict__ w, long rows,
+                                                       long ld, int col0, int H, float eps) {
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * H) return;
+  const int lane = threadIdx.x & 63;
+  const long r = item / H;
+  const int h = (int)(item % H);
+  TA* p = x + r * ld + col0 + h * 128 + 2 * lane;
+  float a, c;
+  load2<TA>(p, a, c);
+  const float inv = rsqrtf(wave_sum(a * a + c * c) / 128.f + eps);
+  store2<TA>(p, a * inv * w[2 * lane], c * inv * w[2 * lane + 1]);
+}
+
+hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
+                           hipStream_t st) {
+  const long items = (long)rows * H;
+  dim3 grid((unsigned)((items + 3) / 4)), block(256);
+  if (bf16)
+    hipLaunchKernelGGL(headnorm_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)x, w, (long)rows, ld, col0, H, eps);
+  else
+    hipLaunchKernelGGL(headnorm_kernel<float>, grid, block, 0, st, (float*)x, w, (long)rows, ld, col0, H, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// timestep features (reference transformer.py:236-248 and model.py:35-42): cat(cos, sin)(t * freq)
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ void time_features_kernel(const float* __restrict__ t, const float* __restrict__ freqs, int fdim,
+                                     const float* __restrict__ inv_freq, int D, TA* __restrict__ temb,
+                                     float* __restrict__ tsin) {
+  const int j = blockIdx.x;
+  const float tv = t[j];
+  const int hf = fdim / 2, hd = D / 2;
+  for (int i = threadIdx.x; i < hf; i += blockDim.x) {
+    const float a = tv * freqs[i];
+    Elem<TA>::store(temb + (long)j * fdim + i, cosf(a));
+    Elem<TA>::store(temb + (long)j * fdim + hf + i, sinf(a));
+  }
+  for (int i = threadIdx.x; i < hd; i += blockDim.x) {
+    const float a = tv * inv_freq[i];
+    tsin[(long)j * D + i] = cosf(a);
+    tsin[(long)j * D + hd + i] = sinf(a);
+  }
+}
+
+hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,
+                                void* temb, float* tsin, bool bf16, hipStream_t st) {
+  if (bf16)
+    hipLaunchKernelGGL(time_features_kernel<bf16_t>, dim3(nt), dim3(256), 0, st, t, freqs, fdim, inv_freq, D,
+                       (bf16_t*)temb, tsin);
+  else
+    hipLaunchKernelGGL(time_features_kernel<float>, dim3(nt), dim3(256), 0, st, t, freqs, fdim, inv_freq, D,
+                       (float*)temb, tsin);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// memory = memory_proj(text) + timestep_emb   (reference model.py:170-172) -> AT operand
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const float* __restrict__ x, const float* __restrict__ vec,
+                                                         long vec_ld, TA* __restrict__ out, long rows, int D,
+                                                         int rows_per_b) {
+  const int n4 = D >> 2;
+  const long total = rows * n4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / n4;
+    const int c4 = (int)(i % n4);
+    float4 v = ((const float4*)x)[i];
+    float4 a = *(const float4*)(vec + (r / rows_per_b) * vec_ld + 4 * c4);
+    store4<TA>(out + 4 * i, v.x + a.x, v.y + a.y, v.z + a.z, v.w + a.w);
+  }
+}
+
+hipError_t launch_add_rowvec(const float* x, const float* vec, long vec_ld, void* out, bool bf16, int rows, int D,
+                             int rows_per_b, hipStream_t st) {
+  long total = (long)rows * (D / 4);
+  int gx = (int)((total + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (bf16)
+    hipLaunchKernelGGL(add_rowvec_kernel<bf16_t>, dim3(gx), dim3(256), 0, st, x, vec, vec_ld, (bf16_t*)out,
+                       (long)rows, D, rows_per_b);
+  else
+    hipLaunchKernelGGL(add_rowvec_kernel<float>, dim3(gx), dim3(256), 0, st, x, vec, vec_ld, (float*)out, (long)rows,
+                       D, rows_per_b);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// anchor embedding gather (reference model.py:61: embed(anchor_ids.gather(1, anchor_alignment)))
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ void anchor_gather_kernel(const float* __restrict__ emb, const long* __restrict__ ids, int n_ids,
+                                     const long* __restrict__ align, TA* __restrict__ out, int T, int E) {
+  const long r = blockIdx.x;  // row b*T + t
+  const long b = r / T;
+  const long slot = align[r];
+  const long tok = ids[b * n_ids + slot];
+  for (int i = threadIdx.x; i < E; i += blockDim.x) Elem<TA>::store(out + r * E + i, emb[tok * E + i]);
+}
+
+hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, const long* align, void* out, bool bf16,
+                                int B, int T, int E, hipStream_t st) {
+  if (bf16)
+    hipLaunchKernelGGL(anchor_gather_kernel<bf16_t>, dim3(B * T), dim3(64), 0, st, emb, ids, n_ids, align,
+                       (bf16_t*)out, T, E);
+  else
+    hipLaunchKernelGGL(anchor_gather_kernel<float>, dim3(B * T), dim3(64), 0, st, emb, ids, n_ids, align, (float*)out,
+                       T, E);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> AT copy into a (halo-padded, channel-padded) channels-last buffer
+// ------------------------------------------------------------------------------------------------
+template <typename TA>
+__global__ __launch_bounds__(256) void to_act_kernel(const float* __restrict__ in, long in_bstride, long in_ld,
+                                                     int in_col0, TA* __restrict__ out, long out_bstride, long T,
+                                                     int C_in, int C_out, int halo) {
+  const int b = blockIdx.y;
+  const long total = T * C_out;
+  const float* ib = in + (long)b * in_bstride + in_col0;
+  TA* ob = out + (long)b * out_bstride + (long)halo * C_out;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long t = i / C_out;
+    const int c = (int)(i % C_out);
+    Elem<TA>::store(ob + i, c < C_in ? ib[t * in_ld + c] : 0.f);
+  }
+}
+
+hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_col0, void* out, long out_bstride,
+                         bool bf16, int B, long T, int C_in, int C_out, int halo, hipStream_t st) {
+  if (out_bstride == 0) out_bstride = (T + 2L * halo) * C_out;
+  long total = T * C_out;
+  int gx = (int)((total + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  if (bf16)
+    hipLaunchKernelGGL(to_act_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, st, in, in_bstride, in_ld, in_col0,
+                       (bf16_t*)out, out_bstride, T, C_in, C_out, halo);
+  else
+    hipLaunchKernelGGL(to_act_kernel<float>, dim3(gx, B), dim3(256), 0, st, in, in_bstride, in_ld, in_col0,
+                       (float*)out, out_bstride, T, C_in, C_out, halo);
+  return hipGetLastError();
+}
+
+template <typename TA>
+__global__ void zero_halo_kernel(TA* __restrict__ buf, long T, int C, int halo) {
+  const int b = blockIdx.y;
+  TA* base = buf + (long)b * (T + 2L * halo) * C;
+  const long n = (long)halo * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    Elem<TA>::store(base + i, 0.f);
+    Elem<TA>::store(base + (T + halo) * C + i, 0.f);
+  }
+}
+
+hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t st) {
+  long n = (long)halo * C;
+  int gx = (int)((n + 255) / 256);
+  if (gx > 64) gx = 64;
+  if (bf16)
+    hipLaunchKernelGGL(zero_halo_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, st, (bf16_t*)buf, T, C, halo);
+  else
+    hipLaunchKernelGGL(zero_halo_kernel<float>, dim3(gx, B), dim3(256), 0, st, (float*)buf, T, C, halo);
+  return hipGetLastError();
+}
+
+}  // namespace sa

@@ -1,0 +1,131 @@
+"""ctypes binding of libsamaudio_hip.so (C ABI in include/samaudio.h).
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, importing the
+product path raises.  (The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsamaudio_hip.so")
+
+F32, BF16 = 0, 1
+DT_F32, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3
+ODE_EULER, ODE_MIDPOINT = 0, 1
+ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU = 0, 1, 2, 3
+
+ERR_ARG, ERR_WEIGHT, ERR_WORKSPACE, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5
+
+
+class SamAudioHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    """Mirror of `samaudio_config`."""
+    _fields_ = [
+        ("precision", C.c_int32), ("dim", C.c_int32), ("n_heads", C.c_int32), ("n_layers", C.c_int32),
+        ("ffn_hidden", C.c_int32), ("latent_channels", C.c_int32), ("text_dim", C.c_int32),
+        ("video_dim", C.c_int32), ("freq_dim", C.c_int32), ("anchor_dim", C.c_int32),
+        ("anchor_vocab", C.c_int32), ("max_positions", C.c_int32), ("norm_eps", C.c_float),
+        ("codec_dim", C.c_int32), ("codec_latent", C.c_int32), ("enc_dim", C.c_int32),
+        ("dec_dim", C.c_int32), ("enc_rates", C.c_int32 * 4), ("dec_rates", C.c_int32 * 4),
+    ]
+
+
+class GemmParams(C.Structure):
+    """Mirror of `sa::GemmParams` (sam_audio_amd/csrc/common.h) for the samaudio_op_gemm test hook."""
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p),
+        ("a_off", C.c_long), ("a_bstride", C.c_long), ("lda", C.c_long), ("tap_stride", C.c_long),
+        ("kc", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("nbatch", C.c_int),
+        ("bias", C.c_void_p), ("chan_mod", C.c_int), ("swiglu", C.c_int),
+        ("gate_tab", C.c_void_p), ("gate", C.c_void_p), ("gate_ld", C.c_long),
+        ("rows_per_gate", C.c_int), ("alpha", C.c_float),
+        ("res", C.c_void_p), ("res_bstride", C.c_long), ("res_ld", C.c_long), ("res_off", C.c_long),
+        ("out_f32", C.c_void_p), ("f32_bstride", C.c_long), ("f32_ld", C.c_long), ("f32_off", C.c_long),
+        ("out_act", C.c_void_p), ("act_bstride", C.c_long), ("act_ld", C.c_long), ("act_off", C.c_long),
+        ("act", C.c_int), ("f32_act", C.c_int), ("act_alpha", C.c_void_p),
+        ("c_lo", C.c_long), ("c_hi", C.c_long), ("c_ld_rel", C.c_long),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+_PROTOS = {
+    "samaudio_last_error": (C.c_char_p, []),
+    "samaudio_version": (C.c_char_p, []),
+    "samaudio_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "samaudio_destroy": (None, [C.c_void_p]),
+    "samaudio_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "samaudio_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "samaudio_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "samaudio_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "samaudio_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "samaudio_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "samaudio_ode_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
+    "samaudio_codec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "samaudio_codec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "samaudio_op_gemm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "samaudio_op_rmsnorm_mod": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                             C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "samaudio_op_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "samaudio_op_qkv_prep": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "samaudio_op_self_attention": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "samaudio_op_cross_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "samaudio_op_layernorm_accum": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SamAudioHipError(
+                f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or sam_audio_amd/csrc/build.sh.  There is no CPU fallback for the separate() hot path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    """Map C status codes to the exception types the reference raises at the same boundary
+    (SURVEY.md §8b 'Errors')."""
+    if code == 0:
+        return
+    msg = lib().samaudio_last_error().decode()
+    if code == ERR_ARG:
+        raise AssertionError(msg)
+    if code == ERR_WEIGHT:
+        raise RuntimeError(msg)
+    raise SamAudioHipError(f"[{code}] {msg}")
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "tensor handed to the HIP library must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def shape_array(shape: Sequence[int]):
+    return (C.c_int64 * len(shape))(*[int(s) for s in shape])

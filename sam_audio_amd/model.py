@@ -1,0 +1,333 @@
+"""`SAMAudio` - drop-in host class for the reference's SAMAudio.separate() path
+(reference sam_audio/model/model.py:75-359), backed by libsamaudio_hip.so.
+
+PyTorch-ROCm is used for device memory, streams, RNG and weight plumbing only; every arithmetic step
+of separate() - DAC-VAE encode, the 32 DiT evaluations of the midpoint ODE, DAC-VAE decode - runs in
+hand-written HIP kernels behind the C ABI of include/samaudio.h.  No eager/CPU fallback exists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+import warnings
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+
+from . import hip
+from .config import SAMAudioConfig
+from .processor import Batch
+from .weights import convert_codec, convert_dit, split_missing_unexpected
+
+DFLT_ODE_OPT = {"method": "midpoint", "options": {"step_size": 2 / 32}}  # reference model.py:22
+
+
+@dataclass
+class SeparationResult:  # reference model.py:68-72
+    target: List[torch.Tensor]
+    residual: List[torch.Tensor]
+    noise: torch.Tensor
+
+
+def ode_grid(ode_opt: Dict[str, Any], t0: float = 0.0, t1: float = 1.0):
+    """(method id, grid) for the fixed-grid solvers torchdiffeq would run for `ode_opt`
+    (reference model.py:285-290; quirk Q11).  Anything but midpoint/euler + step_size is rejected."""
+    method = ode_opt.get("method", "midpoint")
+    if method not in ("midpoint", "euler"):
+        raise ValueError(f"ode method {method!r} is not supported by the HIP path (midpoint | euler)")
+    options = dict(ode_opt.get("options", {}))
+    step = options.pop("step_size", None)
+    if step is None or options:
+        raise ValueError("ode_opt['options'] must be exactly {'step_size': float}")
+    n = int(math.ceil((t1 - t0) / step + 1))
+    grid = [min(t0 + k * step, t1) for k in range(n)]
+    grid[-1] = t1
+    return (hip.ODE_MIDPOINT if method == "midpoint" else hip.ODE_EULER), grid
+
+
+class SAMAudio:
+    config_cls = SAMAudioConfig
+
+    def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
+                 text_encoder: Optional[Callable] = None):
+        cfg.check_supported()
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.cfg = cfg
+        self.precision = precision
+        self.device = torch.device(device) if device is not None else None
+        self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])
+        self.visual_ranker = None             # rerankers are 'next' rows
+        self.text_ranker = None
+        self.fix_span_order = False           # quirk Q13: kept for API compatibility, see separate()
+        self._lib = hip.lib()                 # raises if the HIP library is not built
+        self._ctx = C.c_void_p()
+        self._tensors: Dict[str, torch.Tensor] = {}
+        self._workspace: Optional[torch.Tensor] = None
+        self._has_dit = self._has_codec = False
+        t, c = cfg.transformer, cfg.audio_codec
+        hc = hip.Config(
+            precision=hip.BF16 if precision == "bf16" else hip.F32, dim=t.dim, n_heads=t.n_heads,
+            n_layers=t.n_layers, ffn_hidden=t.ffn_hidden, latent_channels=t.out_channels,
+            text_dim=cfg.text_encoder.dim, video_dim=cfg.vision_encoder.dim, freq_dim=t.frequency_embedding_dim,
+            anchor_dim=cfg.anchor_embedding_dim, anchor_vocab=cfg.num_anchors + 1, max_positions=t.max_positions,
+            norm_eps=t.norm_eps, codec_dim=c.codebook_dim, codec_latent=c.latent_dim, enc_dim=c.encoder_dim,
+            dec_dim=c.decoder_dim, enc_rates=(C.c_int32 * 4)(*c.encoder_rates),
+            dec_rates=(C.c_int32 * 4)(*c.decoder_rates))
+        hip.check(self._lib.samaudio_create(C.byref(hc), C.byref(self._ctx)))
+
+    def __del__(self):
+        ctx = getattr(self, "_ctx", None)
+        if ctx:
+            self._lib.samaudio_destroy(ctx)
+            self._ctx = None
+
+    # ------------------------------------------------------------------ nn.Module-ish surface
+    @property
+    def act_dtype(self) -> torch.dtype:
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    @property
+    def sample_rate(self) -> int:  # reference model.py:104-106
+        return self.cfg.audio_codec.sample_rate
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if self._tensors and self.device != device:
+            raise RuntimeError("move the model before load_state_dict (weights are converted onto the device)")
+        self.device = device
+        return self
+
+    def cuda(self, index: int = 0):
+        return self.to(f"cuda:{index}")
+
+    @classmethod
+    def from_pretrained(cls, model_id: str, map_location: str = "cpu", strict: bool = True,
+                        precision: str = "bf16", device: Optional[str] = None, **model_kwargs):
+        """Local directory with the reference's `config.json` + `checkpoint.pt`
+        (reference base.py:17-62; hub download needs network access this build does not have)."""
+        if not os.path.isdir(model_id):
+            raise FileNotFoundError(f"{model_id}: only local checkpoint directories are supported offline")
+        with open(os.path.join(model_id, "config.json")) as fin:
+            config = json.load(fin)
+        for key, value in model_kwargs.items():
+            if key in config:
+                config[key] = value
+        model = cls(SAMAudioConfig(**config), precision=precision, device=device)
+        sd = torch.load(os.path.join(model_id, "checkpoint.pt"), weights_only=True, map_location=map_location)
+        model.load_state_dict(sd, strict=strict)
+        return model
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
+        """Reference key names in, engine tensors out (see weights.py).  Missing text-encoder / ranker /
+        span-predictor keys are tolerated exactly like reference model.py:346-359."""
+        if self.device is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise hip.SamAudioHipError("SAMAudio needs a ROCm GPU: the separate() hot path has no CPU fallback")
+        missing, unexpected = split_missing_unexpected(state_dict.keys(), self.cfg)
+        codec_missing = [k for k in missing if k.startswith("audio_codec.")]
+        dit_missing = [k for k in missing if not k.startswith("audio_codec.")]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Missing keys: {missing}, unexpected_keys: {unexpected}")
+        with torch.cuda.device(self.device):
+            if not dit_missing:
+                self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device))
+                hip.check(self._lib.samaudio_finalize(self._ctx, 0))
+                self._has_dit = True
+            if not codec_missing:
+                self._register(convert_codec(state_dict, self.cfg, self.act_dtype, self.device))
+                hip.check(self._lib.samaudio_finalize(self._ctx, 1))
+                self._has_codec = True
+        return missing, unexpected
+
+    def _register(self, tensors: Dict[str, torch.Tensor]) -> None:
+        for name, t in tensors.items():
+            dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+            self._tensors[name] = t  # keep alive: the library borrows the pointer
+            hip.check(self._lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
+                                                    hip.shape_array(t.shape)))
+
+    def engine_tensors(self) -> Dict[str, torch.Tensor]:
+        return self._tensors
+
+    # ------------------------------------------------------------------ workspace
+    def _ensure_workspace(self, rows: int, frames: int, text_len: int, codec_items: int, samples: int) -> None:
+        need = self._lib.samaudio_workspace_bytes(self._ctx, rows, frames, max(1, text_len), codec_items, samples)
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = self._workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        hip.check(self._lib.samaudio_set_workspace(self._ctx, C.c_void_p(aligned),
+                                                   self._workspace.numel() - (aligned - base)))
+
+    def _codec_chunk(self, items: int) -> int:
+        return min(items, int(os.environ.get("SAMAUDIO_CODEC_CHUNK", "16")))
+
+    # ------------------------------------------------------------------ codec (reference codec.py)
+    def _pad_to_hop(self, wavs: torch.Tensor) -> torch.Tensor:
+        hop = self.cfg.audio_codec.hop_length
+        rem = wavs.size(-1) % hop
+        return wavs if rem == 0 else torch.nn.functional.pad(wavs, (0, hop - rem), mode="reflect")
+
+    def encode_audio(self, audios: torch.Tensor) -> torch.Tensor:
+        """audios [B,1,Tw] -> mean latent, channels-last [B, T, codebook_dim] (reference codec.py:65-78;
+        the reference returns [B, C, T] and transposes at model.py:183)."""
+        if not self._has_codec:
+            raise RuntimeError("audio_codec weights are not loaded")
+        wav = self._pad_to_hop(audios.to(self.device, torch.float32)).squeeze(1).contiguous()
+        items, samples = wav.shape
+        frames = samples // self.cfg.audio_codec.hop_length
+        z = torch.empty(items, frames, self.cfg.audio_codec.codebook_dim, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples)
+            hip.check(self._lib.samaudio_codec_encode(self._ctx, hip.ptr(wav), items, samples, hip.ptr(z),
+                                                      hip.current_stream_ptr()))
+        return z
+
+    def decode_audio(self, latents: torch.Tensor) -> torch.Tensor:
+        """latents channels-last [N, T, codebook_dim] -> [N, T*hop] (reference codec.py:86-89)."""
+        if not self._has_codec:
+            raise RuntimeError("audio_codec weights are not loaded")
+        lat = latents.to(self.device, torch.float32).contiguous()
+        items, frames, _ = lat.shape
+        samples = frames * self.cfg.audio_codec.hop_length
+        wav = torch.empty(items, samples, device=self.device)
+        with torch.cuda.device(self.device):
+            self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples)
+            hip.check(self._lib.samaudio_codec_decode(self._ctx, hip.ptr(lat), items, frames, hip.ptr(wav),
+                                                      hip.current_stream_ptr()))
+        return wav
+
+    # ------------------------------------------------------------------ DiT
+    def _prepare(self, audio_features, text_features, text_mask, masked_video_features, anchor_ids,
+                 anchor_alignment, audio_pad_mask) -> None:
+        dev = self.device
+        feats = audio_features.to(dev, torch.float32).contiguous()
+        rows, frames, _ = feats.shape
+        text = tmask = video = ids = align = pad = None
+        text_len = 1
+        if text_features is not None:
+            text = text_features.to(dev, torch.float32).contiguous()
+            assert text.size(0) == rows, "text_features batch mismatch"
+            text_len = text.size(1)
+            if text_mask is not None:
+                tmask = text_mask.to(dev).to(torch.uint8).contiguous()
+        if masked_video_features is not None:  # reference layout [B, C, T] -> channels-last
+            video = masked_video_features.to(dev, torch.float32).transpose(1, 2).contiguous()
+            assert video.shape[:2] == (rows, frames), "masked_video_features must be [B, C, T]"
+        n_ids = 0
+        if anchor_ids is not None:
+            ids = anchor_ids.to(dev, torch.long).contiguous()
+            align = anchor_alignment.to(dev, torch.long).contiguous()
+            n_ids = ids.size(1)
+            assert int(align.max()) < n_ids, "anchor_alignment points past anchor_ids"
+        if audio_pad_mask is not None:
+            pad = audio_pad_mask.to(dev).to(torch.uint8).contiguous()
+        self._live = (feats, text, tmask, video, ids, align, pad)
+        self._ensure_workspace(rows, frames, text_len, 0, 0)
+        hip.check(self._lib.samaudio_prepare(
+            self._ctx, rows, frames, text_len, hip.ptr(feats), hip.ptr(text), hip.ptr(tmask), hip.ptr(video),
+            hip.ptr(ids), n_ids, hip.ptr(align), hip.ptr(pad), hip.current_stream_ptr()))
+
+    def forward(self, noisy_audio: torch.Tensor, audio_features: torch.Tensor, text_features: torch.Tensor,
+                time: torch.Tensor, masked_video_features: Optional[torch.Tensor] = None,
+                text_mask: Optional[torch.Tensor] = None, anchor_ids: Optional[torch.Tensor] = None,
+                anchor_alignment: Optional[torch.Tensor] = None,
+                audio_pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One ODE function evaluation; same signature as reference model.py:130-141."""
+        if not self._has_dit:
+            raise RuntimeError("transformer weights are not loaded")
+        with torch.cuda.device(self.device):
+            self._prepare(audio_features, text_features, text_mask, masked_video_features, anchor_ids,
+                          anchor_alignment, audio_pad_mask)
+            noisy = noisy_audio.to(self.device, torch.float32).contiguous()
+            t = time.to(self.device, torch.float32).reshape(-1).contiguous()
+            out = torch.empty_like(noisy)
+            hip.check(self._lib.samaudio_forward(self._ctx, hip.ptr(noisy), hip.ptr(t), t.numel(), hip.ptr(out),
+                                                 hip.current_stream_ptr()))
+        return out
+
+    __call__ = forward
+
+    def solve(self, noise: torch.Tensor, ode_opt: Dict[str, Any] = DFLT_ODE_OPT) -> torch.Tensor:
+        """Integrate the flow ODE from `noise` with the conditioning of the last `_prepare` call."""
+        method, grid = ode_grid(ode_opt)
+        state = noise.to(self.device, torch.float32).clone().contiguous()
+        g = (C.c_float * len(grid))(*grid)
+        with torch.cuda.device(self.device):
+            hip.check(self._lib.samaudio_ode_solve(self._ctx, hip.ptr(state), method, g, len(grid),
+                                                   hip.current_stream_ptr()))
+        return state
+
+    # ------------------------------------------------------------------ separate()
+    def _text(self, batch: Batch):
+        if batch.text_features is not None:
+            feats = batch.text_features
+            mask = batch.text_mask if batch.text_mask is not None else torch.ones(feats.shape[:2], dtype=torch.bool)
+            return feats, mask
+        if self.text_encoder is None:
+            raise RuntimeError(
+                "no text encoder is attached (t5-base cannot be downloaded offline): pass "
+                "text_features/text_mask to the processor or set model.text_encoder")
+        return self.text_encoder(batch.descriptions)
+
+    @staticmethod
+    def _repeat(x: Optional[torch.Tensor], candidates: int):
+        """Sample-major repeat, reference model.py:193-203."""
+        if x is None or candidates == 1:
+            return x
+        return x.repeat_interleave(candidates, dim=0)
+
+    @torch.inference_mode()
+    def separate(self, batch: Batch, noise: Optional[torch.Tensor] = None,
+                 ode_opt: Dict[str, Any] = DFLT_ODE_OPT, reranking_candidates: int = 1,
+                 predict_spans: bool = False) -> SeparationResult:
+        """Reference model.py:247-338.  `predict_spans` needs the PE-A-Frame span predictor, which is a
+        'next' row of this build; like the reference without `span_predictor` it is then a no-op (and in
+        the reference snapshot the predicted spans never reach the ODE anyway - quirk Q13)."""
+        if not (self._has_dit and self._has_codec):
+            raise RuntimeError("load_state_dict() first")
+        cand = int(reranking_candidates)
+        with torch.cuda.device(self.device):
+            z = self.encode_audio(batch.audios)                                  # [B, T, 128]
+            feats = torch.cat([z, z], dim=2)                                     # model.py:182-184
+            B, T, C2 = feats.shape
+            text, text_mask = self._text(batch)
+            video = None
+            if batch.masked_video is not None:
+                raise NotImplementedError("visual prompting needs the PE-Core tower (SURVEY.md §8 f3)")
+            if predict_spans and batch.anchors is None:
+                warnings.warn("predict_spans=True ignored: no span predictor in this build (SURVEY.md §8 f2)")
+            feats_r = self._repeat(feats, cand)
+            if noise is None:
+                noise = torch.randn_like(feats_r)                                # model.py:274-275
+            assert noise.shape == feats_r.shape, "noise must be [B*candidates, T, 256]"
+            self._prepare(feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), video,
+                          self._repeat(batch.anchor_ids, cand), self._repeat(batch.anchor_alignment, cand),
+                          self._repeat(batch.audio_pad_mask, cand))
+            latent = self.solve(noise, ode_opt)                                  # states[-1], [Bc, T, 256]
+            self.last_latent = latent
+            # [Bc, T, 2C] -> rows (2b, 2b+1) = (target, residual) latents, channels-last (model.py:291-295)
+            Bc, half = latent.size(0), C2 // 2
+            lat = latent.reshape(Bc, T, 2, half).permute(0, 2, 1, 3).reshape(2 * Bc, T, half).contiguous()
+            wavs = self.decode_audio(lat).view(Bc, 2, -1)
+            sizes = (batch.sizes.to(self.device) * self.cfg.audio_codec.hop_length).int()  # codec.py:91-97
+            target = self.unbatch(wavs[:, 0].view(B, cand, -1), sizes)
+            residual = self.unbatch(wavs[:, 1].view(B, cand, -1), sizes)
+            idxs = torch.zeros(B, dtype=torch.long, device=self.device)          # no ranker: model.py:329-330
+            return SeparationResult(
+                target=[w[i] for w, i in zip(target, idxs)],
+                residual=[w[i] for w, i in zip(residual, idxs)],
+                noise=noise)
+
+    def unbatch(self, wavs: torch.Tensor, sizes: torch.Tensor, time_dim: int = -1):
+        """reference model.py:340-344"""
+        return [row.narrow(dim=time_dim, start=0, length=int(size)) for row, size in zip(wavs, sizes)]

@@ -1,0 +1,168 @@
+"""Host-side batching for SAMAudio.separate(): the reference's `SAMAudioProcessor` / `Batch` API
+(reference sam_audio/processor.py:39-124, 158-260) for tensor inputs.
+
+This is small integer / memcpy work and stays on the CPU.  File decoding needs
+torchaudio / torchcodec, which are not part of this build's environment: string paths raise.
+Bit-exact parity of ``anchor_ids`` / ``anchor_alignment`` / ``sizes`` with the reference is pinned
+by tests/golden/anchors.npz (minted from the reference's own Batch class).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .config import SAMAudioConfig
+
+Anchor = Tuple[str, float, float]
+ANCHOR_VOCAB = {"<null>": 0, "+": 1, "-": 2, "<pad>": 3}
+
+
+def mask_from_sizes(sizes: torch.Tensor) -> torch.Tensor:
+    """[B] lengths -> [B, max] bool, True = valid (reference processor.py:127-128)."""
+    steps = torch.arange(int(sizes.max()))
+    return steps.unsqueeze(0) < sizes.unsqueeze(1)
+
+
+def batch_audio(audios: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Mono mix-down + right zero-padding (reference processor.py:23-36, tensor branch)."""
+    mono = []
+    for a in audios:
+        if isinstance(a, str):
+            raise ValueError("audio file paths need torchaudio, which this build does not ship; "
+                             "pass a (channels, samples) tensor at 48 kHz")
+        if a.dim() != 2:
+            raise ValueError(f"expected a (channels, samples) tensor, got shape {tuple(a.shape)}")
+        mono.append(a.float().mean(0))
+    sizes = torch.tensor([m.numel() for m in mono])
+    out = torch.zeros(len(mono), 1, int(sizes.max()))
+    for i, m in enumerate(mono):
+        out[i, 0, : m.numel()] = m
+    return out, sizes
+
+
+class Batch:
+    """Same fields as the reference Batch (processor.py:39-64) plus two optional ones,
+    ``text_features`` / ``text_mask``, for callers that bring pre-computed T5 features (the t5-base
+    tokenizer cannot be fetched offline)."""
+
+    def __init__(self, audios: torch.Tensor, sizes: torch.Tensor, wav_sizes: torch.Tensor,
+                 descriptions: List[str], hop_length: int, audio_sampling_rate: int,
+                 anchors: Optional[List[List[Anchor]]] = None, audio_pad_mask: Optional[torch.Tensor] = None,
+                 masked_video: Optional[List[torch.Tensor]] = None,
+                 text_features: Optional[torch.Tensor] = None, text_mask: Optional[torch.Tensor] = None):
+        assert audios.size(0) == len(descriptions), "one description per audio"
+        self.audios = audios
+        self.sizes = sizes
+        self.wav_sizes = wav_sizes
+        self.descriptions = descriptions
+        self.audio_pad_mask = audio_pad_mask
+        self.masked_video = masked_video
+        self.hop_length = hop_length
+        self.audio_sampling_rate = audio_sampling_rate
+        self.text_features = text_features
+        self.text_mask = text_mask
+        self.process_anchors(anchors)
+
+    def _frame_of(self, seconds: float) -> int:
+        return math.ceil(seconds * self.audio_sampling_rate / self.hop_length)
+
+    def process_anchors(self, anchors: Optional[List[List[Anchor]]]) -> None:
+        """Anchors -> (anchor_ids [B, 2+n], anchor_alignment [B, T]); reference processor.py:78-124.
+        Slot 0 is <null>, slot 1 is <pad>; frame t of a span [ceil(start*25), ceil(end*25)) points at
+        that anchor's slot, padded frames point at slot 1, everything else at slot 0."""
+        n = len(self.audios)
+        frames = self.audio_pad_mask.size(-1)
+        alignment = torch.zeros(n, frames, dtype=torch.long)
+        alignment[~self.audio_pad_mask.cpu()] = 1
+        if anchors is None:
+            ids = torch.tensor([[ANCHOR_VOCAB["<null>"], ANCHOR_VOCAB["<pad>"]]] * n, dtype=torch.long)
+        else:
+            rows = []
+            for i, spans in enumerate(anchors):
+                row = [ANCHOR_VOCAB["<null>"], ANCHOR_VOCAB["<pad>"]]
+                for token, start, end in spans:
+                    alignment[i, self._frame_of(start): self._frame_of(end)] = len(row)
+                    row.append(ANCHOR_VOCAB[token])
+                rows.append(row)
+            width = max(len(r) for r in rows)
+            ids = torch.full((n, width), ANCHOR_VOCAB["<pad>"], dtype=torch.long)
+            for i, r in enumerate(rows):
+                ids[i, : len(r)] = torch.tensor(r)
+        self.anchor_ids = ids.to(self.audios.device)
+        self.anchor_alignment = alignment.to(self.audios.device)
+        self.anchors = anchors
+
+    def to(self, device) -> "Batch":
+        for name in ("audios", "anchor_ids", "anchor_alignment", "sizes", "wav_sizes", "audio_pad_mask",
+                     "text_features", "text_mask"):
+            value = getattr(self, name)
+            if value is not None:
+                setattr(self, name, value.to(device))
+        if self.masked_video is not None:
+            self.masked_video = [v.to(device) for v in self.masked_video]
+        return self
+
+
+def sample_video_frames(sizes: torch.Tensor, videos: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """One frame per latent step, uniformly spread (reference processor.py:147-153, tensor branch)."""
+    picked = []
+    for size, video in zip(sizes, videos):
+        if isinstance(video, str):
+            raise ValueError("video file paths need torchcodec, which this build does not ship")
+        assert video.size(1) == 3, f"expected NCHW video, found {video.size(1)} channels"
+        idx = torch.linspace(0, video.size(0) - 1, int(size)).round().long()
+        picked.append(video[idx])
+    return picked
+
+
+class SAMAudioProcessor:
+    def __init__(self, audio_hop_length: int, audio_sampling_rate: int):
+        self.audio_hop_length = audio_hop_length
+        self.audio_sampling_rate = audio_sampling_rate
+
+    @classmethod
+    def from_config(cls, cfg: SAMAudioConfig) -> "SAMAudioProcessor":
+        return cls(cfg.audio_codec.hop_length, cfg.audio_codec.sample_rate)
+
+    @classmethod
+    def from_pretrained(cls, model_name_or_path: str) -> "SAMAudioProcessor":
+        """Local directory holding the reference's config.json (processor.py:165-185); hub ids need
+        network access this build does not have."""
+        path = os.path.join(model_name_or_path, "config.json")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: only local checkpoints are supported offline")
+        with open(path) as fin:
+            return cls.from_config(SAMAudioConfig(**json.load(fin)))
+
+    def feature_to_wav_idx(self, feature_idx):
+        return feature_idx * self.audio_hop_length
+
+    def wav_to_feature_idx(self, wav_idx):
+        if torch.is_tensor(wav_idx):
+            return torch.ceil(wav_idx / self.audio_hop_length)
+        return math.ceil(wav_idx / self.audio_hop_length)
+
+    def mask_videos(self, videos: Sequence[torch.Tensor], masks: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """Zero the masked object out of each frame (reference processor.py:197-204, tensor branch)."""
+        return [v * m.eq(0) for v, m in zip(videos, masks)]
+
+    def __call__(self, descriptions: List[str], audios: Sequence[torch.Tensor],
+                 anchors: Optional[List[List[Anchor]]] = None,
+                 masked_videos: Optional[Sequence[torch.Tensor]] = None,
+                 text_features: Optional[torch.Tensor] = None,
+                 text_mask: Optional[torch.Tensor] = None) -> Batch:
+        assert len(descriptions) == len(audios)
+        assert anchors is None or len(descriptions) == len(anchors)
+        assert masked_videos is None or len(descriptions) == len(masked_videos)
+        wavs, wav_sizes = batch_audio(audios)
+        sizes = self.wav_to_feature_idx(wav_sizes)
+        pad_mask = mask_from_sizes(sizes)
+        video = None if masked_videos is None else sample_video_frames(sizes, masked_videos)
+        return Batch(audios=wavs, sizes=sizes, wav_sizes=wav_sizes, descriptions=list(descriptions),
+                     hop_length=self.audio_hop_length, audio_sampling_rate=self.audio_sampling_rate,
+                     anchors=anchors, audio_pad_mask=pad_mask, masked_video=video,
+                     text_features=text_features, text_mask=text_mask)

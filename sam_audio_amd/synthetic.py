@@ -17,10 +17,14 @@ from .config import SAMAudioConfig
 
 
 def _uniform(gen, shape, bound, device):
+    if gen is None:  # meta device: shapes only
+        return torch.empty(shape, device=device, dtype=torch.float32)
     return (torch.rand(shape, generator=gen, device=device, dtype=torch.float32) * 2 - 1) * bound
 
 
 def _normal(gen, shape, std, device):
+    if gen is None:
+        return torch.empty(shape, device=device, dtype=torch.float32)
     return torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std
 
 
@@ -31,8 +35,10 @@ def init_state_dict(cfg: SAMAudioConfig, seed: int = 0, device="cpu",
     to 0.5 (the reference initialises them to 0, align.py:26 / model.py:51, which would switch
     the video / anchor terms off and leave them untested)."""
     dev = torch.device(device)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
+    gen = None
+    if dev.type != "meta":
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
     t = cfg.transformer
     D, F, hd = t.dim, t.ffn_hidden, t.head_dim
     sd: Dict[str, torch.Tensor] = {}
@@ -84,10 +90,10 @@ def init_state_dict(cfg: SAMAudioConfig, seed: int = 0, device="cpu",
     sd["align_masked_video.conv.bias"] = _uniform(gen, (D,), 1.0, dev)
     norm_w("align_masked_video.layer_norm.weight", D)
     sd["align_masked_video.layer_norm.bias"] = _normal(gen, (D,), 0.1, dev)
-    sd["align_masked_video.gate"] = torch.tensor([0.5], device=dev)
+    sd["align_masked_video.gate"] = torch.full((1,), 0.5, device=dev)
     emb = _normal(gen, (cfg.num_anchors + 1, cfg.anchor_embedding_dim), 1.0, dev)
     sd["embed_anchors.embed.weight"] = emb
-    sd["embed_anchors.gate"] = torch.tensor([0.5], device=dev)
+    sd["embed_anchors.gate"] = torch.full((1,), 0.5, device=dev)
     lin("embed_anchors.proj", D, cfg.anchor_embedding_dim)
 
     if with_codec:
@@ -115,7 +121,7 @@ def init_codec_state_dict(cfg: SAMAudioConfig, gen, dev) -> Dict[str, torch.Tens
         sd[name + ".bias"] = _uniform(gen, (co,), b, dev)
 
     def snake(name, ch):
-        sd[name + ".alpha"] = (1.0 + _normal(gen, (1, ch, 1), 0.25, dev)).clamp_(0.3, 2.0)
+        sd[name + ".alpha"] = (1.0 + _normal(gen, (1, ch, 1), 0.25, dev)).clamp(0.3, 2.0)
 
     def res_unit(name, ch):
         snake(name + ".block.0", ch)

@@ -1,0 +1,226 @@
+"""Reference state_dict -> engine tensors.
+
+The checkpoint format is the reference's flat ``state_dict`` (``checkpoint.pt``, reference
+sam_audio/model/base.py:56-61; key names enumerated in SURVEY.md §8b).  The HIP engine wants a few
+one-time re-layouts, all done here on the weights' device:
+
+* **Q1 interleaved heads** (reference transformer.py:121-126): q/k/v projection channel ``c = d*H + h``.
+  Rows of wq/wk/wv are permuted to head-major (``h*128 + d``) so a 128-wide column block of the QKV
+  GEMM is one head; ``wo`` already consumes head-major channels (transformer.py:160).
+* wq|wk|wv fused into one [3D, D] operand; cross-attention wk|wv fused into [2D, D].
+* SwiGLU ``w1``/``w3`` interleaved in 16-row blocks so the GEMM epilogue finds silu(w1 x) and w3 x of
+  the same column in one lane (transformer.py:195-206, :69-80).
+* **Q10**: columns 256..511 of ``proj`` multiply zeros (model.py:116-123) and are dropped; the other two
+  blocks are split into ``proj_wy`` (noisy audio) and ``proj_wf`` (audio features, hoisted out of the ODE).
+* Conv1d weights [Cout, Cin, k] -> [Cout, k*Cin] (tap-major K, channels-last activations);
+  ConvTranspose1d [Cin, Cout, 2s] -> [s*Cout, 2*Cin] (phase-major rows);
+  K zero-padded to the GEMM slab (64 bf16 / 32 f32 elements); weight-norm (g, v) pairs are folded.
+* tanh(gate) of the anchor term is folded into ``anc_w`` (model.py:65).
+* RoPE / sinusoid tables are computed once on the CPU with the reference's own op sequence
+  (rope.py:116-145, model.py:27-33, transformer.py:228-234) and kept in fp32 (quirk Q17).
+"""
+from __future__ import annotations
+
+import math
+import re
+from typing import Dict, List, Tuple
+
+import torch
+
+from .config import SAMAudioConfig
+
+# keys the reference checkpoint does not carry (reference model.py:351-355)
+OPTIONAL_KEY_RE = re.compile(r"(^text_encoder|^visual_ranker|^text_ranker|^span_predictor)")
+
+
+def _head_major(w: torch.Tensor, n_heads: int) -> torch.Tensor:
+    out_f, in_f = w.shape
+    hd = out_f // n_heads
+    return w.reshape(hd, n_heads, in_f).permute(1, 0, 2).reshape(out_f, in_f)
+
+
+def _interleave16(w1: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    f, k = w1.shape
+    assert f % 16 == 0
+    return torch.stack([w1.reshape(f // 16, 16, k), w3.reshape(f // 16, 16, k)], dim=1).reshape(2 * f, k)
+
+
+def _pad_k(w: torch.Tensor, slab: int) -> torch.Tensor:
+    n, k = w.shape
+    kp = (k + slab - 1) // slab * slab
+    if kp == k:
+        return w
+    out = w.new_zeros(n, kp)
+    out[:, :k] = w
+    return out
+
+
+def _conv_weight(sd: Dict[str, torch.Tensor], name: str, transposed: bool = False) -> torch.Tensor:
+    """Plain `weight`, or weight-norm in either the legacy (weight_g / weight_v) or the parametrised
+    (parametrizations.weight.original0/1) spelling; norm over all dims but 0 (torch weight_norm default)."""
+    if name + ".weight" in sd:
+        return sd[name + ".weight"].float()
+    for g_key, v_key in ((".weight_g", ".weight_v"),
+                         (".parametrizations.weight.original0", ".parametrizations.weight.original1")):
+        if name + g_key in sd:
+            g, v = sd[name + g_key].float(), sd[name + v_key].float()
+            norm = v.flatten(1).norm(dim=1).reshape(-1, *([1] * (v.dim() - 1)))
+            return g * v / norm
+    raise KeyError(name + ".weight")
+
+
+def expected_keys(cfg: SAMAudioConfig, with_codec: bool = True) -> List[str]:
+    from .synthetic import init_state_dict  # key enumeration only (meta device: no memory)
+    return list(init_state_dict(cfg, device="meta", with_codec=with_codec).keys())
+
+
+def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype,
+                device) -> Dict[str, torch.Tensor]:
+    t = cfg.transformer
+    D, H, F = t.dim, t.n_heads, t.ffn_hidden
+    out: Dict[str, torch.Tensor] = {}
+
+    def f32(x):
+        return x.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def op(x):  # GEMM operand
+        return x.detach().to(device=device, dtype=torch.float32).to(act_dtype).contiguous()
+
+    def W(key):
+        return sd[key].detach().to(device=device, dtype=torch.float32)
+
+    P = "transformer."
+    for i in range(t.n_layers):
+        L, E = f"{P}layers.{i}.", f"L{i}."
+        out[E + "attn_norm"] = f32(sd[L + "attention_norm.weight"])
+        out[E + "ffn_norm"] = f32(sd[L + "ffn_norm.weight"])
+        out[E + "mod_table"] = f32(sd[L + "scale_shift_table"])
+        out[E + "q_norm"] = f32(sd[L + "attention.q_norm.weight"])
+        out[E + "k_norm"] = f32(sd[L + "attention.k_norm.weight"])
+        out[E + "c_q_norm"] = f32(sd[L + "cross_attention.q_norm.weight"])
+        out[E + "c_k_norm"] = f32(sd[L + "cross_attention.k_norm.weight"])
+        out[E + "wqkv"] = op(torch.cat([_head_major(W(L + f"attention.{n}.weight"), H) for n in ("wq", "wk", "wv")]))
+        out[E + "wo"] = op(W(L + "attention.wo.weight"))
+        out[E + "c_wq"] = op(_head_major(W(L + "cross_attention.wq.weight"), H))
+        out[E + "c_wkv"] = op(torch.cat([_head_major(W(L + f"cross_attention.{n}.weight"), H) for n in ("wk", "wv")]))
+        out[E + "c_wo"] = op(W(L + "cross_attention.wo.weight"))
+        out[E + "w13"] = op(_interleave16(W(L + "feed_forward.w1.weight"), W(L + "feed_forward.w3.weight")))
+        out[E + "w2"] = op(W(L + "feed_forward.w2.weight"))
+    out["final_table"] = f32(sd[P + "final_layer_scale_shift_table"])
+    out["final_norm"] = f32(sd[P + "norm.weight"])
+    out["w_out"] = op(W(P + "output.weight"))
+    for n, blk in ((1, "block1"), (2, "block2")):
+        B = f"{P}x_embedder.block.{blk}."
+        out[f"patch{n}.gn_w"] = f32(sd[B + "groupnorm.weight"])
+        out[f"patch{n}.gn_b"] = f32(sd[B + "groupnorm.bias"])
+        out[f"patch{n}.w"] = op(W(B + "project.weight").permute(0, 2, 1).reshape(D, 3 * D))
+        out[f"patch{n}.b"] = f32(sd[B + "project.bias"])
+    for pre, name in (("y", "y_embedder"), ("t", "t_embedder")):
+        Q = f"{P}{name}.projection."
+        out[f"{pre}_w13"] = op(_interleave16(W(Q + "w1.weight"), W(Q + "w3.weight")))
+        out[f"{pre}_w2"] = op(W(Q + "w2.weight"))
+    out["tb_w"] = op(W(P + "t_block.weight"))
+    out["tb_b"] = f32(sd[P + "t_block.bias"])
+
+    c2 = t.out_channels
+    proj = W("proj.weight")
+    assert proj.shape[1] == 3 * c2, "proj expects [noisy | zeros | features]"
+    out["proj_wy"] = op(proj[:, :c2])
+    out["proj_wf"] = op(proj[:, 2 * c2:])
+    out["proj_b"] = f32(sd["proj.bias"])
+    out["mem_w"] = op(W("memory_proj.weight"))
+    out["mem_b"] = f32(sd["memory_proj.bias"])
+    out["vid_w"] = op(W("align_masked_video.conv.weight").squeeze(-1))
+    out["vid_b"] = f32(sd["align_masked_video.conv.bias"])
+    out["vid_ln_w"] = f32(sd["align_masked_video.layer_norm.weight"])
+    out["vid_ln_b"] = f32(sd["align_masked_video.layer_norm.bias"])
+    out["vid_gate"] = f32(sd["align_masked_video.gate"].reshape(1))
+    out["anc_emb"] = f32(sd["embed_anchors.embed.weight"])
+    out["anc_w"] = op(torch.tanh(W("embed_anchors.gate")).reshape(1, 1) * W("embed_anchors.proj.weight"))
+
+    # fp32 tables, computed with the reference's op sequence on the CPU
+    hd = t.head_dim
+    freqs = 1.0 / (t.rope_theta ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))
+    ang = torch.outer(torch.arange(t.max_positions), freqs).float()
+    out["rope_cos"], out["rope_sin"] = f32(ang.cos()), f32(ang.sin())
+    half = t.frequency_embedding_dim // 2
+    out["t_freqs"] = f32(torch.exp(-math.log(10000) * torch.arange(0, half, dtype=torch.float32) / half))
+    half = D // 2
+    out["mem_inv_freq"] = f32(torch.exp(-math.log(10000) * torch.arange(half).float() / half))
+    return out
+
+
+def convert_codec(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype, device,
+                  prefix: str = "audio_codec.") -> Dict[str, torch.Tensor]:
+    c = cfg.audio_codec
+    slab = 64 if act_dtype == torch.bfloat16 else 32
+    out: Dict[str, torch.Tensor] = {}
+
+    def f32(x):
+        return x.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def op(x):
+        return x.detach().to(device=device, dtype=torch.float32).to(act_dtype).contiguous()
+
+    def conv(name):  # [Cout, Cin, k] -> [Cout, k*Cin]
+        w = _conv_weight(sd, prefix + name).to(device)
+        return op(_pad_k(w.permute(0, 2, 1).reshape(w.shape[0], -1), slab))
+
+    def alpha(name):
+        return f32(sd[prefix + name + ".alpha"].reshape(-1))
+
+    def bias(name):
+        return f32(sd[prefix + name + ".bias"])
+
+    def res_unit(src: str, dst: str):
+        out[dst + "a1"], out[dst + "w1"], out[dst + "b1"] = alpha(src + ".block.0"), conv(src + ".block.1"), bias(src + ".block.1")
+        out[dst + "a2"], out[dst + "w2"], out[dst + "b2"] = alpha(src + ".block.2"), conv(src + ".block.3"), bias(src + ".block.3")
+
+    # encoder ------------------------------------------------------------------------------------
+    w_in = _conv_weight(sd, prefix + "encoder.block.0").to(device)  # [C0, 1, 7]
+    w8 = w_in.new_zeros(w_in.shape[0], 8, 8)                          # [C0, tap(8), channel(8)]
+    w8[:, :7, 0] = w_in[:, 0, :]
+    out["enc.in.w"], out["enc.in.b"] = op(w8.reshape(w_in.shape[0], 64)), bias("encoder.block.0")
+    for i in range(len(c.encoder_rates)):
+        B = f"encoder.block.{i + 1}.block."
+        for j in range(3):
+            res_unit(f"{B}{j}", f"enc.s{i}.r{j}.")
+        out[f"enc.s{i}.a"] = alpha(B + "3")
+        out[f"enc.s{i}.down.w"], out[f"enc.s{i}.down.b"] = conv(B + "4"), bias(B + "4")
+    out["enc.out.a"] = alpha("encoder.block.5")
+    out["enc.out.w"], out["enc.out.b"] = conv("encoder.block.6"), bias("encoder.block.6")
+    w_ip = _conv_weight(sd, prefix + "quantizer.in_proj").to(device).squeeze(-1)  # [2*cd, latent]
+    out["enc.proj.w"] = op(w_ip[: c.codebook_dim])                                   # mean half only (codec.py:68)
+    out["enc.proj.b"] = f32(sd[prefix + "quantizer.in_proj.bias"][: c.codebook_dim])
+    # decoder ------------------------------------------------------------------------------------
+    out["dec.proj.w"] = op(_conv_weight(sd, prefix + "quantizer.out_proj").to(device).squeeze(-1))
+    out["dec.proj.b"] = bias("quantizer.out_proj")
+    out["dec.in.w"], out["dec.in.b"] = conv("decoder.model.0"), bias("decoder.model.0")
+    for i, s in enumerate(c.decoder_rates):
+        B = f"decoder.model.{i + 1}.block."
+        out[f"dec.s{i}.a"] = alpha(B + "0")
+        w = _conv_weight(sd, prefix + B + "1", transposed=True).to(device)  # ConvTranspose1d [Cin, Cout, 2s]
+        cin, cout, k = w.shape
+        assert k == 2 * s
+        wg = torch.stack([w[:, :, s:], w[:, :, :s]], dim=0)            # [j, Cin, Cout, r]: j=0 <- x[q-1], j=1 <- x[q]
+        out[f"dec.s{i}.up.w"] = op(wg.permute(3, 2, 0, 1).reshape(s * cout, 2 * cin))
+        out[f"dec.s{i}.up.b"] = bias(B + "1")
+        for j in range(3):
+            res_unit(f"{B}{j + 2}", f"dec.s{i}.r{j}.")
+    out["dec.out.a"] = alpha("decoder.model.5")
+    out["dec.out.w"], out["dec.out.b"] = conv("decoder.model.6"), bias("decoder.model.6")
+    return out
+
+
+def split_missing_unexpected(sd_keys, cfg: SAMAudioConfig) -> Tuple[List[str], List[str]]:
+    """Key bookkeeping of reference SAMAudio.load_state_dict (model.py:346-359)."""
+    want = set(expected_keys(cfg))
+    have = set(sd_keys)
+
+    def canon(k):  # weight-norm spellings count as the plain weight
+        return re.sub(r"\.(weight_g|weight_v|parametrizations\.weight\.original[01])$", ".weight", k)
+
+    have_c = {canon(k) for k in have}
+    missing = sorted(k for k in want if k not in have_c and not OPTIONAL_KEY_RE.search(k))
+    unexpected = sorted(k for k in have if canon(k) not in want and not OPTIONAL_KEY_RE.search(k))
+    return missing, unexpected

@@ -1,0 +1,52 @@
+"""world_size-2 gloo test of the N>1 path: weight broadcast + batch sharding + timing gather."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from sam_audio_amd import SAMAudioProcessor, preset_config
+from sam_audio_amd.dist import shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from sam_audio_amd import dist as sdist
+    from sam_audio_amd.synthetic import init_state_dict, synthetic_text_features
+    r, w, _ = sdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=42, with_codec=False) if rank == 0 else None
+    got = sdist.broadcast_state_dict(sd, src=0)
+    want = init_state_dict(cfg, seed=42, with_codec=False)
+    assert list(got) == list(want) and all(torch.equal(got[k], want[k]) for k in want)
+    proc = SAMAudioProcessor.from_config(cfg)
+    clips = [torch.full((1, 1920 * (2 + i)), float(i)) for i in range(5)]
+    text, mask = synthetic_text_features(5, 3)
+    batch = proc([f"c{i}" for i in range(5)], clips, anchors=[[("+", 0.0, 0.04)]] * 5, text_features=text, text_mask=mask)
+    mine = sdist.shard_batch(batch, rank, world)
+    rows = list(shard_range(5, rank, world))
+    assert mine.descriptions == [f"c{i}" for i in rows]
+    assert mine.audios.shape == (len(rows), 1, 1920 * (2 + rows[-1]))
+    assert float(mine.audios[0, 0, 0]) == float(rows[0]) and mine.audio_pad_mask.shape[1] == 2 + rows[-1]
+    assert torch.equal(mine.text_features, text[rows]) and mine.anchor_ids.shape[0] == len(rows)
+    table = sdist.gather_floats([float(rank), 10.0 + rank])
+    if rank == 0:
+        assert table == [[0.0, 10.0], [1.0, 11.0]]
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").close()
+
+
+def test_two_rank_broadcast_and_sharding(tmp_path):
+    assert [list(shard_range(32, r, 8)) for r in (0, 7)] == [[0, 1, 2, 3], [28, 29, 30, 31]]
+    assert [len(shard_range(5, r, 2)) for r in range(2)] == [3, 2]
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]

@@ -1,0 +1,146 @@
+"""Host logic and the C-ABI surface, no GPU needed: the library loads, exports every symbol that
+include/samaudio.h declares, and its host-side validation behaves like the reference's error surface."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from sam_audio_amd import SAMAudioProcessor, hip, preset_config
+from sam_audio_amd.config import SAMAudioConfig, TransformerConfig
+from sam_audio_amd.synthetic import init_state_dict
+from sam_audio_amd.weights import (_head_major, _interleave16, convert_codec, convert_dit, expected_keys,
+                                   split_missing_unexpected)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "samaudio.h")).read()
+    declared = set(re.findall(r"\b(samaudio_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = hip.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libsamaudio_hip.so does not export {name}"
+    assert declared == set(hip.EXPORTED_SYMBOLS)
+    assert b"gfx950" in lib.samaudio_version()
+
+
+def test_config_defaults_match_reference_rule():
+    t = TransformerConfig()
+    assert (t.dim, t.n_heads, t.n_layers, t.head_dim, t.ffn_hidden, t.rope_theta) == (2048, 16, 16, 128, 5504, 20000.0)
+    assert preset_config("large*").transformer.ffn_hidden == 7552
+    assert preset_config("small*").transformer.ffn_hidden == 4096
+    assert SAMAudioConfig().audio_codec.hop_length == 1920
+    with pytest.raises(NotImplementedError):
+        SAMAudioConfig(transformer=dict(dim=2048, n_heads=32)).check_supported()
+    with pytest.raises(TypeError):
+        SAMAudioConfig(transformer=dict(bogus=1))
+
+
+def test_weight_relayout_is_a_permutation_of_reference_semantics():
+    H, hd, K = 3, 128, 64
+    w = torch.randn(H * hd, K)
+    x = torch.randn(5, K)
+    ref = (x @ w.T).reshape(5, hd, H).permute(0, 2, 1)             # reference reshape_heads: c = d*H + h
+    mine = (x @ _head_major(w, H).T).reshape(5, H, hd)             # head-major columns
+    assert torch.equal(ref, mine)
+    w1, w3 = torch.randn(64, 8), torch.randn(64, 8)
+    w13 = _interleave16(w1, w3)
+    assert torch.equal(w13[0:16], w1[0:16]) and torch.equal(w13[16:32], w3[0:16]) and torch.equal(w13[32:48], w1[16:32])
+
+
+def test_state_dict_key_bookkeeping():
+    cfg = preset_config("tiny")
+    keys = expected_keys(cfg)
+    assert "transformer.layers.1.cross_attention.k_norm.weight" in keys and "audio_codec.decoder.model.6.weight" in keys
+    missing, unexpected = split_missing_unexpected(keys + ["text_encoder.model.x", "bogus.weight"], cfg)
+    assert missing == [] and unexpected == ["bogus.weight"]
+    missing, _ = split_missing_unexpected([k for k in keys if k != "proj.bias"], cfg)
+    assert missing == ["proj.bias"]
+    wn = [k.replace(".weight", ".weight_g") if k.endswith("decoder.model.0.weight") else k for k in keys]
+    wn.append("audio_codec.decoder.model.0.weight_v")
+    assert split_missing_unexpected(wn, cfg) == ([], [])
+
+
+def _ctx(cfg, precision):
+    t, c = cfg.transformer, cfg.audio_codec
+    hc = hip.Config(precision=precision, dim=t.dim, n_heads=t.n_heads, n_layers=t.n_layers, ffn_hidden=t.ffn_hidden,
+                    latent_channels=256, text_dim=768, video_dim=1024, freq_dim=256, anchor_dim=128, anchor_vocab=4,
+                    max_positions=t.max_positions, norm_eps=1e-5, codec_dim=128, codec_latent=1024, enc_dim=64,
+                    dec_dim=1536, enc_rates=(C.c_int32 * 4)(2, 8, 10, 12), dec_rates=(C.c_int32 * 4)(12, 10, 8, 2))
+    ctx = C.c_void_p()
+    hip.check(hip.lib().samaudio_create(C.byref(hc), C.byref(ctx)))
+    return ctx
+
+
+@pytest.mark.parametrize("prec,dtype", [(hip.F32, torch.float32), (hip.BF16, torch.bfloat16)])
+def test_engine_accepts_converted_weights_and_reports_missing_ones(prec, dtype):
+    """set_tensor/finalize only look at names, dtypes and shapes, so CPU pointers are fine here."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=0)
+    lib = hip.lib()
+    ctx = _ctx(cfg, prec)
+    keep = []
+    for group, what in ((convert_dit(sd, cfg, dtype, "cpu"), 0), (convert_codec(sd, cfg, dtype, "cpu"), 1)):
+        with pytest.raises(RuntimeError, match="missing weight"):
+            hip.check(lib.samaudio_finalize(ctx, what))
+        for name, t in group.items():
+            keep.append(t)
+            dt = hip.DT_BF16 if t.dtype == torch.bfloat16 else hip.DT_F32
+            hip.check(lib.samaudio_set_tensor(ctx, name.encode(), hip.ptr(t), dt, t.dim(), hip.shape_array(t.shape)))
+        hip.check(lib.samaudio_finalize(ctx, what))
+    bad = torch.zeros(3, 3)
+    hip.check(lib.samaudio_set_tensor(ctx, b"final_norm", hip.ptr(bad), hip.DT_F32, 2, hip.shape_array(bad.shape)))
+    with pytest.raises(RuntimeError, match="final_norm"):
+        hip.check(lib.samaudio_finalize(ctx, 0))
+    small = lib.samaudio_workspace_bytes(ctx, 1, 250, 8, 0, 0)
+    big = lib.samaudio_workspace_bytes(ctx, 8, 250, 8, 0, 0)
+    codec = lib.samaudio_workspace_bytes(ctx, 0, 0, 0, 2, 480000)
+    assert 0 < small < big and codec > 2 * 480000 * 64 * 4
+    with pytest.raises(hip.SamAudioHipError):  # no workspace yet -> state/workspace error, not a crash
+        hip.check(lib.samaudio_prepare(ctx, 1, 8, 1, C.c_void_p(1 << 20), None, None, None, None, 0, None, None, None))
+    lib.samaudio_destroy(ctx)
+
+
+def test_ode_options_are_validated():
+    from sam_audio_amd.model import DFLT_ODE_OPT, ode_grid
+    method, grid = ode_grid(DFLT_ODE_OPT)
+    assert method == hip.ODE_MIDPOINT and len(grid) == 17 and grid[0] == 0.0 and grid[-1] == 1.0
+    assert ode_grid({"method": "euler", "options": {"step_size": 0.3}})[1] == [0.0, 0.3, 0.6, 0.8999999999999999, 1.0]
+    with pytest.raises(ValueError):
+        ode_grid({"method": "dopri5", "options": {"step_size": 0.1}})
+    with pytest.raises(ValueError):
+        ode_grid({"method": "midpoint", "options": {"rtol": 1e-3}})
+
+
+def test_processor_batching_matches_reference_semantics():
+    proc = SAMAudioProcessor(1920, 48000)
+    a, b = torch.randn(2, 4000), torch.randn(1, 1920 * 3)
+    batch = proc(descriptions=["a", "b"], audios=[a, b])
+    assert batch.audios.shape == (2, 1, 5760)
+    assert torch.allclose(batch.audios[0, 0, :4000], a.mean(0)) and float(batch.audios[0, 0, 4000:].abs().max()) == 0
+    assert batch.sizes.tolist() == [3.0, 3.0] and batch.wav_sizes.tolist() == [4000, 5760]
+    assert batch.audio_pad_mask.all() and batch.anchor_ids.tolist() == [[0, 3], [0, 3]]
+    short = proc(descriptions=["a", "b"], audios=[a[:, :1000], b])
+    assert short.audio_pad_mask.tolist() == [[True, False, False], [True, True, True]]
+    assert short.anchor_alignment.tolist() == [[0, 1, 1], [0, 0, 0]]
+    with pytest.raises(AssertionError):
+        proc(descriptions=["a"], audios=[a, b])
+    with pytest.raises(ValueError):
+        proc(descriptions=["a"], audios=["file.wav"])
+    masked = proc.mask_videos([torch.ones(2, 3, 4, 4)], [torch.tensor([[[[1.0]]]]).expand(2, 3, 4, 4)])
+    assert float(masked[0].abs().max()) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    """The host class refuses to run without a GPU instead of silently computing elsewhere."""
+    from sam_audio_amd import SAMAudio
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = SAMAudio(preset_config("tiny"), precision="fp32", device="cpu")
+    with pytest.raises(hip.SamAudioHipError):
+        model.load_state_dict(init_state_dict(preset_config("tiny"), 0))
+    src = "".join(open(os.path.join(ROOT, "sam_audio_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "sam_audio_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src

@@ -1,0 +1,149 @@
+"""Parity of the norm / RoPE / attention kernels against the CPU oracle (oracle/samaudio_oracle.py).
+
+Tolerances (floating point): fp32 mode 2e-4 max-abs on O(1) data (summation order, fast exp);
+bf16 mode compares against the oracle fed with bf16-rounded inputs; the bound is dominated by the
+bf16 rounding of the stored outputs (2^-9 relative) and of P in the attention (documented per test).
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+from oracle import samaudio_oracle as O
+from sam_audio_amd import hip
+from tests import util
+
+pytestmark = pytest.mark.gpu
+PRECS = ["fp32", "bf16"]
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("shared_time", [False, True])
+def test_rmsnorm_modulate(gpu, prec, shared_time):
+    B, T, D = 3, 37, 512
+    x, w = _mk((B * T, D), 1), _mk((D,), 2, 0.1) + 1
+    tab = _mk((6, D), 3, 0.2)
+    t0 = _mk((1 if shared_time else B, 6 * D), 4, 0.2)
+    out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
+    tab_d = tab.to(gpu)
+    hip.check(hip.lib().samaudio_op_rmsnorm_mod(
+        hip.ptr(x.to(gpu)), hip.ptr(w.to(gpu)), C.c_void_p(tab_d[3].data_ptr()), C.c_void_p(tab_d[4].data_ptr()),
+        hip.ptr(t0.to(gpu)), 0 if shared_time else 6 * D, 3 * D, 4 * D, hip.ptr(out), util.PREC[prec], B * T, D, T,
+        1e-5, util.stream()))
+    t0b = t0.expand(B, -1)
+    shift = (tab[3][None] + t0b[:, 3 * D:4 * D]).repeat_interleave(T, 0)
+    scale = (tab[4][None] + t0b[:, 4 * D:5 * D]).repeat_interleave(T, 0)
+    want = O.rms_norm(x, w, 1e-5) * (1 + scale) + shift
+    util.report(f"rmsnorm_mod {prec}", out, want, 1e-5 if prec == "fp32" else 4e-2)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_groupnorm_silu(gpu, prec):
+    B, T, Cc, halo = 2, 50, 256, 1
+    x = _mk((B, T, Cc), 5) * 2 + 0.3
+    w, b = _mk((Cc,), 6, 0.1) + 1, _mk((Cc,), 7, 0.1)
+    part = torch.zeros(B * 64 * 2, dtype=torch.float64, device=gpu)
+    out = torch.zeros(B, T + 2 * halo, Cc, device=gpu, dtype=util.ACT_DT[prec])
+    hip.check(hip.lib().samaudio_op_groupnorm_silu(hip.ptr(x.to(gpu)), hip.ptr(w.to(gpu)), hip.ptr(b.to(gpu)),
+                                                   hip.ptr(part), hip.ptr(out), util.PREC[prec], B, T, Cc, halo, 1e-5,
+                                                   util.stream()))
+    want = torch.nn.functional.silu(O.group_norm_1(x, w, b))
+    util.report(f"groupnorm_silu {prec}", out[:, halo:halo + T], want, 2e-5 if prec == "fp32" else 3e-2)
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, -1].abs().max()) == 0
+
+
+def _qkv_case(prec, B=2, T=70, H=2, seed=10):
+    D = H * 128
+    qkv = _mk((B, T, 3 * D), seed)
+    qw, kw = _mk((128,), seed + 1, 0.1) + 1, _mk((128,), seed + 2, 0.1) + 1
+    cos, sin = O.rope_tables(128, 128, 20000.0)
+    return D, qkv, qw, kw, cos, sin
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_qkv_prep(gpu, prec):
+    B, T, H = 2, 70, 2
+    Tp = 128
+    D, qkv, qw, kw, cos, sin = _qkv_case(prec, B, T, H)
+    q = torch.full((B, H, Tp, 128), float("nan"), device=gpu, dtype=util.ACT_DT[prec])
+    k, vt = torch.full_like(q, float("nan")), torch.full((B, H, 128, Tp), float("nan"), device=gpu, dtype=util.ACT_DT[prec])
+    hip.check(hip.lib().samaudio_op_qkv_prep(
+        hip.ptr(util.as_act(qkv, prec, gpu)), hip.ptr(qw.to(gpu)), hip.ptr(kw.to(gpu)), hip.ptr(cos.to(gpu).contiguous()),
+        hip.ptr(sin.to(gpu).contiguous()), hip.ptr(q), hip.ptr(k), hip.ptr(vt), util.PREC[prec], B, T, Tp, H, 1e-5,
+        util.stream()))
+    x = util.rounded(qkv, prec)
+    heads = lambda z: z.reshape(B, T, H, 128).permute(0, 2, 1, 3)  # head-major columns
+    qr = O.apply_rope(O.rms_norm(heads(x[..., :D]), qw, 1e-5), cos, sin)
+    kr = O.apply_rope(O.rms_norm(heads(x[..., D:2 * D]), kw, 1e-5), cos, sin)
+    vr = heads(x[..., 2 * D:])
+    tol = 2e-5 if prec == "fp32" else 4e-2
+    util.report(f"qkv_prep q {prec}", q[:, :, :T], qr, tol)
+    util.report(f"qkv_prep k {prec}", k[:, :, :T], kr, tol)
+    util.report(f"qkv_prep vt {prec}", vt[:, :, :, :T], vr.transpose(2, 3), 1e-6)
+    assert float(q[:, :, T:].abs().max()) == 0 and float(vt[:, :, :, T:].abs().max()) == 0, "padding must be zero"
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("T", [50, 250])
+def test_self_attention(gpu, prec, T):
+    B, H = 2, 2
+    Tp = (T + 63) // 64 * 64
+    D = H * 128
+    q, k, v = _mk((B, H, T, 128), 20), _mk((B, H, T, 128), 21), _mk((B, H, T, 128), 22)
+    q = q * 1.5  # sharpen the softmax a little
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[1, T - 13:] = False
+    pad = lambda z: torch.nn.functional.pad(z, (0, 0, 0, Tp - T))
+    qd, kd = util.as_act(pad(q), prec, gpu), util.as_act(pad(k), prec, gpu)
+    vtd = util.as_act(pad(v).transpose(2, 3), prec, gpu)
+    out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
+    hip.check(hip.lib().samaudio_op_self_attention(hip.ptr(qd), hip.ptr(kd), hip.ptr(vtd),
+                                                   hip.ptr(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec],
+                                                   B, T, Tp, H, util.stream()))
+    qq, kk, vv = util.rounded(q, prec), util.rounded(k, prec), util.rounded(v, prec)
+    s = (qq @ kk.transpose(-1, -2)) / math.sqrt(128)
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ vv).permute(0, 2, 1, 3).reshape(B * T, D)
+    # bf16: P is rounded to bf16 before P@V (2^-9 relative on weights that sum to 1) and so is the output
+    util.report(f"self_attention {prec} T{T}", out, want, 2e-5 if prec == "fp32" else 2e-2)
+
+
+@pytest.mark.parametrize("prec", PRECS)
+def test_cross_attention(gpu, prec):
+    B, T, Lt, H = 2, 40, 6, 2
+    D = H * 128
+    q, kv = _mk((B * T, D), 30), _mk((B * Lt, 2 * D), 31)
+    qw, kw = _mk((128,), 32, 0.1) + 1, _mk((128,), 33, 0.1) + 1
+    mask = torch.ones(B, Lt, dtype=torch.bool)
+    mask[1, 4:] = False
+    out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
+    kv_d = util.as_act(kv, prec, gpu)
+    hip.check(hip.lib().samaudio_op_cross_attention(
+        hip.ptr(util.as_act(q, prec, gpu)), hip.ptr(qw.to(gpu)), hip.ptr(kv_d), hip.ptr(kw.to(gpu)),
+        hip.ptr(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec], B, T, Lt, H, 1e-5, util.stream()))
+    qq = O.rms_norm(util.rounded(q, prec).reshape(B, T, H, 128).permute(0, 2, 1, 3), qw, 1e-5)
+    kk = O.rms_norm(util.rounded(kv[:, :D], prec).reshape(B, Lt, H, 128).permute(0, 2, 1, 3), kw, 1e-5)
+    if prec == "bf16":
+        kk = kk.to(torch.bfloat16).float()  # the normalised keys are stored back in bf16
+    vv = util.rounded(kv[:, D:], prec).reshape(B, Lt, H, 128).permute(0, 2, 1, 3)
+    s = (qq @ kk.transpose(-1, -2)) / math.sqrt(128)
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ vv).permute(0, 2, 1, 3).reshape(B * T, D)
+    util.report(f"cross_attention {prec}", out, want, 2e-5 if prec == "fp32" else 2e-2)
+
+
+def test_layernorm_accum(gpu):
+    M, D = 77, 512
+    x, w, b, acc = _mk((M, D), 40) * 3 + 1, _mk((D,), 41, 0.1) + 1, _mk((D,), 42, 0.1), _mk((M, D), 43)
+    gate = torch.tensor([0.7])
+    acc_d = acc.to(gpu)
+    hip.check(hip.lib().samaudio_op_layernorm_accum(hip.ptr(x.to(gpu)), hip.ptr(w.to(gpu)), hip.ptr(b.to(gpu)),
+                                                    hip.ptr(gate.to(gpu)), hip.ptr(acc_d), M, D, 1e-5, util.stream()))
+    want = acc + torch.tanh(gate) * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    util.report("layernorm_accum", acc_d, want, 1e-5)

@@ -1,0 +1,181 @@
+"""End-to-end parity of the HIP hot path (through the SAMAudio host class -> C ABI) against
+(i) the golden fixtures minted from the reference's own classes and (ii) the CPU oracle.
+
+Tolerance: BASELINE.json's north_star asks for 1e-3 max-abs on the generated latent.  fp32 mode is held
+to it (and typically lands ~1e-5); bf16 mode (bf16 GEMM operands, fp32 accumulation / residual stream /
+norms) is checked against looser, stated bounds and its measured error is printed - see DESIGN.md
+"Numerics".
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import samaudio_oracle as O
+from oracle.gen_golden import CASES, case_inputs
+from sam_audio_amd import SAMAudio, SAMAudioProcessor, preset_config
+from sam_audio_amd.synthetic import init_state_dict, synthetic_clip, synthetic_noise, synthetic_text_features
+from tests import util
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL = {"fp32": 1e-3, "bf16": 1.5e-1}
+
+
+def _model(cfg, sd, prec, gpu):
+    m = SAMAudio(cfg, precision=prec, device=str(gpu))
+    m.load_state_dict(sd, strict=False)
+    return m
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_forward_matches_reference_golden(gpu, prec, name):
+    inp = case_inputs(name)
+    cfg = inp["cfg"]
+    sd = init_state_dict(cfg, seed=inp["seed"], with_codec=False)
+    model = _model(cfg, sd, prec, gpu)
+    out = model.forward(inp["noisy"], inp["feats"], inp["text"], inp["time"], masked_video_features=inp["video"],
+                        text_mask=inp["text_mask"], anchor_ids=inp["anchor_ids"],
+                        anchor_alignment=inp["anchor_alignment"], audio_pad_mask=inp["pad_mask"])
+    gold = np.load(os.path.join(GOLDEN, f"forward_{name}.npz"))
+    util.report(f"forward {name} {prec}", out, torch.from_numpy(gold["out"]), TOL[prec])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_forward_optional_inputs(gpu, prec):
+    """No video (zeros, quirk Q8), default anchors (quirk Q9), shared scalar time, no pad mask."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=5, with_codec=False)
+    B, T, Lt = 2, 40, 3
+    g = torch.Generator().manual_seed(1)
+    noisy, z = torch.randn(B, T, 256, generator=g), torch.randn(B, T, 128, generator=g)
+    feats, text = torch.cat([z, z], 2), torch.randn(B, Lt, 768, generator=g)
+    time = torch.tensor([0.4375, 0.4375])
+    pad = torch.ones(B, T, dtype=torch.bool)
+    ids, align = O.anchors_to_ids(None, pad, 1920, 48000)
+    with torch.inference_mode():
+        want = O.samaudio_forward(sd, cfg, noisy, feats, text, time, video=torch.zeros(B, 1024, T),
+                                  text_mask=None, anchor_ids=ids, anchor_alignment=align, pad_mask=None)
+    model = _model(cfg, sd, prec, gpu)
+    out = model.forward(noisy, feats, text, time[:1], anchor_ids=ids, anchor_alignment=align)
+    util.report(f"forward optional {prec}", out, want, TOL[prec])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_codec_roundtrip_pieces(gpu, prec):
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=6)
+    hop = cfg.audio_codec.hop_length
+    wav = torch.stack([synthetic_clip(i, 3 * hop) for i in range(3)])  # [3,1,5760]
+    lat = torch.randn(4, 3, 128, generator=torch.Generator().manual_seed(2))
+    with torch.inference_mode():
+        z_ref = O.dac_encode(sd, cfg.audio_codec, wav).transpose(1, 2)
+        w_ref = O.dac_decode(sd, cfg.audio_codec, lat.transpose(1, 2)).squeeze(1)
+    model = _model(cfg, sd, prec, gpu)
+    z = model.encode_audio(wav)
+    w = model.decode_audio(lat)
+    util.report(f"codec encode {prec}", z, z_ref, 1e-3 if prec == "fp32" else 1e-1)
+    util.report(f"codec decode {prec}", w, w_ref, 1e-3 if prec == "fp32" else 1e-1)
+
+
+def test_codec_chunked_equals_unchunked(gpu, monkeypatch):
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=6)
+    model = _model(cfg, sd, "bf16", gpu)
+    lat = torch.randn(5, 2, 128, generator=torch.Generator().manual_seed(3))
+    full = model.decode_audio(lat).clone()
+    monkeypatch.setenv("SAMAUDIO_CODEC_CHUNK", "2")
+    model._workspace = None
+    part = model.decode_audio(lat)
+    assert torch.equal(full, part)
+
+
+@pytest.mark.parametrize("method", ["midpoint", "euler"])
+def test_separate_matches_oracle_fp32(gpu, method):
+    """Whole separate(): ragged clip lengths, ragged text mask, anchors, explicit CPU noise (quirk Q12)."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=7)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(0, 6 * hop), synthetic_clip(1, 4 * hop + 100)]
+    text, tmask = synthetic_text_features(2, 5, ragged=True)
+    anchors = [[("+", 0.04, 0.12)], [("-", 0.0, 0.08), ("+", 0.08, 0.16)]]
+    proc = SAMAudioProcessor.from_config(cfg)
+    batch = proc(descriptions=["x", "y"], audios=clips, anchors=anchors, text_features=text, text_mask=tmask)
+    noise = synthetic_noise(2, 6)
+    opt = {"method": method, "options": {"step_size": 1 / 4}}
+    with torch.inference_mode():
+        t_ref, r_ref, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise,
+                                           anchors=anchors, method=method, step_size=1 / 4)
+    model = _model(cfg, sd, "fp32", gpu)
+    res = model.separate(batch.to(gpu), noise=noise.to(gpu), ode_opt=opt)
+    util.report(f"separate latent {method}", model.last_latent, lat_ref, 1e-3)
+    assert [t.numel() for t in res.target] == [t.numel() for t in t_ref]
+    for got, want in zip(res.target + res.residual, t_ref + r_ref):
+        util.report("separate waveform", got, want, 1e-3)
+
+
+def test_separate_bf16_error_is_reported_and_bounded(gpu):
+    cfg = preset_config("mini")
+    sd = init_state_dict(cfg, seed=8)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 25 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 8)
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["x", "y"], audios=clips, text_features=text, text_mask=tmask)
+    noise = synthetic_noise(2, 25)
+    with torch.inference_mode():
+        _, _, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise, decode=False)
+    errs = {}
+    for prec in ("fp32", "bf16"):
+        model = _model(cfg, sd, prec, gpu)
+        model.separate(batch.to(gpu), noise=noise.to(gpu))
+        errs[prec] = (model.last_latent.cpu() - lat_ref).abs().max().item()
+    print(f"full 16-step midpoint ODE, 'mini' dims: latent max-abs err fp32 {errs['fp32']:.3e}, bf16 {errs['bf16']:.3e}"
+          f" (latent max {lat_ref.abs().max().item():.2f})")
+    assert errs["fp32"] < 1e-3
+    assert errs["bf16"] < 0.25
+
+
+def test_candidates_repeat_is_sample_major(gpu):
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=9)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 4 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 4)
+    proc = SAMAudioProcessor.from_config(cfg)
+    noise = synthetic_noise(4, 4)
+    model = _model(cfg, sd, "fp32", gpu)
+    opt = {"method": "euler", "options": {"step_size": 0.5}}
+    model.separate(proc(["x", "y"], clips, text_features=text, text_mask=tmask).to(gpu), noise=noise.to(gpu),
+                   ode_opt=opt, reranking_candidates=2)
+    lat2 = model.last_latent.clone()
+    # rows (0,1) belong to clip 0, rows (2,3) to clip 1: compare with single-candidate runs on the same noise rows
+    model.separate(proc(["x", "y"], clips, text_features=text, text_mask=tmask).to(gpu), noise=noise[[0, 2]].to(gpu),
+                   ode_opt=opt)
+    assert torch.equal(lat2[[0, 2]], model.last_latent)
+
+
+def test_batch_sharding_is_bitwise_invariant_at_full_width(gpu):
+    """concat(shard outputs) == whole-batch output, bit for bit, at the reference's default
+    width (D=2048; 2 layers keep it quick) and the real 10 s sequence length, bf16 mode."""
+    cfg = preset_config("default", transformer=dict(n_layers=2))
+    sd = init_state_dict(cfg, seed=10, device=gpu, with_codec=False)
+    B, T = 4, 250
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(B, T, 128, generator=g)
+    feats, text = torch.cat([z, z], 2), torch.randn(B, 8, 768, generator=g)
+    noise = synthetic_noise(B, T)
+    model = _model(cfg, sd, "bf16", gpu)
+    opt = {"method": "midpoint", "options": {"step_size": 0.5}}
+
+    def run(rows):
+        model._prepare(feats[rows], text[rows], None, None, None, None, None)
+        return model.solve(noise[rows].to(gpu), opt)
+
+    whole = run(slice(0, 4))
+    again = run(slice(0, 4))
+    assert torch.equal(whole, again), "run-to-run determinism"
+    parts = torch.cat([run(slice(0, 1)), run(slice(1, 4))])
+    assert torch.equal(whole, parts), "batch sharding changed the result"
+    assert torch.isfinite(whole).all()
