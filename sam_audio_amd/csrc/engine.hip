@@ -40,8 +40,10 @@ Status Engine::set_tensor(const char* name, const void* p, int dtype, int ndim, 
   t.p = p;
   t.dtype = dtype;
   t.shape.assign(shape, shape + ndim);
+  // Re-registering a name invalidates the resolved pointers: finalize() must run again.  Adding new names
+  // (e.g. the codec set after the DiT set) leaves an already finalized set valid.
+  if (tensors_.count(name)) dit_ready_ = codec_ready_ = false;
   tensors_[name] = t;
-  dit_ready_ = codec_ready_ = false;
   return Status{};
 }
 

@@ -18,6 +18,18 @@ pytestmark = pytest.mark.gpu
 PRECS = ["fp32", "bf16"]
 
 
+_KEEP = []
+
+
+def P(t):
+    """Device pointer of a freshly made tensor; the tensor is kept alive past the async launch (a bare
+    hip.ptr(x.to(gpu)) frees the temporary at once and the next .to(gpu) reuses its memory)."""
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        del _KEEP[:32]
+    return hip.ptr(t)
+
+
 def _mk(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -33,8 +45,8 @@ def test_rmsnorm_modulate(gpu, prec, shared_time):
     out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
     tab_d = tab.to(gpu)
     hip.check(hip.lib().samaudio_op_rmsnorm_mod(
-        hip.ptr(x.to(gpu)), hip.ptr(w.to(gpu)), C.c_void_p(tab_d[3].data_ptr()), C.c_void_p(tab_d[4].data_ptr()),
-        hip.ptr(t0.to(gpu)), 0 if shared_time else 6 * D, 3 * D, 4 * D, hip.ptr(out), util.PREC[prec], B * T, D, T,
+        P(x.to(gpu)), P(w.to(gpu)), C.c_void_p(tab_d[3].data_ptr()), C.c_void_p(tab_d[4].data_ptr()),
+        P(t0.to(gpu)), 0 if shared_time else 6 * D, 3 * D, 4 * D, hip.ptr(out), util.PREC[prec], B * T, D, T,
         1e-5, util.stream()))
     t0b = t0.expand(B, -1)
     shift = (tab[3][None] + t0b[:, 3 * D:4 * D]).repeat_interleave(T, 0)
@@ -50,7 +62,7 @@ def test_groupnorm_silu(gpu, prec):
     w, b = _mk((Cc,), 6, 0.1) + 1, _mk((Cc,), 7, 0.1)
     part = torch.zeros(B * 64 * 2, dtype=torch.float64, device=gpu)
     out = torch.zeros(B, T + 2 * halo, Cc, device=gpu, dtype=util.ACT_DT[prec])
-    hip.check(hip.lib().samaudio_op_groupnorm_silu(hip.ptr(x.to(gpu)), hip.ptr(w.to(gpu)), hip.ptr(b.to(gpu)),
+    hip.check(hip.lib().samaudio_op_groupnorm_silu(P(x.to(gpu)), P(w.to(gpu)), P(b.to(gpu)),
                                                    hip.ptr(part), hip.ptr(out), util.PREC[prec], B, T, Cc, halo, 1e-5,
                                                    util.stream()))
     want = torch.nn.functional.silu(O.group_norm_1(x, w, b))
@@ -74,8 +86,8 @@ def test_qkv_prep(gpu, prec):
     q = torch.full((B, H, Tp, 128), float("nan"), device=gpu, dtype=util.ACT_DT[prec])
     k, vt = torch.full_like(q, float("nan")), torch.full((B, H, 128, Tp), float("nan"), device=gpu, dtype=util.ACT_DT[prec])
     hip.check(hip.lib().samaudio_op_qkv_prep(
-        hip.ptr(util.as_act(qkv, prec, gpu)), hip.ptr(qw.to(gpu)), hip.ptr(kw.to(gpu)), hip.ptr(cos.to(gpu).contiguous()),
-        hip.ptr(sin.to(gpu).contiguous()), hip.ptr(q), hip.ptr(k), hip.ptr(vt), util.PREC[prec], B, T, Tp, H, 1e-5,
+        P(util.as_act(qkv, prec, gpu)), P(qw.to(gpu)), P(kw.to(gpu)), P(cos.to(gpu).contiguous()),
+        P(sin.to(gpu).contiguous()), hip.ptr(q), hip.ptr(k), hip.ptr(vt), util.PREC[prec], B, T, Tp, H, 1e-5,
         util.stream()))
     x = util.rounded(qkv, prec)
     heads = lambda z: z.reshape(B, T, H, 128).permute(0, 2, 1, 3)  # head-major columns
@@ -104,7 +116,7 @@ def test_self_attention(gpu, prec, T):
     vtd = util.as_act(pad(v).transpose(2, 3), prec, gpu)
     out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
     hip.check(hip.lib().samaudio_op_self_attention(hip.ptr(qd), hip.ptr(kd), hip.ptr(vtd),
-                                                   hip.ptr(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec],
+                                                   P(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec],
                                                    B, T, Tp, H, util.stream()))
     qq, kk, vv = util.rounded(q, prec), util.rounded(k, prec), util.rounded(v, prec)
     s = (qq @ kk.transpose(-1, -2)) / math.sqrt(128)
@@ -125,8 +137,8 @@ def test_cross_attention(gpu, prec):
     out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
     kv_d = util.as_act(kv, prec, gpu)
     hip.check(hip.lib().samaudio_op_cross_attention(
-        hip.ptr(util.as_act(q, prec, gpu)), hip.ptr(qw.to(gpu)), hip.ptr(kv_d), hip.ptr(kw.to(gpu)),
-        hip.ptr(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec], B, T, Lt, H, 1e-5, util.stream()))
+        P(util.as_act(q, prec, gpu)), P(qw.to(gpu)), hip.ptr(kv_d), P(kw.to(gpu)),
+        P(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec], B, T, Lt, H, 1e-5, util.stream()))
     qq = O.rms_norm(util.rounded(q, prec).reshape(B, T, H, 128).permute(0, 2, 1, 3), qw, 1e-5)
     kk = O.rms_norm(util.rounded(kv[:, :D], prec).reshape(B, Lt, H, 128).permute(0, 2, 1, 3), kw, 1e-5)
     if prec == "bf16":
@@ -143,7 +155,7 @@ def test_layernorm_accum(gpu):
     x, w, b, acc = _mk((M, D), 40) * 3 + 1, _mk((D,), 41, 0.1) + 1, _mk((D,), 42, 0.1), _mk((M, D), 43)
     gate = torch.tensor([0.7])
     acc_d = acc.to(gpu)
-    hip.check(hip.lib().samaudio_op_layernorm_accum(hip.ptr(x.to(gpu)), hip.ptr(w.to(gpu)), hip.ptr(b.to(gpu)),
-                                                    hip.ptr(gate.to(gpu)), hip.ptr(acc_d), M, D, 1e-5, util.stream()))
+    hip.check(hip.lib().samaudio_op_layernorm_accum(P(x.to(gpu)), P(w.to(gpu)), P(b.to(gpu)),
+                                                    P(gate.to(gpu)), hip.ptr(acc_d), M, D, 1e-5, util.stream()))
     want = acc + torch.tanh(gate) * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
     util.report("layernorm_accum", acc_d, want, 1e-5)
