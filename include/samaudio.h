@@ -114,6 +114,22 @@ int samaudio_codec_encode(samaudio_ctx* ctx, const float* wav, int items, int64_
 int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int frames, float* wav,
                           samaudio_stream stream);
 
+/* ---- measurement ----------------------------------------------------------------------------------- */
+
+/* Live per-kernel timing for bench.py's roofline leg (the reference has no counterpart: it publishes no
+ * throughput numbers).  Between begin and end every GEMM launch on the hot path is
+ * bracketed by a hipEvent pair recorded on the launch stream; end synchronises and returns, per GEMM tile
+ * variant, the number of launches, the summed ALGORITHMIC flops (2*M*N*K of the contraction, zero padding
+ * of K excluded) and the summed event time in ms. */
+typedef struct {
+  char name[64];
+  int64_t launches;
+  double flops;
+  double ms;
+} samaudio_kernel_stat;
+int samaudio_profile_begin(samaudio_ctx* ctx);
+int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capacity, int* count);
+
 /* ---- per-kernel hooks (parity tests; each is one kernel of the path above) -------------------------- */
 
 /* C[b] = epilogue(A(b) @ W^T): generalised GEMM / implicit conv, see sam_audio_amd/csrc/common.h GemmParams.

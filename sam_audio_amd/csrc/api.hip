@@ -101,6 +101,30 @@ int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int
   return ret(ctx->engine->codec_decode(latent, items, frames, wav, (hipStream_t)stream));
 }
 
+int samaudio_profile_begin(samaudio_ctx* ctx) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->profile_begin());
+}
+
+int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capacity, int* count) {
+  if (!ctx || !count || (capacity > 0 && !out)) return bad("samaudio_profile_end: null argument");
+  std::vector<sa::Engine::KernelStat> st;
+  const int rc = ret(ctx->engine->profile_end(st));
+  if (rc) return rc;
+  int n = 0;
+  for (const auto& k : st) {
+    if (n >= capacity) break;
+    std::memset(&out[n], 0, sizeof(out[n]));
+    std::strncpy(out[n].name, k.name.c_str(), sizeof(out[n].name) - 1);
+    out[n].launches = k.launches;
+    out[n].flops = k.flops;
+    out[n].ms = k.ms;
+    ++n;
+  }
+  *count = n;
+  return SAMAUDIO_OK;
+}
+
 // ---- per-kernel hooks ------------------------------------------------------------------------------
 int samaudio_op_gemm(const void* params_host, size_t params_bytes, int precision, samaudio_stream stream) {
   if (!params_host || params_bytes != sizeof(sa::GemmParams)) return bad("samaudio_op_gemm: GemmParams size mismatch");

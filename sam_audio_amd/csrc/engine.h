@@ -58,6 +58,17 @@ class Engine {
   Status codec_encode(const float* wav, int items, int64_t samples, float* latent, hipStream_t st);
   Status codec_decode(const float* latent, int items, int frames, float* wav, hipStream_t st);
 
+  // Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg): between begin and end
+  // every GEMM launch is bracketed by an event pair; end synchronises and folds them per tile variant.
+  struct KernelStat {
+    std::string name;
+    long launches = 0;
+    double flops = 0, ms = 0;
+  };
+  Status profile_begin();
+  Status profile_end(std::vector<KernelStat>& out);
+  ~Engine();
+
  private:
   struct DitBuffers;
   struct DitW;
@@ -67,7 +78,18 @@ class Engine {
                     hipStream_t st);
   Status plan_dit(Bump& b, int rows, int frames, int text_len, bool assign);
   size_t codec_bytes(int items, int64_t samples) const;
-  Status gemm(const GemmParams& p, hipStream_t st);
+  // alg_flops < 0: 2*M*N*K*nbatch (exact unless K carries zero padding, then the caller passes the true count)
+  Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0);
+  struct ProfRec {
+    int variant;
+    double flops;
+    hipEvent_t e0, e1;
+  };
+  bool prof_on_ = false;
+  std::vector<ProfRec> prof_;
+  std::vector<hipEvent_t> ev_pool_;
+  size_t ev_used_ = 0;
+  Status prof_event(hipEvent_t* e);
   const TensorRef* find(const std::string& name) const;
   Status need(const std::string& name, int dtype, std::vector<int64_t> shape, const void** out);
 

@@ -280,10 +280,61 @@ Status Engine::set_workspace(void* p, size_t bytes) {
   return Status{};
 }
 
-Status Engine::gemm(const GemmParams& p, hipStream_t st) {
+Status Engine::gemm(const GemmParams& p, hipStream_t st, double alg_flops) {
   if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
+  if (!prof_on_) {
+    SA_HIP(launch_gemm(p, bf16_, st));
+    return Status{};
+  }
+  ProfRec r;
+  r.variant = gemm_variant(p);
+  r.flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
+  SA_TRY(prof_event(&r.e0));
+  SA_TRY(prof_event(&r.e1));
+  SA_HIP(hipEventRecord(r.e0, st));
   SA_HIP(launch_gemm(p, bf16_, st));
+  SA_HIP(hipEventRecord(r.e1, st));
+  prof_.push_back(r);
   return Status{};
+}
+
+Status Engine::prof_event(hipEvent_t* e) {
+  if (ev_used_ == ev_pool_.size()) {
+    hipEvent_t ev;
+    SA_HIP(hipEventCreate(&ev));
+    ev_pool_.push_back(ev);
+  }
+  *e = ev_pool_[ev_used_++];
+  return Status{};
+}
+
+Status Engine::profile_begin() {
+  prof_.clear();
+  ev_used_ = 0;
+  prof_on_ = true;
+  return Status{};
+}
+
+Status Engine::profile_end(std::vector<KernelStat>& out) {
+  prof_on_ = false;
+  out.assign(3, KernelStat{});
+  for (int v = 0; v < 3; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  for (const ProfRec& r : prof_) {
+    SA_HIP(hipEventSynchronize(r.e1));
+    float ms = 0.f;
+    SA_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    KernelStat& k = out[r.variant];
+    k.launches += 1;
+    k.flops += r.flops;
+    k.ms += ms;
+  }
+  prof_.clear();
+  ev_used_ = 0;
+  return Status{};
+}
+
+Engine::~Engine() {
+  for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
 }
 
 static GemmParams lin(const void* A, long lda, const void* W, long M, int N, int K) {
@@ -593,7 +644,7 @@ Status Engine::codec_encode(const float* wav, int items, int64_t S, float* laten
       GemmParams p = lin(in8, 8, enc_.in_w, S, encC[0], 64);
       p.a_off = (long)(HALO - 3) * 8; p.a_bstride = (S + 2L * HALO) * 8; p.nbatch = n; p.bias = enc_.in_b;
       halo_out(p, sb[0].raw, sb[0].act, S, encC[0], ACT_SNAKE, enc_.s[0].r[0].a1);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, 2.0 * S * encC[0] * 7 * n));
     }
     for (int i = 0; i < 4; ++i) {
       const StageW& sw = enc_.s[i];
@@ -605,12 +656,12 @@ Status Engine::codec_encode(const float* wav, int items, int64_t S, float* laten
         GemmParams p = conv_same(sb[i].act, T, C, 7, dil[j], r.w1, r.k1pad, C, n);
         p.bias = r.b1;
         halo_out(p, nullptr, sb[i].tmp, T, C, ACT_SNAKE, r.a2);
-        SA_TRY(gemm(p, st));
+        SA_TRY(gemm(p, st, 2.0 * T * C * 7 * C * n));
         p = conv_same(sb[i].tmp, T, C, 1, 1, r.w2, r.k2pad, C, n);
         p.bias = r.b2;
         p.res = sb[i].raw; p.res_bstride = (T + 2L * HALO) * C; p.res_ld = C; p.res_off = (long)HALO * C;
         halo_out(p, sb[i].raw, sb[i].act, T, C, ACT_SNAKE, j < 2 ? sw.r[j + 1].a1 : sw.a);
-        SA_TRY(gemm(p, st));
+        SA_TRY(gemm(p, st, 2.0 * T * C * C * n));
       }
       // strided conv k = 2s, stride s, pad s/2: the 2s input rows of one output are contiguous
       const int pad = (s + 1) / 2;
@@ -691,7 +742,7 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
         p.f32_ld = p.act_ld = (long)s * C;
         p.f32_off = p.act_off = (long)(HALO - pad) * C;
         p.c_ld_rel = (long)s * C; p.c_lo = (long)pad * C; p.c_hi = (Tout + pad) * (long)C;
-        SA_TRY(gemm(p, st));
+        SA_TRY(gemm(p, st, 2.0 * Tout * C * 2 * Cin * n));
       }
       const int dil[3] = {1, 3, 9};
       for (int j = 0; j < 3; ++j) {
@@ -699,13 +750,13 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
         GemmParams p = conv_same(sb[i + 1].act, Tout, C, 7, dil[j], r.w1, r.k1pad, C, n);
         p.bias = r.b1;
         halo_out(p, nullptr, sb[i + 1].tmp, Tout, C, ACT_SNAKE, r.a2);
-        SA_TRY(gemm(p, st));
+        SA_TRY(gemm(p, st, 2.0 * Tout * C * 7 * C * n));
         p = conv_same(sb[i + 1].tmp, Tout, C, 1, 1, r.w2, r.k2pad, C, n);
         p.bias = r.b2;
         p.res = sb[i + 1].raw; p.res_bstride = (Tout + 2L * HALO) * C; p.res_ld = C; p.res_off = (long)HALO * C;
         const float* next_alpha = j < 2 ? sw.r[j + 1].a1 : (i < 3 ? dec_.s[i + 1].a : dec_.out_a);
         halo_out(p, sb[i + 1].raw, sb[i + 1].act, Tout, C, ACT_SNAKE, next_alpha);
-        SA_TRY(gemm(p, st));
+        SA_TRY(gemm(p, st, 2.0 * Tout * C * C * n));
       }
     }
     {  // conv k7 (C -> 1) + tanh
@@ -715,7 +766,7 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
       p.bias = dec_.out_b;
       p.act = ACT_TANH; p.f32_act = 1;
       p.out_f32 = wav + (long)i0 * T; p.f32_bstride = T; p.f32_ld = 1; p.f32_off = 0;
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, 2.0 * T * 7 * C * n));
     }
   }
   return Status{};

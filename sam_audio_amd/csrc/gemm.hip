@@ -205,14 +205,28 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// tile variant: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Narrow outputs (codec stages with 1 / 64 / 96 / 192
+// channels) use narrower N tiles.
+int gemm_variant(const GemmParams& p) {
+  const int N = p.N;
+  if (p.swiglu) return 0;
+  if (N <= 32 || N == 96) return 2;
+  if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N <= 448)) return 1;
+  return 0;
+}
+const char* gemm_variant_name(int v, bool is_bf16) {
+  static const char* names[2][3] = {{"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32"},
+                                    {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32"}};
+  return names[is_bf16 ? 1 : 0][v];
+}
+
 template <typename T>
 static hipError_t launch_t(const GemmParams& p, hipStream_t st) {
-  // narrow outputs (codec stages with 1 / 64 / 96 / 192 channels) use narrower N tiles
-  const int N = p.N;
-  if (p.swiglu) return launch_cfg<T, 128, 128, 2, 2>(p, st);
-  if (N <= 32 || N == 96) return launch_cfg<T, 128, 32, 4, 1>(p, st);
-  if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N <= 448)) return launch_cfg<T, 128, 64, 2, 2>(p, st);
-  return launch_cfg<T, 128, 128, 2, 2>(p, st);
+  switch (gemm_variant(p)) {
+    case 2: return launch_cfg<T, 128, 32, 4, 1>(p, st);
+    case 1: return launch_cfg<T, 128, 64, 2, 2>(p, st);
+    default: return launch_cfg<T, 128, 128, 2, 2>(p, st);
+  }
 }
 
 // host entry used by the engine and by the C-ABI test hook; is_bf16 selects the element type

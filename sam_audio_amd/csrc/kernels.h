@@ -7,6 +7,8 @@ namespace sa {
 
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
+int gemm_variant(const GemmParams& p);                    // which tile shape launch_gemm picks
+const char* gemm_variant_name(int variant, bool is_bf16);
 
 // out[m,:] = AT( rmsnorm(x[m,:]) * w * (1 + scale) + shift ),  shift = shift_tab + tvec[b, shift_off:],
 // scale likewise; b = m / rows_per_b; tvec_ld = 0 shares one conditioning row.  tvec == nullptr: no modulation.

@@ -54,6 +54,11 @@ class GemmParams(C.Structure):
     ]
 
 
+class KernelStat(C.Structure):
+    """Mirror of `samaudio_kernel_stat`."""
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("flops", C.c_double), ("ms", C.c_double)]
+
+
 _lib: Optional[C.CDLL] = None
 
 _PROTOS = {
@@ -71,6 +76,8 @@ _PROTOS = {
     "samaudio_ode_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_void_p]),
     "samaudio_codec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "samaudio_codec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "samaudio_profile_begin": (C.c_int, [C.c_void_p]),
+    "samaudio_profile_end": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
     "samaudio_op_gemm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "samaudio_op_rmsnorm_mod": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                              C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

@@ -157,6 +157,19 @@ class SAMAudio:
     def engine_tensors(self) -> Dict[str, torch.Tensor]:
         return self._tensors
 
+    # ------------------------------------------------------------------ measurement (bench.py)
+    def profile_begin(self) -> None:
+        """Bracket every GEMM launch with a hipEvent pair on the launch stream until profile_end()."""
+        hip.check(self._lib.samaudio_profile_begin(self._ctx))
+
+    def profile_end(self) -> List[Dict[str, Any]]:
+        """[{name, launches, flops, ms}] per GEMM tile variant since profile_begin() (synchronises)."""
+        buf = (hip.KernelStat * 8)()
+        n = C.c_int(0)
+        hip.check(self._lib.samaudio_profile_end(self._ctx, buf, 8, C.byref(n)))
+        return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), flops=float(buf[i].flops),
+                     ms=float(buf[i].ms)) for i in range(n.value)]
+
     # ------------------------------------------------------------------ workspace
     def _ensure_workspace(self, rows: int, frames: int, text_len: int, codec_items: int, samples: int) -> None:
         need = self._lib.samaudio_workspace_bytes(self._ctx, rows, frames, max(1, text_len), codec_items, samples)
