@@ -101,6 +101,8 @@ int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int
   return ret(ctx->engine->codec_decode(latent, items, frames, wav, (hipStream_t)stream));
 }
 
+void samaudio_debug_force_gemm_variant(int variant) { sa::gemm_force_variant(variant); }
+
 int samaudio_profile_begin(samaudio_ctx* ctx) {
   if (!ctx) return bad("null context");
   return ret(ctx->engine->profile_begin());
@@ -113,6 +115,7 @@ int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capac
   if (rc) return rc;
   int n = 0;
   for (const auto& k : st) {
+    if (k.launches == 0) continue;
     if (n >= capacity) break;
     std::memset(&out[n], 0, sizeof(out[n]));
     std::strncpy(out[n].name, k.name.c_str(), sizeof(out[n].name) - 1);

@@ -7,12 +7,12 @@ OUT=../libsamaudio_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in gemm kernels attention engine api; do
+for f in gemm gemm2 kernels attention engine api; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ ../../include/samaudio.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/kernels.o build/attention.o build/engine.o build/api.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/gemm2.o build/kernels.o build/attention.o build/engine.o build/api.o -o $OUT
 echo "built $OUT"

@@ -287,7 +287,7 @@ Status Engine::gemm(const GemmParams& p, hipStream_t st, double alg_flops) {
     return Status{};
   }
   ProfRec r;
-  r.variant = gemm_variant(p);
+  r.variant = gemm_variant(p, bf16_);
   r.flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
   SA_TRY(prof_event(&r.e0));
   SA_TRY(prof_event(&r.e1));
@@ -317,8 +317,8 @@ Status Engine::profile_begin() {
 
 Status Engine::profile_end(std::vector<KernelStat>& out) {
   prof_on_ = false;
-  out.assign(3, KernelStat{});
-  for (int v = 0; v < 3; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  out.assign(6, KernelStat{});
+  for (int v = 0; v < 6; ++v) out[v].name = gemm_variant_name(v, bf16_);
   for (const ProfRec& r : prof_) {
     SA_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;

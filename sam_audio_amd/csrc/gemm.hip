@@ -19,6 +19,7 @@
 //     chunk (exact fp32, k-ordered fma chain) - identical staging, identical fragment addressing.
 //   * accumulation order depends only on k => results are bitwise independent of M / batch sharding.
 #include "common.h"
+#include "kernels.h"
 
 namespace sa {
 
@@ -205,24 +206,39 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-// tile variant: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Narrow outputs (codec stages with 1 / 64 / 96 / 192
-// channels) use narrower N tiles.
-int gemm_variant(const GemmParams& p) {
+static int g_force = -1;
+void gemm_force_variant(int v) { g_force = v; }
+
+// tile variant of gemm.hip: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Narrow outputs (codec stages with 1 / 64 /
+// 96 / 192 channels) use narrower N tiles.
+static int gemm1_variant(const GemmParams& p) {
   const int N = p.N;
   if (p.swiglu) return 0;
   if (N <= 32 || N == 96) return 2;
   if (N <= 64 || (N % 128 != 0 && N % 64 == 0 && N <= 448)) return 1;
   return 0;
 }
+// Which kernel launch_gemm runs: 0..2 = gemm.hip tiles, 3 + v = gemm2.hip variant v (bf16 only).  The choice
+// depends on (N, K, epilogue) only - never on M or the batch count - so that sharding the batch cannot change
+// the accumulation order of any output element.
+int gemm_variant(const GemmParams& p, bool is_bf16) {
+  const bool g2 = is_bf16 && gemm2_ok(p);
+  if (g_force >= 3) return g2 ? g_force : gemm1_variant(p);
+  if (g_force >= 0) return gemm1_variant(p);
+  if (g2 && p.N >= 512 && p.K >= 256) return p.N >= 12288 ? 5 : 4;  // measured: tools/gemm_bench.py, DESIGN.md
+  return gemm1_variant(p);
+}
 const char* gemm_variant_name(int v, bool is_bf16) {
-  static const char* names[2][3] = {{"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32"},
-                                    {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32"}};
+  static const char* names[2][6] = {
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", ""},
+      {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
+       "gemm2_bf16_256x256_s2"}};
   return names[is_bf16 ? 1 : 0][v];
 }
 
 template <typename T>
-static hipError_t launch_t(const GemmParams& p, hipStream_t st) {
-  switch (gemm_variant(p)) {
+static hipError_t launch_t(const GemmParams& p, int variant, hipStream_t st) {
+  switch (variant) {
     case 2: return launch_cfg<T, 128, 32, 4, 1>(p, st);
     case 1: return launch_cfg<T, 128, 64, 2, 2>(p, st);
     default: return launch_cfg<T, 128, 128, 2, 2>(p, st);
@@ -231,7 +247,9 @@ static hipError_t launch_t(const GemmParams& p, hipStream_t st) {
 
 // host entry used by the engine and by the C-ABI test hook; is_bf16 selects the element type
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st) {
-  return is_bf16 ? launch_t<bf16_t>(p, st) : launch_t<float>(p, st);
+  const int v = gemm_variant(p, is_bf16);
+  if (v >= 3) return launch_gemm2(p, v - 3, st);
+  return is_bf16 ? launch_t<bf16_t>(p, v, st) : launch_t<float>(p, v, st);
 }
 
 const char* gemm_check(const GemmParams& p, bool is_bf16) {

@@ -7,8 +7,14 @@ namespace sa {
 
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
-int gemm_variant(const GemmParams& p);                    // which tile shape launch_gemm picks
+int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
+// gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
+bool gemm2_ok(const GemmParams& p);
+hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
+// test / tuning hook: force a variant for every eligible bf16 GEMM (-1 = automatic, 0..2 = gemm.hip tiles only,
+// 3.. = gemm2 variant when gemm2_ok)
+void gemm_force_variant(int v);
 
 // out[m,:] = AT( rmsnorm(x[m,:]) * w * (1 + scale) + shift ),  shift = shift_tab + tvec[b, shift_off:],
 // scale likewise; b = m / rows_per_b; tvec_ld = 0 shares one conditioning row.  tvec == nullptr: no modulation.

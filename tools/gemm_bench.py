@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""GEMM variant sweep on the real DiT shapes (run on the GPU box): correctness of every kernel variant against a
+torch fp32 matmul on the same bf16-rounded operands, then timing (HIP events on the launch stream, random data).
+
+    python tools/gemm_bench.py [--dims large*|default|small*] [--batch 32] [--iters 10]
+"""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+from sam_audio_amd import hip  # noqa: E402
+from sam_audio_amd.config import preset_config  # noqa: E402
+from tests import util  # noqa: E402
+
+VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2"}
+
+
+def interleave16(w1, w3):
+    F_, K = w1.shape
+    return torch.stack([w1.view(F_ // 16, 16, K), w3.view(F_ // 16, 16, K)], 1).reshape(2 * F_, K)
+
+
+def run_case(name, M, N, K, kind, dev, iters, T=250):
+    g = torch.Generator(device=dev).manual_seed(1)
+    A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
+    flops = 2.0 * M * N * K
+    kw = {}
+    if kind == "swiglu":
+        w1 = (torch.randn(N // 2, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        w3 = (torch.randn(N // 2, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        W = interleave16(w1, w3).contiguous()
+        ref = (F.silu(A.float() @ w1.float().T) * (A.float() @ w3.float().T))
+        out_act = torch.empty(M, N // 2, device=dev, dtype=torch.bfloat16)
+        kw = dict(swiglu=1, out_act=out_act, act_geom=(0, N // 2, 0))
+        outs = [("act", out_act, ref, 6e-2)]
+    else:
+        W = (torch.randn(N, K, generator=g, device=dev) / math.sqrt(K)).to(torch.bfloat16)
+        base = A.float() @ W.float().T
+        if kind == "plain":
+            out_act = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            kw = dict(out_act=out_act, act_geom=(0, N, 0))
+            outs = [("act", out_act, base, 6e-2)]
+        else:  # gated residual, fp32 + bf16 outputs (wo / w2 epilogue)
+            B = (M + T - 1) // T
+            tab = torch.randn(N, generator=g, device=dev)
+            gate = torch.randn(B, 6 * N, generator=g, device=dev)
+            res = torch.randn(M, N, generator=g, device=dev)
+            out = torch.empty(M, N, device=dev)
+            out_act = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            rows = torch.arange(M, device=dev) // T
+            ref = base * (tab[None] + gate[rows, 2 * N:3 * N]) + res
+            gsl = gate[:, 2 * N:]
+            kw = dict(gate_tab=tab, gate=gsl, gate_ld=6 * N, rows_per_gate=T, res=res, res_geom=(0, N, 0), out_f32=out,
+                      f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
+            outs = [("f32", out, ref, 2e-3), ("act", out_act, ref, 1e-1)]
+    line = f"{name:>22s} M={M} N={N} K={K} {kind:7s}"
+    for v, vname in VARIANTS.items():
+        hip.lib().samaudio_debug_force_gemm_variant(v)
+        for _, o, _, _ in outs:
+            o.fill_(float("nan"))
+        util.gemm("bf16", A, W, M, N, K, **kw)
+        torch.cuda.synchronize()
+        errs = []
+        ok = True
+        for oname, o, ref, tol in outs:
+            e = (o.float() - ref).abs().max().item()
+            errs.append(f"{oname} {e:.1e}")
+            ok &= e <= tol and bool(torch.isfinite(o.float()).all())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            util.gemm("bf16", A, W, M, N, K, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        line += f" | {vname}: {us:8.1f} us {flops / us / 1e6:7.1f} TF {'ok' if ok else 'WRONG'} ({', '.join(errs)})"
+    hip.lib().samaudio_debug_force_gemm_variant(-1)
+    print(line, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dims", default="large*")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    t = preset_config(args.dims).transformer
+    D, Fh = t.dim, t.ffn_hidden
+    M = args.batch * 250
+    # small correctness shapes first: ragged M, N tails, several K
+    run_case("edge small", 300, 640, 192, "plain", dev, 2)
+    run_case("edge gated", 517, 1152, 320, "gated", dev, 2, T=47)
+    run_case("edge swiglu", 333, 1280, 256, "swiglu", dev, 2)
+    if args.quick:
+        return
+    run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
+    run_case("wo/c_wo (gate+res)", M, D, D, "gated", dev, args.iters)
+    run_case("c_wq", M, D, D, "plain", dev, args.iters)
+    run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
+    run_case("w2 (gate+res)", M, D, Fh, "gated", dev, args.iters)
+    run_case("c_wkv (text rows)", args.batch * 8, 2 * D, D, "plain", dev, args.iters)
+
+
+if __name__ == "__main__":
+    main()
