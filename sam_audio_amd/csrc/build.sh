@@ -9,7 +9,11 @@ mkdir -p build
 pids=()
 for f in gemm gemm2 kernels attention engine api; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ ../../include/samaudio.h -nt build/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o build/$f.o &
+    EXTRA=""
+    # gemm2.hip: the fully unrolled 4x4-fragment epilogue exceeds clang's default pragma-unroll budget; without the
+    # full unroll the accumulator array is indexed dynamically and lands in scratch memory.
+    if [ $f = gemm2 ]; then EXTRA="-mllvm -pragma-unroll-threshold=262144"; fi
+    hipcc $FLAGS $EXTRA -c $f.hip -o build/$f.o &
     pids+=($!)
   fi
 done

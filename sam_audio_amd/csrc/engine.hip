@@ -317,8 +317,8 @@ Status Engine::profile_begin() {
 
 Status Engine::profile_end(std::vector<KernelStat>& out) {
   prof_on_ = false;
-  out.assign(6, KernelStat{});
-  for (int v = 0; v < 6; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  out.assign(16, KernelStat{});
+  for (int v = 0; v < 16; ++v) out[v].name = gemm_variant_name(v, bf16_);
   for (const ProfRec& r : prof_) {
     SA_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;

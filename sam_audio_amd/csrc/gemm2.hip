@@ -36,29 +36,128 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float act_apply(float v, int act) {
+__device__ __forceinline__ float act_apply(float v, int act, float snake_alpha) {
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_SNAKE) {  // x + sin^2(a x) / a; the result feeds a bf16 operand, so the hardware sine suffices
+    const float sn = __sinf(snake_alpha * v);
+    return v + sn * sn / (snake_alpha + 1e-9f);
+  }
   return v;
 }
 
 }  // namespace
 
-template <int BM, int BN, int WM_, int WN_, int STAGES>
-__global__ __launch_bounds__(WM_* WN_ * 64) void gemm2_kernel(const GemmParams p) {
+// ---- epilogue shared by the gemm2 / gemm3 kernels -----------------------------------------------------------
+// swapped operands: D[n][m]; a lane holds m = m_first + i*32 + l31 and, per 32x32 fragment j, the columns
+// n = n_first + j*32 + 8*g + 4*lh + (0..3) for register group g = reg>>2.  Per fragment all loads (bias / gate /
+// residual, float4 each) are issued first, then the arithmetic, then 16-byte fp32 / 8-byte bf16 stores.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[FM][FN], int b, int m_first,
+                                              int n_first, int l31, int lh) {
+  const long bM = (long)b * p.M;
+  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
+             has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
+  const int NG = p.swiglu ? 2 : 4;       // swiglu: groups 0,1 = w1 rows of the 32-row block, groups 2,3 = matching w3 rows
+  const int n_out = p.swiglu ? p.N >> 1 : p.N;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m_first + i * 32 + l31;
+    const bool m_ok = m < p.M;
+    const int mc = m_ok ? m : p.M - 1;
+    const float* grow = has_gate ? p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld : nullptr;
+    const float* rrow = has_res ? p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld : nullptr;
+    float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld : nullptr;
+    bf16_t* arow = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int nf = n_first + j * 32;  // first GEMM column of this 32-wide fragment
+      const int nb = (p.swiglu ? nf >> 1 : nf) + 4 * lh;
+      // two register groups (8 output columns per lane) per round trip: 32 registers of loads in flight
+#pragma unroll
+      for (int gp = 0; gp < 4; gp += 2) {
+        if (gp >= NG) continue;
+        int ncol[2];
+        float4 bb[2], gg[2], tt[2], rr[2], sa[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int n = nb + 8 * (gp + u);
+          ncol[u] = n;
+          const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+          const int ch = p.chan_mod ? nc % p.chan_mod : nc;  // channel of a (phase, channel) column: transposed conv
+          if (has_bias) bb[u] = *(const float4*)(p.bias + ch);
+          if (has_snake) sa[u] = *(const float4*)(p.act_alpha + ch);
+          if (has_gate) gg[u] = *(const float4*)(grow + nc);
+          if (has_tab) tt[u] = *(const float4*)(p.gate_tab + nc);
+          if (has_res) rr[u] = *(const float4*)(rrow + nc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int g = gp + u;
+          float v[4];
+          if (p.swiglu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[i][j][4 * g + e]) * acc[i][j][4 * ((g + 2) & 3) + e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          }
+          if (has_bias) { v[0] += bb[u].x; v[1] += bb[u].y; v[2] += bb[u].z; v[3] += bb[u].w; }
+          if (has_gate) {
+            float4 q = gg[u];
+            if (has_tab) { q.x += tt[u].x; q.y += tt[u].y; q.z += tt[u].z; q.w += tt[u].w; }
+            v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+          if (has_res) { v[0] += rr[u].x; v[1] += rr[u].y; v[2] += rr[u].z; v[3] += rr[u].w; }
+          float a[4];
+          a[0] = act_apply(v[0], p.act, has_snake ? sa[u].x : 0.f);
+          a[1] = act_apply(v[1], p.act, has_snake ? sa[u].y : 0.f);
+          a[2] = act_apply(v[2], p.act, has_snake ? sa[u].z : 0.f);
+          a[3] = act_apply(v[3], p.act, has_snake ? sa[u].w : 0.f);
+          bool ok = m_ok && ncol[u] < n_out;
+          if (p.c_ld_rel) {  // transposed conv: keep only the (row, phase) pairs that fall inside the output
+            const long erel = (long)m * p.c_ld_rel + ncol[u];
+            ok = ok && erel >= p.c_lo && erel < p.c_hi;
+          }
+          if (ok) {
+            if (frow) {
+              if (p.f32_act) *(float4*)(frow + ncol[u]) = make_float4(a[0], a[1], a[2], a[3]);
+              else *(float4*)(frow + ncol[u]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (arow) store4<bf16_t>(arow + ncol[u], a[0], a[1], a[2], a[3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// BK = k-elements per LDS slab (64: 128-byte rows, 8 chunks, swizzle (row>>1)&7;  32: 64-byte rows, 4 chunks,
+// swizzle (row>>2)&3 - both make the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte bank slots).
+// 4-wave configurations (BK = 32, <= 80 KiB LDS) run TWO workgroups per CU: the two are not barrier-coupled, so
+// one's MFMAs cover the other's barrier / LDS-latency / epilogue time.
+template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
+__global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 256 ? 1 : 2)) void gemm2_kernel(
+    const GemmParams p) {
   constexpr int NW = WM_ * WN_;
-  constexpr int NT = NW * 64;
   constexpr int WTM = BM / WM_, WTN = BN / WN_;
   constexpr int FM = WTM / 32, FN = WTN / 32;
-  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);  // DMA instructions per wave per slab
+  constexpr int RB = BK * 2;        // bytes per LDS row
+  constexpr int CPR = RB / 16;      // 16-byte chunks per row
+  constexpr int RPI = 1024 / RB;    // rows filled by one wave-wide DMA instruction
+  constexpr int KS = BK / 16;       // MFMA k-steps per slab
+  constexpr int AI = BM / (RPI * NW), BI = BN / (RPI * NW);  // DMA instructions per wave per slab
   constexpr int G = AI + BI;
-  constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
-  constexpr int BK = 64, CH = 8;
-  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
+  constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
+  constexpr int CH = 8;
+  static_assert(BK == 64 || BK == 32, "BK");
+  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
   static_assert(STAGES >= 2 && STAGES * STAGE <= 160 * 1024, "LDS budget");
   static_assert((STAGES - 2) * G <= 63, "vmcnt range");
+  static_assert(NW % 2 == 0, "swizzle bookkeeping assumes an even wave count");
   __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE];
-  (void)NT;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -89,23 +188,24 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm2_kernel(const GemmParams p
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- per-lane DMA sources (see gemm.hip): wave-instruction j = wave + NW*i fills tile rows 8j..8j+7 ----
-  const int r8 = lane >> 3;
-  const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
+  // ---- per-lane DMA sources (see gemm.hip): wave-instruction j = wave + NW*i fills tile rows RPI*j .. RPI*j+RPI-1;
+  // lane -> (row RPI*j + lane/CPR, 16-byte slot lane%CPR); slot s of row r holds source chunk s ^ swz(r) ----
+  const int r8 = lane / CPR;
+  const int chunk = BK == 64 ? (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7) : (lane & 3) ^ ((r8 >> 2) & 3);
   const bf16_t* a_rows[AI];
   const bf16_t* w_rows[BI];
   {
     const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      int m = m0 + (wave + NW * i) * 8 + r8;
+      int m = m0 + (wave + NW * i) * RPI + r8;
       m = m < p.M ? m : p.M - 1;
       a_rows[i] = A + (long)m * p.lda;
     }
     const bf16_t* W = (const bf16_t*)p.W;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      int n = n0 + (wave + NW * i) * 8 + r8;
+      int n = n0 + (wave + NW * i) * RPI + r8;
       n = n < p.N ? n : p.N - 1;
       w_rows[i] = W + (long)n * p.K + chunk * CH;
     }
@@ -128,16 +228,18 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm2_kernel(const GemmParams p
   };
 
   f32x16_t acc[FM][FN];
+  {
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
+  }
 
   const int l31 = lane & 31, lh = lane >> 5;
-  const int swz = (l31 >> 1) & 7;  // (row>>1)&7 for every fragment row of this lane (fragment bases are multiples of 32)
-  const int a_base = (wm * WTM + l31) * 128, b_base = (wn * WTN + l31) * 128;
+  // swizzle of every fragment row of this lane (fragment bases are multiples of 32 rows)
+  const int swz = BK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+  const int a_base = (wm * WTM + l31) * RB, b_base = (wn * WTN + l31) * RB;
 
   const int nslab = p.K / BK;
   // prologue: STAGES-1 slabs in flight
@@ -155,13 +257,13 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm2_kernel(const GemmParams p
     const char* sA = smem + st_c * STAGE;
     const char* sB = sA + TILE_A;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int coff = ((ks * 2 + lh) ^ swz) << 4;
       bf16x8_t af[FM], wf[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(sA + a_base + i * 32 * 128 + coff);
+      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(sA + a_base + i * 32 * RB + coff);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(sB + b_base + j * 32 * 128 + coff);
+      for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(sB + b_base + j * 32 * RB + coff);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -172,85 +274,211 @@ __global__ __launch_bounds__(WM_* WN_ * 64) void gemm2_kernel(const GemmParams p
     st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
   }
 
-  // ---- epilogue --------------------------------------------------------------------------------------
-  // swapped operands: D[n][m]; lane holds m = l31, n = 8*g + 4*lh + (0..3) for register group g = reg>>2.
-  // Per 32x32 fragment: all loads (bias / gate / residual, float4 each) are issued first, then the arithmetic,
-  // then the 16-byte fp32 / 8-byte bf16 stores - one memory round trip per fragment instead of one per value.
-  const long bM = (long)b * p.M;
-  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
-             has_res = p.res != nullptr;
-  const int NG = p.swiglu ? 2 : 4;       // swiglu: groups 0,1 = w1 rows of the 32-row block, groups 2,3 = matching w3 rows
-  const int n_out = p.swiglu ? p.N >> 1 : p.N;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m0 + wm * WTM + i * 32 + l31;
-    const bool m_ok = m < p.M;
-    const int mc = m_ok ? m : p.M - 1;
-    const float* grow = has_gate ? p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld : nullptr;
-    const float* rrow = has_res ? p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld : nullptr;
-    float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld : nullptr;
-    bf16_t* arow = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld : nullptr;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nf = n0 + wn * WTN + j * 32;  // first GEMM column of this 32-wide fragment
-      const int nb = (p.swiglu ? nf >> 1 : nf) + 4 * lh;
-      int ncol[4];
-      float4 bb[4], gg[4], tt[4], rr[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = nb + 8 * g;
-        ncol[g] = n;
-        const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
-        if (has_bias) bb[g] = *(const float4*)(p.bias + nc);
-        if (has_gate) gg[g] = *(const float4*)(grow + nc);
-        if (has_tab) tt[g] = *(const float4*)(p.gate_tab + nc);
-        if (has_res) rr[g] = *(const float4*)(rrow + nc);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g >= NG) continue;
-        float v[4];
-        if (p.swiglu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[i][j][4 * g + e]) * acc[i][j][4 * ((g + 2) & 3) + e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-        }
-        if (has_bias) { v[0] += bb[g].x; v[1] += bb[g].y; v[2] += bb[g].z; v[3] += bb[g].w; }
-        if (has_gate) {
-          float4 q = gg[g];
-          if (has_tab) { q.x += tt[g].x; q.y += tt[g].y; q.z += tt[g].z; q.w += tt[g].w; }
-          v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-        if (has_res) { v[0] += rr[g].x; v[1] += rr[g].y; v[2] += rr[g].z; v[3] += rr[g].w; }
-        float a[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = act_apply(v[e], p.act);
-        if (m_ok && ncol[g] < n_out) {
-          if (frow) {
-            if (p.f32_act) *(float4*)(frow + ncol[g]) = make_float4(a[0], a[1], a[2], a[3]);
-            else *(float4*)(frow + ncol[g]) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-          if (arow) store4<bf16_t>(arow + ncol[g], a[0], a[1], a[2], a[3]);
-        }
-      }
-    }
-  }
+  gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES>
+// ---- gemm3: role-split ("ping-pong") main loop ---------------------------------------------------------------
+// PMC on gemm2 (profiles/r1_pmc_gemm): MFMA busy 42 %, no LDS bank conflicts, L2 hit 81 %, waves parked 40 % of
+// their cycles in s_waitcnt / s_barrier - all 8 waves read LDS together and then fight for the matrix pipe together.
+// Here the two waves that share a SIMD (wave w and w+4: groups 0 and 1) run ONE PHASE APART: while group 0 issues
+// the MFMAs of a half-slab from registers (s_setprio 1, nothing else in the stream), group 1 fetches its next
+// fragments from LDS (+ issues the next slab's DMA), then they swap.  Every phase boundary is one s_barrier for all
+// 8 waves; group 1 simply idles through the first phase.  Fragments of a phase live in registers (KSP k-steps:
+// KSP*(FM+FN) ds_read_b128 per wave), two LDS stages, BK = 64.
+//   global phase p, group g: local step q = p - g;  q even -> R(h = q/2): ds_reads of half-slab h (+ DMA of slab
+//   s+1 when h is the first half of slab s);  q odd -> M(h): MFMAs of half-slab h.
+//   Slab s is read during global phases [2*HPS*s, 2*HPS*(s+1)) only, so the DMA of slab s+1 (same stage as slab
+//   s-1) may start at phase 2*HPS*s and must have landed before phase 2*HPS*(s+1): every wave drains its own
+//   vmcnt before the barrier that ends phase 2*HPS*(s+1)-1.
+// ABL (tuning only, wrong results): 1 = no DMA after the prologue, 2 = no MFMA, 3 = no LDS fragment reads.
+template <int BM, int BN, int WM_, int WN_, int KSP, int NS, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
+  constexpr int NW = 8;
+  static_assert(WM_ * WN_ == NW && (WM_ == 2 || WN_ == 2), "8 waves; the 2-wide axis is the group axis");
+  constexpr int WTM = BM / WM_, WTN = BN / WN_;
+  constexpr int FM = WTM / 32, FN = WTN / 32;
+  constexpr int BK = 64, RB = 128, CH = 8, KS = 4;
+  constexpr int HPS = KS / KSP;  // phases pairs ("half-slabs") per slab
+  static_assert(KSP == 2 || KSP == 4, "KSP");
+  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
+  constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
+  constexpr int G = AI + BI;
+  static_assert(BM % 64 == 0 && BN % 64 == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile");
+  static_assert((NS == 2 || NS == 3) && NS * STAGE <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // waves w and w+4 share a SIMD
+  const int wm = WM_ == 2 ? grp : (wave & 3), wn = WM_ == 2 ? (wave & 3) : grp;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int per_batch = tiles_m * tiles_n;
+  int b, tm, tn;
+  {
+    const int total = per_batch * p.nbatch;
+    const int bid = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    b = L / per_batch;
+    const int l2 = L - b * per_batch;
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n;
+    const int gi = l2 / per_group;
+    const int first_m = gi * GM;
+    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    const int in_grp = l2 - gi * per_group;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // DMA bookkeeping kept to a handful of registers (the accumulators and the phase's fragments own the file):
+  // piece i of this wave covers tile row (wave + 8*i)*8 + r8; its source address is rebuilt at issue time from
+  // the clamped global row and the running k offset.
+  const int r8 = lane >> 3;
+  const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
+  const bf16_t* const Abase = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+  const bf16_t* const Wbase = (const bf16_t*)p.W;
+  const int row0 = wave * 8 + r8;
+  int a_in = chunk * CH;
+  long a_tap = 0;
+  while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
+  int w_k = chunk * CH;
+
+  auto issue = [&](int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + TILE_A;
+    const long a_k = a_tap + a_in;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      int m = m0 + row0 + 64 * i;
+      m = m < p.M ? m : p.M - 1;
+      dma16(Abase + (long)m * p.lda + a_k, sA + (wave + NW * i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int n = n0 + row0 + 64 * i;
+      n = n < p.N ? n : p.N - 1;
+      dma16(Wbase + (long)n * p.K + w_k, sB + (wave + NW * i) * 1024);
+    }
+    a_in += BK;
+    while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
+    w_k += BK;
+  };
+
+  f32x16_t acc[FM][FN];
+  {
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+  const int a_base = (wm * WTM + l31) * RB, b_base = TILE_A + (wn * WTN + l31) * RB;
+
+  const int nslab = p.K / BK;
+  bf16x8_t af[KSP][FM], wf[KSP][FN];
+
+  auto phase_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: NS-1 slabs in flight, slab 0 landed
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nslab) issue(s);
+  if (NS == 3 && nslab > 1) wait_vmcnt<G>();
+  else wait_vmcnt<0>();
+  phase_barrier();
+  // Both groups run the same straight-line program  R(h) | M(h) | R(h+1) | M(h+1) ...  with one barrier per
+  // phase; group 1 executes one extra barrier first (so it runs one phase behind) and group 0 one extra at the end.
+  // Slab s+NS-1 is DMA'd into the stage slab s-1 occupied (last read in global phase 2*HPS*s-1) from phase
+  // 2*HPS*s on; slab s+1 must have landed before phase 2*HPS*(s+1): each wave drains its own share (all but the
+  // G pieces of slab s+2 when NS = 3) before the barrier that ends phase 2*HPS*(s+1)-1.
+  auto drain = [&](int s) {
+    if (NS == 3 && s + 2 < nslab) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+  };
+  if (grp == 1) phase_barrier();
+  int st_c = 0, st_i = NS - 1;
+  for (int s = 0; s < nslab; ++s) {
+    const char* st = smem + st_c * STAGE;
+#pragma unroll
+    for (int hh = 0; hh < HPS; ++hh) {
+      // ---- R: fragments of this half-slab -> registers (+ DMA of a later slab behind the first half)
+      if (ABL != 1 && hh == 0 && s + NS - 1 < nslab) issue(st_i);
+      if (ABL != 3 || s == 0) {
+#pragma unroll
+        for (int kk = 0; kk < KSP; ++kk) {
+          const int coff = ((((hh * KSP + kk) << 1) + lh) ^ swz) << 4;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[kk][i] = *(const bf16x8_t*)(st + a_base + i * 32 * RB + coff);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wf[kk][j] = *(const bf16x8_t*)(st + b_base + j * 32 * RB + coff);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the stage may be overwritten
+      if (hh == HPS - 1 && grp == 1) drain(s);             // group 1: this is global phase 2*HPS*(s+1)-1
+      phase_barrier();
+      // ---- M: matrix pipe only
+      __builtin_amdgcn_s_setprio(1);
+      if (ABL == 2 && s > 0) {  // keep the fragments alive without touching the matrix pipe
+#pragma unroll
+        for (int kk = 0; kk < KSP; ++kk) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[kk][i]));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(wf[kk][j]));
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KSP; ++kk)
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (hh == HPS - 1 && grp == 0) drain(s);             // group 0: this is global phase 2*HPS*(s+1)-1
+      phase_barrier();
+    }
+    st_c = st_c + 1 == NS ? 0 : st_c + 1;
+    st_i = st_i + 1 == NS ? 0 : st_i + 1;
+  }
+  if (grp == 0) phase_barrier();
+
+  gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
+}
+
+template <int BM, int BN, int WM_, int WN_, int KSP, int NS, int ABL = 0>
+static hipError_t launch3(const GemmParams& p, hipStream_t st) {
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM_, WN_, KSP, NS, ABL>), dim3((unsigned)tiles), dim3(512), 0, st, p);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
 static hipError_t launch2(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0, st, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES, BK>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0, st,
+                     p);
   return hipGetLastError();
 }
 
 // Can this problem take the vectorised-epilogue kernels?  (everything else stays on gemm.hip)
 bool gemm2_ok(const GemmParams& p) {
-  if (p.chan_mod || p.c_ld_rel || p.act == ACT_SNAKE) return false;
+  if ((p.chan_mod & 3) || (p.c_ld_rel & 3) || (p.c_lo & 3) || (p.c_hi & 3)) return false;
+  if (p.act == ACT_SNAKE && (!p.act_alpha || ((uintptr_t)p.act_alpha & 15))) return false;
   if (p.N % 4 || p.K % 64) return false;
   if (p.swiglu && p.N % 32) return false;
   auto al4 = [](long v) { return (v & 3) == 0; };
@@ -265,12 +493,25 @@ bool gemm2_ok(const GemmParams& p) {
   return true;
 }
 
-// variants: 0 = 256x128 3-stage, 1 = 256x128 2-stage, 2 = 256x256 2-stage
+// variants: 0 = 256x128 3-stage, 1 = 256x128 2-stage, 2 = 256x256 2-stage (8 waves, BK 64, one workgroup per CU);
+//           3 = 128x256 3-stage, 4 = 256x128 3-stage, 5 = 128x256 2-stage (4 waves, BK 32, two workgroups per CU);
+//           6 = 256x256 ping-pong (half-slab phases, 2 stages), 7 = 256x128 ping-pong (whole-slab phases, 3 stages),
+//           8 = 256x128 ping-pong (half-slab phases, 3 stages)
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
   switch (variant) {
-    case 2: return launch2<256, 256, 2, 4, 2>(p, st);
-    case 1: return launch2<256, 128, 4, 2, 2>(p, st);
-    default: return launch2<256, 128, 4, 2, 3>(p, st);
+    case 12: return launch2<256, 256, 2, 2, 2, 64>(p, st);  // 4 waves, one per SIMD, 128x128 wave tiles (512 registers)
+    case 11: return launch3<256, 256, 2, 4, 2, 2, 3>(p, st);  // ablations (tools/gemm_bench.py --ablate)
+    case 10: return launch3<256, 256, 2, 4, 2, 2, 2>(p, st);
+    case 9: return launch3<256, 256, 2, 4, 2, 2, 1>(p, st);
+    case 8: return launch3<256, 128, 4, 2, 2, 3>(p, st);
+    case 7: return launch3<256, 128, 4, 2, 4, 3>(p, st);
+    case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
+    case 5: return launch2<128, 256, 1, 4, 2, 32>(p, st);
+    case 4: return launch2<256, 128, 2, 2, 3, 32>(p, st);
+    case 3: return launch2<128, 256, 1, 4, 3, 32>(p, st);
+    case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);
+    case 1: return launch2<256, 128, 4, 2, 2, 64>(p, st);
+    default: return launch2<256, 128, 4, 2, 3, 64>(p, st);
   }
 }
 

@@ -164,9 +164,9 @@ class SAMAudio:
 
     def profile_end(self) -> List[Dict[str, Any]]:
         """[{name, launches, flops, ms}] per GEMM tile variant since profile_begin() (synchronises)."""
-        buf = (hip.KernelStat * 8)()
+        buf = (hip.KernelStat * 16)()
         n = C.c_int(0)
-        hip.check(self._lib.samaudio_profile_end(self._ctx, buf, 8, C.byref(n)))
+        hip.check(self._lib.samaudio_profile_end(self._ctx, buf, 16, C.byref(n)))
         return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), flops=float(buf[i].flops),
                      ms=float(buf[i].ms)) for i in range(n.value)]
 

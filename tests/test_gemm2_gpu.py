@@ -1,0 +1,130 @@
+"""Parity of the 256-row-tile bf16 GEMM kernels (sam_audio_amd/csrc/gemm2.hip: gemm2 ring kernels and the
+gemm3 role-split kernels) through the C ABI, every tile variant forced in turn.
+
+Checker: plain PyTorch fp32 on the CPU on the same bf16-rounded operands.  Tolerances: products of bf16 values are
+exact in fp32 and the accumulation is fp32, so fp32 outputs agree to summation-order noise (<= 5e-4 at K <= 1344
+on O(1) data); bf16 outputs add half a bf16 ulp (2^-9 relative to |value| <= 8 -> 3.2e-2).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sam_audio_amd import hip
+from tests import util
+
+pytestmark = pytest.mark.gpu
+# 3 = 256x128 3-stage ring, 4 = 256x128 2-stage, 5 = 256x256 2-stage, 6/7 = 4-wave BK32, 9 = 256x256 role-split,
+# 10/11 = 256x128 role-split (3 LDS stages), 15 = 256x256 4-wave
+VARIANTS = [3, 4, 5, 6, 7, 9, 10, 11, 15]
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.fixture(autouse=True)
+def _restore_variant():
+    yield
+    hip.lib().samaudio_debug_force_gemm_variant(-1)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("M,N,K", [(300, 640, 192), (517, 1152, 320), (1000, 384, 1024), (250, 2816, 256), (64, 96, 704)])
+def test_plain_tails(gpu, variant, M, N, K):
+    hip.lib().samaudio_debug_force_gemm_variant(variant)
+    A, W = _mk((M, K), 1), _mk((N, K), 2, 1 / math.sqrt(K))
+    out = torch.full((M, N), float("nan"), device=gpu)
+    util.gemm("bf16", util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), M, N, K, out_f32=out, f32_geom=(0, N, 0))
+    want = util.rounded(A, "bf16") @ util.rounded(W, "bf16").T
+    util.report(f"gemm2 v{variant} {M}x{N}x{K}", out, want, 5e-4)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_asymmetric_identity(gpu, variant):
+    """A = I with an asymmetric W catches transposed / permuted output fragments exactly."""
+    hip.lib().samaudio_debug_force_gemm_variant(variant)
+    n = 512
+    A = torch.eye(n)
+    W = ((torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251) / 8.0).to(torch.bfloat16).float()
+    out = torch.empty(n, n, device=gpu)
+    util.gemm("bf16", util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), n, n, n, out_f32=out, f32_geom=(0, n, 0))
+    assert torch.equal(out.cpu(), W.T.contiguous())
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_gate_residual_dual_output_and_swiglu(gpu, variant):
+    hip.lib().samaudio_debug_force_gemm_variant(variant)
+    B, T, N, K = 3, 70, 256, 320
+    M = B * T
+    A, W = _mk((M, K), 3), _mk((N, K), 4, 1 / math.sqrt(K))
+    bias, tab, gate, res = _mk((N,), 5), _mk((N,), 6), _mk((B, 2 * N), 7), _mk((M, N), 8)
+    out = torch.empty(M, N, device=gpu)
+    out_act = torch.empty(M, N, device=gpu, dtype=torch.bfloat16)
+    gate_d = gate.to(gpu)
+    keep = [bias.to(gpu), tab.to(gpu), res.to(gpu)]
+    util.gemm("bf16", util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), M, N, K, bias=keep[0], gate_tab=keep[1],
+              gate=gate_d[:, N:], gate_ld=2 * N, rows_per_gate=T, alpha=0.5, res=keep[2], res_geom=(0, N, 0),
+              out_f32=out, f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0), act=hip.ACT_SILU)
+    base = util.rounded(A, "bf16") @ util.rounded(W, "bf16").T + bias
+    want = base * (tab[None] + gate[:, N:].repeat_interleave(T, 0)) * 0.5 + res
+    util.report(f"gated v{variant} f32", out, want, 5e-4)
+    util.report(f"gated v{variant} act", out_act, F.silu(want), 3.2e-2)
+    # swiglu: weights interleaved in 16-row blocks (w1 block, w3 block, ...)
+    Fh = 192
+    w1, w3 = _mk((Fh, K), 9, 1 / math.sqrt(K)), _mk((Fh, K), 10, 1 / math.sqrt(K))
+    W13 = torch.stack([w1.view(Fh // 16, 16, K), w3.view(Fh // 16, 16, K)], 1).reshape(2 * Fh, K)
+    u = torch.empty(M, Fh, device=gpu, dtype=torch.bfloat16)
+    util.gemm("bf16", util.as_act(A, "bf16", gpu), util.as_act(W13, "bf16", gpu), M, 2 * Fh, K, swiglu=1, out_act=u,
+              act_geom=(0, Fh, 0))
+    Ar = util.rounded(A, "bf16")
+    want_u = F.silu(Ar @ util.rounded(w1, "bf16").T) * (Ar @ util.rounded(w3, "bf16").T)
+    util.report(f"swiglu v{variant}", u, want_u, 3.2e-2)
+
+
+@pytest.mark.parametrize("variant", [4, 9, 11])
+def test_conv_forms(gpu, variant):
+    """The codec's implicit-convolution forms on the 256-row kernels: dilated k7 conv with snake epilogue into a
+    halo-padded buffer, and a stride-4 transposed conv (phase-major columns, chan_mod bias, output window mask)."""
+    hip.lib().samaudio_debug_force_gemm_variant(variant)
+    items, T, C, dil, halo = 2, 300, 128, 3, 40
+    x = _mk((items, C, T), 11)
+    w = _mk((C, C, 7), 12, 1 / math.sqrt(7 * C))
+    bias, alpha = _mk((C,), 13, 0.1), (_mk((C,), 14, 0.2) + 1).clamp(0.3, 2)
+    xb = torch.zeros(items, T + 2 * halo, C)
+    xb[:, halo:halo + T] = x.transpose(1, 2)
+    Wm = w.permute(0, 2, 1).reshape(C, 7 * C)  # [Cout][tap][Cin]
+    Kp = 7 * C
+    out_act = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+    keep = [bias.to(gpu), alpha.to(gpu)]
+    util.gemm("bf16", util.as_act(xb, "bf16", gpu), util.as_act(Wm, "bf16", gpu), T, C, Kp, nbatch=items,
+              a_off=(halo - 3 * dil) * C, a_bstride=(T + 2 * halo) * C, lda=C, kc=C, tap_stride=dil * C, bias=keep[0],
+              out_act=out_act, act_geom=((T + 2 * halo) * C, C, halo * C), act=hip.ACT_SNAKE, act_alpha=keep[1])
+    y = F.conv1d(util.rounded(x, "bf16"), util.rounded(w, "bf16"), bias, dilation=dil, padding=3 * dil)
+    a = alpha[None, :, None]
+    want = (y + torch.sin(a * y) ** 2 / (a + 1e-9)).transpose(1, 2)
+    util.report(f"dilated conv+snake v{variant}", out_act[:, halo:halo + T], want, 4e-2)
+    assert float(out_act[:, :halo].abs().max()) == 0 and float(out_act[:, halo + T:].abs().max()) == 0
+
+    # ConvTranspose1d(k = 2s, stride s, padding s/2): rows q, columns (phase r, channel c)
+    s, Cin, Co, Tin = 4, 128, 64, 150
+    pad = s // 2
+    xt = _mk((items, Cin, Tin), 15)
+    wt = _mk((Cin, Co, 2 * s), 16, 1 / math.sqrt(2 * Cin))
+    bt = _mk((Co,), 17, 0.1)
+    xin = torch.zeros(items, Tin + 2 * halo, Cin)
+    xin[:, halo:halo + Tin] = xt.transpose(1, 2)
+    # W[(r, co)][ (x[q-1] | x[q]) ] = (w[:, co, r + s] | w[:, co, r])
+    Wt = torch.cat([wt[:, :, s:].permute(2, 1, 0), wt[:, :, :s].permute(2, 1, 0)], dim=2).reshape(s * Co, 2 * Cin)
+    Tout = Tin * s
+    raw = torch.zeros(items, Tout + 2 * halo, Co, device=gpu)
+    kb = bt.to(gpu)
+    util.gemm("bf16", util.as_act(xin, "bf16", gpu), util.as_act(Wt, "bf16", gpu), Tin + 1, s * Co, 2 * Cin, nbatch=items,
+              a_off=(halo - 1) * Cin, a_bstride=(Tin + 2 * halo) * Cin, lda=Cin, bias=kb, chan_mod=Co, out_f32=raw,
+              f32_geom=((Tout + 2 * halo) * Co, s * Co, (halo - pad) * Co), c_lo=pad * Co, c_hi=(Tout + pad) * Co,
+              c_ld_rel=s * Co)
+    want_t = F.conv_transpose1d(util.rounded(xt, "bf16"), util.rounded(wt, "bf16"), bt, stride=s, padding=pad).transpose(1, 2)
+    util.report(f"convT v{variant}", raw[:, halo:halo + Tout], want_t, 5e-4)
+    assert float(raw[:, :halo].abs().max()) == 0 and float(raw[:, halo + Tout:].abs().max()) == 0

@@ -19,7 +19,7 @@ from sam_audio_amd import hip  # noqa: E402
 from sam_audio_amd.config import preset_config  # noqa: E402
 from tests import util  # noqa: E402
 
-VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2"}
+VARIANTS = {4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256 h", 11: "pp 256x128 h", 15: "256x256 w4"}
 
 
 def interleave16(w1, w3):
@@ -91,8 +91,12 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--ablate", action="store_true", help="time the gemm3 256x256 ablation builds (results are wrong)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.ablate:
+        VARIANTS.clear()
+        VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads"})
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
     M = args.batch * 250
@@ -101,6 +105,10 @@ def main():
     run_case("edge gated", 517, 1152, 320, "gated", dev, 2, T=47)
     run_case("edge swiglu", 333, 1280, 256, "swiglu", dev, 2)
     if args.quick:
+        return
+    if args.ablate:
+        run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
+        run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
         return
     run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
     run_case("wo/c_wo (gate+res)", M, D, D, "gated", dev, args.iters)
