@@ -178,7 +178,7 @@ int samaudio_op_cross_attention(const void* q, const float* q_w, void* kv, const
   hipError_t e = sa::launch_headnorm(kv, k_w, bf16, batch * text_len, 2L * heads * 128, 0, heads, eps,
                                      (hipStream_t)stream);
   if (e != hipSuccess) return hip_ret(e, "headnorm");
-  return hip_ret(sa::launch_cross_attention(q, q_w, kv, mask, out, bf16, batch, frames, text_len, heads, eps,
+  return hip_ret(sa::launch_cross_attention(q, q_w, kv, 2L * heads * 128, mask, out, bf16, batch, frames, text_len, heads, eps,
                                             (hipStream_t)stream), "cross_attention");
 }
 

@@ -241,7 +241,7 @@ hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, c
 // ---------------------------------------------------------------------------------------------------
 template <typename TA>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ q, const float* __restrict__ qw,
-                                                         const TA* __restrict__ kv,
+                                                         const TA* __restrict__ kv, long kv_ld,
                                                          const unsigned char* __restrict__ mask, TA* __restrict__ out,
                                                          long M, int T, int Lt, int H, float eps) {
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ 
   float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
   for (int j = 0; j < Lt; ++j) {
     if (!mask[b * Lt + j]) continue;  // wave-uniform
-    const TA* krow = kv + (b * Lt + j) * (2L * D) + h * 128 + 2 * lane;
+    const TA* krow = kv + (b * Lt + j) * kv_ld + h * 128 + 2 * lane;
     float k0, k1, v0, v1;
     load2<TA>(krow, k0, k1);
     load2<TA>(krow + D, v0, v1);
@@ -276,15 +276,140 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ 
   store2<TA>(out + m * D + h * 128 + 2 * lane, o0 * il, o1 * il);
 }
 
-hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, const unsigned char* mask,
-                                  void* out, bool bf16, int B, int T, int Lt, int H, float eps, hipStream_t st) {
+// ---------------------------------------------------------------------------------------------------
+// bf16 MFMA cross-attention for short memories (Lt <= 16 text tokens).  grid (ceil(T/64), H, B), 4 waves x 16 rows.
+// Both contractions run transposed so that every lane keeps ONE query row:
+//   S^T[token][row] = K[token][:] . Qn[row][:]   (A = K rows, B = normalised q)  -> lane: 4 tokens of its row
+//   O^T[d][row]     = V^T[d][:]   . P[row][:]    (A = V^T from LDS, B = P)       -> lane: 4 consecutive d of its row
+// so the q-norm statistics and the softmax are lane-local plus two 16/32-lane shuffles, and the output is written
+// as 8-byte stores.  Traffic = q in + out (2*M*D*2 B); K/V of the (batch, head) are 4 KB from L2.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __restrict__ q, const float* __restrict__ qw,
+                                                              const bf16_t* __restrict__ kv, long kv_ld,
+                                                              const unsigned char* __restrict__ mask,
+                                                              bf16_t* __restrict__ out, int T, int Lt, int H, float eps) {
+  __shared__ __attribute__((aligned(16))) unsigned short Vt[128 * 16];  // [d][token], tokens >= Lt are zero
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int D = H * 128;
+  for (int idx = tid; idx < 128 * 16; idx += 256) {
+    const int d = idx >> 4, j = idx & 15;
+    Vt[idx] = j < Lt ? kv[((long)b * Lt + j) * kv_ld + D + h * 128 + d].v : (unsigned short)0;
+  }
+  // K fragments: rows = tokens
+  bf16x8_t kf[4];
+  const bool tok_ok = r < Lt && mask[(long)b * Lt + (r < Lt ? r : 0)] != 0;
+  {
+    const bf16_t* krow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + h * 128 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = *(const uint4*)(krow + ks * 32);
+      if (!tok_ok) v = make_uint4(0u, 0u, 0u, 0u);
+      kf[ks] = *(const bf16x8_t*)&v;
+    }
+  }
+  // q rows: lane holds d = ks*32 + g*8 .. +8 of row r
+  const int t = blockIdx.x * 64 + wave * 16 + r;
+  const int tc = t < T ? t : T - 1;
+  const long m = (long)b * T + tc;
+  float qv[4][8];
+  float ss = 0.f;
+  {
+    const bf16_t* qrow = q + m * D + h * 128 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint4 v = *(const uint4*)(qrow + ks * 32);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qv[ks][2 * e] = __uint_as_float(w4[e] << 16);
+        qv[ks][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+        ss += qv[ks][2 * e] * qv[ks][2 * e] + qv[ks][2 * e + 1] * qv[ks][2 * e + 1];
+      }
+    }
+  }
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  const float inv = rsqrtf(ss / 128.f + eps);
+  f32x4_t sT = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const float4 w0 = *(const float4*)(qw + ks * 32 + g * 8), w1 = *(const float4*)(qw + ks * 32 + g * 8 + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    unsigned pk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      pk[e] = (unsigned)f2bf(qv[ks][2 * e] * inv * wv[2 * e]) | ((unsigned)f2bf(qv[ks][2 * e + 1] * inv * wv[2 * e + 1]) << 16);
+    const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], *(const bf16x8_t*)&pv, sT, 0, 0, 0);
+  }
+  // softmax over the tokens of row r: lane holds tokens g*4 + e
+  const float scale = 0.08838834764831845f;
+  float p[4], mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int tok = g * 4 + e;
+    const bool ok = tok < Lt && mask[(long)b * Lt + (tok < Lt ? tok : 0)] != 0;
+    p[e] = ok ? sT[e] * scale : -INFINITY;
+    mx = fmaxf(mx, p[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_safe = mx == -INFINITY ? 0.f : mx;
+  float l = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    p[e] = __expf(p[e] - m_safe);
+    l += p[e];
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  // P as the B operand: lane (row r, group g) needs tokens 8g .. 8g+7 = groups 2g and 2g+1 of the same row
+  unsigned ppk[4];
+  {
+    const int src_lo = ((2 * g) & 3) * 16 + r, src_hi = ((2 * g + 1) & 3) * 16 + r;
+    float lo[4], hi[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo[e] = __shfl(p[e], src_lo, 64);
+      hi[e] = __shfl(p[e], src_hi, 64);
+    }
+    const bool live = g < 2;  // tokens 16..31 do not exist
+    ppk[0] = live ? ((unsigned)f2bf(lo[0]) | ((unsigned)f2bf(lo[1]) << 16)) : 0u;
+    ppk[1] = live ? ((unsigned)f2bf(lo[2]) | ((unsigned)f2bf(lo[3]) << 16)) : 0u;
+    ppk[2] = live ? ((unsigned)f2bf(hi[0]) | ((unsigned)f2bf(hi[1]) << 16)) : 0u;
+    ppk[3] = live ? ((unsigned)f2bf(hi[2]) | ((unsigned)f2bf(hi[3]) << 16)) : 0u;
+  }
+  const uint4 pu = make_uint4(ppk[0], ppk[1], ppk[2], ppk[3]);
+  const bf16x8_t pB = *(const bf16x8_t*)&pu;
+  __syncthreads();  // V^T staged
+  const float il = 1.f / l;
+  bf16_t* orow = out + m * D + h * 128 + g * 4;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    const bf16x8_t vf = *(const bf16x8_t*)(Vt + (n * 16 + r) * 16 + g * 8);
+    f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pB, o, 0, 0, 0);
+    if (t < T) store4<bf16_t>(orow + n * 16, o[0] * il, o[1] * il, o[2] * il, o[3] * il);
+  }
+}
+
+hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,
+                                  const unsigned char* mask, void* out, bool bf16, int B, int T, int Lt, int H,
+                                  float eps, hipStream_t st) {
   const long M = (long)B * T;
+  if (bf16 && Lt <= 16) {
+    hipLaunchKernelGGL(cross_attn_mfma_kernel, dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const bf16_t*)q, qw,
+                       (const bf16_t*)kv, kv_ld, mask, (bf16_t*)out, T, Lt, H, eps);
+    return hipGetLastError();
+  }
   dim3 grid((unsigned)((M * H + 3) / 4)), block(256);
   if (bf16)
-    hipLaunchKernelGGL(cross_attn_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, qw, (const bf16_t*)kv, mask,
-                       (bf16_t*)out, M, T, Lt, H, eps);
+    hipLaunchKernelGGL(cross_attn_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, qw, (const bf16_t*)kv, kv_ld,
+                       mask, (bf16_t*)out, M, T, Lt, H, eps);
   else
-    hipLaunchKernelGGL(cross_attn_kernel<float>, grid, block, 0, st, (const float*)q, qw, (const float*)kv, mask,
+    hipLaunchKernelGGL(cross_attn_kernel<float>, grid, block, 0, st, (const float*)q, qw, (const float*)kv, kv_ld, mask,
                        (float*)out, M, T, Lt, H, eps);
   return hipGetLastError();
 }

@@ -106,14 +106,15 @@ class Engine {
 
   // resolved weights (pointers into caller memory)
   struct LayerW {
-    const float *attn_norm, *ffn_norm, *mod_table, *q_norm, *k_norm, *c_q_norm, *c_k_norm;
-    const void *wqkv, *wo, *c_wq, *c_wkv, *c_wo, *w13, *w2;
+    const float *attn_norm, *ffn_norm, *mod_table, *q_norm, *k_norm, *c_q_norm;
+    const void *wqkv, *wo, *c_wq, *c_wo, *w13, *w2;
   };
   std::vector<LayerW> layers_;
   struct {
     const float *final_table, *final_norm, *gn1_w, *gn1_b, *gn2_w, *gn2_b, *pb1, *pb2, *tb_b, *t_freqs, *mem_inv_freq,
-        *rope_cos, *rope_sin, *proj_b, *mem_b, *vid_b, *vid_ln_w, *vid_ln_b, *vid_gate, *anc_emb;
-    const void *w_out, *pw1, *pw2, *y_w13, *y_w2, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w;
+        *rope_cos, *rope_sin, *proj_b, *mem_b, *vid_b, *vid_ln_w, *vid_ln_b, *vid_gate, *anc_emb, *c_k_norm_all;
+    const void *w_out, *pw1, *pw2, *y_w13, *y_w2, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w,
+        *c_wkv_all;
   } g_;
   struct ResUnitW {
     const float *a1, *b1, *a2, *b2;

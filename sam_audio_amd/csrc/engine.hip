@@ -88,11 +88,9 @@ Status Engine::finalize(int what) {
       NEEDF(w.q_norm, P + "q_norm", 128);
       NEEDF(w.k_norm, P + "k_norm", 128);
       NEEDF(w.c_q_norm, P + "c_q_norm", 128);
-      NEEDF(w.c_k_norm, P + "c_k_norm", 128);
       NEEDW(w.wqkv, P + "wqkv", 3 * D, D);
       NEEDW(w.wo, P + "wo", D, D);
       NEEDW(w.c_wq, P + "c_wq", D, D);
-      NEEDW(w.c_wkv, P + "c_wkv", 2 * D, D);
       NEEDW(w.c_wo, P + "c_wo", D, D);
       NEEDW(w.w13, P + "w13", 2 * F, D);
       NEEDW(w.w2, P + "w2", D, F);
@@ -130,6 +128,10 @@ Status Engine::finalize(int what) {
     NEEDF(g_.vid_gate, "vid_gate", 1);
     NEEDF(g_.anc_emb, "anc_emb", cfg_.anchor_vocab, cfg_.anchor_dim);
     NEEDW(g_.anc_w, "anc_w", D, cfg_.anchor_dim);
+    // cross-attention K|V projections of ALL layers as one operand: the text memory changes with t only through
+    // the y-embedder, so one GEMM per evaluation serves the 22 layers (reference transformer.py:382-388, :102-114)
+    NEEDW(g_.c_wkv_all, "c_wkv_all", (int64_t)L * 2 * D, D);
+    NEEDF(g_.c_k_norm_all, "c_k_norm_all", L, 128);
     dit_ready_ = true;
   } else {
     const int CD = cfg_.codec_dim, CL = cfg_.codec_latent;
@@ -212,7 +214,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   void* Vt = act((long)rows * H * 128 * Tp);
   void* attn = act(M * D); void* hbf = act(M * D); void* qc = act(M * D); void* ca = act(M * D); void* u = act(M * F);
   void* gnbuf = act((long)rows * (T + 2) * D); void* mem = act(Mt * D); void* yu = act(Mt * D); void* yemb = act(Mt * D);
-  void* kvc = act(Mt * 2 * D); void* temb = act(nt * cfg_.freq_dim); void* tu = act(nt * D); void* tsilu = act(nt * D);
+  void* kvc = act(Mt * 2 * D * cfg_.n_layers); void* temb = act(nt * cfg_.freq_dim); void* tu = act(nt * D); void* tsilu = act(nt * D);
   void* feats = act(M * C2); void* text = act(Mt * cfg_.text_dim); void* video = act(M * cfg_.video_dim);
   void* anch = act(M * cfg_.anchor_dim);
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
@@ -317,8 +319,8 @@ Status Engine::profile_begin() {
 
 Status Engine::profile_end(std::vector<KernelStat>& out) {
   prof_on_ = false;
-  out.assign(16, KernelStat{});
-  for (int v = 0; v < 16; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  out.assign(20, KernelStat{});
+  for (int v = 0; v < 20; ++v) out[v].name = gemm_variant_name(v, bf16_);
   for (const ProfRec& r : prof_) {
     SA_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;
@@ -481,6 +483,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_TRY(gemm(p, st));
   }
 
+  const long kv_ld = 2L * D * cfg_.n_layers;
+  if (cfg_.n_layers > 0) {  // cross-attention keys / values of every layer (k-normed), [Mt, L*2D]
+    GemmParams p = lin(d_.yemb, D, g_.c_wkv_all, Mt, (int)kv_ld, D);
+    out_act(p, d_.kvc, kv_ld);
+    SA_TRY(gemm(p, st));
+    SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
+  }
   for (int l = 0; l < cfg_.n_layers; ++l) {  // DiTBlock.forward, transformer.py:354-391
     const LayerW& w = layers_[l];
     const float* tab = w.mod_table;
@@ -508,12 +517,9 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
       out_act(p, d_.qc, D);
       SA_TRY(gemm(p, st));
-      p = lin(d_.yemb, D, w.c_wkv, Mt, 2 * D, D);
-      out_act(p, d_.kvc, 2L * D);
-      SA_TRY(gemm(p, st));
     }
-    SA_HIP(launch_headnorm(d_.kvc, w.c_k_norm, bf16_, (int)Mt, 2L * D, 0, H, eps, st));
-    SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, d_.kvc, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
+    SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, (const char*)d_.kvc + (size_t)l * 2 * D * esz_, kv_ld, d_.text_mask,
+                                  d_.ca, bf16_, rows, T, Lt, H, eps, st));
     {
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);

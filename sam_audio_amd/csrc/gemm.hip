@@ -231,11 +231,11 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
   return gemm1_variant(p);
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
-  static const char* names[2][16] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+  static const char* names[2][20] = {
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
        "gemm2_bf16_256x256_s2", "gemm2_bf16_128x256_k32s3_w4", "gemm2_bf16_256x128_k32s3_w4",
-       "gemm2_bf16_128x256_k32s2_w4", "gemm3_bf16_256x256_pp2", "gemm3_bf16_256x128_pp4", "gemm3_bf16_256x128_pp2", "abl_nodma", "abl_nomfma", "abl_noread", "gemm2_bf16_256x256_s2_w4"}};
+       "gemm2_bf16_128x256_k32s2_w4", "gemm3_bf16_256x256_pp2", "gemm3_bf16_256x128_pp4", "gemm3_bf16_256x128_pp2", "abl_nodma", "abl_nomfma", "abl_noread", "gemm2_bf16_256x256_s2_w4", "gemm2_bf16_256x128_s2_pipe", "gemm2_bf16_256x256_s2_pipe", "abl_vgprfill", "abl_vgprfill_nomfma"}};
   return names[is_bf16 ? 1 : 0][v];
 }
 

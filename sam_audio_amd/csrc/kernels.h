@@ -44,10 +44,15 @@ hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, c
 hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
                            hipStream_t st);
 
-// cross attention: q [M, D] (raw, q-norm applied here), kv [B*Lt, 2D] (k already normalised | v),
-// mask [B, Lt] bytes; out [M, D]
-hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, const unsigned char* mask,
-                                  void* out, bool bf16, int B, int T, int Lt, int H, float eps, hipStream_t st);
+// cross attention: q [M, D] (raw, q-norm applied here), kv rows b*Lt + j with row stride kv_ld elements holding
+// (k already normalised | v) in columns [0, 2D); mask [B, Lt] bytes; out [M, D]
+hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,
+                                  const unsigned char* mask, void* out, bool bf16, int B, int T, int Lt, int H,
+                                  float eps, hipStream_t st);
+// per-(row, layer, head) RMSNorm of the K halves of kv_all [rows, L*2D] (all layers' cross-attention keys at
+// once); w_all [L, 128]
+hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,
+                                  hipStream_t st);
 
 // timestep features: temb [nt, fdim] (AT) = cat(cos, sin)(t*freqs);  tsin [nt, D] fp32 likewise with inv_freq
 hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,

@@ -276,6 +276,37 @@ hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld
   return hipGetLastError();
 }
 
+// K halves of all layers' cross-attention key/value projections in one launch: kv_all [rows, L*2D], item =
+// (row, layer, head); weight w_all[layer][128]
+template <typename TA>
+__global__ __launch_bounds__(256) void headnorm_layers_kernel(TA* __restrict__ x, const float* __restrict__ w_all,
+                                                              long rows, int L, int H, float eps) {
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * L * H) return;
+  const int lane = threadIdx.x & 63;
+  const int h = (int)(item % H);
+  const int l = (int)((item / H) % L);
+  const long r = item / ((long)H * L);
+  const long D2 = 2L * H * 128;
+  TA* p = x + r * (D2 * L) + l * D2 + h * 128 + 2 * lane;
+  const float* w = w_all + l * 128;
+  float a, c;
+  load2<TA>(p, a, c);
+  const float inv = rsqrtf(wave_sum(a * a + c * c) / 128.f + eps);
+  store2<TA>(p, a * inv * w[2 * lane], c * inv * w[2 * lane + 1]);
+}
+
+hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,
+                                  hipStream_t st) {
+  const long items = (long)rows * L * H;
+  dim3 grid((unsigned)((items + 3) / 4)), block(256);
+  if (bf16)
+    hipLaunchKernelGGL(headnorm_layers_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)kv_all, w_all, (long)rows, L, H, eps);
+  else
+    hipLaunchKernelGGL(headnorm_layers_kernel<float>, grid, block, 0, st, (float*)kv_all, w_all, (long)rows, L, H, eps);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // timestep features (reference transformer.py:236-248 and model.py:35-42): cat(cos, sin)(t * freq)
 // ------------------------------------------------------------------------------------------------

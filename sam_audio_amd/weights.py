@@ -98,14 +98,16 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
         out[E + "q_norm"] = f32(sd[L + "attention.q_norm.weight"])
         out[E + "k_norm"] = f32(sd[L + "attention.k_norm.weight"])
         out[E + "c_q_norm"] = f32(sd[L + "cross_attention.q_norm.weight"])
-        out[E + "c_k_norm"] = f32(sd[L + "cross_attention.k_norm.weight"])
         out[E + "wqkv"] = op(torch.cat([_head_major(W(L + f"attention.{n}.weight"), H) for n in ("wq", "wk", "wv")]))
         out[E + "wo"] = op(W(L + "attention.wo.weight"))
         out[E + "c_wq"] = op(_head_major(W(L + "cross_attention.wq.weight"), H))
-        out[E + "c_wkv"] = op(torch.cat([_head_major(W(L + f"cross_attention.{n}.weight"), H) for n in ("wk", "wv")]))
         out[E + "c_wo"] = op(W(L + "cross_attention.wo.weight"))
         out[E + "w13"] = op(_interleave16(W(L + "feed_forward.w1.weight"), W(L + "feed_forward.w3.weight")))
         out[E + "w2"] = op(W(L + "feed_forward.w2.weight"))
+    # cross-attention K|V projections and k-norm weights of all layers, stacked: one GEMM per evaluation
+    out["c_wkv_all"] = op(torch.cat([_head_major(W(f"{P}layers.{i}.cross_attention.{n}.weight"), H)
+                                     for i in range(t.n_layers) for n in ("wk", "wv")]))
+    out["c_k_norm_all"] = f32(torch.stack([sd[f"{P}layers.{i}.cross_attention.k_norm.weight"] for i in range(t.n_layers)]))
     out["final_table"] = f32(sd[P + "final_layer_scale_shift_table"])
     out["final_norm"] = f32(sd[P + "norm.weight"])
     out["w_out"] = op(W(P + "output.weight"))

@@ -17,7 +17,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 # 3 = 256x128 3-stage ring, 4 = 256x128 2-stage, 5 = 256x256 2-stage, 6/7 = 4-wave BK32, 9 = 256x256 role-split,
 # 10/11 = 256x128 role-split (3 LDS stages), 15 = 256x256 4-wave
-VARIANTS = [3, 4, 5, 6, 7, 9, 10, 11, 15]
+VARIANTS = [3, 4, 5, 6, 7, 9, 10, 11, 15, 16, 17]
 
 
 def _mk(shape, seed, scale=1.0):

@@ -19,7 +19,7 @@ from sam_audio_amd import hip  # noqa: E402
 from sam_audio_amd.config import preset_config  # noqa: E402
 from tests import util  # noqa: E402
 
-VARIANTS = {4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256 h", 11: "pp 256x128 h", 15: "256x256 w4"}
+VARIANTS = {4: "256x128 s2", 16: "256x128 s2 pipe", 5: "256x256 s2", 17: "256x256 s2 pipe", 9: "pp 256x256 h"}
 
 
 def interleave16(w1, w3):
@@ -96,7 +96,7 @@ def main():
     dev = torch.device("cuda:0")
     if args.ablate:
         VARIANTS.clear()
-        VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads"})
+        VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads", 18: "VGPR fill", 19: "VGPR fill, no MFMA"})
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
     M = args.batch * 250
