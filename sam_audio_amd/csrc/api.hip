@@ -102,6 +102,7 @@ int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int
 }
 
 void samaudio_debug_force_gemm_variant(int variant) { sa::gemm_force_variant(variant); }
+void samaudio_debug_set_flag(int flag, int value) { sa::set_debug_flag(flag, value); }
 
 int samaudio_profile_begin(samaudio_ctx* ctx) {
   if (!ctx) return bad("null context");

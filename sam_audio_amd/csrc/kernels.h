@@ -5,6 +5,11 @@
 
 namespace sa {
 
+// tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
+//   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
+void set_debug_flag(int flag, int value);
+int debug_flag(int flag);
+
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks

@@ -5,6 +5,12 @@
 
 namespace sa {
 
+static int g_debug_flags[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+void set_debug_flag(int flag, int value) {
+  if (flag >= 0 && flag < 8) g_debug_flags[flag] = value;
+}
+int debug_flag(int flag) { return flag >= 0 && flag < 8 ? g_debug_flags[flag] : 0; }
+
 // ------------------------------------------------------------------------------------------------
 // RMSNorm (+ adaLN modulate).  Reference transformer.py:36-47 (fp32 inside, eps in the rsqrt),
 // :21-22 modulate = x*(1+scale)+shift, :360-372 / :507-518 where shift/scale = table + t-vector.
@@ -234,12 +240,100 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const TA* __restrict__ qk
   }
 }
 
+// bf16 fast path: 16 lanes x 16 bytes per 128-wide head row (4 rows per wave-instruction), so every global access
+// is a 16-byte load / store; the V tile is transposed through LDS as 16-bit words and leaves as 16-byte rows of V^T.
+__global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ qw,
+                                                            const float* __restrict__ kw, const float* __restrict__ rc,
+                                                            const float* __restrict__ rs, bf16_t* __restrict__ Q,
+                                                            bf16_t* __restrict__ K, bf16_t* __restrict__ Vt, int T,
+                                                            int Tp, int H, float eps) {
+  __shared__ __attribute__((aligned(16))) unsigned short vt[64 * 136];  // [t][d], row stride 136 (272 B) spreads banks
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * 128;
+  const long ld = 3L * D;
+  const int tid = threadIdx.x;
+  const int sub = tid & 15;   // 8-element chunk of the head row
+  const int rgrp = tid >> 4;  // 16 row groups
+  const long bh = (long)b * H + h;
+  float wq[8], wk[8];
+  {
+    const float4 a = *(const float4*)(qw + sub * 8), c = *(const float4*)(qw + sub * 8 + 4);
+    const float4 e = *(const float4*)(kw + sub * 8), f = *(const float4*)(kw + sub * 8 + 4);
+    wq[0] = a.x; wq[1] = a.y; wq[2] = a.z; wq[3] = a.w; wq[4] = c.x; wq[5] = c.y; wq[6] = c.z; wq[7] = c.w;
+    wk[0] = e.x; wk[1] = e.y; wk[2] = e.z; wk[3] = e.w; wk[4] = f.x; wk[5] = f.y; wk[6] = f.z; wk[7] = f.w;
+  }
+  auto unpack = [](const uint4& v, float (&x)[8]) {
+    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      x[2 * e] = __uint_as_float(w4[e] << 16);
+      x[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+    }
+  };
+  auto pack = [](const float (&x)[8]) {
+    return make_uint4((unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16), (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16),
+                      (unsigned)f2bf(x[4]) | ((unsigned)f2bf(x[5]) << 16), (unsigned)f2bf(x[6]) | ((unsigned)f2bf(x[7]) << 16));
+  };
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tt = it * 16 + rgrp;
+    const int t = t0 + tt;
+    uint4 qo = make_uint4(0u, 0u, 0u, 0u), ko = qo, vv = qo;
+    if (t < T) {  // uniform over each 16-lane row group
+      const bf16_t* row = qkv + ((long)b * T + t) * ld + h * 128 + sub * 8;
+      const uint4 qi = *(const uint4*)row, ki = *(const uint4*)(row + D);
+      vv = *(const uint4*)(row + 2 * D);
+      float q[8], k[8];
+      unpack(qi, q);
+      unpack(ki, k);
+      float sq = 0.f, sk = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
+      const float iq = rsqrtf(sq / 128.f + eps), ik = rsqrtf(sk / 128.f + eps);
+      const float4 c4 = *(const float4*)(rc + (long)t * 64 + sub * 4), s4 = *(const float4*)(rs + (long)t * 64 + sub * 4);
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = q[2 * e] * iq * wq[2 * e], a1 = q[2 * e + 1] * iq * wq[2 * e + 1];
+        q[2 * e] = a0 * cc[e] - a1 * sn[e];
+        q[2 * e + 1] = a0 * sn[e] + a1 * cc[e];
+        const float b0 = k[2 * e] * ik * wk[2 * e], b1 = k[2 * e + 1] * ik * wk[2 * e + 1];
+        k[2 * e] = b0 * cc[e] - b1 * sn[e];
+        k[2 * e + 1] = b0 * sn[e] + b1 * cc[e];
+      }
+      qo = pack(q);
+      ko = pack(k);
+    }
+    *(uint4*)(Q + (bh * Tp + t) * 128 + sub * 8) = qo;
+    *(uint4*)(K + (bh * Tp + t) * 128 + sub * 8) = ko;
+    *(uint4*)(vt + tt * 136 + sub * 8) = vv;
+  }
+  __syncthreads();
+  // V^T rows: thread -> (d, 8 consecutive t); 128 d x 8 chunks = 1024 items, 4 per thread
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = it * 256 + tid;
+    const int d = item >> 3, c = item & 7;
+    unsigned short x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = vt[(c * 8 + e) * 136 + d];
+    const uint4 o = make_uint4((unsigned)x[0] | ((unsigned)x[1] << 16), (unsigned)x[2] | ((unsigned)x[3] << 16),
+                               (unsigned)x[4] | ((unsigned)x[5] << 16), (unsigned)x[6] | ((unsigned)x[7] << 16));
+    *(uint4*)(Vt + (bh * 128 + d) * Tp + t0 + c * 8) = o;
+  }
+}
+
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st) {
   dim3 grid(Tp / 64, H, B), block(256);
-  if (bf16)
+  if (bf16 && debug_flag(1))
     hipLaunchKernelGGL(qkv_prep_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin,
+                       (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
+  else if (bf16)
+    hipLaunchKernelGGL(qkv_prep_bf16_kernel, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin,
                        (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
   else
     hipLaunchKernelGGL(qkv_prep_kernel<float>, grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin,

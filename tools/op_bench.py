@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Times the non-GEMM kernels of one DiT layer at the benchmark shape (B=32, T=250, large* dims) with HIP events on
+the launch stream; prints achieved GB/s against the bytes each kernel must move."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from sam_audio_amd import hip  # noqa: E402
+from sam_audio_amd.config import preset_config  # noqa: E402
+
+dev = torch.device("cuda:0")
+L = hip.lib()
+t = preset_config("large*").transformer
+B, T, H, D, Lt = 32, 250, t.n_heads, t.dim, 8
+Tp, M = 256, B * T
+st = hip.current_stream_ptr
+
+
+def timeit(name, fn, nbytes, iters=20):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    print(f"{name:32s} {us:8.1f} us   {nbytes / us / 1e3:7.1f} GB/s  ({nbytes / 1e6:.0f} MB algorithmic)", flush=True)
+
+
+qkv = torch.randn(M, 3 * D, device=dev).to(torch.bfloat16)
+qw, kw = torch.rand(128, device=dev) + 0.5, torch.rand(128, device=dev) + 0.5
+ang = torch.rand(10000, 64, device=dev)
+cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+Q = torch.empty(B, H, Tp, 128, device=dev, dtype=torch.bfloat16)
+K, Vt = torch.empty_like(Q), torch.empty(B, H, 128, Tp, device=dev, dtype=torch.bfloat16)
+mask = torch.ones(B, T, dtype=torch.uint8, device=dev)
+out = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+
+
+def prep():
+    hip.check(L.samaudio_op_qkv_prep(hip.ptr(qkv), hip.ptr(qw), hip.ptr(kw), hip.ptr(cos), hip.ptr(sin), hip.ptr(Q),
+                                     hip.ptr(K), hip.ptr(Vt), hip.BF16, B, T, Tp, H, 1e-5, st()))
+
+
+for flag, name in ((1, "qkv_prep (first generation)"), (0, "qkv_prep (16-byte accesses)")):
+    L.samaudio_debug_set_flag(1, flag)
+    timeit(name, prep, 2 * M * 3 * D * 2)
+L.samaudio_debug_set_flag(1, 0)
+timeit("self_attention", lambda: hip.check(L.samaudio_op_self_attention(
+    hip.ptr(Q), hip.ptr(K), hip.ptr(Vt), hip.ptr(mask), hip.ptr(out), hip.BF16, B, T, Tp, H, st())), 4 * M * D * 2)
+x = torch.randn(M, D, device=dev)
+w = torch.rand(D, device=dev)
+tab = torch.randn(6, D, device=dev)
+t0 = torch.randn(1, 6 * D, device=dev)
+xn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+timeit("rmsnorm_mod", lambda: hip.check(L.samaudio_op_rmsnorm_mod(
+    hip.ptr(x), hip.ptr(w), C.c_void_p(tab[0].data_ptr()), C.c_void_p(tab[1].data_ptr()), hip.ptr(t0), 0, 0, D, hip.ptr(xn),
+    hip.BF16, M, D, T, 1e-5, st())), M * D * 6)
+q = torch.randn(M, D, device=dev).to(torch.bfloat16)
+kv = torch.randn(B * Lt, 2 * D, device=dev).to(torch.bfloat16)
+tmask = torch.ones(B, Lt, dtype=torch.uint8, device=dev)
+timeit("cross_attention (+k headnorm)", lambda: hip.check(L.samaudio_op_cross_attention(
+    hip.ptr(q), hip.ptr(qw), hip.ptr(kv), hip.ptr(kw), hip.ptr(tmask), hip.ptr(out), hip.BF16, B, T, Lt, H, 1e-5, st())),
+    2 * M * D * 2)
