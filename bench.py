@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--streams", type=int, default=1, help="row groups of the batch solved concurrently on separate HIP streams")
     return ap.parse_args()
 
 
@@ -146,7 +147,7 @@ def main():
     sd = broadcast_state_dict(sd, src=0, device=dev)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     sd_cpu = {k: v.cpu() for k, v in sd.items()} if want_cpu else None
-    model = SAMAudio(cfg, precision=args.precision, device=str(dev))
+    model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=args.streams)
     model.load_state_dict(sd, strict=False)
     del sd
     torch.cuda.empty_cache()
@@ -192,9 +193,11 @@ def main():
     # ---- roofline of the dominant kernel: one extra, instrumented step (HIP events on the launch stream) --
     roofline = None
     if rank == 0 and not args.no_roofline:
+        model.streams = 1  # events bracket single launches: keep the GPU to one stream while they are recorded
         model.profile_begin()
         step()
         stats = model.profile_end()
+        model.streams = args.streams
         dom = max(stats, key=lambda k: k["ms"])
         if dom["ms"] > 0:
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -229,6 +232,7 @@ def main():
                              f"F={tcfg.ffn_hidden}) {args.precision}, batch={B}x10 s clips per GPU, text prompt "
                              f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"),
                 "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"clip-sharded x{world}",
+                "streams_per_gpu": args.streams,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }

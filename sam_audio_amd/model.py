@@ -48,11 +48,35 @@ def ode_grid(ode_opt: Dict[str, Any], t0: float = 0.0, t1: float = 1.0):
     return (hip.ODE_MIDPOINT if method == "midpoint" else hip.ODE_EULER), grid
 
 
+class _Lane:
+    """An extra engine context bound to its own HIP stream.  It borrows the model's weight tensors (no copy) and
+    owns only a workspace; `SAMAudio(streams=S)` solves S contiguous row groups of a batch concurrently so that one
+    group's GEMM tails / epilogues / launch gaps are filled by the other group's workgroups."""
+
+    def __init__(self, model: "SAMAudio"):
+        self.lib = model._lib
+        self._ctx = C.c_void_p()
+        hip.check(self.lib.samaudio_create(C.byref(model._hc), C.byref(self._ctx)))
+        for name, t in model._tensors.items():
+            dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+            hip.check(self.lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
+                                                   hip.shape_array(t.shape)))
+        hip.check(self.lib.samaudio_finalize(self._ctx, 0))
+        self._workspace: Optional[torch.Tensor] = None
+        self._live = None
+        self.stream = torch.cuda.Stream(device=model.device)
+
+    def __del__(self):
+        if getattr(self, "_ctx", None):
+            self.lib.samaudio_destroy(self._ctx)
+            self._ctx = None
+
+
 class SAMAudio:
     config_cls = SAMAudioConfig
 
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_encoder: Optional[Callable] = None):
+                 text_encoder: Optional[Callable] = None, streams: int = 1):
         cfg.check_supported()
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
@@ -68,6 +92,12 @@ class SAMAudio:
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self._has_dit = self._has_codec = False
+        if int(streams) not in (1, 2):
+            # measured on MI355X: 2 groups +3 %; 3 groups produced non-finite latents (cause not
+            # yet found), so more than two concurrent engine contexts are refused rather than risked.
+            raise ValueError("streams must be 1 or 2")
+        self.streams = int(streams)           # row groups solved concurrently on separate HIP streams
+        self._lanes: List[_Lane] = []
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
             precision=hip.BF16 if precision == "bf16" else hip.F32, dim=t.dim, n_heads=t.n_heads,
@@ -77,6 +107,7 @@ class SAMAudio:
             norm_eps=t.norm_eps, codec_dim=c.codebook_dim, codec_latent=c.latent_dim, enc_dim=c.encoder_dim,
             dec_dim=c.decoder_dim, enc_rates=(C.c_int32 * 4)(*c.encoder_rates),
             dec_rates=(C.c_int32 * 4)(*c.decoder_rates))
+        self._hc = hc
         hip.check(self._lib.samaudio_create(C.byref(hc), C.byref(self._ctx)))
 
     def __del__(self):
@@ -171,15 +202,17 @@ class SAMAudio:
                      ms=float(buf[i].ms)) for i in range(n.value)]
 
     # ------------------------------------------------------------------ workspace
-    def _ensure_workspace(self, rows: int, frames: int, text_len: int, codec_items: int, samples: int) -> None:
-        need = self._lib.samaudio_workspace_bytes(self._ctx, rows, frames, max(1, text_len), codec_items, samples)
-        if self._workspace is None or self._workspace.numel() < need:
-            self._workspace = None
-            self._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
-        base = self._workspace.data_ptr()
+    def _ensure_workspace(self, rows: int, frames: int, text_len: int, codec_items: int, samples: int,
+                          lane: Optional[_Lane] = None) -> None:
+        own = lane if lane is not None else self   # whoever owns the context owns its workspace
+        need = self._lib.samaudio_workspace_bytes(own._ctx, rows, frames, max(1, text_len), codec_items, samples)
+        if own._workspace is None or own._workspace.numel() < need:
+            own._workspace = None
+            own._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = own._workspace.data_ptr()
         aligned = (base + 255) // 256 * 256
-        hip.check(self._lib.samaudio_set_workspace(self._ctx, C.c_void_p(aligned),
-                                                   self._workspace.numel() - (aligned - base)))
+        hip.check(self._lib.samaudio_set_workspace(own._ctx, C.c_void_p(aligned),
+                                                   own._workspace.numel() - (aligned - base)))
 
     def _codec_chunk(self, items: int) -> int:
         return min(items, int(os.environ.get("SAMAUDIO_CODEC_CHUNK", "16")))
@@ -221,8 +254,9 @@ class SAMAudio:
 
     # ------------------------------------------------------------------ DiT
     def _prepare(self, audio_features, text_features, text_mask, masked_video_features, anchor_ids,
-                 anchor_alignment, audio_pad_mask) -> None:
+                 anchor_alignment, audio_pad_mask, lane: Optional[_Lane] = None) -> None:
         dev = self.device
+        own = lane if lane is not None else self
         feats = audio_features.to(dev, torch.float32).contiguous()
         rows, frames, _ = feats.shape
         text = tmask = video = ids = align = pad = None
@@ -244,10 +278,10 @@ class SAMAudio:
             assert int(align.max()) < n_ids, "anchor_alignment points past anchor_ids"
         if audio_pad_mask is not None:
             pad = audio_pad_mask.to(dev).to(torch.uint8).contiguous()
-        self._live = (feats, text, tmask, video, ids, align, pad)
-        self._ensure_workspace(rows, frames, text_len, 0, 0)
+        own._live = (feats, text, tmask, video, ids, align, pad)
+        self._ensure_workspace(rows, frames, text_len, 0, 0, lane)
         hip.check(self._lib.samaudio_prepare(
-            self._ctx, rows, frames, text_len, hip.ptr(feats), hip.ptr(text), hip.ptr(tmask), hip.ptr(video),
+            own._ctx, rows, frames, text_len, hip.ptr(feats), hip.ptr(text), hip.ptr(tmask), hip.ptr(video),
             hip.ptr(ids), n_ids, hip.ptr(align), hip.ptr(pad), hip.current_stream_ptr()))
 
     def forward(self, noisy_audio: torch.Tensor, audio_features: torch.Tensor, text_features: torch.Tensor,
@@ -278,6 +312,49 @@ class SAMAudio:
         with torch.cuda.device(self.device):
             hip.check(self._lib.samaudio_ode_solve(self._ctx, hip.ptr(state), method, g, len(grid),
                                                    hip.current_stream_ptr()))
+        return state
+
+    def _solve_concurrent(self, noise: torch.Tensor, ode_opt: Dict[str, Any], cond: List[Optional[torch.Tensor]],
+                          groups: int) -> torch.Tensor:
+        """prepare + ODE solve of `groups` contiguous row groups, each on its own engine context and HIP stream, driven
+        by one host thread per group (the C calls release the GIL).  Rows are independent, so
+        the result equals the single-stream one bit for bit."""
+        import threading
+        from .dist import shard_range
+        method, grid = ode_grid(ode_opt)
+        g = (C.c_float * len(grid))(*grid)
+        state = noise.to(self.device, torch.float32).clone().contiguous()
+        rows = state.size(0)
+        while len(self._lanes) < groups - 1:
+            self._lanes.append(_Lane(self))
+        main = torch.cuda.current_stream(self.device)
+        errors: List[BaseException] = []
+
+        def work(i: int, lane: Optional[_Lane]):
+            try:
+                rr = shard_range(rows, i, groups)
+                sl = slice(rr.start, rr.stop)
+                part = [None if c is None else c[sl] for c in cond]
+                stream = main if lane is None else lane.stream
+                with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                    self._prepare(*part, lane=lane)
+                    ctx = self._ctx if lane is None else lane._ctx
+                    hip.check(self._lib.samaudio_ode_solve(ctx, hip.ptr(state[sl]), method, g, len(grid),
+                                                           hip.current_stream_ptr()))
+            except BaseException as exc:  # re-raised on the caller's thread
+                errors.append(exc)
+
+        for lane in self._lanes[:groups - 1]:
+            lane.stream.wait_stream(main)
+        threads = [threading.Thread(target=work, args=(i, None if i == 0 else self._lanes[i - 1])) for i in range(groups)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for lane in self._lanes[:groups - 1]:
+            main.wait_stream(lane.stream)
+        if errors:
+            raise errors[0]
         return state
 
     # ------------------------------------------------------------------ separate()
@@ -323,10 +400,16 @@ class SAMAudio:
             if noise is None:
                 noise = torch.randn_like(feats_r)                                # model.py:274-275
             assert noise.shape == feats_r.shape, "noise must be [B*candidates, T, 256]"
-            self._prepare(feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), video,
-                          self._repeat(batch.anchor_ids, cand), self._repeat(batch.anchor_alignment, cand),
-                          self._repeat(batch.audio_pad_mask, cand))
-            latent = self.solve(noise, ode_opt)                                  # states[-1], [Bc, T, 256]
+            cond = [feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), video,
+                    self._repeat(batch.anchor_ids, cand), self._repeat(batch.anchor_alignment, cand),
+                    self._repeat(batch.audio_pad_mask, cand)]
+            groups = min(self.streams, feats_r.size(0))
+            if groups > 1:
+                cond = [None if c is None else c.to(self.device) for c in cond]
+                latent = self._solve_concurrent(noise, ode_opt, cond, groups)
+            else:
+                self._prepare(*cond)
+                latent = self.solve(noise, ode_opt)                              # states[-1], [Bc, T, 256]
             self.last_latent = latent
             # [Bc, T, 2C] -> rows (2b, 2b+1) = (target, residual) latents, channels-last (model.py:291-295)
             Bc, half = latent.size(0), C2 // 2

@@ -179,3 +179,27 @@ def test_batch_sharding_is_bitwise_invariant_at_full_width(gpu):
     parts = torch.cat([run(slice(0, 1)), run(slice(1, 4))])
     assert torch.equal(whole, parts), "batch sharding changed the result"
     assert torch.isfinite(whole).all()
+
+
+def test_concurrent_streams_are_bitwise_equal_to_one_stream(gpu):
+    """SAMAudio(streams=2) solves two row groups on two engine contexts / HIP streams from two host threads; rows
+    are independent, so the latent must equal the single-stream result bit for bit."""
+    cfg = preset_config("mini")
+    sd = init_state_dict(cfg, seed=11)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 12 * hop) for i in range(5)]
+    text, tmask = synthetic_text_features(5, 6, ragged=True)
+    proc = SAMAudioProcessor.from_config(cfg)
+    batch = proc(descriptions=["x"] * 5, audios=clips, text_features=text, text_mask=tmask).to(gpu)
+    noise = synthetic_noise(5, 12).to(gpu)
+    opt = {"method": "midpoint", "options": {"step_size": 0.25}}
+    one = _model(cfg, sd, "bf16", gpu)
+    one.separate(batch, noise=noise, ode_opt=opt)
+    ref = one.last_latent.clone()
+    two = SAMAudio(cfg, precision="bf16", device=str(gpu), streams=2)
+    two.load_state_dict(sd, strict=False)
+    for _ in range(2):
+        res = two.separate(batch, noise=noise, ode_opt=opt)
+        torch.cuda.synchronize()
+        assert torch.equal(two.last_latent, ref)
+    assert all(torch.isfinite(w).all() for w in res.target)
