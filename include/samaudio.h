@@ -129,7 +129,8 @@ typedef struct {
 } samaudio_kernel_stat;
 int samaudio_profile_begin(samaudio_ctx* ctx);
 /* Tuning / test hook: force the GEMM kernel variant (-1 automatic; 0..2 the 128-row tiles of gemm.hip;
- * 3 = 256x128 3-stage, 4 = 256x128 2-stage, 5 = 256x256 2-stage of gemm2.hip where eligible). */
+ * 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 9 = 256x256 role-split of
+ * gemm2.hip where eligible). */
 void samaudio_debug_force_gemm_variant(int variant);
 /* Tuning hook: A/B switches between kernel generations (flag 1 = first-generation bf16 qkv_prep); 0 = shipped. */
 void samaudio_debug_set_flag(int flag, int value);

@@ -106,6 +106,8 @@ struct GemmParams {
   const float* act_alpha;  // snake alpha per channel (n % chan_mod)
   long c_lo, c_hi;         // valid range of (m*c_ld_rel + n); c_ld_rel = f32_ld or act_ld
   long c_ld_rel;
+  long w_bstride;          // per-batch offset of W in elements (0: one weight matrix for every batch)
+  int raster_gm;           // gemm2/gemm3 tile raster: M-tiles per group (0 = default 8)
 };
 
 }  // namespace sa

@@ -319,8 +319,8 @@ Status Engine::profile_begin() {
 
 Status Engine::profile_end(std::vector<KernelStat>& out) {
   prof_on_ = false;
-  out.assign(20, KernelStat{});
-  for (int v = 0; v < 20; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  out.assign(15, KernelStat{});
+  for (int v = 0; v < 15; ++v) out[v].name = gemm_variant_name(v, bf16_);
   for (const ProfRec& r : prof_) {
     SA_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       m = m < p.M ? m : p.M - 1;
       a_rows[i] = A + (long)m * p.lda;
     }
-    const T* W = (const T*)p.W;
+    const T* W = (const T*)p.W + (long)b * p.w_bstride;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       int n = n0 + (wave + 4 * i) * 8 + r8;
@@ -223,7 +223,10 @@ static int gemm1_variant(const GemmParams& p) {
 // the accumulation order of any output element.
 int gemm_variant(const GemmParams& p, bool is_bf16) {
   const bool g2 = is_bf16 && gemm2_ok(p);
-  if (g_force >= 3) return g2 ? g_force : gemm1_variant(p);
+  if (g_force >= 3) {
+    const bool known = g_force == 3 || g_force == 4 || g_force == 5 || g_force == 9 || (g_force >= 12 && g_force <= 14);
+    return g2 && known ? g_force : gemm1_variant(p);
+  }
   if (g_force >= 0) return gemm1_variant(p);
   // measured (tools/gemm_bench.py, profiles/r1_gemm_variants_*.log): 256x256 ping-pong for the widest outputs,
   // 256x128 elsewhere; codec convolutions with >= 96 output channels ride the same kernels
@@ -231,11 +234,10 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
   return gemm1_variant(p);
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
-  static const char* names[2][20] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+  static const char* names[2][15] = {
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
-       "gemm2_bf16_256x256_s2", "gemm2_bf16_128x256_k32s3_w4", "gemm2_bf16_256x128_k32s3_w4",
-       "gemm2_bf16_128x256_k32s2_w4", "gemm3_bf16_256x256_pp2", "gemm3_bf16_256x128_pp4", "gemm3_bf16_256x128_pp2", "abl_nodma", "abl_nomfma", "abl_noread", "gemm2_bf16_256x256_s2_w4", "gemm2_bf16_256x128_s2_pipe", "gemm2_bf16_256x256_s2_pipe", "abl_vgprfill", "abl_vgprfill_nomfma"}};
+       "gemm2_bf16_256x256_s2", "", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma", "abl_noread"}};
   return names[is_bf16 ? 1 : 0][v];
 }
 

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective for any total
     b = L / per_batch;
     const int l2 = L - b * per_batch;
-    constexpr int GM = 8;
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
     const int per_group = GM * tiles_n;
     const int grp = l2 / per_group;
     const int first_m = grp * GM;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 
       m = m < p.M ? m : p.M - 1;
       a_rows[i] = A + (long)m * p.lda;
     }
-    const bf16_t* W = (const bf16_t*)p.W;
+    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       int n = n0 + (wave + NW * i) * RPI + r8;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
     const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     b = L / per_batch;
     const int l2 = L - b * per_batch;
-    constexpr int GM = 8;
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
     const int per_group = GM * tiles_n;
     const int gi = l2 / per_group;
     const int first_m = gi * GM;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
   const int r8 = lane >> 3;
   const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
   const bf16_t* const Abase = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
-  const bf16_t* const Wbase = (const bf16_t*)p.W;
+  const bf16_t* const Wbase = (const bf16_t*)p.W + (long)b * p.w_bstride;
   const int row0 = wave * 8 + r8;
   int a_in = chunk * CH;
   long a_tap = 0;
@@ -399,23 +399,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
     for (int i = 0; i < AI; ++i) {
       int m = m0 + row0 + 64 * i;
       m = m < p.M ? m : p.M - 1;
-      if (ABL >= 4) {  // same bytes through the L1 into VGPRs (discarded): is the LDS write port the limit?
-        const f32x4_t v = *(const f32x4_t*)(Abase + (long)m * p.lda + a_k);
-        asm volatile("" ::"v"(v));
-      } else {
-        dma16(Abase + (long)m * p.lda + a_k, sA + (wave + NW * i) * 1024);
-      }
+      dma16(Abase + (long)m * p.lda + a_k, sA + (wave + NW * i) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       int n = n0 + row0 + 64 * i;
       n = n < p.N ? n : p.N - 1;
-      if (ABL >= 4) {
-        const f32x4_t v = *(const f32x4_t*)(Wbase + (long)n * p.K + w_k);
-        asm volatile("" ::"v"(v));
-      } else {
-        dma16(Wbase + (long)n * p.K + w_k, sB + (wave + NW * i) * 1024);
-      }
+      dma16(Wbase + (long)n * p.K + w_k, sB + (wave + NW * i) * 1024);
     }
     a_in += BK;
     while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
@@ -483,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
       phase_barrier();
       // ---- M: matrix pipe only
       __builtin_amdgcn_s_setprio(1);
-      if ((ABL == 2 || ABL == 5) && s > 0) {  // keep the fragments alive without touching the matrix pipe
+      if (ABL == 2 && s > 0) {  // keep the fragments alive without touching the matrix pipe
 #pragma unroll
         for (int kk = 0; kk < KSP; ++kk) {
 #pragma unroll
@@ -545,29 +535,23 @@ bool gemm2_ok(const GemmParams& p) {
   return true;
 }
 
-// variants: 0 = 256x128 3-stage, 1 = 256x128 2-stage, 2 = 256x256 2-stage (8 waves, BK 64, one workgroup per CU);
-//           3 = 128x256 3-stage, 4 = 256x128 3-stage, 5 = 128x256 2-stage (4 waves, BK 32, two workgroups per CU);
-//           6 = 256x256 ping-pong (half-slab phases, 2 stages), 7 = 256x128 ping-pong (whole-slab phases, 3 stages),
-//           8 = 256x128 ping-pong (half-slab phases, 3 stages)
+// variants: 0 = 256x128 3-stage ring, 1 = 256x128 2-stage ring, 2 = 256x256 2-stage ring (8 waves, BK 64, one
+// workgroup per CU); 6 = 256x256 role-split (half-slab phases, 2 stages).
+// Measured and dropped (profiles/r1_gemm_variants_*.log): 4-wave BK-32 tiles with two workgroups per CU (3-5),
+// 256x128 role-split with 3 stages (7, 8), 256x256 with one 512-register wave per SIMD (12), hand-pipelined asm
+// fragment reads (13, 14) - all within +-3 % of the kept kernels or slower.  Ablation builds (9-11: no DMA / no MFMA /
+// no LDS reads; wrong results, timing only) compile with -DSAMAUDIO_GEMM_ABLATIONS.
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
   switch (variant) {
-    case 16: return launch3<256, 256, 2, 4, 2, 2, 5>(p, st);
-    case 15: return launch3<256, 256, 2, 4, 2, 2, 4>(p, st);
-    case 14: return launch2<256, 256, 2, 4, 2, 64, 1>(p, st);  // hand-pipelined fragment reads
-    case 13: return launch2<256, 128, 4, 2, 2, 64, 1>(p, st);
-    case 12: return launch2<256, 256, 2, 2, 2, 64>(p, st);  // 4 waves, one per SIMD, 128x128 wave tiles (512 registers)
-    case 11: return launch3<256, 256, 2, 4, 2, 2, 3>(p, st);  // ablations (tools/gemm_bench.py --ablate)
+#ifdef SAMAUDIO_GEMM_ABLATIONS
+    case 11: return launch3<256, 256, 2, 4, 2, 2, 3>(p, st);
     case 10: return launch3<256, 256, 2, 4, 2, 2, 2>(p, st);
     case 9: return launch3<256, 256, 2, 4, 2, 2, 1>(p, st);
-    case 8: return launch3<256, 128, 4, 2, 2, 3>(p, st);
-    case 7: return launch3<256, 128, 4, 2, 4, 3>(p, st);
+#endif
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
-    case 5: return launch2<128, 256, 1, 4, 2, 32>(p, st);
-    case 4: return launch2<256, 128, 2, 2, 3, 32>(p, st);
-    case 3: return launch2<128, 256, 1, 4, 3, 32>(p, st);
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);
-    case 1: return launch2<256, 128, 4, 2, 2, 64>(p, st);
-    default: return launch2<256, 128, 4, 2, 3, 64>(p, st);
+    case 0: return launch2<256, 128, 4, 2, 3, 64>(p, st);
+    default: return launch2<256, 128, 4, 2, 2, 64>(p, st);
   }
 }
 

@@ -51,6 +51,7 @@ class GemmParams(C.Structure):
         ("out_act", C.c_void_p), ("act_bstride", C.c_long), ("act_ld", C.c_long), ("act_off", C.c_long),
         ("act", C.c_int), ("f32_act", C.c_int), ("act_alpha", C.c_void_p),
         ("c_lo", C.c_long), ("c_hi", C.c_long), ("c_ld_rel", C.c_long),
+        ("w_bstride", C.c_long), ("raster_gm", C.c_int),
     ]
 
 

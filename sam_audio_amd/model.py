@@ -208,7 +208,12 @@ class SAMAudio:
         need = self._lib.samaudio_workspace_bytes(own._ctx, rows, frames, max(1, text_len), codec_items, samples)
         if own._workspace is None or own._workspace.numel() < need:
             own._workspace = None
-            own._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+            if os.environ.get("SAMAUDIO_POISON"):
+                # test aid: every byte 0xFF = NaN in fp32 and bf16, so a kernel that reads scratch nobody wrote shows up
+                # as NaN deterministically instead of depending on what the allocator handed out
+                own._workspace = torch.full((need + 256,), 255, dtype=torch.uint8, device=self.device)
+            else:
+                own._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = own._workspace.data_ptr()
         aligned = (base + 255) // 256 * 256
         hip.check(self._lib.samaudio_set_workspace(own._ctx, C.c_void_p(aligned),
@@ -336,7 +341,7 @@ class SAMAudio:
                 sl = slice(rr.start, rr.stop)
                 part = [None if c is None else c[sl] for c in cond]
                 stream = main if lane is None else lane.stream
-                with torch.cuda.device(self.device), torch.cuda.stream(stream):
+                with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(stream):
                     self._prepare(*part, lane=lane)
                     ctx = self._ctx if lane is None else lane._ctx
                     hip.check(self._lib.samaudio_ode_solve(ctx, hip.ptr(state[sl]), method, g, len(grid),

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# Scratch handed to the engine is filled with 0xFF bytes (NaN in fp32 and bf16) in every test, so a kernel that reads
+# scratch nobody wrote fails deterministically instead of depending on what the allocator returned.
+os.environ.setdefault("SAMAUDIO_POISON", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

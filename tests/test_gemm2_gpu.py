@@ -15,9 +15,8 @@ from sam_audio_amd import hip
 from tests import util
 
 pytestmark = pytest.mark.gpu
-# 3 = 256x128 3-stage ring, 4 = 256x128 2-stage, 5 = 256x256 2-stage, 6/7 = 4-wave BK32, 9 = 256x256 role-split,
-# 10/11 = 256x128 role-split (3 LDS stages), 15 = 256x256 4-wave
-VARIANTS = [3, 4, 5, 6, 7, 9, 10, 11, 15, 16, 17]
+# 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 9 = 256x256 role-split
+VARIANTS = [3, 4, 5, 9]
 
 
 def _mk(shape, seed, scale=1.0):
@@ -84,7 +83,7 @@ def test_gate_residual_dual_output_and_swiglu(gpu, variant):
     util.report(f"swiglu v{variant}", u, want_u, 3.2e-2)
 
 
-@pytest.mark.parametrize("variant", [4, 9, 11])
+@pytest.mark.parametrize("variant", [3, 4, 9])
 def test_conv_forms(gpu, variant):
     """The codec's implicit-convolution forms on the 256-row kernels: dilated k7 conv with snake epilogue into a
     halo-padded buffer, and a stride-4 transposed conv (phase-major columns, chan_mod bias, output window mask)."""

@@ -19,7 +19,8 @@ from sam_audio_amd import hip  # noqa: E402
 from sam_audio_amd.config import preset_config  # noqa: E402
 from tests import util  # noqa: E402
 
-VARIANTS = {4: "256x128 s2", 16: "256x128 s2 pipe", 5: "256x256 s2", 17: "256x256 s2 pipe", 9: "pp 256x256 h"}
+RASTER = [0]
+VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256"}
 
 
 def interleave16(w1, w3):
@@ -60,7 +61,8 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
             kw = dict(gate_tab=tab, gate=gsl, gate_ld=6 * N, rows_per_gate=T, res=res, res_geom=(0, N, 0), out_f32=out,
                       f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
             outs = [("f32", out, ref, 2e-3), ("act", out_act, ref, 1e-1)]
-    line = f"{name:>22s} M={M} N={N} K={K} {kind:7s}"
+    kw["raster_gm"] = RASTER[0]
+    line = f"{name:>22s} M={M} N={N} K={K} {kind:7s} gm={RASTER[0]}"
     for v, vname in VARIANTS.items():
         hip.lib().samaudio_debug_force_gemm_variant(v)
         for _, o, _, _ in outs:
@@ -92,11 +94,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="time the gemm3 256x256 ablation builds (results are wrong)")
+    ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size on the shipped variants")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.ablate:
         VARIANTS.clear()
-        VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads", 18: "VGPR fill", 19: "VGPR fill, no MFMA"})
+        VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads"})  # needs -DSAMAUDIO_GEMM_ABLATIONS
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
     M = args.batch * 250
@@ -105,6 +108,15 @@ def main():
     run_case("edge gated", 517, 1152, 320, "gated", dev, 2, T=47)
     run_case("edge swiglu", 333, 1280, 256, "swiglu", dev, 2)
     if args.quick:
+        return
+    if args.raster:
+        VARIANTS.clear()
+        VARIANTS.update({4: "256x128 s2", 9: "pp 256x256"})
+        for gm in (8, 2, 4, 16, 32, 8):
+            RASTER[0] = gm
+            run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
+            run_case("c_wq", M, D, D, "plain", dev, args.iters)
+            run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
         return
     if args.ablate:
         run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
