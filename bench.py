@@ -213,6 +213,20 @@ def main():
                 "gemm_ms_per_step": round(sum(k["ms"] for k in stats), 2),
             }
 
+    # HBM traffic of the dominant kernel: PMC numbers come from separate profiled runs (tools/profile_bench.sh ->
+    # tools/pmc_traffic.py -> profiles/r1_traffic.json); they cannot be collected inside a timed run.
+    if roofline is not None:
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["kernels"]
+            key = {"gemm2_bf16_256x128_s2": "gemm2_kernel<256, 128, 4, 2, 2, 64, 0>",
+                   "gemm3_bf16_256x256_pp2": "gemm3_kernel<256, 256, 2, 4, 2, 2, 0>"}.get(roofline["kernel"], "")
+            hit = [v for k, v in traffic.items() if key and key in k]
+            if hit:
+                roofline["traffic"] = round(hit[0]["traffic_bytes_per_launch"])
+                roofline["traffic_note"] = "HBM bytes per launch, rocprofv3 PMC passes (profiles/r1_traffic.json)"
+        except (OSError, KeyError, ValueError):
+            pass
+
     cpu = None
     if want_cpu:
         threads = args.cpu_threads or usable_cores()

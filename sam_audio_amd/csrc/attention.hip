@@ -18,14 +18,17 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // ---------------------------------------------------------------------------------------------------
 // bf16 MFMA self-attention.  grid (Tp/64, H, B), 256 threads (4 waves x 16 query rows).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                             const bf16_t* __restrict__ Vt,
-                                                             const unsigned char* __restrict__ key_mask,
-                                                             bf16_t* __restrict__ out, int T, int Tp, int H) {
+// NW waves x 16 query rows per workgroup: NW = 8 (128 rows) halves the K / V^T staging traffic and barrier count per
+// query row; it needs Tp % 128 == 0 (the launcher falls back to NW = 4 otherwise).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                                 const bf16_t* __restrict__ Vt,
+                                                                 const unsigned char* __restrict__ key_mask,
+                                                                 bf16_t* __restrict__ out, int T, int Tp, int H) {
   __shared__ __attribute__((aligned(16))) char Ks[64 * 256];   // [key][128 d] bf16, chunk ^= key & 15
   __shared__ __attribute__((aligned(16))) char Vs[128 * 128];  // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
-  __shared__ __attribute__((aligned(16))) char Ps[4 * 16 * 128];  // per wave [16 q][64 keys] bf16
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  __shared__ __attribute__((aligned(16))) char Ps[NW * 16 * 128];  // per wave [16 q][64 keys] bf16
+  const int q0 = blockIdx.x * (16 * NW), h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const long bh = (long)b * H + h;
@@ -48,8 +51,8 @@ __global__ __launch_bounds__(256) void self_attn_bf16_kernel(const bf16_t* __res
   for (int kt = 0; kt < Tp; kt += 64) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + 256 * it;
+    for (int it = 0; it < 16 / NW; ++it) {
+      const int idx = tid + 64 * NW * it;
       {
         const int row = idx >> 4, c = idx & 15;
         const uint4 v = *(const uint4*)(K + (bh * Tp + kt + row) * 128 + c * 8);
@@ -226,8 +229,11 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
 
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                  void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
-  if (bf16)
-    hipLaunchKernelGGL(self_attn_bf16_kernel, dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q,
+  if (bf16 && Tp % 128 == 0)
+    hipLaunchKernelGGL(self_attn_bf16_kernel<8>, dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else if (bf16)
+    hipLaunchKernelGGL(self_attn_bf16_kernel<4>, dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q,
                        (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
   else
     hipLaunchKernelGGL(self_attn_f32_kernel, dim3((T + 31) / 32, H, B), dim3(256), 0, st, (const float*)Q,
@@ -393,6 +399,149 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pB, o, 0, 0, 0);
     if (t < T) store4<bf16_t>(orow + n * 16, o[0] * il, o[1] * il, o[2] * il, o[3] * il);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Folded cross-attention output projection (bf16 mode, Lt <= 16).
+//   reference: h += Wo . concat_h( P_h V_h )      (transformer.py:153-161, :382-388)
+//   folded:    h += P . U,   U[(h, j), :] = Wo[:, h*128:(h+1)*128] . V[j, h, :]
+// The contraction over D = H*128 channels of the c_wo GEMM becomes a contraction over H*Lt (176 at H = 22, Lt = 8)
+// probabilities: 16x fewer MFMA flops for that GEMM, and the attention kernel writes [M, H*Lt] instead of [M, D].
+//
+// cross_attn_probs_kernel: same scores / softmax as cross_attn_mfma_kernel, output P[m][h*LtP + token] (normalised,
+// bf16), LtP = 8 or 16.  grid (ceil(T/64), H, B).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __restrict__ q, const float* __restrict__ qw,
+                                                               const bf16_t* __restrict__ kv, long kv_ld,
+                                                               const unsigned char* __restrict__ mask,
+                                                               bf16_t* __restrict__ P, int ldp, int T, int Lt, int LtP,
+                                                               int H, float eps) {
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int D = H * 128;
+  bf16x8_t kf[4];
+  const bool tok_ok = r < Lt && mask[(long)b * Lt + (r < Lt ? r : 0)] != 0;
+  {
+    const bf16_t* krow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + h * 128 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 v = *(const uint4*)(krow + ks * 32);
+      if (!tok_ok) v = make_uint4(0u, 0u, 0u, 0u);
+      kf[ks] = *(const bf16x8_t*)&v;
+    }
+  }
+  const int t = blockIdx.x * 64 + wave * 16 + r;
+  const int tc = t < T ? t : T - 1;
+  const long m = (long)b * T + tc;
+  float qv[4][8];
+  float ss = 0.f;
+  {
+    const bf16_t* qrow = q + m * D + h * 128 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const uint4 v = *(const uint4*)(qrow + ks * 32);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qv[ks][2 * e] = __uint_as_float(w4[e] << 16);
+        qv[ks][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+        ss += qv[ks][2 * e] * qv[ks][2 * e] + qv[ks][2 * e + 1] * qv[ks][2 * e + 1];
+      }
+    }
+  }
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  const float inv = rsqrtf(ss / 128.f + eps);
+  f32x4_t sT = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const float4 w0 = *(const float4*)(qw + ks * 32 + g * 8), w1 = *(const float4*)(qw + ks * 32 + g * 8 + 4);
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    unsigned pk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      pk[e] = (unsigned)f2bf(qv[ks][2 * e] * inv * wv[2 * e]) | ((unsigned)f2bf(qv[ks][2 * e + 1] * inv * wv[2 * e + 1]) << 16);
+    const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], *(const bf16x8_t*)&pv, sT, 0, 0, 0);
+  }
+  const float scale = 0.08838834764831845f;
+  float p[4], mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int tok = g * 4 + e;
+    const bool ok = tok < Lt && mask[(long)b * Lt + (tok < Lt ? tok : 0)] != 0;
+    p[e] = ok ? sT[e] * scale : -INFINITY;
+    mx = fmaxf(mx, p[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float m_safe = mx == -INFINITY ? 0.f : mx;
+  float l = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    p[e] = __expf(p[e] - m_safe);
+    l += p[e];
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float il = 1.f / l;
+  if (t < T && g * 4 < LtP) store4<bf16_t>(P + m * ldp + h * LtP + g * 4, p[0] * il, p[1] * il, p[2] * il, p[3] * il);
+}
+
+// cross_attn_fold_kernel: U^T[b][n][h*LtP + j] = sum_d Wo[n][h*128 + d] * V[b][j][h*128 + d]   (bf16, zero for
+// j >= Lt), the per-batch weight operand ([N = D][K = KP], K contiguous) of the folded GEMM.
+// One wave = one (head, 16 output channels n): its Wo fragment stays in registers while it walks the batch.
+// MFMA orientation: rows = tokens (A = V), columns = n (B = Wo^T) -> a lane owns 4 consecutive tokens of one n.
+__global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
+                                                              long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
+                                                              int LtP, int H) {
+  const int h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int D = H * 128;
+  const int n = (blockIdx.x * 4 + wave) * 16 + r;  // D % 64 == 0
+  bf16x8_t wf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
+  // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    uint4 v[4][4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int b = b0 + bb < B ? b0 + bb : B - 1;
+      const bf16_t* vrow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + D + h * 128 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) v[bb][ks] = *(const uint4*)(vrow + ks * 32);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 x = v[bb][ks];
+        if (r >= Lt) x = make_uint4(0u, 0u, 0u, 0u);
+        u = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&x, wf[ks], u, 0, 0, 0);
+      }
+      // lane: tokens g*4 .. g*4+3 of column n
+      if (b0 + bb < B && g * 4 < LtP)
+        store4<bf16_t>(UT + ((long)(b0 + bb) * D + n) * KP + h * LtP + g * 4, u[0], u[1], u[2], u[3]);
+    }
+  }
+}
+
+hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
+                                   void* P, int ldp, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(cross_attn_probs_kernel, dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const bf16_t*)q, qw,
+                     (const bf16_t*)kv, kv_ld, mask, (bf16_t*)P, ldp, T, Lt, LtP, H, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
+                                  int H, hipStream_t st) {
+  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H), dim3(256), 0, st, (const bf16_t*)wo,
+                     (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
+  return hipGetLastError();
 }
 
 hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,

@@ -102,6 +102,7 @@ class Engine {
   char* ws_ = nullptr;
   size_t ws_bytes_ = 0;
   int rows_ = 0, frames_ = 0, text_len_ = 0, frames_pad_ = 0;
+  int fold_ltp_ = 0, fold_kp_ = 0;  // folded cross-attention: tokens per head slot (8 | 16; 0 = not folded), padded K
   bool has_anchor_ = false;
 
   // resolved weights (pointers into caller memory)
@@ -137,7 +138,7 @@ class Engine {
   struct {
     float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
-        *feats, *text, *video, *anch;
+        *feats, *text, *video, *anch, *probs, *ut;
     unsigned char *pad_mask, *text_mask;
     double* gn_part;
   } d_;

@@ -3,6 +3,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace sa {
@@ -217,6 +218,10 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   void* kvc = act(Mt * 2 * D * cfg_.n_layers); void* temb = act(nt * cfg_.freq_dim); void* tu = act(nt * D); void* tsilu = act(nt * D);
   void* feats = act(M * C2); void* text = act(Mt * cfg_.text_dim); void* video = act(M * cfg_.video_dim);
   void* anch = act(M * cfg_.anchor_dim);
+  // folded cross-attention (bf16, Lt <= 16): probabilities [M, KP] and the per-batch operand U^T [rows][D][KP]
+  const long ltp = Lt <= 8 ? 8 : 16, kp = round_up(H * ltp, 64);
+  void* probs = (bf16_ && Lt <= 16) ? act(M * kp) : nullptr;
+  void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
@@ -225,7 +230,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
     d.t0 = t0; d.tsin = tsin; d.vtmp = vtmp; d.times = times; d.ybf = ybf; d.xn = xn; d.qkv = qkv; d.Q = Q; d.K = K;
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
-    d.video = video; d.anch = anch; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
+    d.video = video; d.anch = anch; d.probs = probs; d.ut = ut; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
   }
   return Status{};
 }
@@ -396,6 +401,14 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
     SA_HIP(launch_layernorm_accum(d_.vtmp, g_.vid_ln_w, g_.vid_ln_b, g_.vid_gate, d_.cond, (int)M, D, 1e-5f, st));
   }
   // cond += tanh(g_a) * proj(Emb[ids.gather(alignment)])            (model.py:54-65; tanh folded into anc_w)
+  // folded cross-attention output projection: zero the probability buffer once (its K padding columns stay zero)
+  fold_ltp_ = fold_kp_ = 0;
+  if (bf16_ && Lt <= 16 && !std::getenv("SAMAUDIO_NO_FOLD")) {
+    fold_ltp_ = Lt <= 8 ? 8 : 16;
+    fold_kp_ = (int)round_up((long)cfg_.n_heads * fold_ltp_, 64);
+    SA_HIP(hipMemsetAsync(d_.probs, 0, (size_t)M * fold_kp_ * esz_, st));
+    SA_HIP(hipMemsetAsync(d_.ut, 0, (size_t)rows * D * fold_kp_ * esz_, st));  // 0 * (K padding of U) must stay 0
+  }
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
     SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment, d_.anch,
@@ -518,9 +531,23 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_act(p, d_.qc, D);
       SA_TRY(gemm(p, st));
     }
-    SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, (const char*)d_.kvc + (size_t)l * 2 * D * esz_, kv_ld, d_.text_mask,
-                                  d_.ca, bf16_, rows, T, Lt, H, eps, st));
-    {
+    const void* kv_l = (const char*)d_.kvc + (size_t)l * 2 * D * esz_;
+    if (fold_ltp_) {
+      // h += P . U with U = Wo V folded per (batch, head, token): K = H*Lt instead of D (see attention.hip)
+      SA_HIP(launch_cross_attn_probs(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.probs, fold_kp_, rows, T, Lt,
+                                     fold_ltp_, H, eps, st));
+      SA_HIP(launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st));
+      GemmParams p = lin(d_.probs, fold_kp_, d_.ut, T, D, fold_kp_);
+      p.nbatch = rows;
+      p.a_bstride = (long)T * fold_kp_;
+      p.w_bstride = (long)D * fold_kp_;
+      with_res(p, d_.h, D);
+      p.res_bstride = (long)T * D;
+      out_f32(p, d_.h, D);
+      p.f32_bstride = (long)T * D;
+      SA_TRY(gemm(p, st));
+    } else {
+      SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);

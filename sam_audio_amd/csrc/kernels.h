@@ -54,6 +54,12 @@ hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld
 hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,
                                   const unsigned char* mask, void* out, bool bf16, int B, int T, int Lt, int H,
                                   float eps, hipStream_t st);
+// folded cross-attention output projection (bf16, Lt <= 16; see attention.hip): P [M, ldp] = softmax probabilities
+// at column h*LtP + token; UT [B][D][KP] = per-batch weight operand of the GEMM h += P . U
+hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
+                                   void* P, int ldp, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st);
+hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
+                                  int H, hipStream_t st);
 // per-(row, layer, head) RMSNorm of the K halves of kv_all [rows, L*2D] (all layers' cross-attention keys at
 // once); w_all [L, 128]
 hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,
