@@ -3,6 +3,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -21,6 +22,33 @@ namespace sa {
   } while (0)
 
 static Status fail(int code, const std::string& m) { return Status{code, m}; }
+
+// SAMAUDIO_TRACE=1: after each stage of an evaluation, synchronise, copy the stage's buffer to the host and print how
+// many values are non-finite plus the largest magnitude (debugging aid; never on in timed runs).
+static bool trace_on() {
+  static const bool on = std::getenv("SAMAUDIO_TRACE") != nullptr;
+  return on;
+}
+static void trace(const char* name, const void* dev, size_t count, bool is_bf16, hipStream_t st) {
+  if (!trace_on() || !dev || !count) return;
+  (void)hipStreamSynchronize(st);
+  std::vector<unsigned char> host(count * (is_bf16 ? 2 : 4));
+  if (hipMemcpy(host.data(), dev, host.size(), hipMemcpyDeviceToHost) != hipSuccess) return;
+  size_t bad = 0;
+  double mx = 0.0;
+  for (size_t i = 0; i < count; ++i) {
+    float v;
+    if (is_bf16) {
+      const unsigned u = (unsigned)((const unsigned short*)host.data())[i] << 16;
+      std::memcpy(&v, &u, 4);
+    } else {
+      v = ((const float*)host.data())[i];
+    }
+    if (!std::isfinite(v)) ++bad;
+    else if (std::fabs(v) > mx) mx = std::fabs(v);
+  }
+  std::fprintf(stderr, "[samaudio trace] %-22s n=%zu non-finite=%zu max|x|=%.4g\n", name, count, bad, mx);
+}
 static long round_up(long v, long m) { return (v + m - 1) / m * m; }
 
 Engine::Engine(const samaudio_config& c) : cfg_(c) {
@@ -463,6 +491,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     p.f32_bstride = (long)T * D;
     return gemm(p, st);
   };
+  trace("cond", d_.cond, (size_t)M * D, false, st);
+  trace("aligned", d_.aligned, (size_t)M * D, false, st);
   SA_HIP(launch_groupnorm_silu(d_.aligned, g_.gn1_w, g_.gn1_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st));
   SA_TRY(patch_conv(g_.pw1, g_.pb1, nullptr, d_.hp1));
   SA_HIP(launch_groupnorm_silu(d_.hp1, g_.gn2_w, g_.gn2_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st));
@@ -496,6 +526,9 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_TRY(gemm(p, st));
   }
 
+  trace("patcher out h", d_.h, (size_t)M * D, false, st);
+  trace("t0", d_.t0, (size_t)nt * 6 * D, false, st);
+  trace("yemb", d_.yemb, (size_t)Mt * D, bf16_, st);
   const long kv_ld = 2L * D * cfg_.n_layers;
   if (cfg_.n_layers > 0) {  // cross-attention keys / values of every layer (k-normed), [Mt, L*2D]
     GemmParams p = lin(d_.yemb, D, g_.c_wkv_all, Mt, (int)kv_ld, D);
@@ -503,6 +536,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_TRY(gemm(p, st));
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
   }
+  trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
   for (int l = 0; l < cfg_.n_layers; ++l) {  // DiTBlock.forward, transformer.py:354-391
     const LayerW& w = layers_[l];
     const float* tab = w.mod_table;
@@ -516,7 +550,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     }
     SA_HIP(launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp,
                            H, eps, st));
+    trace("  xn", d_.xn, (size_t)M * D, bf16_, st);
+    trace("  qkv", d_.qkv, (size_t)M * 3 * D, bf16_, st);
+    trace("  Q", d_.Q, (size_t)rows * H * Tp * 128, bf16_, st);
+    trace("  K", d_.K, (size_t)rows * H * Tp * 128, bf16_, st);
+    trace("  Vt", d_.Vt, (size_t)rows * H * Tp * 128, bf16_, st);
     SA_HIP(launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st));
+    trace("  attn", d_.attn, (size_t)M * D, bf16_, st);
     {
       GemmParams p = lin(d_.attn, D, w.wo, M, D, D);  // h = x + gate_msa * attn
       p.gate_tab = tab + 2 * D; p.gate = d_.t0 + 2 * D; p.gate_ld = t6; p.rows_per_gate = T;
@@ -525,6 +565,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_act(p, d_.hbf, D);
       SA_TRY(gemm(p, st));
     }
+    trace("  h after wo", d_.h, (size_t)M * D, false, st);
     // cross-attention branch: h = h + CA(h, y)   (no norm, no gate: quirk Q4)
     {
       GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
@@ -553,6 +594,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_f32(p, d_.h, D);
       SA_TRY(gemm(p, st));
     }
+    trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
+    trace("  h after cross", d_.h, (size_t)M * D, false, st);
     // feed-forward branch
     SA_HIP(launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_,
                               (int)M, D, T, eps, st));
@@ -568,6 +611,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       SA_TRY(gemm(p, st));
     }
   }
+  trace("h after layers", d_.h, (size_t)M * D, false, st);
   // final modulated norm + output projection                         (transformer.py:507-519)
   SA_HIP(launch_rmsnorm_mod(d_.h, g_.final_norm, g_.final_table, g_.final_table + D, d_.t_emb, t1, 0, 0, d_.xn, bf16_,
                             (int)M, D, T, eps, st));
