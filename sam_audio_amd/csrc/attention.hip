@@ -394,7 +394,14 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
   bf16_t* orow = out + m * D + h * 128 + g * 4;
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
-    const bf16x8_t vf = *(const bf16x8_t*)(Vt + (n * 16 + r) * 16 + g * 8);
+    // lane groups 2, 3 stand for tokens 16..31, which do not exist: their operand must be an exact zero (reading
+    // past the 16-token row would pick up the next row - or, for d = 127, LDS left behind by an earlier kernel,
+    // and 0 * NaN from there poisons the whole tile: seen as box-dependent NaNs before this guard existed)
+    bf16x8_t vf = *(const bf16x8_t*)(Vt + (n * 16 + r) * 16 + (g & 1) * 8);
+    if (g >= 2) {
+      const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+      vf = *(const bf16x8_t*)&z;
+    }
     f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
     o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pB, o, 0, 0, 0);
     if (t < T) store4<bf16_t>(orow + n * 16, o[0] * il, o[1] * il, o[2] * il, o[3] * il);

