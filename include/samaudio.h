@@ -134,6 +134,9 @@ int samaudio_profile_begin(samaudio_ctx* ctx);
 void samaudio_debug_force_gemm_variant(int variant);
 /* Tuning hook: A/B switches between kernel generations (flag 1 = first-generation bf16 qkv_prep); 0 = shipped. */
 void samaudio_debug_set_flag(int flag, int value);
+/* Test aid: leave the LDS of every CU filled with NaN bit patterns (LDS is not cleared between kernels), so that a
+ * kernel consuming LDS it never wrote fails deterministically. */
+int samaudio_debug_poison_lds(samaudio_stream stream);
 int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capacity, int* count);
 
 /* ---- per-kernel hooks (parity tests; each is one kernel of the path above) -------------------------- */

@@ -103,6 +103,9 @@ int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int
 
 void samaudio_debug_force_gemm_variant(int variant) { sa::gemm_force_variant(variant); }
 void samaudio_debug_set_flag(int flag, int value) { sa::set_debug_flag(flag, value); }
+int samaudio_debug_poison_lds(samaudio_stream stream) {
+  return hip_ret(sa::launch_poison_lds((hipStream_t)stream), "poison_lds");
+}
 
 int samaudio_profile_begin(samaudio_ctx* ctx) {
   if (!ctx) return bad("null context");

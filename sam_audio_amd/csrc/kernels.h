@@ -5,6 +5,9 @@
 
 namespace sa {
 
+// test aid: fill the LDS of every CU with NaN bit patterns (LDS persists between kernels)
+hipError_t launch_poison_lds(hipStream_t st);
+
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
 void set_debug_flag(int flag, int value);

@@ -402,6 +402,23 @@ hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Test aid: leave every CU's LDS full of 0xFFFF words (NaN as bf16 and as fp32).  LDS is not cleared between
+// kernels, so a kernel that consumes LDS it never wrote (e.g. an MFMA operand of padding lanes) then produces NaNs
+// deterministically instead of depending on which kernel last ran on the CU.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink) {
+  __shared__ unsigned buf[160 * 1024 / 4];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) buf[i] = 0xffffffffu;
+  __syncthreads();
+  if (sink && buf[(threadIdx.x * 37) % (160 * 1024 / 4)] == 0u) sink[0] = 1u;  // keeps the stores alive
+}
+
+hipError_t launch_poison_lds(hipStream_t st) {
+  hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), 0, st, (unsigned*)nullptr);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // timestep features (reference transformer.py:236-248 and model.py:35-42): cat(cos, sin)(t * freq)
 // ------------------------------------------------------------------------------------------------
 template <typename TA>

@@ -80,6 +80,7 @@ _PROTOS = {
     "samaudio_profile_begin": (C.c_int, [C.c_void_p]),
     "samaudio_debug_force_gemm_variant": (None, [C.c_int]),
     "samaudio_debug_set_flag": (None, [C.c_int, C.c_int]),
+    "samaudio_debug_poison_lds": (C.c_int, [C.c_void_p]),
     "samaudio_profile_end": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
     "samaudio_op_gemm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "samaudio_op_rmsnorm_mod": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -25,3 +25,14 @@ def gpu():
     from sam_audio_amd import hip
     hip.lib()  # fail loudly if the HIP library is missing on a GPU box
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _poison_lds(request):
+    """Before every GPU test, leave all LDS full of NaN bit patterns (see samaudio_debug_poison_lds)."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import torch
+        if torch.cuda.is_available():
+            from sam_audio_amd import hip
+            hip.check(hip.lib().samaudio_debug_poison_lds(hip.current_stream_ptr()))
+    yield
