@@ -4,7 +4,7 @@
 //
 //   * bf16 mode: flash-style, both contractions on v_mfma_f32_16x16x32_bf16.  S = Q K^T with Q fragments
 //     held in registers; the softmax runs in the accumulator layout (row statistics by 16-lane shuffles);
-//     P is re-laid as an A operand through a per-wave LDS tile; V arrives pre-transposed ([d][key]) so that
+//     (16-lane DPP row reductions, no LDS round trip); P is re-laid as an A operand through a per-wave LDS tile; V arrives pre-transposed ([d][key]) so that
 //     P@V is again a K-contiguous contraction.  LDS tiles are XOR-swizzled against ds_read_b128 conflicts.
 //   * fp32 mode (parity path): same tiling on the vector ALU, exact fp32 with expf.
 //   * cross-attention (Lt ~ a handful of T5 tokens): one wave per (row, head), q-norm fused, online softmax.
@@ -91,8 +91,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
         s[nb][r] = valid[nb] ? s[nb][r] * scale : -INFINITY;
         mx = fmaxf(mx, s[nb][r]);
       }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      mx = row16_max(mx);
       const float m_new = fmaxf(m_i[r], mx);
       const float m_safe = m_new == -INFINITY ? 0.f : m_new;
       const float alpha = __expf(m_i[r] - m_safe);
@@ -103,8 +102,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
         s[nb][r] = pv;
         rs += pv;
       }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) rs += __shfl_xor(rs, off, 64);
+      rs = row16_sum(rs);
       l_i[r] = l_i[r] * alpha + rs;
       m_i[r] = m_new;
 #pragma unroll

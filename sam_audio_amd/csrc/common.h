@@ -56,6 +56,28 @@ __device__ __forceinline__ float snake_f(float x, float a) {
   return x + s * s / (a + 1e-9f);
 }
 
+// Reductions over the 16 lanes of one DPP row (lanes 16k .. 16k+15) on the VALU: v_max / v_add with a row_ror
+// DPP modifier, no LDS round trip (__shfl_xor lowers to ds_bpermute_b32: ~100 cycles of lgkmcnt wait per step, which
+// PMC showed as half of the attention kernel's wave cycles).  Every lane ends up with the reduction of its row; for
+// the sum the association order differs from lane to lane by design (each lane's result is still deterministic).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0x128>(v));  // row_ror:8
+  v = fmaxf(v, dpp_mov<0x124>(v));  // row_ror:4
+  v = fmaxf(v, dpp_mov<0x122>(v));  // row_ror:2
+  v = fmaxf(v, dpp_mov<0x121>(v));  // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0x128>(v);
+  v += dpp_mov<0x124>(v);
+  v += dpp_mov<0x122>(v);
+  v += dpp_mov<0x121>(v);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
