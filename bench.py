@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
-    ap.add_argument("--streams", type=int, default=2, help="row groups of the batch solved concurrently on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=1, help="row groups of the batch solved concurrently on separate HIP streams")
     return ap.parse_args()
 
 
