@@ -36,16 +36,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-// LDS read the compiler cannot reschedule; the caller waits (wait_lgkmcnt + sched_barrier) before the first use.
-__device__ __forceinline__ bf16x8_t lds_read_b128(unsigned addr, int imm) {
-  bf16x8_t v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(imm));
-  return v;
-}
-
 __device__ __forceinline__ float act_apply(float v, int act, float snake_alpha) {
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_TANH) return tanhf(v);
@@ -148,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 // swizzle (row>>2)&3 - both make the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte bank slots).
 // 4-wave configurations (BK = 32, <= 80 KiB LDS) run TWO workgroups per CU: the two are not barrier-coupled, so
 // one's MFMAs cover the other's barrier / LDS-latency / epilogue time.
-template <int BM, int BN, int WM_, int WN_, int STAGES, int BK, int PIPE = 0>
+template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
 __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 256 ? 1 : 2)) void gemm2_kernel(
     const GemmParams p) {
   constexpr int NW = WM_ * WN_;
@@ -266,51 +256,19 @@ __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 
     if (s + STAGES - 1 < nslab) issue(st_i);
     const char* sA = smem + st_c * STAGE;
     const char* sB = sA + TILE_A;
-    if (PIPE == 0) {  // compiler-scheduled: reads of a k-step, then its MFMAs
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int coff = ((ks * 2 + lh) ^ swz) << 4;
-        bf16x8_t af[FM], wf[FN];
+    for (int ks = 0; ks < KS; ++ks) {
+      const int coff = ((ks * 2 + lh) ^ swz) << 4;
+      bf16x8_t af[FM], wf[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(sA + a_base + i * 32 * RB + coff);
+      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(sA + a_base + i * 32 * RB + coff);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(sB + b_base + j * 32 * RB + coff);
+      for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(sB + b_base + j * 32 * RB + coff);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-      }
-    } else {
-      // hand-pipelined: the ds_reads of k-step ks+1 (inline asm, so hipcc can neither sink them nor fold the two
-      // fragment sets into one register set) are in flight while the MFMAs of k-step ks issue; counted lgkmcnt.
-      const unsigned sbase = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(sA);
-      bf16x8_t af[2][FM], wf[2][FN];
-      auto rd = [&](int ks, int buf) {
-        const unsigned coff = (unsigned)(((ks * 2 + lh) ^ swz) << 4);
-        const unsigned aa = sbase + a_base + coff, bb = sbase + TILE_A + b_base + coff;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[buf][i] = lds_read_b128(aa, i * 32 * RB);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) wf[buf][j] = lds_read_b128(bb, j * 32 * RB);
-      };
-      rd(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
-          rd(ks + 1, (ks + 1) & 1);
-          wait_lgkmcnt<FM + FN>();  // k-step ks landed; the FM+FN reads of ks+1 stay in flight
-        } else {
-          wait_lgkmcnt<0>();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
     st_c = st_c + 1 == STAGES ? 0 : st_c + 1;
     st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
@@ -509,10 +467,10 @@ static hipError_t launch3(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, int BK, int PIPE = 0>
+template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
 static hipError_t launch2(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES, BK, PIPE>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0,
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES, BK>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0,
                      st, p);
   return hipGetLastError();
 }

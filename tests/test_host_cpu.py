@@ -144,3 +144,27 @@ def test_product_path_has_no_cpu_fallback():
         model.load_state_dict(init_state_dict(preset_config("tiny"), 0))
     src = "".join(open(os.path.join(ROOT, "sam_audio_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "sam_audio_amd")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_streams_argument_is_validated():
+    from sam_audio_amd import SAMAudio
+    cfg = preset_config("tiny")
+    for ok in (1, 2):
+        assert SAMAudio(cfg, precision="bf16", streams=ok).streams == ok
+    with pytest.raises(ValueError):
+        SAMAudio(cfg, precision="bf16", streams=3)
+
+
+def test_bench_core_detection_and_gemm_params_mirror():
+    """bench.py's cpu_baseline must not oversubscribe a cgroup-limited box, and the ctypes mirror of GemmParams must
+    have the size the library checks in samaudio_op_gemm (a stale mirror would only show up on the GPU otherwise)."""
+    import bench
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    p = hip.GemmParams()
+    # an empty problem is rejected for its contents (ERR_ARG), a size mismatch would be rejected with the same code
+    # but a different message
+    rc = hip.lib().samaudio_op_gemm(C.byref(p), C.sizeof(p), hip.BF16, None)
+    assert rc == hip.ERR_ARG and b"size mismatch" not in hip.lib().samaudio_last_error()
+    rc = hip.lib().samaudio_op_gemm(C.byref(p), C.sizeof(p) - 8, hip.BF16, None)
+    assert rc == hip.ERR_ARG and b"size mismatch" in hip.lib().samaudio_last_error()
