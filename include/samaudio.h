@@ -159,6 +159,10 @@ int samaudio_op_self_attention(const void* q, const void* k, const void* vt, con
 int samaudio_op_cross_attention(const void* q, const float* q_w, void* kv, const float* k_w, const uint8_t* mask,
                                 void* out, int precision, int batch, int frames, int text_len, int heads, float eps,
                                 samaudio_stream stream);
+/* U^T[b][n][h*ltp + j] = sum_d wo[n][h*128+d] * V[b][j][h*128+d] (bf16; V = columns [D, 2D) of kv rows b*text_len+j):
+ * the per-batch operand of the folded cross-attention output projection. */
+int samaudio_op_cross_attn_fold(const void* wo, const void* kv, int64_t kv_ld, void* ut, int kp, int batch, int text_len,
+                                int ltp, int heads, samaudio_stream stream);
 int samaudio_op_layernorm_accum(const float* x, const float* w, const float* b, const float* gate, float* acc,
                                 int rows, int dim, float eps, samaudio_stream stream);
 

@@ -186,6 +186,13 @@ int samaudio_op_cross_attention(const void* q, const float* q_w, void* kv, const
                                             (hipStream_t)stream), "cross_attention");
 }
 
+int samaudio_op_cross_attn_fold(const void* wo, const void* kv, int64_t kv_ld, void* ut, int kp, int batch, int text_len,
+                                int ltp, int heads, samaudio_stream stream) {
+  if (text_len > 16 || (ltp != 8 && ltp != 16) || kp % 64 || kp < heads * ltp) return bad("cross_attn_fold: shape");
+  return hip_ret(sa::launch_cross_attn_fold(wo, kv, kv_ld, ut, kp, batch, text_len, ltp, heads, (hipStream_t)stream),
+                 "cross_attn_fold");
+}
+
 int samaudio_op_layernorm_accum(const float* x, const float* w, const float* b, const float* gate, float* acc,
                                 int rows, int dim, float eps, samaudio_stream stream) {
   return hip_ret(sa::launch_layernorm_accum(x, w, b, gate, acc, rows, dim, eps, (hipStream_t)stream),

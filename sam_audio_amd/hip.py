@@ -89,6 +89,7 @@ _PROTOS = {
     "samaudio_op_qkv_prep": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     "samaudio_op_self_attention": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "samaudio_op_cross_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "samaudio_op_cross_attn_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "samaudio_op_layernorm_accum": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
 }
 

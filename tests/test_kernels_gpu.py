@@ -159,3 +159,23 @@ def test_layernorm_accum(gpu):
                                                     P(gate.to(gpu)), hip.ptr(acc_d), M, D, 1e-5, util.stream()))
     want = acc + torch.tanh(gate) * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
     util.report("layernorm_accum", acc_d, want, 1e-5)
+
+
+@pytest.mark.parametrize("Lt,ltp", [(3, 8), (8, 8), (11, 16)])
+def test_cross_attn_fold_operand(gpu, Lt, ltp):
+    """U^T of the folded cross-attention output projection against an fp32 einsum."""
+    B, H = 3, 4
+    D = H * 128
+    kp = (H * ltp + 63) // 64 * 64
+    wo = _mk((D, D), 30, 1 / math.sqrt(D)).to(torch.bfloat16)
+    kv = _mk((B * Lt, 2 * D), 31).to(torch.bfloat16)
+    ut = torch.zeros(B, D, kp, device=gpu, dtype=torch.bfloat16)
+    hip.check(hip.lib().samaudio_op_cross_attn_fold(P(wo.to(gpu)), P(kv.to(gpu)), 2 * D, hip.ptr(ut), kp, B, Lt, ltp, H,
+                                                    util.stream()))
+    v = kv.float()[:, D:].reshape(B, Lt, H, 128)
+    w = wo.float().reshape(D, H, 128)
+    ref = torch.zeros(B, D, H, ltp)
+    ref[..., :Lt] = torch.einsum("nhd,bjhd->bnhj", w, v)
+    want = torch.zeros(B, D, kp)
+    want[:, :, :H * ltp] = ref.reshape(B, D, H * ltp)
+    util.report(f"fold Lt{Lt}", ut, want, 2e-2)

@@ -68,3 +68,9 @@ tmask = torch.ones(B, Lt, dtype=torch.uint8, device=dev)
 timeit("cross_attention (+k headnorm)", lambda: hip.check(L.samaudio_op_cross_attention(
     hip.ptr(q), hip.ptr(qw), hip.ptr(kv), hip.ptr(kw), hip.ptr(tmask), hip.ptr(out), hip.BF16, B, T, Lt, H, 1e-5, st())),
     2 * M * D * 2)
+
+wo = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
+KP = (H * 8 + 63) // 64 * 64
+ut = torch.zeros(B, D, KP, device=dev, dtype=torch.bfloat16)
+timeit("cross_attn_fold", lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
+                                                                         8, H, st())), B * D * KP * 2 + D * D * 2)
