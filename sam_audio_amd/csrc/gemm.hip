@@ -224,20 +224,20 @@ static int gemm1_variant(const GemmParams& p) {
 int gemm_variant(const GemmParams& p, bool is_bf16) {
   const bool g2 = is_bf16 && gemm2_ok(p);
   if (g_force >= 3) {
-    const bool known = g_force == 3 || g_force == 4 || g_force == 5 || g_force == 9 || (g_force >= 12 && g_force <= 14);
+    const bool known = g_force == 3 || g_force == 4 || g_force == 5 || g_force == 6 || g_force == 9 || (g_force >= 12 && g_force <= 14);
     return g2 && known ? g_force : gemm1_variant(p);
   }
   if (g_force >= 0) return gemm1_variant(p);
   // measured (tools/gemm_bench.py, profiles/r1_gemm_variants_*.log): 256x256 ping-pong for the widest outputs,
   // 256x128 elsewhere; codec convolutions with >= 96 output channels ride the same kernels
-  if (g2 && p.N >= 96 && p.K >= 128) return p.N >= 12288 ? 9 : 4;
+  if (g2 && p.N >= 96 && p.K >= 128) return p.N >= 12288 ? 9 : (p.N == 192 && !debug_flag(4) ? 6 : 4);
   return gemm1_variant(p);
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   static const char* names[2][15] = {
       {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
-       "gemm2_bf16_256x256_s2", "", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma", "abl_noread"}};
+       "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma", "abl_noread"}};
   return names[is_bf16 ? 1 : 0][v];
 }
 

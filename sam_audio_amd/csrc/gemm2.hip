@@ -494,7 +494,7 @@ bool gemm2_ok(const GemmParams& p) {
 }
 
 // variants: 0 = 256x128 3-stage ring, 1 = 256x128 2-stage ring, 2 = 256x256 2-stage ring (8 waves, BK 64, one
-// workgroup per CU); 6 = 256x256 role-split (half-slab phases, 2 stages).
+// workgroup per CU); 3 = 256x192 2-stage ring; 6 = 256x256 role-split (half-slab phases, 2 stages).
 // Measured and dropped (profiles/r1_gemm_variants_*.log): 4-wave BK-32 tiles with two workgroups per CU (3-5),
 // 256x128 role-split with 3 stages (7, 8), 256x256 with one 512-register wave per SIMD (12), hand-pipelined asm
 // fragment reads (13, 14) - all within +-3 % of the kept kernels or slower.  Ablation builds (9-11: no DMA / no MFMA /
@@ -507,6 +507,7 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
     case 9: return launch3<256, 256, 2, 4, 2, 2, 1>(p, st);
 #endif
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
+    case 3: return launch2<256, 192, 4, 2, 2, 64>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);
     case 0: return launch2<256, 128, 4, 2, 3, 64>(p, st);
     default: return launch2<256, 128, 4, 2, 2, 64>(p, st);

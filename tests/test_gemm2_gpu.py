@@ -15,8 +15,9 @@ from sam_audio_amd import hip
 from tests import util
 
 pytestmark = pytest.mark.gpu
-# 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 9 = 256x256 role-split
-VARIANTS = [3, 4, 5, 9]
+# 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 6 = 256x192 2-stage ring,
+# 9 = 256x256 role-split
+VARIANTS = [3, 4, 5, 6, 9]
 
 
 def _mk(shape, seed, scale=1.0):
@@ -31,7 +32,8 @@ def _restore_variant():
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("M,N,K", [(300, 640, 192), (517, 1152, 320), (1000, 384, 1024), (250, 2816, 256), (64, 96, 704)])
+@pytest.mark.parametrize("M,N,K", [(300, 640, 192), (517, 1152, 320), (1000, 384, 1024), (250, 2816, 256), (64, 96, 704),
+                                   (700, 192, 1344)])
 def test_plain_tails(gpu, variant, M, N, K):
     hip.lib().samaudio_debug_force_gemm_variant(variant)
     A, W = _mk((M, K), 1), _mk((N, K), 2, 1 / math.sqrt(K))

@@ -74,3 +74,18 @@ KP = (H * 8 + 63) // 64 * 64
 ut = torch.zeros(B, D, KP, device=dev, dtype=torch.bfloat16)
 timeit("cross_attn_fold", lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
                                                                          8, H, st())), B * D * KP * 2 + D * D * 2)
+
+# DAC decoder stage with 192 channels: dilated k7 conv as implicit GEMM (N = 192, K = 1344), 8 waveforms
+from tests import util  # noqa: E402
+items, Tc, Cc = 8, 240000, 192
+xa = torch.randn(items, Tc + 80, Cc, device=dev).to(torch.bfloat16)
+wc = (torch.randn(Cc, 7 * Cc, device=dev) / (7 * Cc) ** 0.5).to(torch.bfloat16)
+oc = torch.empty(items, Tc + 80, Cc, device=dev, dtype=torch.bfloat16)
+bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+for flag, name in ((1, "codec conv7 C=192 (2 x 128-wide tiles)"), (0, "codec conv7 C=192 (256x192 tile)")):
+    L.samaudio_debug_set_flag(4, flag)
+    timeit(name, lambda: util.gemm("bf16", xa, wc, Tc, Cc, 7 * Cc, nbatch=items, a_off=(40 - 9) * Cc, a_bstride=(Tc + 80) * Cc,
+                                   lda=Cc, kc=Cc, tap_stride=3 * Cc, bias=bias_c, out_act=oc,
+                                   act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c),
+           2 * items * Tc * Cc * 2, iters=5)
+L.samaudio_debug_set_flag(4, 0)
