@@ -352,8 +352,8 @@ Status Engine::profile_begin() {
 
 Status Engine::profile_end(std::vector<KernelStat>& out) {
   prof_on_ = false;
-  out.assign(15, KernelStat{});
-  for (int v = 0; v < 15; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  out.assign(kGemmVariants, KernelStat{});
+  for (int v = 0; v < kGemmVariants; ++v) out[v].name = gemm_variant_name(v, bf16_);
   for (const ProfRec& r : prof_) {
     SA_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;

@@ -52,7 +52,8 @@ __device__ __forceinline__ float act_apply(float v, int act, float snake_alpha) 
 // swapped operands: D[n][m]; a lane holds m = m_first + i*32 + l31 and, per 32x32 fragment j, the columns
 // n = n_first + j*32 + 8*g + 4*lh + (0..3) for register group g = reg>>2.  Per fragment all loads (bias / gate /
 // residual, float4 each) are issued first, then the arithmetic, then 16-byte fp32 / 8-byte bf16 stores.
-template <int FM, int FN>
+// U = register groups per round trip (2: 32 registers of loads in flight; 1 for kernels with a 168-register budget).
+template <int FM, int FN, int U = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[FM][FN], int b, int m_first,
                                               int n_first, int l31, int lh) {
   const long bM = (long)b * p.M;
@@ -73,14 +74,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     for (int j = 0; j < FN; ++j) {
       const int nf = n_first + j * 32;  // first GEMM column of this 32-wide fragment
       const int nb = (p.swiglu ? nf >> 1 : nf) + 4 * lh;
-      // two register groups (8 output columns per lane) per round trip: 32 registers of loads in flight
+      // U register groups (4 output columns per lane each) per round trip: 16*U registers of loads in flight
 #pragma unroll
-      for (int gp = 0; gp < 4; gp += 2) {
+      for (int gp = 0; gp < 4; gp += U) {
         if (gp >= NG) continue;
-        int ncol[2];
-        float4 bb[2], gg[2], tt[2], rr[2], sa[2];
+        int ncol[U];
+        float4 bb[U], gg[U], tt[U], rr[U], sa[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int n = nb + 8 * (gp + u);
           ncol[u] = n;
           const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
@@ -92,7 +93,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
           if (has_res) rr[u] = *(const float4*)(rrow + nc);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int g = gp + u;
           float v[4];
           if (p.swiglu) {
@@ -139,7 +140,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 // 4-wave configurations (BK = 32, <= 80 KiB LDS) run TWO workgroups per CU: the two are not barrier-coupled, so
 // one's MFMAs cover the other's barrier / LDS-latency / epilogue time.
 template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
-__global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 256 ? 1 : 2)) void gemm2_kernel(
+__global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 256 ? 1 : (WM_ * WN_ == 8 && BK == 32 ? 4 : 2)))
+    void gemm2_kernel(
     const GemmParams p) {
   constexpr int NW = WM_ * WN_;
   constexpr int WTM = BM / WM_, WTN = BN / WN_;
@@ -460,6 +462,237 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
   gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
 }
 
+// ---- gemm5: dedicated loader waves (EXPERIMENTAL - reachable only through samaudio_debug_force_gemm_variant) ----
+// The ablation runs on gemm3 (profiles/r1_gemm_ablation.log) are close to ADDITIVE: MFMA-only ~380 us, DMA ~285 us,
+// fragment reads ~180 us against 791 us for the full kernel - i.e. in the 8-wave kernels, where every wave issues its
+// share of the slab's global_load_lds pieces between its MFMAs, the three hardly overlap (a piece costs the issuing
+// wave 100-190 cycles in a phase that also carries ds_reads, MI355X_MICROARCH.md "LDS-DMA piece issue cost").
+// Here the roles are split by WAVE instead of by phase: 8 compute waves (2 per SIMD) never touch VMEM inside the K
+// loop, and 4 loader waves (1 per SIMD, a handful of live registers) issue every DMA piece and own the vmcnt waits.
+// One s_barrier per slab couples them (g = running slab count of this workgroup):
+//   loader :  [vmcnt: slab g landed]  B_g  [issue slab g+NS-1 into the stage slab g-1 occupied] ...
+//   compute:                          B_g  [fragment reads + MFMAs of slab g] ...
+// B_g tells the compute waves that slab g is visible and tells the loaders that every compute wave is done with
+// slab g-1 (its MFMAs were issued, so its fragment reads have returned).  12 waves = 3 per SIMD => <= 168 registers.
+// Same LDS image, swizzle, raster, epilogue and accumulation order as gemm2_kernel.
+//   PF      : the compute waves fetch the fragments of k-step ks+1 into a second register set before issuing the
+//             MFMAs of k-step ks (only the first k-step after each barrier waits for LDS).
+//   PERSIST : one workgroup per CU walks its XCD's run of tiles (slot, slot + W/8, ...); the slab count g simply runs
+//             on across tiles, so the loaders fill the ring with the next tile's first NS-1 slabs while the compute
+//             waves are still in the epilogue (no prologue bubble, no workgroup relaunch per tile).
+struct TileRaster {
+  int tiles_m, tiles_n, per_batch, total;
+  __device__ __forceinline__ void init(const GemmParams& p, int BM, int BN) {
+    tiles_n = (p.N + BN - 1) / BN;
+    tiles_m = (p.M + BM - 1) / BM;
+    per_batch = tiles_m * tiles_n;
+    total = per_batch * p.nbatch;
+  }
+  // tiles owned by XCD x: the contiguous run [first(x), first(x) + count(x))
+  __device__ __forceinline__ int count(int xcd) const { return (total >> 3) + (xcd < (total & 7) ? 1 : 0); }
+  __device__ __forceinline__ int first(int xcd) const {
+    const int q = total >> 3, r = total & 7;
+    return xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  }
+  // L-th tile in XCD-contiguous order -> (batch, m-tile, n-tile), walked in groups of GM m-tiles x all n-tiles
+  __device__ __forceinline__ void locate(const GemmParams& p, int L, int& b, int& tm, int& tn) const {
+    b = L / per_batch;
+    const int l2 = L - b * per_batch;
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
+    const int per_group = GM * tiles_n;
+    const int gi = l2 / per_group;
+    const int first_m = gi * GM;
+    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    const int in_grp = l2 - gi * per_group;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+  }
+};
+
+template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false>
+__global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
+  constexpr int NC = 8, NL = 4;  // compute / loader waves
+  static_assert(WM_ * WN_ == NC, "8 compute waves");
+  constexpr int WTM = BM / WM_, WTN = BN / WN_;
+  constexpr int FM = WTM / 32, FN = WTN / 32;
+  constexpr int RB = BK * 2, CPR = RB / 16, RPI = 1024 / RB, KS = BK / 16, CH = 8;
+  constexpr int PA = BM / RPI, PB = BN / RPI;              // wave-wide DMA pieces per slab (A rows, W rows)
+  static_assert(BK == 64 || BK == 32, "BK");
+  static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
+  constexpr int AI = PA / NL, BI = PB / NL, G = AI + BI;   // pieces per loader wave per slab
+  constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
+  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS budget");
+  static_assert((NS - 2) * G <= 63, "vmcnt range");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  TileRaster ras;
+  ras.init(p, BM, BN);
+  // this workgroup's tiles: L = base + idx0 + k*stride, k = 0 .. ntile-1
+  const int xcd = blockIdx.x & 7;
+  const int base = ras.first(xcd);
+  const int idx0 = blockIdx.x >> 3;
+  const int stride = PERSIST ? (int)(gridDim.x >> 3) : 1;
+  const int cnt = ras.count(xcd);
+  const int ntile = PERSIST ? (idx0 < cnt ? (cnt - idx0 + stride - 1) / stride : 0) : 1;
+  if (ntile == 0) return;  // whole workgroup
+  const int nslab = p.K / BK;
+  const int total_slabs = ntile * nslab;
+
+  if (wave >= NC) {
+    // ================================ loader wave ================================
+    // piece j = lw + NL*i fills tile rows RPI*j .. RPI*j+RPI-1; lane -> (row RPI*j + lane/CPR, slot lane%CPR);
+    // slot s of row r holds source chunk s ^ swz(r)  (NL is even, so (j & 1) == (lw & 1): same form as gemm2_kernel)
+    const int lw = wave - NC;
+    const int r8 = lane / CPR;
+    const int chunk = BK == 64 ? (lane & 7) ^ ((4 * (lw & 1) + (r8 >> 1)) & 7) : (lane & 3) ^ ((r8 >> 2) & 3);
+    const bf16_t* a_rows[AI];
+    const bf16_t* w_rows[BI];
+    int a_in = 0;
+    long a_tap = 0;
+    int tile_k = 0, slab_in_tile = 0;  // issue cursor
+    auto open_tile = [&]() {
+      int b, tm, tn;
+      ras.locate(p, base + idx0 + tile_k * stride, b, tm, tn);
+      const int m0 = tm * BM, n0 = tn * BN;
+      const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        int m = m0 + (lw + NL * i) * RPI + r8;
+        m = m < p.M ? m : p.M - 1;
+        a_rows[i] = A + (long)m * p.lda;
+      }
+      const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        int n = n0 + (lw + NL * i) * RPI + r8;
+        n = n < p.N ? n : p.N - 1;
+        w_rows[i] = W + (long)n * p.K + chunk * CH;
+      }
+      a_in = chunk * CH;
+      a_tap = 0;
+      while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
+    };
+    auto issue = [&](int stage) {  // next slab of the issue cursor -> stage
+      if (slab_in_tile == 0) open_tile();
+      char* sA = smem + stage * STAGE;
+      char* sB = sA + TILE_A;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) dma16(a_rows[i] + a_tap + a_in, sA + (lw + NL * i) * 1024);
+#pragma unroll
+      for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (lw + NL * i) * 1024);
+      a_in += BK;
+      while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) w_rows[i] += BK;
+      if (++slab_in_tile == nslab) { slab_in_tile = 0; ++tile_k; }
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < total_slabs) issue(s);
+    int st_i = (NS - 1) % NS;
+    for (int g = 0; g < total_slabs; ++g) {
+      // slab g has landed once at most the NS-2 younger slabs' pieces of this wave are still outstanding
+      if (NS > 2 && g + NS - 2 < total_slabs) wait_vmcnt<(NS - 2) * G>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // B_g
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + NS - 1 < total_slabs) issue(st_i);
+      st_i = st_i + 1 == NS ? 0 : st_i + 1;
+    }
+    return;
+  }
+
+  // ================================ compute wave ================================
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int swz = BK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+  const int a_base = (wm * WTM + l31) * RB, b_base = TILE_A + (wn * WTN + l31) * RB;
+  int st_c = 0;
+  for (int tk = 0; tk < ntile; ++tk) {
+    f32x16_t acc[FM][FN];
+    {
+      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
+    }
+    for (int s = 0; s < nslab; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // B_g: slab g visible; this wave's reads of slab g-1 returned long ago
+      __builtin_amdgcn_sched_barrier(0);
+      const char* st = smem + st_c * STAGE;
+      if (PF) {
+        bf16x8_t af[2][FM], wf[2][FN];
+        auto fetch = [&](int ks, int buf) {
+          const int coff = ((ks * 2 + lh) ^ swz) << 4;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[buf][i] = *(const bf16x8_t*)(st + a_base + i * 32 * RB + coff);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wf[buf][j] = *(const bf16x8_t*)(st + b_base + j * 32 * RB + coff);
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + 1 < KS) fetch(ks + 1, (ks + 1) & 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int coff = ((ks * 2 + lh) ^ swz) << 4;
+          bf16x8_t af[FM], wf[FN];
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(st + a_base + i * 32 * RB + coff);
+#pragma unroll
+          for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(st + b_base + j * 32 * RB + coff);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      st_c = st_c + 1 == NS ? 0 : st_c + 1;
+    }
+    int b, tm, tn;
+    ras.locate(p, base + idx0 + tk * stride, b, tm, tn);
+    gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
+  }
+}
+
+static int persistent_grid(long tiles) {  // one workgroup per CU, a multiple of the 8 XCDs
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n < 8)
+      n = 256;
+    cus = n & ~7;
+  }
+  const long want = (tiles + 7) & ~7L;
+  return (int)(want < cus ? want : cus);
+}
+
+template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false>
+static hipError_t launch5(const GemmParams& p, hipStream_t st) {
+  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  const unsigned grid = PERSIST ? (unsigned)persistent_grid(tiles) : (unsigned)tiles;
+  hipLaunchKernelGGL((gemm5_kernel<BM, BN, WM_, WN_, NS, BK, PF, PERSIST>), dim3(grid), dim3(768), 0, st, p);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, int WM_, int WN_, int KSP, int NS, int ABL = 0>
 static hipError_t launch3(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
@@ -506,6 +739,14 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
     case 10: return launch3<256, 256, 2, 4, 2, 2, 2>(p, st);
     case 9: return launch3<256, 256, 2, 4, 2, 2, 1>(p, st);
 #endif
+    // experimental, never chosen by gemm_variant() (see "gemm5" above and DESIGN.md section 3.1):
+    case 12: return launch5<256, 256, 2, 4, 2, 64>(p, st);  // loader waves, 2 x 64 KiB stages
+    case 13: return launch5<256, 256, 2, 4, 4, 32>(p, st);  // loader waves, 4 x 32 KiB half-slab stages
+    case 14: return launch5<256, 128, 4, 2, 3, 64>(p, st);  // loader waves, 3 x 48 KiB stages
+    case 15: return launch2<256, 128, 4, 2, 3, 32>(p, st);  // 8 waves, BK 32, 72 KiB => two workgroups per CU
+    case 16: return launch5<256, 128, 4, 2, 3, 64, true>(p, st);  // 14 + register-prefetched fragments
+    case 17: return launch5<256, 128, 4, 2, 3, 64, true, true>(p, st);  // 16 + persistent tile walk
+    case 18: return launch5<256, 256, 2, 4, 2, 64, false, true>(p, st); // 12 + persistent tile walk
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
     case 3: return launch2<256, 192, 4, 2, 2, 64>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);

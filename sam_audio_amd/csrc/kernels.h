@@ -18,6 +18,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
+constexpr int kGemmVariants = 22;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant (15..21 experimental, force-only)
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
 bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);

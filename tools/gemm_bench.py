@@ -21,6 +21,9 @@ from tests import util  # noqa: E402
 
 RASTER = [0]
 VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256"}
+# force-only kernels (gemm2.hip "gemm5" family: 4 loader waves + 8 compute waves; and the BK-32 two-workgroup tile)
+EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 256x256 h4", 17: "ld 256x128 s3",
+                18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist"}
 
 
 def interleave16(w1, w3):
@@ -95,11 +98,15 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--ablate", action="store_true", help="time the gemm3 256x256 ablation builds (results are wrong)")
     ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size on the shipped variants")
+    ap.add_argument("--experimental", action="store_true", help="shipped policy kernels vs the force-only experimental ones")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.ablate:
         VARIANTS.clear()
         VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads"})  # needs -DSAMAUDIO_GEMM_ABLATIONS
+    if args.experimental:
+        VARIANTS.clear()
+        VARIANTS.update(EXPERIMENTAL)
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
     M = args.batch * 250
