@@ -33,6 +33,7 @@ struct Params {
   long window;           // bytes (power of two)
   int shared;            // 1: all workgroups walk the same window (L2 hits), 0: one window per workgroup
   int iters;
+  int barrier;           // 1: every iteration ends with an s_barrier over all waves (the real kernels' per-slab coupling)
   int role[12];          // per wave: index into the role table below, -1 = wave exits at once
   unsigned long long* out;  // [workgroup][12] cycles for `iters` iterations
   float* sink;
@@ -97,6 +98,7 @@ __device__ __forceinline__ void run_role(const Params& p, char* smem, int wave, 
 #pragma unroll
       for (int i = 0; i < R; ++i) asm volatile("" ::"v"(r[i]));
     }
+    if (p.barrier) __builtin_amdgcn_s_barrier();
   }
   wait_vmcnt<0>();
   const unsigned long long t1 = clock64();
@@ -181,13 +183,16 @@ int main(int argc, char** argv) {
       {"(mfma+read) x8 + fill4 x4", 12, {4, 4, 4, 4, 4, 4, 4, 4, 9, 9, 9, 9}},
       {"(mfma+read) x4 + fill8 x4   [1 compute wave/SIMD]", 8, {4, 4, 4, 4, 1, 1, 1, 1}},
   };
-  for (int shared = 1; shared >= 0; --shared) {
-    printf("==== fill source: %s 2 MiB window(s), %d workgroups, %d iterations ====\n",
-           shared ? "one SHARED (L2-resident)" : "one PRIVATE per workgroup (mostly L2 misses)", grid, iters);
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shared = pass != 2, barrier = pass == 1;
+    printf("==== fill source: %s 2 MiB window(s), %s, %d workgroups, %d iterations ====\n",
+           shared ? "one SHARED (L2-resident)" : "one PRIVATE per workgroup (mostly L2 misses)",
+           barrier ? "s_barrier after every iteration" : "free-running waves", grid, iters);
     for (const Scenario& s : sc) {
       Params p;
       memset(&p, 0, sizeof(p));
       p.src = src; p.window = window; p.shared = shared; p.iters = iters; p.out = out; p.sink = sink;
+      p.barrier = barrier;
       for (int w = 0; w < 12; ++w) p.role[w] = w < s.nwaves ? s.role[w] : -1;
       hipEvent_t e0, e1;
       CHECK(hipEventCreate(&e0));
