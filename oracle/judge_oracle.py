@@ -1,0 +1,214 @@
+"""CPU oracle for the reranking / span-prediction rows of SURVEY.md section 8 (a17, a18; "next" rows f1, f2)
+--  TEST INFRASTRUCTURE ONLY (same rules as oracle/samaudio_oracle.py: only tests/, smoke() and bench.py's
+cpu_baseline leg may import it).
+
+What is restated here
+---------------------
+* `peav_transformer`  - the PE-AV `Transformer` the Judge instantiates twice (reference sam_audio/model/judge.py:8,
+  46-47).  Its source lives in the un-vendored `perception_models` package (`core.audio_visual_encoder.transformer`,
+  pyproject.toml:24 "@unpin-deps"); the closest in-container statement of the same network is Hugging Face
+  transformers' port, `transformers/models/pe_audio/modeling_pe_audio.py` (PeAudioEncoder minus its DAC embedder:
+  :198-287 patch embedder with CLS token + masked-GroupNorm ResNet block, :344-490 RMSNorm / qk-norm attention /
+  SwiGLU layer, :616-680 encoder forward).  PINNED against that HF class (oracle/gen_golden_judge.py,
+  tests/test_judge_oracle.py run the HF module on seeded weights and compare).  Whether perception_models' own
+  class differs from the HF port cannot be checked offline: PARITY UNPINNED against perception_models itself.
+* `judge_forward`     - reference sam_audio/model/judge.py:76-132, line by line.  PINNED: oracle/gen_golden_judge.py
+  runs the reference's *own* SAMAudioJudgeModel.forward (imported read-only, with `PEAVTransformer` / `DACVAE`
+  bound to adapters over the HF port / this oracle's DAC) on seeded weights.
+* `rerank_select`     - reference sam_audio/model/model.py:297-338 (candidate selection).
+* `frame_logits` / `spans_from_logits` - PE-A-Frame (un-vendored): per-frame audio-text logits as in
+  modeling_pe_audio.py:810-868; the span thresholding / merging rule exists only in perception_models, so the rule
+  used by this build is DEFINED here (sigmoid(logit) > threshold, runs of consecutive frames, seconds = frame *
+  hop / sample_rate) and documented as an assumption.  PARITY UNPINNED.
+
+State-dict key names follow the HF port for the transformer (`layers.{i}.self_attn.q_proj.weight`, ...) and the
+reference for everything judge.py itself owns (`data_proj`, `cat_audio_proj`, `text_proj1`, ..., `head`, `mean`, `std`).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .samaudio_oracle import apply_rope, conv3_same, dac_encode, rms_norm, rope_tables
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+SPAN_GUARD_S = 1e-6
+
+
+# ----------------------------------------------------------------------------------------------
+# PE-AV transformer
+# ----------------------------------------------------------------------------------------------
+def masked_group_norm_1(x_btc: Tensor, mask_bt: Optional[Tensor], weight: Tensor, bias: Tensor,
+                        eps: float = 1e-5) -> Tensor:
+    """modeling_pe_audio.py:198-221 (PeAudioMaskedGroupNorm, num_groups=1): statistics over the valid
+    (frame, channel) entries only, affine, then the output is multiplied by the mask.  Channels-last here."""
+    if mask_bt is None:
+        mean = x_btc.mean(dim=(1, 2), keepdim=True)
+        var = x_btc.var(dim=(1, 2), unbiased=False, keepdim=True)
+        return (x_btc - mean) / torch.sqrt(var + eps) * weight + bias
+    m = mask_bt[:, :, None].to(x_btc.dtype)
+    n = (m.sum(dim=(1, 2), keepdim=True) * x_btc.shape[2]).clamp_min(1.0)
+    mean = (x_btc * m).sum(dim=(1, 2), keepdim=True) / n
+    var = (((x_btc - mean) ** 2) * m).sum(dim=(1, 2), keepdim=True) / n
+    return ((x_btc - mean) / torch.sqrt(var + eps) * weight + bias) * m
+
+
+def peav_patch_embed(sd: SD, p: str, x: Tensor, pad_mask: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+    """modeling_pe_audio.py:266-287: prepend the class token (its mask bit copies frame 0's), then the ResNet
+    block :241-263 = x + conv(silu(gn(conv(silu(gn(x)))))) with masked GroupNorm and k3 'same' convolutions."""
+    B = x.shape[0]
+    h = torch.cat([sd[p + "patch_embedder.class_embedding"].expand(B, -1, -1), x], dim=1)
+    mask = None if pad_mask is None else torch.cat([pad_mask[:, :1], pad_mask], dim=1)
+    r = h
+    for blk in ("block1", "block2"):
+        q = f"{p}patch_embedder.resnet_block.{blk}."
+        r = masked_group_norm_1(r, mask, sd[q + "groupnorm.weight"], sd[q + "groupnorm.bias"])
+        r = conv3_same(F.silu(r), sd[q + "project.weight"], sd[q + "project.bias"])
+    return h + r, mask
+
+
+def peav_layer(sd: SD, p: str, x: Tensor, n_heads: int, eps: float, mask: Optional[Tensor], rope) -> Tensor:
+    """modeling_pe_audio.py:457-490 (layer), :344-426 (attention: head-major split, per-head q/k RMSNorm, RoPE on
+    adjacent pairs, softmax(q k^T / sqrt(hd) + mask) v), :429-441 (SwiGLU MLP)."""
+    B, S, D = x.shape
+    hd = D // n_heads
+
+    def lin(t, name):
+        return F.linear(t, sd[p + name + ".weight"], sd.get(p + name + ".bias"))
+
+    a = rms_norm(x, sd[p + "input_layernorm.weight"], eps)
+    q = lin(a, "self_attn.q_proj").view(B, S, n_heads, hd)
+    k = lin(a, "self_attn.k_proj").view(B, S, n_heads, hd)
+    v = lin(a, "self_attn.v_proj").view(B, S, n_heads, hd).transpose(1, 2)
+    q = rms_norm(q, sd[p + "self_attn.q_norm.weight"], eps).transpose(1, 2)
+    k = rms_norm(k, sd[p + "self_attn.k_norm.weight"], eps).transpose(1, 2)
+    q, k = apply_rope(q, *rope), apply_rope(k, *rope)
+    scores = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)
+    if mask is not None:
+        scores = scores.masked_fill(~mask[:, None, None, :], float("-inf"))
+    o = torch.matmul(torch.softmax(scores.float(), dim=-1), v).transpose(1, 2).reshape(B, S, D)
+    h = x + lin(o, "self_attn.o_proj")
+    f = rms_norm(h, sd[p + "post_attention_layernorm.weight"], eps)
+    ff = F.linear(F.silu(F.linear(f, sd[p + "mlp.gate_proj.weight"])) * F.linear(f, sd[p + "mlp.up_proj.weight"]),
+                  sd[p + "mlp.down_proj.weight"])
+    return h + ff
+
+
+def peav_transformer(sd: SD, prefix: str, x: Tensor, pad_mask: Optional[Tensor], *, n_heads: int, n_layers: int,
+                     eps: float = 1e-5, rope_theta: float = 20000.0,
+                     taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+    """modeling_pe_audio.py:640-680 without the embedder: x [B, T, D] (already projected), pad_mask [B, T] bool
+    (True = valid) or None -> (last_hidden_state [B, T, D], pooler_output [B, D])."""
+    h, mask = peav_patch_embed(sd, prefix, x, pad_mask)
+    if taps is not None:
+        taps["patch"] = h
+    D = h.shape[2]
+    rope = rope_tables(D // n_heads, h.shape[1], rope_theta)
+    for i in range(n_layers):
+        h = peav_layer(sd, f"{prefix}layers.{i}.", h, n_heads, eps, mask, rope)
+        if taps is not None:
+            taps[f"layer{i}"] = h
+    h = F.linear(rms_norm(h, sd[prefix + "norm.weight"], eps), sd[prefix + "output.weight"])
+    return h[:, 1:], h[:, 0]
+
+
+# ----------------------------------------------------------------------------------------------
+# Judge
+# ----------------------------------------------------------------------------------------------
+def judge_forward(sd: SD, cfg, text_pooled: Tensor, input_values: Tensor, separated_values: Tensor,
+                  padding_mask: Optional[Tensor] = None, taps: Optional[dict] = None) -> Tensor:
+    """reference sam_audio/model/judge.py:90-132.  `cfg` is a SAMAudioJudgeConfig (sam_audio_amd.config);
+    `text_pooled` [B, text_hidden] is `_get_text_output(...).pooler_output` (:76-88: token 0 of the n-th hidden
+    state of the text model, computed by the caller); input_values / separated_values [B, 1, Tw]; padding_mask
+    [B, Tw] bool.  Returns the de-normalised scores [B, 4] = (overall, recall, precision, faithfulness)."""
+    tc, fc = cfg.transformer, cfg.finetune_transformer
+    text_features = F.linear(text_pooled, sd["text_proj1.weight"])                        # :98-100
+    stacked = torch.cat([input_values, separated_values], dim=0)                          # :101
+    codec = dac_encode(sd, cfg.audio_codec, stacked, prefix="audio_codec.")               # :102  [2B, 128, T]
+    fmask = None
+    if padding_mask is not None:
+        fmask = padding_mask[:, :: cfg.audio_codec.hop_length]                            # :104-107
+    x = F.linear(codec.transpose(1, 2), sd["data_proj.weight"], sd["data_proj.bias"])     # :109
+    # the reference hands the [B, T] mask to a [2B, T, D] stack (:108-111); the un-vendored transformer must
+    # broadcast it somehow - the only reading that treats both halves alike is to repeat it per half
+    smask = None if fmask is None else torch.cat([fmask, fmask], dim=0)
+    hid, _ = peav_transformer(sd, "transformer.", x, smask, n_heads=tc.num_attention_heads,
+                              n_layers=tc.num_hidden_layers, eps=tc.rms_norm_eps, rope_theta=tc.rope_theta)
+    inp, hyp = hid.chunk(2, 0)                                                            # :112
+    audio = F.linear(torch.cat([hyp, inp], dim=2), sd["cat_audio_proj.weight"], sd["cat_audio_proj.bias"])  # :113-115
+    t2 = F.linear(text_features, sd["text_proj2.weight"], sd["text_proj2.bias"])
+    t2 = F.layer_norm(t2, (t2.shape[-1],), sd["layer_norm.weight"], sd["layer_norm.bias"], 1e-5)
+    expanded = t2.unsqueeze(1).expand_as(audio)                                           # :116-120
+    at = F.linear(torch.cat([audio, expanded], dim=2), sd["proj_audio_and_text.weight"],
+                  sd["proj_audio_and_text.bias"])                                         # :121-123
+    if taps is not None:
+        taps.update(codec=codec, hidden=hid, audio=audio, audio_and_text=at)
+    fx = F.linear(at, sd["finetune_data_proj.weight"], sd["finetune_data_proj.bias"])     # :124-126
+    fout, _ = peav_transformer(sd, "finetune_transformer.", fx, fmask, n_heads=fc.num_attention_heads,
+                               n_layers=fc.num_hidden_layers, eps=fc.rms_norm_eps, rope_theta=fc.rope_theta)
+    result = F.linear(fout, sd["head.weight"])                                            # :127
+    if fmask is not None:                                                                 # :128-130 masked mean
+        m = fmask.unsqueeze(-1).to(result.dtype)
+        pooled = (result * m).sum(dim=1) / m.sum(dim=1)
+    else:
+        pooled = result.mean(dim=1)
+    return pooled * sd["std"] + sd["mean"]                                                # :131-132
+
+
+def rerank_select(scores: Tensor) -> Tensor:
+    """reference model.py:317,328: idxs = scores.argmax(dim=1) over the candidates of each clip."""
+    return scores.argmax(dim=1)
+
+
+# ----------------------------------------------------------------------------------------------
+# PE-A-Frame span predictor
+# ----------------------------------------------------------------------------------------------
+def frame_logits(sd: SD, cfg, text_pooled: Tensor, codec_features: Tensor, pad_mask: Optional[Tensor]) -> Tensor:
+    """Per-frame audio-text logits of PE-A-Frame for batch-paired (audio, description) rows.
+    modeling_pe_audio.py:158-181 (data_proj on codec features), :640-680 (encoder), :184-195 (heads: LayerNorm
+    eps 1e-6 + bias-free projection), :842-856 (logits = <audio_embeds[b,t], text_embed[b]> * scale + bias; the HF
+    model scores every audio against every text, the reference call site model.py:234-243 pairs them).
+    codec_features [B, T, 128] (= audio_features[:, :, :128] of model.py:239), pad_mask [B, T] bool."""
+    ac = cfg.audio
+    x = F.linear(codec_features, sd["audio_encoder.embedder.data_proj.weight"],
+                 sd["audio_encoder.embedder.data_proj.bias"])
+    hid, _ = peav_transformer(sd, "audio_encoder.", x, pad_mask, n_heads=ac.num_attention_heads,
+                              n_layers=ac.num_hidden_layers, eps=ac.rms_norm_eps, rope_theta=ac.rope_theta)
+
+    def head(t, p):
+        t = F.layer_norm(t, (t.shape[-1],), sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"], 1e-6)
+        return F.linear(t, sd[p + "proj.weight"])
+
+    a = head(hid, "audio_head.")                      # [B, T, E]
+    t = head(text_pooled, "text_audio_head.")         # [B, E]
+    logits = torch.einsum("bte,be->bt", a, t)
+    return logits * sd["text_audio_logit_scale"] + sd["text_audio_logit_bias"]
+
+
+def spans_from_logits(logits: Tensor, pad_mask: Optional[Tensor], hop: int, sample_rate: int,
+                      threshold: float = 0.5) -> List[List[List[float]]]:
+    """DEFINED BY THIS BUILD (the reference's `return_spans=True` rule is un-vendored):
+    frame t is active iff sigmoid(logit) > threshold (i.e. logit > log(th/(1-th))) and the frame is valid; every
+    maximal run of active frames [s, e) becomes the span [s*hop/sr - 1us, e*hop/sr - 1us] seconds (start clamped
+    at 0).  The microsecond guard makes the round trip through `Batch.process_anchors` (processor.py:107-121:
+    ceil(seconds*sr/hop), where e.g. 3*0.04*25 = 3.0000000000000004 would ceil to 4) land on exactly the frames
+    [s, e) - pinned bit-exactly in tests/test_judge_oracle.py."""
+    cut = math.log(threshold / (1.0 - threshold))
+    active = logits > cut
+    if pad_mask is not None:
+        active = active & pad_mask
+    out: List[List[List[float]]] = []
+    for row in active.tolist():
+        spans, start = [], None
+        for t, on in enumerate(row + [False]):
+            if on and start is None:
+                start = t
+            elif not on and start is not None:
+                spans.append([max(0.0, start * hop / sample_rate - SPAN_GUARD_S), t * hop / sample_rate - SPAN_GUARD_S])
+                start = None
+        out.append(spans)
+    return out

@@ -200,6 +200,97 @@ class SAMAudioConfig:
             raise NotImplementedError("anchor_embedding_dim / codebook_dim must be multiples of 64")
 
 
+@dataclass
+class PEAVTransformerConfig:
+    """Configuration of the PE-AV `Transformer` the Judge / PE-A-Frame instantiate (reference judge.py:46-47;
+    the class is `core.audio_visual_encoder.config.TransformerConfig` of the un-vendored perception_models, used by
+    the reference only as a type: config.py:6,238-249).  Field names follow the Hugging Face port of the same
+    network (transformers/models/pe_audio/configuration_pe_audio.py:50-68, defaults = pe-av-large) - a documented
+    assumption, since the original field names are not reachable offline."""
+    hidden_size: int = 1792
+    intermediate_size: int = 4800
+    num_hidden_layers: int = 6
+    num_attention_heads: int = 14
+    num_key_value_heads: Optional[int] = None
+    head_dim: int = 128
+    hidden_act: str = "silu"
+    max_position_embeddings: int = 10000
+    rms_norm_eps: float = 1e-5
+    rope_parameters: Optional[Dict[str, Any]] = None
+    attention_bias: bool = False
+    attention_dropout: float = 0.0
+    initializer_range: float = 0.02
+
+    @property
+    def rope_theta(self) -> float:
+        return float((self.rope_parameters or {}).get("rope_theta", 20000))
+
+    def check_supported(self) -> None:
+        problems = []
+        if self.head_dim != 128 or self.hidden_size != self.num_attention_heads * 128:
+            problems.append("hidden_size must be num_attention_heads * 128")
+        if self.hidden_size % 256:
+            problems.append("hidden_size must be a multiple of 256")
+        if self.num_key_value_heads not in (None, self.num_attention_heads):
+            problems.append("grouped-query attention")
+        if self.hidden_act != "silu":
+            problems.append("hidden_act must be 'silu'")
+        if self.intermediate_size % 64:
+            problems.append("intermediate_size must be a multiple of 64")
+        if (self.rope_parameters or {}).get("rope_type", "default") != "default":
+            problems.append("only default RoPE")
+        if problems:
+            raise NotImplementedError("PEAVTransformerConfig outside the HIP path's family: " + "; ".join(problems))
+
+
+class SAMAudioJudgeConfig:
+    """reference config.py:234-251.  `text_model` stays a plain dict of ModernBertConfig arguments (the text tower
+    runs on PyTorch-ROCm through transformers)."""
+
+    def __init__(self, audio_codec=None, transformer=None, text_model: Optional[Dict[str, Any]] = None,
+                 finetune_transformer=None, nth_text_layer: Optional[int] = 22, bottleneck_dim: int = 256):
+        self.audio_codec = _build(DACVAEConfig, audio_codec)
+        self.transformer = _build(PEAVTransformerConfig, transformer)
+        self.text_model = dict(text_model or {})
+        self.finetune_transformer = _build(PEAVTransformerConfig, finetune_transformer)
+        self.nth_text_layer = nth_text_layer
+        self.bottleneck_dim = bottleneck_dim
+
+    @property
+    def text_hidden(self) -> int:
+        return int(self.text_model.get("hidden_size", 768))  # ModernBertConfig default
+
+    def check_supported(self) -> None:
+        self.transformer.check_supported()
+        self.finetune_transformer.check_supported()
+        if self.bottleneck_dim % 64 or self.audio_codec.codebook_dim % 64 or self.text_hidden % 64:
+            raise NotImplementedError("bottleneck_dim / codebook_dim / text hidden size must be multiples of 64")
+
+
+class PEAudioFrameConfig:
+    """PE-A-Frame span predictor (reference model.py:96-102: `PEAudioFrame.from_config("pe-a-frame-large")`,
+    un-vendored).  Shape of the Hugging Face port: transformers/models/pe_audio/configuration_pe_audio.py:88-135
+    (audio tower = PE-AV transformer on DAC codec features, text tower = ModernBERT, contrastive heads)."""
+
+    def __init__(self, audio=None, text_model: Optional[Dict[str, Any]] = None, codebook_dim: int = 128,
+                 threshold: float = 0.5):
+        self.audio = _build(PEAVTransformerConfig, audio)
+        tm = dict(hidden_size=1024, intermediate_size=2624, num_hidden_layers=22, num_attention_heads=16)
+        tm.update(text_model or {})
+        self.text_model = tm
+        self.codebook_dim = codebook_dim
+        self.threshold = threshold
+
+    @property
+    def text_hidden(self) -> int:
+        return int(self.text_model["hidden_size"])
+
+    def check_supported(self) -> None:
+        self.audio.check_supported()
+        if self.codebook_dim % 64 or self.text_hidden % 64:
+            raise NotImplementedError("codebook_dim / text hidden size must be multiples of 64")
+
+
 # Labelled stand-ins for the checkpoint sizes whose real config.json is not reachable offline
 # (SURVEY.md §0, §8d).  head_dim 128 and the reference FFN rule are kept.
 SIZE_PRESETS: Dict[str, Dict[str, int]] = {

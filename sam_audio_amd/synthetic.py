@@ -185,3 +185,107 @@ def synthetic_noise(batch: int, frames: int, channels: int = 256, seed: int = 99
     """ODE start state, generated on the CPU so CPU-oracle and GPU runs share it (quirk Q12)."""
     g = torch.Generator().manual_seed(seed)
     return torch.randn(batch, frames, channels, generator=g)
+
+
+# ----------------------------------------------------------------------------------------------
+# Judge reranker / PE-A-Frame span predictor (SURVEY.md section 8 rows a17, a18)
+# ----------------------------------------------------------------------------------------------
+def init_peav_state_dict(tc, prefix: str, gen, dev, bias_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Random weights of one PE-AV transformer.  Key names follow the Hugging Face port
+    (transformers/models/pe_audio/modeling_pe_audio.py:241-287,344-490,616-640)."""
+    D, Fh, hd = tc.hidden_size, tc.intermediate_size, tc.head_dim
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out_f, in_f, bias=False):
+        b = 1.0 / math.sqrt(in_f)
+        sd[prefix + name + ".weight"] = _uniform(gen, (out_f, in_f), b, dev)
+        if bias:
+            sd[prefix + name + ".bias"] = _uniform(gen, (out_f,), b * bias_gain, dev)
+
+    def norm_w(name, n):
+        sd[prefix + name] = 1.0 + _normal(gen, (n,), 0.1, dev)
+
+    sd[prefix + "patch_embedder.class_embedding"] = _normal(gen, (1, 1, D), 0.5, dev)
+    for blk in ("block1", "block2"):
+        B = f"patch_embedder.resnet_block.{blk}."
+        norm_w(B + "groupnorm.weight", D)
+        sd[prefix + B + "groupnorm.bias"] = _normal(gen, (D,), 0.1, dev)
+        b = 1 / math.sqrt(3 * D)
+        sd[prefix + B + "project.weight"] = _uniform(gen, (D, D, 3), b, dev)
+        sd[prefix + B + "project.bias"] = _uniform(gen, (D,), b, dev)
+    for i in range(tc.num_hidden_layers):
+        L = f"layers.{i}."
+        for w in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            lin(L + "self_attn." + w, D, D, bias=tc.attention_bias)
+        norm_w(L + "self_attn.q_norm.weight", hd)
+        norm_w(L + "self_attn.k_norm.weight", hd)
+        lin(L + "mlp.gate_proj", Fh, D)
+        lin(L + "mlp.up_proj", Fh, D)
+        lin(L + "mlp.down_proj", D, Fh)
+        norm_w(L + "input_layernorm.weight", D)
+        norm_w(L + "post_attention_layernorm.weight", D)
+    norm_w("norm.weight", D)
+    lin("output", D, D)
+    return sd
+
+
+def _encoder_only_codec(cfg_codec, gen, dev) -> Dict[str, torch.Tensor]:
+    class _Wrap:  # init_codec_state_dict wants an object with .audio_codec
+        audio_codec = cfg_codec
+    full = init_codec_state_dict(_Wrap, gen, dev)
+    return {k: v for k, v in full.items() if ".decoder." not in k and "quantizer.out_proj" not in k}
+
+
+def init_judge_state_dict(cfg, seed: int = 0, device="cpu", with_codec: bool = True) -> Dict[str, torch.Tensor]:
+    """Random checkpoint of the Judge (reference judge.py:39-74; the ModernBERT text tower is not part of it - the
+    reference builds it with AutoModel.from_config and this build keeps it on PyTorch-ROCm).  `cfg` is a
+    SAMAudioJudgeConfig.  mean/std are drawn non-trivially so that the de-normalisation is exercised."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    D, D2, Bn = cfg.transformer.hidden_size, cfg.finetune_transformer.hidden_size, cfg.bottleneck_dim
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out_f, in_f, bias=True):
+        b = 1.0 / math.sqrt(in_f)
+        sd[name + ".weight"] = _uniform(gen, (out_f, in_f), b, dev)
+        if bias:
+            sd[name + ".bias"] = _uniform(gen, (out_f,), b, dev)
+
+    lin("data_proj", D, cfg.audio_codec.codebook_dim)
+    sd.update(init_peav_state_dict(cfg.transformer, "transformer.", gen, dev))
+    sd.update(init_peav_state_dict(cfg.finetune_transformer, "finetune_transformer.", gen, dev))
+    lin("cat_audio_proj", Bn, 2 * D)
+    lin("text_proj1", D, cfg.text_hidden, bias=False)
+    lin("text_proj2", Bn, D)
+    sd["layer_norm.weight"] = 1.0 + _normal(gen, (Bn,), 0.1, dev)
+    sd["layer_norm.bias"] = _normal(gen, (Bn,), 0.1, dev)
+    lin("proj_audio_and_text", Bn, 2 * Bn)
+    lin("finetune_data_proj", D2, Bn)
+    lin("head", 4, D2, bias=False)
+    sd["mean"] = _normal(gen, (4,), 1.0, dev)
+    sd["std"] = 0.5 + torch.rand(4, generator=gen, device=dev)
+    if with_codec:
+        sd.update(_encoder_only_codec(cfg.audio_codec, gen, dev))
+    return sd
+
+
+def init_frame_state_dict(cfg, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """Random checkpoint of the PE-A-Frame span predictor's audio side + heads (`cfg` is a PEAudioFrameConfig;
+    key names follow the HF port, modeling_pe_audio.py:158-195,721-735)."""
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    D, E = cfg.audio.hidden_size, cfg.text_hidden
+    sd: Dict[str, torch.Tensor] = {}
+    b = 1.0 / math.sqrt(cfg.codebook_dim)
+    sd["audio_encoder.embedder.data_proj.weight"] = _uniform(gen, (D, cfg.codebook_dim), b, dev)
+    sd["audio_encoder.embedder.data_proj.bias"] = _uniform(gen, (D,), b, dev)
+    sd.update(init_peav_state_dict(cfg.audio, "audio_encoder.", gen, dev))
+    for head, width in (("audio_head.", D), ("text_audio_head.", E)):
+        sd[head + "layer_norm.weight"] = 1.0 + _normal(gen, (width,), 0.1, dev)
+        sd[head + "layer_norm.bias"] = _normal(gen, (width,), 0.1, dev)
+        sd[head + "proj.weight"] = _uniform(gen, (E, width), 1.0 / math.sqrt(width), dev)
+    sd["text_audio_logit_scale"] = torch.full((1,), 4.0, device=dev)
+    sd["text_audio_logit_bias"] = torch.full((1,), -0.5, device=dev)
+    return sd
