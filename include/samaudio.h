@@ -72,7 +72,8 @@ void samaudio_destroy(samaudio_ctx* ctx);
  * (transformer.layers.{i}.attention.wq.weight, ...) to engine names. */
 int samaudio_set_tensor(samaudio_ctx* ctx, const char* name, const void* data, int dtype, int ndim,
                         const int64_t* shape);
-/* Check that the DiT (what=0) or codec (what=1) weight set is complete and shaped for the config. */
+/* Check that the DiT (what=0), codec (what=1) or codec-encoder-only (what=2: the Judge's DACVAEEncoder,
+ * reference codec.py:42-78) weight set is complete and shaped for the config. */
 int samaudio_finalize(samaudio_ctx* ctx, int what);
 
 /* Scratch.  `codec_items`: waveforms processed per codec pass (0 = no codec use), `samples`: padded
@@ -113,6 +114,77 @@ int samaudio_codec_encode(samaudio_ctx* ctx, const float* wav, int items, int64_
                           samaudio_stream stream);
 int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int frames, float* wav,
                           samaudio_stream stream);
+
+/* ---- reranking and span prediction ------------------------------------------ */
+
+/* One PE-AV transformer (perception_models core.audio_visual_encoder.transformer.Transformer, un-vendored; the
+ * reference instantiates it at sam_audio/model/judge.py:46-47; restated from its Hugging Face port
+ * transformers/models/pe_audio/modeling_pe_audio.py:241-287,344-490,616-680). */
+typedef struct {
+  int32_t dim, n_heads, n_layers, ffn_hidden; /* hidden_size, num_attention_heads, num_hidden_layers, intermediate_size */
+  int32_t in_dim;                             /* width of the features entering the input projection */
+  int32_t max_positions;                      /* rows of the RoPE table */
+  int32_t attn_bias;                          /* 1: q/k/v/o projections carry biases */
+  float norm_eps;
+} samaudio_peav_dims;
+
+/* SAMAudioJudgeModel (reference sam_audio/model/judge.py:35-132, config.py:234-251).  The ModernBERT text tower and
+ * the tokenizer stay with the caller (PyTorch-ROCm); the DAC encoder is a codec-only samaudio_ctx. */
+typedef struct {
+  int32_t precision;
+  samaudio_peav_dims transformer, finetune_transformer;
+  int32_t codec_dim;      /* 128: transformer.in_dim */
+  int32_t text_hidden;    /* text_model.hidden_size */
+  int32_t bottleneck_dim; /* 256: finetune_transformer.in_dim */
+} samaudio_judge_config;
+
+typedef struct samaudio_judge samaudio_judge;
+int samaudio_judge_create(const samaudio_judge_config* cfg, samaudio_judge** out);
+void samaudio_judge_destroy(samaudio_judge* j);
+/* engine names: sam_audio_amd/judge.py documents the mapping from the reference state_dict keys */
+int samaudio_judge_set_tensor(samaudio_judge* j, const char* name, const void* data, int dtype, int ndim,
+                              const int64_t* shape);
+int samaudio_judge_finalize(samaudio_judge* j);
+size_t samaudio_judge_workspace_bytes(samaudio_judge* j, int inputs, int candidates, int frames);
+int samaudio_judge_set_workspace(samaudio_judge* j, void* workspace, size_t bytes);
+/* SAMAudioJudgeModel.forward after the codec and the text tower (judge.py:98-132):
+ *   input_latent     [inputs, frames, codec_dim] f32              DAC mean latents of the mixtures (codec.py:65-70)
+ *   separated_latent [inputs*candidates, frames, codec_dim] f32   ... of the candidate separations, sample-major
+ *   text_pooled      [inputs*candidates, text_hidden] f32         _get_text_output(...).pooler_output (judge.py:76-88)
+ *   pad_mask         [inputs, frames] u8 or NULL                  padding_mask[:, ::hop] (judge.py:104-107), 1 = valid
+ *   scores           [inputs*candidates, 4] f32                   overall, recall, precision, faithfulness (de-normalised)
+ * The reference repeats every mixture once per candidate (ranking/judge.py:31-33); all ops are per-row, so the
+ * mixture branch runs once per clip here.  candidates = 1 is the plain forward(). */
+int samaudio_judge_score(samaudio_judge* j, const float* input_latent, const float* separated_latent, int inputs,
+                         int candidates, int frames, const float* text_pooled, const uint8_t* pad_mask, float* scores,
+                         samaudio_stream stream);
+/* parity hook: transformer `which` (0 = transformer, 1 = finetune_transformer) alone:
+ * x [rows, frames, in_dim] f32 -> hidden [rows, frames + 1, dim] f32 (row 0 of each item = pooler_output). */
+int samaudio_judge_encode(samaudio_judge* j, int which, const float* x, const uint8_t* pad_mask, int rows, int frames,
+                          float* hidden, samaudio_stream stream);
+
+/* PE-A-Frame span predictor (reference model.py:96-102,231-245; un-vendored PEAudioFrame; Hugging Face port
+ * modeling_pe_audio.py:810-868): per-frame audio-text logits for batch-paired (audio, description) rows. */
+typedef struct {
+  int32_t precision;
+  samaudio_peav_dims audio;
+  int32_t codec_dim;  /* 128 */
+  int32_t embed_dim;  /* text hidden size = width of the joint space */
+} samaudio_frame_config;
+
+typedef struct samaudio_frame samaudio_frame;
+int samaudio_frame_create(const samaudio_frame_config* cfg, samaudio_frame** out);
+void samaudio_frame_destroy(samaudio_frame* f);
+int samaudio_frame_set_tensor(samaudio_frame* f, const char* name, const void* data, int dtype, int ndim,
+                              const int64_t* shape);
+int samaudio_frame_finalize(samaudio_frame* f);
+size_t samaudio_frame_workspace_bytes(samaudio_frame* f, int rows, int frames);
+int samaudio_frame_set_workspace(samaudio_frame* f, void* workspace, size_t bytes);
+/* codec_features [rows, frames, codec_dim] f32 (= audio_features[:, :, :128], model.py:239), text_pooled
+ * [rows, embed_dim] f32 (token 0 of the text tower's last hidden state), pad_mask [rows, frames] u8 or NULL
+ * -> logits [rows, frames] f32 */
+int samaudio_frame_logits(samaudio_frame* f, const float* codec_features, const float* text_pooled,
+                          const uint8_t* pad_mask, int rows, int frames, float* logits, samaudio_stream stream);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
 
@@ -165,6 +237,13 @@ int samaudio_op_cross_attn_fold(const void* wo, const void* kv, int64_t kv_ld, v
                                 int ltp, int heads, samaudio_stream stream);
 int samaudio_op_layernorm_accum(const float* x, const float* w, const float* b, const float* gate, float* acc,
                                 int rows, int dim, float eps, samaudio_stream stream);
+/* masked GroupNorm(1) + SiLU of the PE-AV patch embedder: x [batch, frames, channels] f32, mask [batch, frames] u8,
+ * partials_f64: batch*64*3 doubles of scratch, out [batch][halo + frames + halo][channels] (halo rows untouched) */
+int samaudio_op_masked_groupnorm_silu(const float* x, const float* w, const float* b, const uint8_t* mask,
+                                      void* partials_f64, void* out, int precision, int batch, int frames,
+                                      int channels, int halo, float eps, samaudio_stream stream);
+int samaudio_op_layernorm_rows(const float* x, int64_t x_ld, const float* w, const float* b, float* out_f32,
+                               void* out_act, int precision, int64_t rows, int dim, float eps, samaudio_stream stream);
 
 #ifdef __cplusplus
 }

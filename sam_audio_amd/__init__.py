@@ -4,7 +4,7 @@ Public surface mirrors `sam_audio` (reference sam_audio/__init__.py:3-4) for tha
 SAMAudio, SAMAudioProcessor, Batch, SeparationResult.
 """
 from .config import SAMAudioConfig, preset_config  # noqa: F401
-from .processor import Batch, SAMAudioProcessor  # noqa: F401
+from .processor import Batch, SAMAudioJudgeProcessor, SAMAudioProcessor  # noqa: F401
 
 
 def __getattr__(name):
@@ -13,7 +13,11 @@ def __getattr__(name):
     if name in ("SAMAudio", "SeparationResult", "DFLT_ODE_OPT"):
         from . import model
         return getattr(model, name)
+    if name in ("SAMAudioJudgeModel", "SAMAudioJudgeOutput", "PEAudioFrame"):
+        from . import judge
+        return getattr(judge, name)
     raise AttributeError(name)
 
 
-__all__ = ["SAMAudio", "SAMAudioProcessor", "Batch", "SeparationResult", "SAMAudioConfig", "preset_config"]
+__all__ = ["SAMAudio", "SAMAudioProcessor", "SAMAudioJudgeProcessor", "SAMAudioJudgeModel", "Batch", "SeparationResult",
+           "SAMAudioConfig", "preset_config"]

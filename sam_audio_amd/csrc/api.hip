@@ -3,9 +3,16 @@
 #include <string>
 
 #include "engine.h"
+#include "peav.h"
 
 struct samaudio_ctx {
   sa::Engine* engine;
+};
+struct samaudio_judge {
+  sa::Judge* judge;
+};
+struct samaudio_frame {
+  sa::FramePredictor* frame;
 };
 
 namespace {
@@ -197,6 +204,116 @@ int samaudio_op_layernorm_accum(const float* x, const float* w, const float* b, 
                                 int rows, int dim, float eps, samaudio_stream stream) {
   return hip_ret(sa::launch_layernorm_accum(x, w, b, gate, acc, rows, dim, eps, (hipStream_t)stream),
                  "layernorm_accum");
+}
+
+int samaudio_op_masked_groupnorm_silu(const float* x, const float* w, const float* b, const uint8_t* mask,
+                                      void* partials_f64, void* out, int precision, int batch, int frames,
+                                      int channels, int halo, float eps, samaudio_stream stream) {
+  if (channels % 4 || !mask) return bad("masked_groupnorm: channels % 4 / null mask");
+  return hip_ret(sa::launch_masked_groupnorm_silu(x, w, b, mask, (double*)partials_f64, out, precision == SAMAUDIO_BF16,
+                                                  batch, frames, channels, halo, eps, (hipStream_t)stream),
+                 "masked_groupnorm_silu");
+}
+
+int samaudio_op_layernorm_rows(const float* x, int64_t x_ld, const float* w, const float* b, float* out_f32,
+                               void* out_act, int precision, int64_t rows, int dim, float eps, samaudio_stream stream) {
+  if (dim % 4 || x_ld % 4) return bad("layernorm_rows: dim % 4");
+  return hip_ret(sa::launch_layernorm_rows(x, x_ld, w, b, out_f32, out_act, precision == SAMAUDIO_BF16, rows, dim, eps,
+                                           (hipStream_t)stream), "layernorm_rows");
+}
+
+// ---- Judge reranker ----------------------------------------------------------------------------------
+int samaudio_judge_create(const samaudio_judge_config* cfg, samaudio_judge** out) {
+  if (!cfg || !out) return bad("samaudio_judge_create: null argument");
+  if (cfg->precision != SAMAUDIO_F32 && cfg->precision != SAMAUDIO_BF16) return bad("samaudio_judge_create: precision");
+  samaudio_judge* j = new samaudio_judge;
+  j->judge = new sa::Judge(*cfg);
+  *out = j;
+  return SAMAUDIO_OK;
+}
+
+void samaudio_judge_destroy(samaudio_judge* j) {
+  if (!j) return;
+  delete j->judge;
+  delete j;
+}
+
+int samaudio_judge_set_tensor(samaudio_judge* j, const char* name, const void* data, int dtype, int ndim,
+                              const int64_t* shape) {
+  if (!j) return bad("null judge");
+  return ret(j->judge->set_tensor(name, data, dtype, ndim, shape));
+}
+
+int samaudio_judge_finalize(samaudio_judge* j) {
+  if (!j) return bad("null judge");
+  return ret(j->judge->finalize());
+}
+
+size_t samaudio_judge_workspace_bytes(samaudio_judge* j, int inputs, int candidates, int frames) {
+  if (!j) return 0;
+  return j->judge->workspace_bytes(inputs, candidates, frames);
+}
+
+int samaudio_judge_set_workspace(samaudio_judge* j, void* workspace, size_t bytes) {
+  if (!j) return bad("null judge");
+  return ret(j->judge->set_workspace(workspace, bytes));
+}
+
+int samaudio_judge_score(samaudio_judge* j, const float* input_latent, const float* separated_latent, int inputs,
+                         int candidates, int frames, const float* text_pooled, const uint8_t* pad_mask, float* scores,
+                         samaudio_stream stream) {
+  if (!j) return bad("null judge");
+  return ret(j->judge->score(input_latent, separated_latent, inputs, candidates, frames, text_pooled, pad_mask, scores,
+                             (hipStream_t)stream));
+}
+
+int samaudio_judge_encode(samaudio_judge* j, int which, const float* x, const uint8_t* pad_mask, int rows, int frames,
+                          float* hidden, samaudio_stream stream) {
+  if (!j) return bad("null judge");
+  return ret(j->judge->encode(which, x, pad_mask, rows, frames, hidden, (hipStream_t)stream));
+}
+
+// ---- PE-A-Frame span predictor -------------------------------------------------------------------------
+int samaudio_frame_create(const samaudio_frame_config* cfg, samaudio_frame** out) {
+  if (!cfg || !out) return bad("samaudio_frame_create: null argument");
+  if (cfg->precision != SAMAUDIO_F32 && cfg->precision != SAMAUDIO_BF16) return bad("samaudio_frame_create: precision");
+  samaudio_frame* f = new samaudio_frame;
+  f->frame = new sa::FramePredictor(*cfg);
+  *out = f;
+  return SAMAUDIO_OK;
+}
+
+void samaudio_frame_destroy(samaudio_frame* f) {
+  if (!f) return;
+  delete f->frame;
+  delete f;
+}
+
+int samaudio_frame_set_tensor(samaudio_frame* f, const char* name, const void* data, int dtype, int ndim,
+                              const int64_t* shape) {
+  if (!f) return bad("null frame predictor");
+  return ret(f->frame->set_tensor(name, data, dtype, ndim, shape));
+}
+
+int samaudio_frame_finalize(samaudio_frame* f) {
+  if (!f) return bad("null frame predictor");
+  return ret(f->frame->finalize());
+}
+
+size_t samaudio_frame_workspace_bytes(samaudio_frame* f, int rows, int frames) {
+  if (!f) return 0;
+  return f->frame->workspace_bytes(rows, frames);
+}
+
+int samaudio_frame_set_workspace(samaudio_frame* f, void* workspace, size_t bytes) {
+  if (!f) return bad("null frame predictor");
+  return ret(f->frame->set_workspace(workspace, bytes));
+}
+
+int samaudio_frame_logits(samaudio_frame* f, const float* codec_features, const float* text_pooled,
+                          const uint8_t* pad_mask, int rows, int frames, float* logits, samaudio_stream stream) {
+  if (!f) return bad("null frame predictor");
+  return ret(f->frame->logits(codec_features, text_pooled, pad_mask, rows, frames, logits, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -98,7 +98,7 @@ class Engine {
   size_t esz_;  // bytes per activation / GEMM-operand element
   int at_dtype_;
   std::map<std::string, TensorRef> tensors_;
-  bool dit_ready_ = false, codec_ready_ = false, prepared_ = false;
+  bool dit_ready_ = false, codec_ready_ = false, enc_ready_ = false, prepared_ = false;
   char* ws_ = nullptr;
   size_t ws_bytes_ = 0;
   int rows_ = 0, frames_ = 0, text_len_ = 0, frames_pad_ = 0;

@@ -71,7 +71,7 @@ Status Engine::set_tensor(const char* name, const void* p, int dtype, int ndim, 
   t.shape.assign(shape, shape + ndim);
   // Re-registering a name invalidates the resolved pointers: finalize() must run again.  Adding new names
   // (e.g. the codec set after the DiT set) leaves an already finalized set valid.
-  if (tensors_.count(name)) dit_ready_ = codec_ready_ = false;
+  if (tensors_.count(name)) dit_ready_ = codec_ready_ = enc_ready_ = false;
   tensors_[name] = t;
   return Status{};
 }
@@ -198,6 +198,8 @@ Status Engine::finalize(int what) {
     NEEDF(enc_.out_b, "enc.out.b", CL);
     NEEDW(enc_.proj_w, "enc.proj.w", CD, CL);
     NEEDF(enc_.proj_b, "enc.proj.b", CD);
+    enc_ready_ = true;
+    if (what == 2) return Status{};  // encoder only: the Judge's DACVAEEncoder (reference codec.py:42-78)
     // decoder
     NEEDW(dec_.proj_w, "dec.proj.w", CL, CD);
     NEEDF(dec_.proj_b, "dec.proj.b", CL);
@@ -685,7 +687,7 @@ static void halo_out(GemmParams& p, float* raw, void* act, long T, int C, int ac
 }
 
 Status Engine::codec_encode(const float* wav, int items, int64_t S, float* latent, hipStream_t st) {
-  if (!codec_ready_) return fail(SAMAUDIO_ERR_STATE, "codec_encode: codec weights not finalized");
+  if (!enc_ready_) return fail(SAMAUDIO_ERR_STATE, "codec_encode: codec weights not finalized");
   long hop = 1;
   for (int i = 0; i < 4; ++i) hop *= cfg_.enc_rates[i];
   if (!wav || !latent || items <= 0 || S <= 0 || S % hop) return fail(SAMAUDIO_ERR_ARG, "codec_encode: samples % hop != 0");

@@ -90,4 +90,26 @@ hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_co
 // zero the halo rows of a [B][halo + T + halo][C] buffer
 hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t st);
 
+// ---- PE-AV transformer / Judge / span predictor (peav_kernels.hip) ------------------------------------------
+// h[b][0][:] = cls; mask_s[b][0] = pad[b][0], mask_s[b][1+t] = pad[b][t]  (pad == nullptr: all valid); h is [B][T+1][D]
+hipError_t launch_peav_cls_mask(float* h, const float* cls, const unsigned char* pad, unsigned char* mask_s, int B,
+                                int T, int D, hipStream_t st);
+// dst[b*rep + c][:] = src[b][:]
+hipError_t launch_repeat_rows_u8(const unsigned char* src, unsigned char* dst, int rows, int rep, int T,
+                                 hipStream_t st);
+// masked GroupNorm(1 group) + SiLU into a halo-padded channels-last buffer; partials: B * 64 * 3 doubles
+hipError_t launch_masked_groupnorm_silu(const float* x, const float* w, const float* b, const unsigned char* mask,
+                                        double* partials, void* out, bool bf16, int B, int S, int C, int halo,
+                                        float eps, hipStream_t st);
+// out[m,:] = LayerNorm(x[m,:]) * w + b; either output may be null
+hipError_t launch_layernorm_rows(const float* x, long x_ld, const float* w, const float* b, float* out_f32,
+                                 void* out_act, bool bf16, long M, int D, float eps, hipStream_t st);
+// scores[b][j] = (masked mean over frames of hidden[b][1+t][:]) . head_w[j][:] * std[j] + mean[j]
+hipError_t launch_judge_pool_head(const float* hidden, const unsigned char* mask_s, const float* head_w,
+                                  const float* mean, const float* std_, float* out, int B, int T, int D,
+                                  hipStream_t st);
+// logits[b][t] = <audio[a_off + b*a_bstride + t*E + :], text[b][:]> * scale[0] + bias[0]
+hipError_t launch_frame_logits(const float* audio, long a_bstride, long a_off, const float* text, const float* scale,
+                               const float* bias, float* out, int B, int T, int E, hipStream_t st);
+
 }  // namespace sa

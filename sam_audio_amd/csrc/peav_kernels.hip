@@ -1,0 +1,279 @@
+// Bandwidth-bound kernels of the PE-AV transformer / Judge / span-predictor rows.
+// The network is the un-vendored perception_models `core.audio_visual_encoder.transformer.Transformer`
+// (reference sam_audio/model/judge.py:8,46-47); line citations below are to its Hugging Face port,
+// transformers/models/pe_audio/modeling_pe_audio.py ("hf:"), which oracle/judge_oracle.py is pinned against.
+#include "kernels.h"
+
+namespace sa {
+
+// ------------------------------------------------------------------------------------------------
+// class token + sequence mask (hf:266-287): h[b][0][:] = cls, mask_s[b][0] = pad[b][0], mask_s[b][1+t] = pad[b][t]
+// (pad == nullptr: everything valid).  grid (B), 256 threads.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void peav_cls_mask_kernel(float* __restrict__ h, const float* __restrict__ cls,
+                                                            const unsigned char* __restrict__ pad,
+                                                            unsigned char* __restrict__ mask_s, int T, int D) {
+  const int b = blockIdx.x, S = T + 1;
+  float4* row = (float4*)(h + (long)b * S * D);
+  for (int i = threadIdx.x; i < (D >> 2); i += 256) row[i] = ((const float4*)cls)[i];
+  unsigned char* ms = mask_s + (long)b * S;
+  const unsigned char* pm = pad ? pad + (long)b * T : nullptr;
+  for (int s = threadIdx.x; s < S; s += 256) ms[s] = pm ? (pm[s == 0 ? 0 : s - 1] ? 1 : 0) : 1;
+}
+
+hipError_t launch_peav_cls_mask(float* h, const float* cls, const unsigned char* pad, unsigned char* mask_s, int B,
+                                int T, int D, hipStream_t st) {
+  hipLaunchKernelGGL(peav_cls_mask_kernel, dim3(B), dim3(256), 0, st, h, cls, pad, mask_s, T, D);
+  return hipGetLastError();
+}
+
+// dst[b*rep + c][:] = src[b][:]  (the mixture's frame mask repeated for each reranking candidate)
+__global__ void repeat_rows_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int rep,
+                                      int T, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long row = i / T;
+  dst[i] = src[(row / rep) * T + (i - row * T)];
+}
+
+hipError_t launch_repeat_rows_u8(const unsigned char* src, unsigned char* dst, int rows, int rep, int T,
+                                 hipStream_t st) {
+  const long total = (long)rows * rep * T;
+  hipLaunchKernelGGL(repeat_rows_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, rep, T,
+                     total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Masked GroupNorm(1 group) + SiLU, channels-last (hf:198-238): statistics over the VALID (frame, channel) entries of
+// a sample, affine, output of masked frames = 0 (x_norm * mask, and silu(0) = 0).  Same two-pass, fixed-order fp64
+// scheme as the DiT patcher's GroupNorm (kernels.hip): MGN_CHUNKS partial (sum, sumsq, valid frames) per sample.
+// ------------------------------------------------------------------------------------------------
+constexpr int MGN_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void mgn_partial_kernel(const float* __restrict__ x,
+                                                          const unsigned char* __restrict__ mask,
+                                                          double* __restrict__ partials, int S, int C) {
+  const int b = blockIdx.y, c = blockIdx.x;
+  const int per_chunk = (S + MGN_CHUNKS - 1) / MGN_CHUNKS;
+  const int lo = c * per_chunk, hi = lo + per_chunk < S ? lo + per_chunk : S;
+  const int n4 = C >> 2;
+  double s = 0.0, q = 0.0;
+  int valid = 0;
+  for (int t = lo; t < hi; ++t) {
+    if (!mask[(long)b * S + t]) continue;  // uniform over the workgroup
+    ++valid;
+    const float4* xr = (const float4*)(x + ((long)b * S + t) * C);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      float4 v = xr[i];
+      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double* o = partials + ((long)b * MGN_CHUNKS + c) * 3;
+    o[0] = sh[0][0];
+    o[1] = sh[1][0];
+    o[2] = (double)valid;
+  }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void mgn_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        const unsigned char* __restrict__ mask,
+                                                        const double* __restrict__ partials, TO* __restrict__ out,
+                                                        int S, int C, int halo, float eps) {
+  const int b = blockIdx.y;
+  double s = 0.0, q = 0.0, rows = 0.0;
+  for (int c = 0; c < MGN_CHUNKS; ++c) {
+    const double* p = partials + ((long)b * MGN_CHUNKS + c) * 3;
+    s += p[0];
+    q += p[1];
+    rows += p[2];
+  }
+  double n = rows * (double)C;
+  if (n < 1.0) n = 1.0;
+  const double mean_d = s / n;
+  double var_d = q / n - mean_d * mean_d;
+  if (var_d < 0.0) var_d = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  const int n4 = C >> 2;
+  const long total4 = (long)S * n4;
+  const float4* xs = (const float4*)(x + (long)b * S * C);
+  TO* ob = out + ((long)b * (S + 2 * halo) + halo) * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int t = (int)(i / n4), c4 = (int)(i - (long)t * n4);
+    if (mask[(long)b * S + t]) {
+      float4 v = xs[i], ww = ((const float4*)w)[c4], bb = ((const float4*)bias)[c4];
+      store4<TO>(ob + 4 * i, silu_f((v.x - mean) * rstd * ww.x + bb.x), silu_f((v.y - mean) * rstd * ww.y + bb.y),
+                 silu_f((v.z - mean) * rstd * ww.z + bb.z), silu_f((v.w - mean) * rstd * ww.w + bb.w));
+    } else {
+      store4<TO>(ob + 4 * i, 0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
+hipError_t launch_masked_groupnorm_silu(const float* x, const float* w, const float* b, const unsigned char* mask,
+                                        double* partials, void* out, bool bf16, int B, int S, int C, int halo,
+                                        float eps, hipStream_t st) {
+  hipLaunchKernelGGL(mgn_partial_kernel, dim3(MGN_CHUNKS, B), dim3(256), 0, st, x, mask, partials, S, C);
+  long total4 = (long)S * (C / 4);
+  int gx = (int)((total4 + 255) / 256);
+  if (gx > 512) gx = 512;
+  if (bf16)
+    hipLaunchKernelGGL(mgn_apply_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, st, x, w, b, mask, partials, (bf16_t*)out,
+                       S, C, halo, eps);
+  else
+    hipLaunchKernelGGL(mgn_apply_kernel<float>, dim3(gx, B), dim3(256), 0, st, x, w, b, mask, partials, (float*)out,
+                       S, C, halo, eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[m,:] = LayerNorm(x[m,:]) * w + b  (reference judge.py:117: torch.nn.LayerNorm(bottleneck_dim), eps 1e-5;
+// hf:184-195 contrastive heads, eps 1e-6).  fp32 in; writes the fp32 result and/or the GEMM-operand copy.
+// x rows have stride x_ld elements.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, long x_ld,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             float* __restrict__ out_f32, TO* __restrict__ out_act,
+                                                             long M, int D, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + row * x_ld);
+  const int n4 = D >> 2;
+  float s = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i];
+    float a = v.x - mean, c = v.y - mean, d = v.z - mean, e = v.w - mean;
+    q += a * a + c * c + d * d + e * e;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  for (int i = lane; i < n4; i += 64) {
+    float4 v = xr[i], ww = ((const float4*)w)[i], bb = ((const float4*)b)[i];
+    const float o0 = (v.x - mean) * rstd * ww.x + bb.x, o1 = (v.y - mean) * rstd * ww.y + bb.y,
+                o2 = (v.z - mean) * rstd * ww.z + bb.z, o3 = (v.w - mean) * rstd * ww.w + bb.w;
+    if (out_f32) *(float4*)(out_f32 + row * D + 4 * i) = make_float4(o0, o1, o2, o3);
+    if (out_act) store4<TO>(out_act + row * D + 4 * i, o0, o1, o2, o3);
+  }
+}
+
+hipError_t launch_layernorm_rows(const float* x, long x_ld, const float* w, const float* b, float* out_f32,
+                                 void* out_act, bool bf16, long M, int D, float eps, hipStream_t st) {
+  dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  if (bf16)
+    hipLaunchKernelGGL(layernorm_rows_kernel<bf16_t>, grid, block, 0, st, x, x_ld, w, b, out_f32, (bf16_t*)out_act, M,
+                       D, eps);
+  else
+    hipLaunchKernelGGL(layernorm_rows_kernel<float>, grid, block, 0, st, x, x_ld, w, b, out_f32, (float*)out_act, M, D,
+                       eps);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Judge head (reference judge.py:127-132): result = head(hidden) [B, T, 4]; pooled = masked mean over frames;
+// scores = pooled * std + mean.  The head is linear and bias-free, so it commutes with the mean: one workgroup per
+// sample first folds the valid frames of hidden[b][1 + t][:] (row 0 is the class token) into LDS, in frame order,
+// then takes the 4 dot products.  D <= 4096.  mask_s is the [B, T+1] sequence mask (entry 0 = class token, skipped).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void judge_pool_head_kernel(const float* __restrict__ hidden,
+                                                              const unsigned char* __restrict__ mask_s,
+                                                              const float* __restrict__ head_w,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ std_, float* __restrict__ out,
+                                                              int T, int D) {
+  __shared__ float pooled[4096];
+  __shared__ float red[4][4];
+  const int b = blockIdx.x, S = T + 1;
+  const unsigned char* ms = mask_s + (long)b * S;
+  int valid = 0;
+  for (int t = 1; t < S; ++t) valid += ms[t] ? 1 : 0;
+  const float inv = 1.f / (float)(valid > 0 ? valid : 1);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int t = 1; t < S; ++t)
+      if (ms[t]) acc += hidden[((long)b * S + t) * D + d];
+    pooled[d] = acc * inv;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dot[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int d = threadIdx.x; d < D; d += 256) {
+    const float pv = pooled[d];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dot[j] += pv * head_w[(long)j * D + d];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float r = wave_sum(dot[j]);
+    if (lane == 0) red[wave][j] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int j = threadIdx.x;
+    const float v = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+    out[(long)b * 4 + j] = v * std_[j] + mean[j];
+  }
+}
+
+hipError_t launch_judge_pool_head(const float* hidden, const unsigned char* mask_s, const float* head_w,
+                                  const float* mean, const float* std_, float* out, int B, int T, int D,
+                                  hipStream_t st) {
+  if (D > 4096) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(judge_pool_head_kernel, dim3(B), dim3(256), 0, st, hidden, mask_s, head_w, mean, std_, out, T, D);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// PE-A-Frame logits (hf:842-856 for batch-paired rows, reference model.py:234-243):
+// logits[b][t] = <audio_embed[b][t][:], text_embed[b][:]> * scale + bias.  One wave per (b, t).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_logits_kernel(const float* __restrict__ audio, long a_bstride, long a_off,
+                                                           const float* __restrict__ text,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int T, int E) {
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (long)B * T) return;
+  const int lane = threadIdx.x & 63;
+  const int b = (int)(item / T), t = (int)(item - (long)b * T);
+  const float4* ar = (const float4*)(audio + a_off + (long)b * a_bstride + (long)t * E);
+  const float4* tr = (const float4*)(text + (long)b * E);
+  float acc = 0.f;
+  for (int i = lane; i < (E >> 2); i += 64) {
+    float4 a = ar[i], c = tr[i];
+    acc += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[item] = acc * scale[0] + bias[0];
+}
+
+hipError_t launch_frame_logits(const float* audio, long a_bstride, long a_off, const float* text, const float* scale,
+                               const float* bias, float* out, int B, int T, int E, hipStream_t st) {
+  const long items = (long)B * T;
+  hipLaunchKernelGGL(frame_logits_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, audio, a_bstride, a_off,
+                     text, scale, bias, out, B, T, E);
+  return hipGetLastError();
+}
+
+}  // namespace sa

@@ -55,6 +55,23 @@ class GemmParams(C.Structure):
     ]
 
 
+class PeavDims(C.Structure):
+    """Mirror of `samaudio_peav_dims`."""
+    _fields_ = [("dim", C.c_int32), ("n_heads", C.c_int32), ("n_layers", C.c_int32), ("ffn_hidden", C.c_int32),
+                ("in_dim", C.c_int32), ("max_positions", C.c_int32), ("attn_bias", C.c_int32), ("norm_eps", C.c_float)]
+
+
+class JudgeConfig(C.Structure):
+    """Mirror of `samaudio_judge_config`."""
+    _fields_ = [("precision", C.c_int32), ("transformer", PeavDims), ("finetune_transformer", PeavDims),
+                ("codec_dim", C.c_int32), ("text_hidden", C.c_int32), ("bottleneck_dim", C.c_int32)]
+
+
+class FrameConfig(C.Structure):
+    """Mirror of `samaudio_frame_config`."""
+    _fields_ = [("precision", C.c_int32), ("audio", PeavDims), ("codec_dim", C.c_int32), ("embed_dim", C.c_int32)]
+
+
 class KernelStat(C.Structure):
     """Mirror of `samaudio_kernel_stat`."""
     _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("flops", C.c_double), ("ms", C.c_double)]
@@ -91,6 +108,27 @@ _PROTOS = {
     "samaudio_op_cross_attention": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     "samaudio_op_cross_attn_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "samaudio_op_layernorm_accum": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "samaudio_op_masked_groupnorm_silu": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "samaudio_op_layernorm_rows": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int, C.c_int64, C.c_int,
+                                                                                          C.c_float, C.c_void_p]),
+    "samaudio_judge_create": (C.c_int, [C.POINTER(JudgeConfig), C.POINTER(C.c_void_p)]),
+    "samaudio_judge_destroy": (None, [C.c_void_p]),
+    "samaudio_judge_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "samaudio_judge_finalize": (C.c_int, [C.c_void_p]),
+    "samaudio_judge_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "samaudio_judge_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "samaudio_judge_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "samaudio_judge_encode": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
+    "samaudio_frame_create": (C.c_int, [C.POINTER(FrameConfig), C.POINTER(C.c_void_p)]),
+    "samaudio_frame_destroy": (None, [C.c_void_p]),
+    "samaudio_frame_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "samaudio_frame_finalize": (C.c_int, [C.c_void_p]),
+    "samaudio_frame_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "samaudio_frame_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "samaudio_frame_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -84,9 +84,17 @@ class SAMAudio:
         self.precision = precision
         self.device = torch.device(device) if device is not None else None
         self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])
-        self.visual_ranker = None             # rerankers are 'next' rows
+        # rerankers (reference model.py:94-95): any callable with the reference's Ranker.forward keywords that returns
+        # scores [B, candidates]; sam_audio_amd.ranking.JudgeRanker is the HIP-backed one.  Configured rankers are
+        # built lazily from LOCAL checkpoint directories only (no hub access offline), see attach_rankers().
+        self.visual_ranker = None
         self.text_ranker = None
-        self.fix_span_order = False           # quirk Q13: kept for API compatibility, see separate()
+        # span predictor (reference model.py:96-102): a sam_audio_amd.judge.PEAudioFrame plus the tokenizer-like
+        # transform that turns descriptions into its text inputs
+        self.span_predictor = None
+        self.span_predictor_transform = None
+        self.vision_encoder = None            # callable: list of [T,3,H,W] videos -> [B, T, vision_encoder.dim]
+        self.fix_span_order = False           # quirk Q13, see separate()
         self._lib = hip.lib()                 # raises if the HIP library is not built
         self._ctx = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
@@ -384,9 +392,9 @@ class SAMAudio:
     def separate(self, batch: Batch, noise: Optional[torch.Tensor] = None,
                  ode_opt: Dict[str, Any] = DFLT_ODE_OPT, reranking_candidates: int = 1,
                  predict_spans: bool = False) -> SeparationResult:
-        """Reference model.py:247-338.  `predict_spans` needs the PE-A-Frame span predictor, which is a
-        'next' row of this build; like the reference without `span_predictor` it is then a no-op (and in
-        the reference snapshot the predicted spans never reach the ODE anyway - quirk Q13)."""
+        """Reference model.py:247-338.  `reranking_candidates > 1` draws that many ODE solutions per clip and lets
+        `visual_ranker` / `text_ranker` pick one (model.py:306-330); `predict_spans` runs `span_predictor` first
+        (model.py:259-268; mind quirk Q13 below)."""
         if not (self._has_dit and self._has_codec):
             raise RuntimeError("load_state_dict() first")
         cand = int(reranking_candidates)
@@ -396,16 +404,29 @@ class SAMAudio:
             B, T, C2 = feats.shape
             text, text_mask = self._text(batch)
             video = None
-            if batch.masked_video is not None:
-                raise NotImplementedError("visual prompting needs the PE-Core tower (SURVEY.md §8 f3)")
+            if batch.masked_video is not None:                                   # model.py:186-191
+                if self.vision_encoder is None:
+                    raise NotImplementedError(
+                        "visual prompting needs a vision encoder: set model.vision_encoder to a callable "
+                        "list[video [T,3,H,W]] -> features [B, T, vision_encoder.dim] (PE-Core tower, SURVEY.md section 8 f3)")
+                video = self.vision_encoder(batch.masked_video).transpose(1, 2)  # reference layout [B, C, T]
+            # forward args are assembled BEFORE the span predictor runs (reference model.py:257 vs :259-268), and
+            # process_anchors rebinds new tensors, so in the reference snapshot predicted spans never reach the ODE
+            # (quirk Q13).  fix_span_order=True opts into the evidently intended order.
+            anchor_ids, anchor_alignment = batch.anchor_ids, batch.anchor_alignment
             if predict_spans and batch.anchors is None:
-                warnings.warn("predict_spans=True ignored: no span predictor in this build (SURVEY.md §8 f2)")
+                if self.span_predictor is None:
+                    warnings.warn("predict_spans=True ignored: no span predictor attached (model.span_predictor)")
+                else:
+                    batch = self.predict_spans(batch, feats, batch.audio_pad_mask)   # model.py:259-268
+                    if self.fix_span_order:
+                        anchor_ids, anchor_alignment = batch.anchor_ids, batch.anchor_alignment
             feats_r = self._repeat(feats, cand)
             if noise is None:
                 noise = torch.randn_like(feats_r)                                # model.py:274-275
             assert noise.shape == feats_r.shape, "noise must be [B*candidates, T, 256]"
             cond = [feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), video,
-                    self._repeat(batch.anchor_ids, cand), self._repeat(batch.anchor_alignment, cand),
+                    self._repeat(anchor_ids, cand), self._repeat(anchor_alignment, cand),
                     self._repeat(batch.audio_pad_mask, cand)]
             groups = min(self.streams, feats_r.size(0))
             if groups > 1:
@@ -422,11 +443,52 @@ class SAMAudio:
             sizes = (batch.sizes.to(self.device) * self.cfg.audio_codec.hop_length).int()  # codec.py:91-97
             target = self.unbatch(wavs[:, 0].view(B, cand, -1), sizes)
             residual = self.unbatch(wavs[:, 1].view(B, cand, -1), sizes)
-            idxs = torch.zeros(B, dtype=torch.long, device=self.device)          # no ranker: model.py:329-330
+            idxs = self._rerank(batch, target, sizes, cand)                      # model.py:306-330
             return SeparationResult(
                 target=[w[i] for w, i in zip(target, idxs)],
                 residual=[w[i] for w, i in zip(residual, idxs)],
                 noise=noise)
+
+    def _rerank(self, batch: Batch, target_wavs: List[torch.Tensor], sizes: torch.Tensor, cand: int) -> torch.Tensor:
+        """Candidate selection, reference model.py:306-330: visual ranker if a masked video came with the batch, else
+        the text ranker, else candidate 0; `idxs = scores.argmax(dim=1)`."""
+        B = len(target_wavs)
+        sr = self.cfg.audio_codec.sample_rate
+        if cand > 1 and batch.masked_video is not None and self.visual_ranker is not None:
+            scores = self.visual_ranker(extracted_audio=target_wavs, videos=batch.masked_video, sample_rate=sr)
+            return scores.argmax(dim=1)
+        if cand > 1 and self.text_ranker is not None:
+            input_audio = [audio[:, : int(size)].expand(cand, -1) for audio, size in zip(batch.audios, sizes)]
+            scores = self.text_ranker(extracted_audio=target_wavs, input_audio=input_audio,
+                                      descriptions=batch.descriptions, sample_rate=sr)
+            return scores.argmax(dim=1)
+        return torch.zeros(B, dtype=torch.long, device=self.device)
+
+    def predict_spans(self, batch: Batch, audio_features: torch.Tensor, audio_pad_mask: torch.Tensor) -> Batch:
+        """reference model.py:231-245: PE-A-Frame on the first 128 feature channels (the codec mean latent) and the
+        descriptions -> spans -> "+" anchors -> batch.process_anchors."""
+        inputs = self.span_predictor_transform(text=batch.descriptions) if self.span_predictor_transform else {}
+        inputs = {k: v for k, v in dict(inputs).items() if k in ("input_ids", "attention_mask", "text_pooled")}
+        half = self.cfg.audio_codec.codebook_dim
+        output = self.span_predictor(input_features=audio_features[:, :, :half].contiguous(),
+                                     padding_mask=audio_pad_mask, return_spans=True, **inputs)
+        anchors = [[("+", float(s), float(e)) for s, e in spans] for spans in output.spans]
+        batch.process_anchors(anchors)
+        return batch
+
+    def attach_rankers(self, **kwargs) -> None:
+        """Build the rankers named in the config (reference model.py:94-95) when they point at LOCAL checkpoint
+        directories; hub ids cannot be resolved offline and are left unattached (a warning says so)."""
+        from .ranking import create_ranker
+        for name in ("visual_ranker", "text_ranker"):
+            rc = getattr(self.cfg, name)
+            if rc is None or getattr(self, name) is not None:
+                continue
+            path = getattr(rc, "checkpoint_or_model_id", None)
+            if path is not None and not os.path.isdir(path):
+                warnings.warn(f"{name}: {path!r} is not a local directory (no hub access offline); not attached")
+                continue
+            setattr(self, name, create_ranker(rc, device=str(self.device) if self.device else None, **kwargs))
 
     def unbatch(self, wavs: torch.Tensor, sizes: torch.Tensor, time_dim: int = -1):
         """reference model.py:340-344"""

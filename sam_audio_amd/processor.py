@@ -166,3 +166,69 @@ class SAMAudioProcessor:
                      hop_length=self.audio_hop_length, audio_sampling_rate=self.audio_sampling_rate,
                      anchors=anchors, audio_pad_mask=pad_mask, masked_video=video,
                      text_features=text_features, text_mask=text_mask)
+
+
+class JudgeBatch(dict):
+    """Dict of tensors with `.to(device)` (stands in for transformers.BatchFeature at reference processor.py:333,358)."""
+
+    def to(self, device) -> "JudgeBatch":
+        return JudgeBatch({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.items()})
+
+
+class SAMAudioJudgeProcessor(SAMAudioProcessor):
+    """Reference processor.py:263-379, tensor branch (file paths need torchcodec, which this build does not ship).
+    `tokenizer` is any callable with the Hugging Face tokenizer call signature."""
+
+    def __init__(self, audio_hop_length: int, audio_sampling_rate: int, tokenizer=None):
+        super().__init__(audio_hop_length, audio_sampling_rate)
+        self.tokenizer = tokenizer
+
+    @classmethod
+    def from_pretrained(cls, model_name_or_path: str) -> "SAMAudioJudgeProcessor":
+        from .config import SAMAudioJudgeConfig
+        path = os.path.join(model_name_or_path, "config.json")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: only local checkpoints are supported offline")
+        with open(path) as fin:
+            cfg = SAMAudioJudgeConfig(**json.load(fin))
+        import transformers
+        tokenizer = transformers.AutoTokenizer.from_pretrained(model_name_or_path, local_files_only=True)
+        return cls(cfg.audio_codec.hop_length, cfg.audio_codec.sample_rate, tokenizer)
+
+    def _reflect_pad(self, wav: torch.Tensor) -> torch.Tensor:  # processor.py:285-291
+        if wav.ndim == 1:
+            wav = wav.unsqueeze(0)
+        rem = wav.size(-1) % self.audio_hop_length
+        if rem == 0:
+            return wav
+        return torch.nn.functional.pad(wav, (0, self.audio_hop_length - rem), mode="reflect")
+
+    def _process_audio(self, raw_audio, sampling_rate: Optional[int] = None) -> JudgeBatch:  # processor.py:297-335
+        if isinstance(raw_audio, str) or (isinstance(raw_audio, (list, tuple)) and raw_audio and isinstance(raw_audio[0], str)):
+            raise ValueError("audio file paths need torchcodec, which this build does not ship; pass tensors")
+        if sampling_rate is not None and sampling_rate != self.audio_sampling_rate:
+            raise ValueError(
+                f"The model corresponding to this feature extractor was trained using a sampling rate of "
+                f"{self.audio_sampling_rate}; got {sampling_rate}.")
+        items = list(raw_audio) if isinstance(raw_audio, (list, tuple)) else list(self._reflect_pad(raw_audio)[:, None])
+        items = [self._reflect_pad(x).T for x in items]          # (num_samples, channels)
+        for example in items:
+            if example.ndim > 2:
+                raise ValueError(f"Expected input shape (channels, num_samples), but got shape ({example.shape})")
+        lengths = torch.tensor([x.size(0) for x in items])
+        input_values = torch.nn.utils.rnn.pad_sequence(items, batch_first=True).transpose(1, 2)
+        padding_mask = torch.arange(int(lengths.max()))[None] < lengths[:, None]
+        return JudgeBatch(input_values=input_values, padding_mask=padding_mask)
+
+    def __call__(self, text=None, input_audio=None, separated_audio=None, sampling_rate: Optional[int] = None,
+                 **kwargs) -> JudgeBatch:  # processor.py:337-363
+        batch = JudgeBatch()
+        if text is not None:
+            if self.tokenizer is None:
+                raise RuntimeError("SAMAudioJudgeProcessor has no tokenizer (none can be downloaded offline)")
+            batch.update(self.tokenizer(text, return_tensors="pt", padding="longest", max_length=512, truncation=True))
+        if input_audio is not None:
+            batch.update(self._process_audio(input_audio, sampling_rate))
+        if separated_audio is not None:
+            batch["separated_values"] = self._process_audio(separated_audio, sampling_rate)["input_values"]
+        return batch

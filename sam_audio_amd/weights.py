@@ -153,7 +153,9 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
 
 
 def convert_codec(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype, device,
-                  prefix: str = "audio_codec.") -> Dict[str, torch.Tensor]:
+                  prefix: str = "audio_codec.", with_decoder: bool = True) -> Dict[str, torch.Tensor]:
+    """`cfg` needs an `.audio_codec` DACVAEConfig.  with_decoder=False converts the encoder + quantizer.in_proj only
+    (the Judge's DACVAEEncoder, reference codec.py:42-78)."""
     c = cfg.audio_codec
     slab = 64 if act_dtype == torch.bfloat16 else 32
     out: Dict[str, torch.Tensor] = {}
@@ -194,6 +196,8 @@ def convert_codec(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: t
     w_ip = _conv_weight(sd, prefix + "quantizer.in_proj").to(device).squeeze(-1)  # [2*cd, latent]
     out["enc.proj.w"] = op(w_ip[: c.codebook_dim])                                   # mean half only (codec.py:68)
     out["enc.proj.b"] = f32(sd[prefix + "quantizer.in_proj.bias"][: c.codebook_dim])
+    if not with_decoder:
+        return out
     # decoder ------------------------------------------------------------------------------------
     out["dec.proj.w"] = op(_conv_weight(sd, prefix + "quantizer.out_proj").to(device).squeeze(-1))
     out["dec.proj.b"] = bias("quantizer.out_proj")
