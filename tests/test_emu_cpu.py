@@ -1,0 +1,281 @@
+"""The product's HOST orchestration code (sam_audio_amd/csrc/{engine,peav,api}.hip, compiled unchanged) run on the CPU
+against an emulation of the kernel launchers (oracle/emu/, test infrastructure) and checked against the oracle.
+
+What this pins without a GPU: which launcher runs when and with which pointers / strides / offsets / workspace
+aliasing - i.e. everything in Engine, PeavEncoder, Judge and FramePredictor except the HIP kernels themselves
+(those are covered by the -m gpu parity tests).  The Engine legs double as a check of the emulation itself: the
+same orchestration is parity-green on MI355X, so emulation + orchestration must reproduce the oracle here too.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gen_golden_judge as G
+from oracle import judge_oracle as J
+from oracle import samaudio_oracle as O
+from oracle.gen_golden import CASES, case_inputs
+from sam_audio_amd import hip, preset_config
+from sam_audio_amd.config import PEAudioFrameConfig
+from sam_audio_amd.judge import convert_frame, convert_judge, peav_dims
+from sam_audio_amd.synthetic import (init_frame_state_dict, init_judge_state_dict, init_state_dict, synthetic_clip,
+                                     synthetic_noise)
+from sam_audio_amd.weights import convert_codec, convert_dit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "oracle", "_emu", "libsamaudio_emu.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection is a bf16 GPU fast path (not emulated)
+
+
+@pytest.fixture(scope="session")
+def emu():
+    srcs = [os.path.join(ROOT, "oracle", "emu", f) for f in ("emu_kernels.cpp", "emu_hip.cpp", "build.sh")]
+    srcs += [os.path.join(ROOT, "sam_audio_amd", "csrc", f) for f in ("engine.hip", "peav.hip", "api.hip", "engine.h",
+                                                                        "peav.h", "kernels.h", "common.h")]
+    if not os.path.exists(EMU) or any(os.path.getmtime(s) > os.path.getmtime(EMU) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "emu", "build.sh")])
+    lib = C.CDLL(EMU)
+    for name, (res, args) in hip._PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def _check(lib, code):
+    assert code == 0, lib.samaudio_last_error().decode()
+
+
+def _set(lib, fn, h, tensors, keep):
+    for name, t in tensors.items():
+        dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+        keep.append(t)
+        _check(lib, fn(h, name.encode(), hip.ptr(t), dt, t.dim(), hip.shape_array(t.shape)))
+
+
+def _ws(nbytes):
+    buf = torch.full((nbytes + 512,), 255, dtype=torch.uint8)  # NaN bytes: unwritten scratch shows up
+    base = buf.data_ptr()
+    aligned = (base + 255) // 256 * 256
+    return buf, C.c_void_p(aligned), buf.numel() - (aligned - base)
+
+
+def _engine(lib, cfg, precision, keep):
+    t, c = cfg.transformer, cfg.audio_codec
+    hc = hip.Config(precision=precision, dim=t.dim, n_heads=t.n_heads, n_layers=t.n_layers, ffn_hidden=t.ffn_hidden,
+                    latent_channels=t.out_channels, text_dim=cfg.text_encoder.dim, video_dim=cfg.vision_encoder.dim,
+                    freq_dim=t.frequency_embedding_dim, anchor_dim=cfg.anchor_embedding_dim,
+                    anchor_vocab=cfg.num_anchors + 1, max_positions=t.max_positions, norm_eps=t.norm_eps,
+                    codec_dim=c.codebook_dim, codec_latent=c.latent_dim, enc_dim=c.encoder_dim, dec_dim=c.decoder_dim,
+                    enc_rates=(C.c_int32 * 4)(*c.encoder_rates), dec_rates=(C.c_int32 * 4)(*c.decoder_rates))
+    ctx = C.c_void_p()
+    _check(lib, lib.samaudio_create(C.byref(hc), C.byref(ctx)))
+    return ctx
+
+
+# ------------------------------------------------------------------------------------------------ Engine (DiT)
+@pytest.mark.parametrize("name", list(CASES)[:1])
+def test_engine_forward_on_the_emulation_matches_the_reference_golden(emu, name):
+    inp = case_inputs(name)
+    cfg = inp["cfg"]
+    sd = init_state_dict(cfg, seed=inp["seed"], with_codec=False)
+    keep = []
+    ctx = _engine(emu, cfg, hip.F32, keep)
+    _set(emu, emu.samaudio_set_tensor, ctx, convert_dit(sd, cfg, torch.float32, "cpu"), keep)
+    _check(emu, emu.samaudio_finalize(ctx, 0))
+    B, T, _ = inp["noisy"].shape
+    Lt = inp["text"].shape[1]
+    buf, p, n = _ws(emu.samaudio_workspace_bytes(ctx, B, T, Lt, 0, 0))
+    _check(emu, emu.samaudio_set_workspace(ctx, p, n))
+    feats, text = inp["feats"].contiguous(), inp["text"].contiguous()
+    tmask = inp["text_mask"].to(torch.uint8).contiguous()
+    video = inp["video"].transpose(1, 2).contiguous()
+    ids, align = inp["anchor_ids"].contiguous(), inp["anchor_alignment"].contiguous()
+    pad = inp["pad_mask"].to(torch.uint8).contiguous()
+    _check(emu, emu.samaudio_prepare(ctx, B, T, Lt, hip.ptr(feats), hip.ptr(text), hip.ptr(tmask), hip.ptr(video),
+                                     hip.ptr(ids), ids.shape[1], hip.ptr(align), hip.ptr(pad), None))
+    noisy, time = inp["noisy"].contiguous(), inp["time"].contiguous()
+    out = torch.empty_like(noisy)
+    _check(emu, emu.samaudio_forward(ctx, hip.ptr(noisy), hip.ptr(time), B, hip.ptr(out), None))
+    gold = torch.from_numpy(np.load(os.path.join(GOLDEN, f"forward_{name}.npz"))["out"])
+    err = (out - gold).abs().max().item()
+    print(f"emulated engine forward vs reference golden: {err:.2e}")
+    assert err < 1e-3
+    emu.samaudio_destroy(ctx)
+
+
+def test_engine_separate_pieces_on_the_emulation_match_the_oracle(emu):
+    """codec encode -> prepare -> 2-step midpoint ODE -> codec decode through the C ABI, against the oracle."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=3)
+    hop = cfg.audio_codec.hop_length
+    frames, B = 2, 2
+    wav = torch.stack([synthetic_clip(i, frames * hop) for i in range(B)])          # [B, 1, Tw]
+    g = torch.Generator().manual_seed(5)
+    text = torch.randn(B, 3, 768, generator=g)
+    tmask = torch.ones(B, 3, dtype=torch.bool)
+    noise = synthetic_noise(B, frames)
+    sizes = torch.tensor([frames, frames])
+    with torch.inference_mode():
+        t_ref, r_ref, lat_ref = O.separate(sd, cfg, wav, sizes, text, tmask, noise, step_size=0.5)
+    keep = []
+    ctx = _engine(emu, cfg, hip.F32, keep)
+    _set(emu, emu.samaudio_set_tensor, ctx, convert_dit(sd, cfg, torch.float32, "cpu"), keep)
+    _check(emu, emu.samaudio_finalize(ctx, 0))
+    _set(emu, emu.samaudio_set_tensor, ctx, convert_codec(sd, cfg, torch.float32, "cpu"), keep)
+    _check(emu, emu.samaudio_finalize(ctx, 1))
+    samples = frames * hop
+    need = max(emu.samaudio_workspace_bytes(ctx, B, frames, 3, 2 * B, samples), 1)
+    buf, p, n = _ws(need)
+    _check(emu, emu.samaudio_set_workspace(ctx, p, n))
+    w2 = wav.squeeze(1).contiguous()
+    z = torch.empty(B, frames, 128)
+    _check(emu, emu.samaudio_codec_encode(ctx, hip.ptr(w2), B, samples, hip.ptr(z), None))
+    z_ref = O.dac_encode(sd, cfg.audio_codec, wav).transpose(1, 2)
+    assert (z - z_ref).abs().max() < 1e-3
+    feats = torch.cat([z, z], 2).contiguous()
+    pad = torch.ones(B, frames, dtype=torch.uint8)
+    ids, align = O.anchors_to_ids(None, pad.bool(), hop, 48000)
+    tm = tmask.to(torch.uint8)
+    _check(emu, emu.samaudio_prepare(ctx, B, frames, 3, hip.ptr(feats), hip.ptr(text), hip.ptr(tm), None,
+                                     hip.ptr(ids), 2, hip.ptr(align), hip.ptr(pad), None))
+    state = noise.clone().contiguous()
+    grid = (C.c_float * 3)(0.0, 0.5, 1.0)
+    _check(emu, emu.samaudio_ode_solve(ctx, hip.ptr(state), hip.ODE_MIDPOINT, grid, 3, None))
+    assert (state - lat_ref).abs().max() < 1e-3
+    lat = state.reshape(B, frames, 2, 128).permute(0, 2, 1, 3).reshape(2 * B, frames, 128).contiguous()
+    out = torch.empty(2 * B, samples)
+    _check(emu, emu.samaudio_codec_decode(ctx, hip.ptr(lat), 2 * B, frames, hip.ptr(out), None))
+    for b in range(B):
+        assert (out[2 * b] - t_ref[b]).abs().max() < 1e-3 and (out[2 * b + 1] - r_ref[b]).abs().max() < 1e-3
+    emu.samaudio_destroy(ctx)
+
+
+# ------------------------------------------------------------------------------------------------ Judge
+def _judge(lib, cfg, sd, precision, dtype, keep):
+    jc = hip.JudgeConfig(precision=precision, transformer=peav_dims(cfg.transformer, cfg.audio_codec.codebook_dim),
+                         finetune_transformer=peav_dims(cfg.finetune_transformer, cfg.bottleneck_dim),
+                         codec_dim=cfg.audio_codec.codebook_dim, text_hidden=cfg.text_hidden,
+                         bottleneck_dim=cfg.bottleneck_dim)
+    h = C.c_void_p()
+    _check(lib, lib.samaudio_judge_create(C.byref(jc), C.byref(h)))
+    _set(lib, lib.samaudio_judge_set_tensor, h, convert_judge(sd, cfg, dtype, "cpu"), keep)
+    _check(lib, lib.samaudio_judge_finalize(h))
+    return h
+
+
+@pytest.mark.parametrize("masked", [True, False])
+def test_judge_encode_on_the_emulation_matches_the_oracle(emu, masked):
+    cfg = G.tiny_judge_config()
+    sd = init_judge_state_dict(cfg, seed=9)
+    keep = []
+    h = _judge(emu, cfg, sd, hip.F32, torch.float32, keep)
+    g = torch.Generator().manual_seed(5)
+    rows, T = 3, 21
+    mask = torch.arange(T)[None] < torch.tensor([21, 13, 6])[:, None]
+    for which, prefix, tc, w, b in ((0, "transformer.", cfg.transformer, "data_proj", None),
+                                    (1, "finetune_transformer.", cfg.finetune_transformer, "finetune_data_proj", None)):
+        z = torch.randn(rows, T, sd[w + ".weight"].shape[1], generator=g)
+        xin = torch.nn.functional.linear(z, sd[w + ".weight"], sd[w + ".bias"])
+        with torch.inference_mode():
+            last, pooled = J.peav_transformer(sd, prefix, xin, mask if masked else None, n_heads=tc.num_attention_heads,
+                                              n_layers=tc.num_hidden_layers, eps=tc.rms_norm_eps, rope_theta=tc.rope_theta)
+        buf, p, n = _ws(emu.samaudio_judge_workspace_bytes(h, rows, 1, T))
+        _check(emu, emu.samaudio_judge_set_workspace(h, p, n))
+        hidden = torch.empty(rows, T + 1, tc.hidden_size)
+        pm = mask.to(torch.uint8).contiguous() if masked else None
+        _check(emu, emu.samaudio_judge_encode(h, which, hip.ptr(z.contiguous()), hip.ptr(pm), rows, T, hip.ptr(hidden), None))
+        valid = (mask if masked else torch.ones_like(mask))[..., None]
+        assert (hidden[:, 0] - pooled).abs().max() < 1e-4
+        assert ((hidden[:, 1:] - last).abs() * valid).max() < 1e-4
+    emu.samaudio_judge_destroy(h)
+
+
+@pytest.mark.parametrize("cand,ragged", [(1, True), (3, True), (2, False)])
+def test_judge_score_on_the_emulation_matches_the_oracle(emu, cand, ragged):
+    cfg = G.tiny_judge_config()
+    sd = init_judge_state_dict(cfg, seed=9)
+    keep = []
+    h = _judge(emu, cfg, sd, hip.F32, torch.float32, keep)
+    g = torch.Generator().manual_seed(2)
+    hop = cfg.audio_codec.hop_length
+    Bi, T = 2, 9
+    lengths = torch.tensor([T * hop, 5 * hop])
+    wpad = torch.arange(T * hop)[None] < lengths[:, None]
+    if not ragged:
+        wpad = torch.ones_like(wpad)
+    wav_in = 0.3 * torch.randn(Bi, 1, T * hop, generator=g) * wpad[:, None]
+    wav_sep = 0.3 * torch.randn(Bi * cand, 1, T * hop, generator=g) * wpad.repeat_interleave(cand, 0)[:, None]
+    pooled = torch.randn(Bi * cand, cfg.text_hidden, generator=g)
+    with torch.inference_mode():
+        want = J.judge_forward(sd, cfg, pooled, wav_in.repeat_interleave(cand, 0), wav_sep,
+                               wpad.repeat_interleave(cand, 0) if ragged else None)
+        in_lat = O.dac_encode(sd, cfg.audio_codec, wav_in).transpose(1, 2).contiguous()
+        sep_lat = O.dac_encode(sd, cfg.audio_codec, wav_sep).transpose(1, 2).contiguous()
+    fmask = wpad[:, ::hop].to(torch.uint8).contiguous() if ragged else None
+    buf, p, n = _ws(emu.samaudio_judge_workspace_bytes(h, Bi, cand, T))
+    _check(emu, emu.samaudio_judge_set_workspace(h, p, n))
+    scores = torch.full((Bi * cand, 4), float("nan"))
+    _check(emu, emu.samaudio_judge_score(h, hip.ptr(in_lat), hip.ptr(sep_lat), Bi, cand, T, hip.ptr(pooled.contiguous()),
+                                         hip.ptr(fmask), hip.ptr(scores), None))
+    err = (scores - want).abs().max().item()
+    print(f"emulated judge_score cand={cand} ragged={ragged}: {err:.2e}")
+    assert err < 1e-4
+    emu.samaudio_judge_destroy(h)
+
+
+def test_judge_score_on_the_emulation_in_bf16_mode(emu):
+    """bf16 operand mode through the same orchestration (emulated with bf16 rounding of operands / activations):
+    stays within the bf16 bound of the GPU tests, i.e. no fp32-only assumption hides in the plumbing."""
+    cfg = G.tiny_judge_config()
+    sd = init_judge_state_dict(cfg, seed=9)
+    keep = []
+    h = _judge(emu, cfg, sd, hip.BF16, torch.bfloat16, keep)
+    g = torch.Generator().manual_seed(2)
+    hop = cfg.audio_codec.hop_length
+    Bi, T, cand = 2, 6, 2
+    wav_in = 0.3 * torch.randn(Bi, 1, T * hop, generator=g)
+    wav_sep = 0.3 * torch.randn(Bi * cand, 1, T * hop, generator=g)
+    pooled = torch.randn(Bi * cand, cfg.text_hidden, generator=g)
+    with torch.inference_mode():
+        want = J.judge_forward(sd, cfg, pooled, wav_in.repeat_interleave(cand, 0), wav_sep, None)
+        in_lat = O.dac_encode(sd, cfg.audio_codec, wav_in).transpose(1, 2).contiguous()
+        sep_lat = O.dac_encode(sd, cfg.audio_codec, wav_sep).transpose(1, 2).contiguous()
+    buf, p, n = _ws(emu.samaudio_judge_workspace_bytes(h, Bi, cand, T))
+    _check(emu, emu.samaudio_judge_set_workspace(h, p, n))
+    scores = torch.full((Bi * cand, 4), float("nan"))
+    _check(emu, emu.samaudio_judge_score(h, hip.ptr(in_lat), hip.ptr(sep_lat), Bi, cand, T, hip.ptr(pooled.contiguous()),
+                                         None, hip.ptr(scores), None))
+    err = (scores - want).abs().max().item()
+    print(f"emulated judge_score bf16: {err:.2e}")
+    assert err < 5e-2
+    emu.samaudio_judge_destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------ PE-A-Frame
+def test_frame_logits_on_the_emulation_match_the_oracle(emu):
+    cfg = PEAudioFrameConfig(audio=G.TINY_TC, text_model=dict(G.TINY_TEXT, hidden_size=64), codebook_dim=64)
+    sd = init_frame_state_dict(cfg, seed=2)
+    keep = []
+    fc = hip.FrameConfig(precision=hip.F32, audio=peav_dims(cfg.audio, cfg.codebook_dim), codec_dim=cfg.codebook_dim,
+                         embed_dim=cfg.text_hidden)
+    h = C.c_void_p()
+    _check(emu, emu.samaudio_frame_create(C.byref(fc), C.byref(h)))
+    _set(emu, emu.samaudio_frame_set_tensor, h, convert_frame(sd, cfg, torch.float32, "cpu"), keep)
+    _check(emu, emu.samaudio_frame_finalize(h))
+    g = torch.Generator().manual_seed(6)
+    feats, pooled = torch.randn(3, 17, 64, generator=g), torch.randn(3, 64, generator=g)
+    pad = torch.arange(17)[None] < torch.tensor([17, 9, 4])[:, None]
+    with torch.inference_mode():
+        want = J.frame_logits(sd, cfg, pooled, feats, pad)
+    buf, p, n = _ws(emu.samaudio_frame_workspace_bytes(h, 3, 17))
+    _check(emu, emu.samaudio_frame_set_workspace(h, p, n))
+    out = torch.full((3, 17), float("nan"))
+    pm = pad.to(torch.uint8).contiguous()
+    _check(emu, emu.samaudio_frame_logits(h, hip.ptr(feats.contiguous()), hip.ptr(pooled.contiguous()), hip.ptr(pm), 3, 17,
+                                          hip.ptr(out), None))
+    assert ((out - want).abs() * pad).max() < 1e-4
+    emu.samaudio_frame_destroy(h)
