@@ -19,7 +19,8 @@ What is restated here
 * `frame_logits` / `spans_from_logits` - PE-A-Frame (un-vendored): per-frame audio-text logits as in
   modeling_pe_audio.py:810-868; the span thresholding / merging rule exists only in perception_models, so the rule
   used by this build is DEFINED here (sigmoid(logit) > threshold, runs of consecutive frames, seconds = frame *
-  hop / sample_rate) and documented as an assumption.  PARITY UNPINNED.
+  hop / sample_rate minus a 1 us guard) and documented as an assumption.  PARITY UNPINNED; the integer round trip
+  through the reference's Batch.process_anchors is pinned bit-exactly.
 
 State-dict key names follow the HF port for the transformer (`layers.{i}.self_attn.q_proj.weight`, ...) and the
 reference for everything judge.py itself owns (`data_proj`, `cat_audio_proj`, `text_proj1`, ..., `head`, `mean`, `std`).

@@ -14,7 +14,12 @@ Pinning status
   published algorithm (fixed grid, midpoint / euler); anchored on the reference call site
   model.py:22,285-290.  PARITY UNPINNED (no reference-side fixture exists).
 * DAC-VAE (dacvae, un-vendored, unpinned in pyproject.toml:18): restated from the HF `dac`
-  topology; anchored on the reference call sites codec.py:45-89.  PARITY UNPINNED.
+  topology; anchored on the reference call sites codec.py:45-89.  PINNED numerically against the
+  two in-container implementations of the same networks (tests/test_dac_pin_cpu.py, strict
+  weight-for-weight key mapping): the encoder against `PeAudioDacEncoder` (the DAC-VAE encoder copy
+  inside the HF port of PE-AV, whose defaults equal the reference's DACVAEConfig), the decoder
+  against `DacDecoder`.  PARITY UNPINNED against the `dacvae` package itself (not reachable
+  offline: weight-norm spelling, any extra head).
 
 Every function cites the reference lines it follows.  State-dict keys are the reference's.
 """
