@@ -1,0 +1,64 @@
+"""`PerceptionEncoder` - host wrapper with the interface of the reference's visual-prompt encoder
+(reference sam_audio/model/vision_encoder.py:40-113; SURVEY.md section 8 row a4 / "next" row f3).
+
+The tower itself is `pe.CLIP.from_config("PE-Core-L14-336")` of the un-vendored perception_models package; neither
+that package nor `timm` (which carries the only other implementation of the PE-Core ViT) is part of this build's
+environment, so there is nothing in the container to restate the network from or to pin it against.  This wrapper
+therefore owns what the reference file owns - resize, scaling, normalisation, chunking by `batch_size`, time padding -
+and takes the tower as an injected callable `encode_image(frames [N,3,S,S] float, normalize=bool) -> [N, dim]`.
+`SAMAudio.vision_encoder = PerceptionEncoder(cfg.vision_encoder, tower)` enables `separate()` with `masked_videos`.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from .config import PerceptionEncoderConfig
+
+_MODES = {"NEAREST": "nearest", "BILINEAR": "bilinear", "BICUBIC": "bicubic"}
+
+
+class PerceptionEncoder:
+    def __init__(self, cfg: Optional[PerceptionEncoderConfig] = None, tower: Optional[Callable] = None, device=None):
+        self.cfg = cfg or PerceptionEncoderConfig()
+        self.batch_size, self.dim = self.cfg.batch_size, self.cfg.dim
+        self.normalize_feature, self.image_size = self.cfg.normalize_feature, self.cfg.image_size
+        mode = self.cfg.interpolation_mode.upper()
+        if mode not in _MODES:  # reference vision_encoder.py:93-99
+            raise ValueError(f"Unsupported interpolation_mode: {self.cfg.interpolation_mode}")
+        self.mode = _MODES[mode]
+        self.tower = tower
+        self.device = device
+
+    def transform(self, video: torch.Tensor) -> torch.Tensor:
+        """uint8 / float frames [T, 3, H, W] -> normalised float [T, 3, S, S] (reference vision_encoder.py:91-113:
+        Resize((S, S), interp) on a tensor -> x / 255 -> Normalize(0.5, 0.5)).  torchvision's tensor Resize
+        antialiases bilinear / bicubic down-scaling by default; F.interpolate(antialias=True) is the same kernel."""
+        x = video.float()
+        if x.shape[-2:] != (self.image_size, self.image_size):
+            kw = {"antialias": True, "align_corners": False} if self.mode != "nearest" else {}
+            x = torch.nn.functional.interpolate(x, size=(self.image_size, self.image_size), mode=self.mode, **kw)
+        return (x / 255.0 - 0.5) / 0.5
+
+    def encode(self, frames: torch.Tensor) -> torch.Tensor:
+        if self.tower is None:
+            raise NotImplementedError(
+                "no PE-Core tower attached: perception_models / timm are not part of this build's environment; pass "
+                "`tower=` (a callable encode_image(frames, normalize=...) -> [N, dim])")
+        return self.tower(frames, normalize=self.normalize_feature)
+
+    @torch.no_grad()
+    def forward(self, videos: List[torch.Tensor]) -> torch.Tensor:
+        """list of [T_i, 3, H, W] -> [B, max T_i, dim], zero-padded along time (reference vision_encoder.py:47-70)."""
+        result = []
+        for video in videos:
+            video = self.transform(video.to(self.device) if self.device is not None else video)
+            if self.batch_size > 0 and video.size(0) > self.batch_size:
+                parts = [self.encode(video[i: i + self.batch_size]) for i in range(0, video.size(0), self.batch_size)]
+                result.append(torch.cat(parts, dim=0))
+            else:
+                result.append(self.encode(video))
+        return torch.nn.utils.rnn.pad_sequence(result, batch_first=True, padding_value=0.0)
+
+    __call__ = forward

@@ -234,3 +234,26 @@ def test_t5_text_encoder_wrapper_matches_the_hf_module():
         T5TextEncoder(T5EncoderConfig(name="unused", dim=768), model=t5, tokenizer=Tok())
     with pytest.raises(FileNotFoundError):
         T5TextEncoder(T5EncoderConfig(name="t5-base"))                           # nothing cached offline
+
+
+def test_perception_encoder_wrapper_transform_chunking_and_padding():
+    from sam_audio_amd.config import PerceptionEncoderConfig
+    from sam_audio_amd.vision_encoder import PerceptionEncoder
+    calls = []
+
+    def tower(frames, normalize=True):
+        calls.append((tuple(frames.shape), normalize))
+        f = frames.mean(dim=(2, 3))                                   # [N, 3]
+        return torch.cat([f, f.new_ones(f.shape[0], 5)], dim=1)
+
+    enc = PerceptionEncoder(PerceptionEncoderConfig(dim=8, batch_size=4, image_size=6), tower)
+    vids = [torch.full((10, 3, 6, 6), 255, dtype=torch.uint8), torch.zeros(3, 3, 12, 9, dtype=torch.uint8)]
+    out = enc(vids)
+    assert out.shape == (2, 10, 8)
+    assert [c[0][0] for c in calls] == [4, 4, 2, 3] and all(c[1] for c in calls)      # chunks of batch_size
+    assert torch.allclose(out[0, :, :3], torch.ones(10, 3)) and torch.allclose(out[1, :3, :3], -torch.ones(3, 3))
+    assert torch.equal(out[1, 3:], torch.zeros(7, 8))                                   # time padding
+    with pytest.raises(ValueError):
+        PerceptionEncoder(PerceptionEncoderConfig(interpolation_mode="lanczos"))
+    with pytest.raises(NotImplementedError):
+        PerceptionEncoder(PerceptionEncoderConfig(image_size=6))([vids[0]])
