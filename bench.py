@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--streams", type=int, default=1, help="row groups of the batch solved concurrently on separate HIP streams")
+    ap.add_argument("--candidates", type=int, default=1,
+                    help="> 1: BASELINE.json configs[3] - reranking_candidates per clip, scored by the HIP Judge "
+                         "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
     return ap.parse_args()
 
 
@@ -120,6 +123,35 @@ def cpu_baseline(cfg, sd_cpu, clip, text, tmask, noise, threads):
     }
 
 
+class _HashTokenizer:
+    """Stand-in for the Judge's ModernBERT tokenizer (no tokenizer files offline): word hashes -> ids, pad-to-longest."""
+
+    def __call__(self, text, return_tensors="pt", padding="longest", max_length=512, truncation=True):
+        rows = [[1] + [3 + (hash(w) % 30000) for w in t.split()][: max_length - 1] for t in text]
+        width = max(len(r) for r in rows)
+        ids = torch.zeros(len(rows), width, dtype=torch.long)
+        att = torch.zeros(len(rows), width, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = torch.tensor(r)
+            att[i, : len(r)] = 1
+        return {"input_ids": ids, "attention_mask": att}
+
+
+def build_judge_ranker(cfg, precision, dev):
+    """SAMAudioJudgeModel with the pe-av-large defaults for both PE-AV transformers (the judge checkpoint's real
+    config.json is not reachable offline), seeded random weights, the SAMAudio codec dims, ModernBERT-base random init."""
+    from sam_audio_amd.config import SAMAudioJudgeConfig
+    from sam_audio_amd.judge import SAMAudioJudgeModel
+    from sam_audio_amd.processor import SAMAudioJudgeProcessor
+    from sam_audio_amd.ranking import JudgeRanker
+    from sam_audio_amd.synthetic import init_judge_state_dict
+    jcfg = SAMAudioJudgeConfig(audio_codec=vars(cfg.audio_codec), text_model=dict(vocab_size=30522 + 8))
+    judge = SAMAudioJudgeModel(jcfg, precision=precision, device=str(dev))
+    judge.load_state_dict(init_judge_state_dict(jcfg, seed=1, device=dev), strict=False)
+    proc = SAMAudioJudgeProcessor(jcfg.audio_codec.hop_length, jcfg.audio_codec.sample_rate, tokenizer=_HashTokenizer())
+    return JudgeRanker(model=judge, processor=proc)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -161,8 +193,12 @@ def main():
     batch = proc(descriptions=["sound"] * B, audios=clips, text_features=text, text_mask=tmask).to(dev)
     os.environ.setdefault("SAMAUDIO_CODEC_CHUNK", "32")
 
+    if args.candidates > 1:
+        model.text_ranker = build_judge_ranker(cfg, args.precision, dev)
+
     def step():
-        return model.separate(batch)  # noise=None: drawn on device inside, like the reference (model.py:274-275)
+        # noise=None: drawn on device inside, like the reference (model.py:274-275)
+        return model.separate(batch, reranking_candidates=args.candidates)
 
     def fence():
         torch.cuda.synchronize()
@@ -246,7 +282,7 @@ def main():
                              f"F={tcfg.ffn_hidden}) {args.precision}, batch={B}x10 s clips per GPU, text prompt "
                              f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"),
                 "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"clip-sharded x{world}",
-                "streams_per_gpu": args.streams,
+                "streams_per_gpu": args.streams, "reranking_candidates": args.candidates,
             },
             "roofline": roofline, "cpu_baseline": cpu,
         }

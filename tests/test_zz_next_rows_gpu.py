@@ -152,7 +152,8 @@ def test_judge_candidate_dedup_equals_the_expanded_batch(gpu, prec):
     cand = 3
     inp = _judge_case(cfg, B=2, T=5, cand=cand)
     tm = G.text_tower(cfg)
-    m = _judge(cfg, sd, prec, gpu, text_model=tm)
+    pooled = G.text_pooled(tm, cfg, inp["input_ids"], inp["attention_mask"]).repeat_interleave(cand, 0)  # on the CPU,
+    m = _judge(cfg, sd, prec, gpu, text_model=tm)                              # before the tower moves to the GPU
     scores = m.score_candidates(inp["input_ids"].to(gpu), inp["input_values"].to(gpu), inp["separated_values"].to(gpu),
                                 cand, attention_mask=inp["attention_mask"].to(gpu), padding_mask=inp["padding_mask"].to(gpu))
     expanded = m(input_ids=inp["input_ids"].repeat_interleave(cand, 0).to(gpu),
@@ -162,7 +163,6 @@ def test_judge_candidate_dedup_equals_the_expanded_batch(gpu, prec):
                  padding_mask=inp["padding_mask"].repeat_interleave(cand, 0).to(gpu))
     assert scores.shape == (2, cand)
     util.report(f"dedup vs expanded {prec}", scores.reshape(-1, 1), expanded.overall.cpu(), 1e-5 if prec == "fp32" else 2e-2)
-    pooled = G.text_pooled(tm, cfg, inp["input_ids"], inp["attention_mask"]).repeat_interleave(cand, 0)
     with torch.inference_mode():
         want = J.judge_forward(sd, cfg, pooled, inp["input_values"].repeat_interleave(cand, 0), inp["separated_values"],
                                inp["padding_mask"].repeat_interleave(cand, 0))
