@@ -164,6 +164,12 @@ def check(code: int) -> None:
     raise SamAudioHipError(f"[{code}] {msg}")
 
 
+def require_gpu(device, who: str) -> None:
+    """The product computes on a ROCm GPU only: weights are converted onto the device and every kernel is HIP."""
+    if device is None or device.type != "cuda":
+        raise SamAudioHipError(f"{who} needs a ROCm GPU: there is no CPU fallback")
+
+
 def current_stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -286,8 +286,7 @@ class SAMAudioJudgeModel:
         """Reference key names in (torch.nn.Module.load_state_dict semantics: strict raises RuntimeError)."""
         if self.device is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        if self.device.type != "cuda":
-            raise hip.SamAudioHipError("SAMAudioJudgeModel needs a ROCm GPU: there is no CPU fallback")
+        hip.require_gpu(self.device, "SAMAudioJudgeModel")
         import re
         canon = lambda k: re.sub(r"\.(weight_g|weight_v|parametrizations\.weight\.original[01])$", ".weight", k)  # noqa: E731
         have = {canon(k) for k in state_dict}
@@ -467,8 +466,7 @@ class PEAudioFrame:
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         if self.device is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        if self.device.type != "cuda":
-            raise hip.SamAudioHipError("PEAudioFrame needs a ROCm GPU: there is no CPU fallback")
+        hip.require_gpu(self.device, "PEAudioFrame")
         text_sd = {k[len("text_model."):]: v for k, v in state_dict.items() if k.startswith("text_model.")}
         if text_sd:
             self.text_model.load_state_dict(text_sd, strict=strict)

@@ -167,8 +167,7 @@ class SAMAudio:
         span-predictor keys are tolerated exactly like reference model.py:346-359."""
         if self.device is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        if self.device.type != "cuda":
-            raise hip.SamAudioHipError("SAMAudio needs a ROCm GPU: the separate() hot path has no CPU fallback")
+        hip.require_gpu(self.device, "SAMAudio (the separate() hot path)")
         missing, unexpected = split_missing_unexpected(state_dict.keys(), self.cfg)
         codec_missing = [k for k in missing if k.startswith("audio_codec.")]
         dit_missing = [k for k in missing if not k.startswith("audio_codec.")]
