@@ -1,0 +1,26 @@
+#!/bin/bash
+# Builds oracle/_simt/libsamaudio_simt.so: EVERY product source (kernels and host orchestration), compiled unchanged
+# as plain C++ against the stand-in <hip/hip_runtime.h> of oracle/simt/stub, so that each hipLaunchKernelGGL runs the
+# real kernel body on the functional SIMT simulator (simt.cpp).  TEST INFRASTRUCTURE ONLY.
+set -e
+cd "$(dirname "$0")"
+SRC=../../sam_audio_amd/csrc
+OUT=../_simt
+mkdir -p $OUT
+CXX=/opt/rocm/lib/llvm/bin/clang++
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro"
+pids=()
+for f in gemm gemm2 kernels attention peav_kernels engine peav api; do
+  src=$SRC/$f.hip
+  if [ ! -f $OUT/$f.o ] || [ $src -nt $OUT/$f.o ] || [ stub/hip/hip_runtime.h -nt $OUT/$f.o ] || [ $SRC/common.h -nt $OUT/$f.o ] || [ $SRC/kernels.h -nt $OUT/$f.o ] || [ $SRC/engine.h -nt $OUT/$f.o ] || [ $SRC/peav.h -nt $OUT/$f.o ]; then
+    EXTRA=""
+    if [ $f = gemm2 ]; then EXTRA="-O1"; fi   # the fully unrolled epilogues are slow to optimise on the host
+    $CXX $FLAGS $EXTRA -c $src -o $OUT/$f.o &
+    pids+=($!)
+  fi
+done
+$CXX $FLAGS -c simt.cpp -o $OUT/simt.o &
+pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+$CXX -shared -fPIC $OUT/gemm.o $OUT/gemm2.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/simt.o -o $OUT/libsamaudio_simt.so
+echo "built $OUT/libsamaudio_simt.so"

@@ -1,0 +1,184 @@
+// Runtime of the functional SIMT simulator  --  TEST INFRASTRUCTURE ONLY (see stub/hip/hip_runtime.h).
+//
+// One fiber per GPU thread, scheduled cooperatively on the calling OS thread: a fiber runs until it reaches a wave
+// collective or a workgroup barrier that is not yet complete, then yields to the scheduler; the last lane to arrive
+// releases the others.  Workgroups of a launch run one after the other (LDS = `static` arrays persists between them,
+// like on the hardware).  Context switches are a hand-written x86-64 callee-saved-register swap.
+#include <sys/mman.h>
+
+#include <hip/hip_runtime.h>
+
+#undef asm
+#undef volatile
+
+namespace simt {
+
+Fiber* cur = nullptr;
+
+namespace {
+void* g_sched_sp = nullptr;
+const std::function<void()>* g_body = nullptr;
+constexpr size_t STACK_BYTES = 512 * 1024;
+
+extern "C" void simt_switch(void** save_sp, void* load_sp);
+__asm__(
+    ".text\n"
+    ".globl simt_switch\n"
+    ".type simt_switch,@function\n"
+    "simt_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n"
+    "  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+    "  ret\n");
+
+void release_if_complete(Fiber* f) {
+  Wave* w = f->wave;
+  if (w->live > 0 && w->arrived == w->live) { w->arrived = 0; w->gen++; }
+  Block* b = f->block;
+  if (b->live > 0 && b->arrived == b->live) { b->arrived = 0; b->gen++; }
+}
+
+extern "C" void simt_fiber_main() {
+  Fiber* f = cur;
+  (*g_body)();
+  f->done = true;
+  f->wave->live--;
+  f->block->live--;
+  release_if_complete(f);  // lanes / waves still waiting must not wait for one that has exited
+  simt_switch(&f->sp, g_sched_sp);
+  std::abort();  // a finished fiber is never resumed
+}
+
+void yield() {
+  Fiber* f = cur;
+  simt_switch(&f->sp, g_sched_sp);
+}
+
+struct StackPool {
+  std::vector<void*> free_;
+  void* get() {
+    if (!free_.empty()) { void* p = free_.back(); free_.pop_back(); return p; }
+    void* p = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (p == MAP_FAILED) { std::perror("simt: mmap"); std::abort(); }
+    return p;
+  }
+  void put(void* p) { free_.push_back(p); }
+} g_stacks;
+}  // namespace
+
+void wave_sync() {
+  Fiber* f = cur;
+  Wave* w = f->wave;
+  const unsigned my = w->gen;
+  if (++w->arrived == w->live) { w->arrived = 0; w->gen++; return; }
+  f->waiting = 1;
+  f->wgen = my;
+  while (w->gen == my) yield();
+  f->waiting = 0;
+}
+
+void block_sync() {
+  Fiber* f = cur;
+  Block* b = f->block;
+  const unsigned my = b->gen;
+  if (++b->arrived == b->live) { b->arrived = 0; b->gen++; return; }
+  f->waiting = 2;
+  f->bgen = my;
+  while (b->gen == my) yield();
+  f->waiting = 0;
+}
+
+const unsigned char* row_publish(const void* data, size_t n) {
+  Fiber* f = cur;
+  Wave* w = f->wave;
+  const int row = f->lane >> 4;
+  if (n > 8) { std::fprintf(stderr, "simt: row publish of %zu bytes\n", n); std::abort(); }
+  unsigned char* buf = &w->rbuf[f->rcount & 1][0][0];
+  std::memcpy(buf + (size_t)f->lane * 8, data, n);
+  f->rcount++;
+  const unsigned my = w->row_gen[row];
+  if (++w->row_arrived[row] == 16) { w->row_arrived[row] = 0; w->row_gen[row]++; return buf; }
+  f->waiting = 3;
+  f->rgen = my;
+  while (w->row_gen[row] == my) yield();
+  f->waiting = 0;
+  return buf;
+}
+
+const unsigned char* wave_publish(const void* data, size_t n) {
+  Fiber* f = cur;
+  if (n > (size_t)XBYTES) { std::fprintf(stderr, "simt: publish of %zu bytes\n", n); std::abort(); }
+  unsigned char* buf = &f->wave->xbuf[f->xcount & 1][0][0];
+  std::memcpy(buf + (size_t)f->lane * XBYTES, data, n);
+  f->xcount++;
+  wave_sync();
+  return buf;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+  if (cur) { std::fprintf(stderr, "simt: nested launch\n"); std::abort(); }
+  const int nthreads = (int)(block.x * block.y * block.z);
+  const int nwaves = (nthreads + WAVE - 1) / WAVE;
+  g_body = &body;
+  std::vector<Fiber> fibers((size_t)nthreads);
+  std::vector<Wave>* waves = new std::vector<Wave>((size_t)nwaves);
+  for (int i = 0; i < nthreads; ++i) fibers[i].stack = g_stacks.get();
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        Block blk;
+        blk.live = nthreads;
+        for (int w = 0; w < nwaves; ++w) {
+          (*waves)[w].live = std::min(WAVE, nthreads - w * WAVE);
+          (*waves)[w].arrived = 0;
+          (*waves)[w].gen = 0;
+          for (int r = 0; r < 4; ++r) { (*waves)[w].row_arrived[r] = 0; (*waves)[w].row_gen[r] = 0; }
+        }
+        for (int i = 0; i < nthreads; ++i) {
+          Fiber& f = fibers[i];
+          void* stack = f.stack;
+          f = Fiber{};
+          f.stack = stack;
+          f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+          f.bid = dim3(bx, by, bz);
+          f.bdim = block;
+          f.gdim = grid;
+          f.lane = i % WAVE;
+          f.wave = &(*waves)[i / WAVE];
+          f.block = &blk;
+          // initial frame: six callee-saved slots, then the entry address; rsp is 16-byte aligned + 8 at entry
+          uintptr_t top = ((uintptr_t)stack + STACK_BYTES) & ~(uintptr_t)15;
+          void** sp = (void**)(top - 8);
+          *--sp = (void*)&simt_fiber_main;
+          for (int k = 0; k < 6; ++k) *--sp = nullptr;
+          f.sp = sp;
+        }
+        int remaining = nthreads;
+        while (remaining > 0) {
+          bool progress = false;
+          for (int i = 0; i < nthreads; ++i) {
+            Fiber& f = fibers[i];
+            if (f.done) continue;
+            if (f.waiting == 1 && f.wave->gen == f.wgen) continue;
+            if (f.waiting == 2 && f.block->gen == f.bgen) continue;
+            if (f.waiting == 3 && f.wave->row_gen[f.lane >> 4] == f.rgen) continue;
+            cur = &f;
+            simt_switch(&g_sched_sp, f.sp);
+            cur = nullptr;
+            progress = true;
+            if (f.done) --remaining;
+          }
+          if (!progress) {
+            std::fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d threads wait at a barrier / collective the "
+                                 "others never reach\n", bx, by, bz, remaining);
+            std::abort();
+          }
+        }
+      }
+  for (int i = 0; i < nthreads; ++i) g_stacks.put(fibers[i].stack);
+  delete waves;
+  g_body = nullptr;
+}
+
+}  // namespace simt

@@ -25,7 +25,12 @@ def pytest_configure(config):
 # GPU tests themselves can be shaken out without hardware.  It proves nothing about the HIP kernels and is never
 # active in a normal run: it needs the env switch, and it is set up here - not in the product - by monkeypatching.
 # ---------------------------------------------------------------------------------------------------------------
-EMU_DRYRUN = os.environ.get("SAMAUDIO_EMU_DRYRUN") == "1"
+#     SAMAUDIO_EMU_DRYRUN=simt ... goes one level deeper: oracle/_simt/libsamaudio_simt.so is EVERY product source, kernels
+# included, compiled unchanged for the host and executed on a functional SIMT simulator (oracle/simt/: one fiber per GPU
+# thread, 64-lane waves, barriers, LDS, MFMA / DMA / DPP builtins emulated lane-exactly).  It checks what a kernel
+# computes - indexing, fragment layouts, swizzles, masks, epilogues - not when (no timing, no races).
+EMU_MODE = os.environ.get("SAMAUDIO_EMU_DRYRUN", "")
+EMU_DRYRUN = EMU_MODE in ("1", "simt")
 
 
 def _enable_emu_dryrun():
@@ -34,9 +39,9 @@ def _enable_emu_dryrun():
     import subprocess
     import torch
     from sam_audio_amd import hip
-    emu = os.path.join(ROOT, "oracle", "_emu", "libsamaudio_emu.so")
-    if not os.path.exists(emu):
-        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "emu", "build.sh")])
+    which = "simt" if EMU_MODE == "simt" else "emu"
+    emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}.so")
+    subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")])
     lib = C.CDLL(emu)
     for name, (res, args) in hip._PROTOS.items():
         fn = getattr(lib, name)
@@ -44,9 +49,20 @@ def _enable_emu_dryrun():
     hip._lib = lib
     hip.require_gpu = lambda device, who: None
     hip.current_stream_ptr = lambda: C.c_void_p(0)
+    # `x.to(gpu)` is a copy on a real GPU; tests rely on that (a kernel that works in place must not change the CPU
+    # original the reference is computed from), so make it a copy here too
+    orig_to = torch.Tensor.to
+
+    def to_copy(self, *a, **k):
+        r = orig_to(self, *a, **k)
+        names_device = "device" in k or any(isinstance(x, (torch.device, str)) for x in a)
+        return r.clone() if (r is self and names_device) else r
+
+    torch.Tensor.to = to_copy
     torch.cuda.device = lambda *a, **k: contextlib.nullcontext()
     torch.cuda.current_stream = lambda *a, **k: None
-    os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection is a GPU-only bf16 fast path
+    if which == "emu":
+        os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection's kernels are not emulated
 
 
 if EMU_DRYRUN:
