@@ -14,7 +14,14 @@ for f in gemm gemm2 kernels attention peav_kernels engine peav api; do
   src=$SRC/$f.hip
   if [ ! -f $OUT/$f.o ] || [ $src -nt $OUT/$f.o ] || [ stub/hip/hip_runtime.h -nt $OUT/$f.o ] || [ $SRC/common.h -nt $OUT/$f.o ] || [ $SRC/kernels.h -nt $OUT/$f.o ] || [ $SRC/engine.h -nt $OUT/$f.o ] || [ $SRC/peav.h -nt $OUT/$f.o ]; then
     EXTRA=""
-    if [ $f = gemm2 ]; then EXTRA="-O1"; fi   # the fully unrolled epilogues are slow to optimise on the host
+    if [ $f = gemm2 ]; then
+      EXTRA="-O1 -I $SRC"   # the fully unrolled epilogues are slow to optimise on the host
+      # the one inline-asm statement whose vmcnt count is an asm OPERAND (invisible to the preprocessor) is rewritten to
+      # the simulator's call; everything else in the file is compiled as it stands
+      sed 's|asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");|simt::wait_vmcnt(N);|' $src > $OUT/gemm2_simt.hip
+      grep -q "simt::wait_vmcnt(N);" $OUT/gemm2_simt.hip || { echo "gemm2.hip: wait_vmcnt<N> statement not found"; exit 1; }
+      src=$OUT/gemm2_simt.hip
+    fi
     $CXX $FLAGS $EXTRA -c $src -o $OUT/$f.o &
     pids+=($!)
   fi

@@ -89,6 +89,35 @@ void block_sync() {
   f->waiting = 0;
 }
 
+bool dma_late() {
+  static const bool late = [] { const char* e = std::getenv("SAMAUDIO_SIMT_DMA"); return e && std::string(e) == "late"; }();
+  return late;
+}
+
+void wait_vmcnt(int n) {
+  wave_sync();
+  Wave* w = cur->wave;  // the first lane through does the work, the others find nothing left to do
+  while ((long)w->pending.size() > (long)n) {
+    Wave::Dma& d = w->pending.front();
+    for (int l = 0; l < WAVE; ++l) std::memcpy(d.base + 16 * l, d.data[l], 16);
+    w->pending.pop_front();
+    w->dma_first++;
+  }
+}
+
+// `asm volatile("...")` statements of the kernels: a wave-synchronous point; `s_waitcnt vmcnt(<literal>)` retires DMAs.
+// (The one statement whose count is an asm operand, gemm2.hip wait_vmcnt<N>, is rewritten to simt::wait_vmcnt(N) by
+// oracle/simt/build.sh - the preprocessor cannot see an operand's value.)
+void asm_stmt(const char* text) {
+  const char* v = std::strstr(text, "vmcnt(");
+  if (v) {
+    if (v[6] < '0' || v[6] > '9') { std::fprintf(stderr, "simt: vmcnt with a non-literal count: %s\n", text); std::abort(); }
+    wait_vmcnt(std::atoi(v + 6));
+    return;
+  }
+  wave_sync();
+}
+
 const unsigned char* row_publish(const void* data, size_t n) {
   Fiber* f = cur;
   Wave* w = f->wave;
@@ -134,6 +163,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
           (*waves)[w].arrived = 0;
           (*waves)[w].gen = 0;
           for (int r = 0; r < 4; ++r) { (*waves)[w].row_arrived[r] = 0; (*waves)[w].row_gen[r] = 0; }
+          (*waves)[w].pending.clear();  // DMAs still in flight when a workgroup ends are dropped
+          (*waves)[w].dma_first = 0;
         }
         for (int i = 0; i < nthreads; ++i) {
           Fiber& f = fibers[i];

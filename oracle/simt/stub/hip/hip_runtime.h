@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <map>
 #include <string>
@@ -59,6 +60,11 @@ struct Wave {
   unsigned row_gen[4] = {0, 0, 0, 0};
   alignas(64) unsigned char xbuf[2][WAVE][XBYTES];
   alignas(64) unsigned char rbuf[2][WAVE][8];
+  // global_load_lds instructions issued by this wave and not yet retired by one of its s_waitcnt vmcnt(N)
+  // (only used in the "late" DMA mode, see dma_late())
+  struct Dma { char* base; unsigned char data[WAVE][16]; };
+  std::deque<Dma> pending;
+  unsigned long dma_first = 0;  // sequence number of pending.front()
 };
 struct Block {
   int live = 0, arrived = 0;
@@ -70,6 +76,7 @@ struct Fiber {
   dim3 tid, bid, bdim, gdim;
   int lane = 0;
   unsigned xcount = 0, rcount = 0;
+  unsigned long dma_seq = 0;  // global_load_lds instructions this lane has issued
   Wave* wave = nullptr;
   Block* block = nullptr;
   bool done = false;
@@ -85,6 +92,15 @@ void block_sync();
 const unsigned char* wave_publish(const void* data, size_t n);
 // the same among the 16 lanes of the caller's DPP row (lanes 16k .. 16k+15), n <= 8; all 16 must take part
 const unsigned char* row_publish(const void* data, size_t n);
+// DMA model.  Default ("early"): a global_load_lds lands in LDS when it is issued.  SAMAUDIO_SIMT_DMA=late: it lands as
+// LATE as the ISA allows - when the issuing wave's s_waitcnt vmcnt(N) retires it (oldest first, until N remain), or at
+// that wave's __syncthreads() (which the compiler precedes with vmcnt(0)).  A kernel whose vmcnt counting lets a wave
+// read a slab before it was retired then reads stale LDS and fails its parity test; "early" catches the opposite
+// hazard (a slab overwritten while still being read).  Only DMA counts: other VMEM loads a wave has in flight would
+// make the real vmcnt(N) retire fewer DMAs than this model assumes.
+bool dma_late();
+void wait_vmcnt(int n);   // wave-synchronous
+void asm_stmt(const char* text);
 }  // namespace simt
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
@@ -100,7 +116,10 @@ const unsigned char* row_publish(const void* data, size_t n);
 #define blockIdx (simt::cur->bid)
 #define blockDim (simt::cur->bdim)
 #define gridDim (simt::cur->gdim)
-inline void __syncthreads() { simt::block_sync(); }
+inline void __syncthreads() {
+  if (simt::dma_late()) simt::wait_vmcnt(0);  // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) before the s_barrier
+  simt::block_sync();
+}
 
 // ---------------------------------------------------------------------------------------------------- vector types
 struct float2 { float x, y; };
@@ -171,7 +190,18 @@ inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(
   const unsigned char* x = simt::wave_publish(&mine, sizeof(void*));
   void* base;
   std::memcpy(&base, x, sizeof(void*));
-  std::memcpy((char*)base + off + 16 * simt::cur->lane, (const void*)g, 16);
+  simt::Fiber* f = simt::cur;
+  if (!simt::dma_late()) {
+    std::memcpy((char*)base + off + 16 * f->lane, (const void*)g, 16);
+    return;
+  }
+  simt::Wave* w = f->wave;
+  const unsigned long seq = f->dma_seq++;
+  while (w->dma_first + w->pending.size() <= seq) {
+    w->pending.emplace_back();
+    w->pending.back().base = (char*)base + off;
+  }
+  std::memcpy(w->pending[seq - w->dma_first].data[f->lane], (const void*)g, 16);
 }
 
 // ---------------------------------------------------------------------------------------------------- MFMA
@@ -247,4 +277,4 @@ inline simt::v4f __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, simt::v4
 // (every lane of a wave executes them together on the GPU).  Must stay the LAST thing this header does: the standard
 // headers above are already included and guarded.
 #define asm
-#define volatile(...) simt::wave_sync()
+#define volatile(...) simt::asm_stmt(#__VA_ARGS__)

@@ -41,7 +41,8 @@ def _enable_emu_dryrun():
     from sam_audio_amd import hip
     which = "simt" if EMU_MODE == "simt" else "emu"
     emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}.so")
-    subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")])
+    if not os.environ.get("SAMAUDIO_EMU_NOBUILD"):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")])
     lib = C.CDLL(emu)
     for name, (res, args) in hip._PROTOS.items():
         fn = getattr(lib, name)
