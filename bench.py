@@ -145,7 +145,7 @@ def build_judge_ranker(cfg, precision, dev):
     from sam_audio_amd.processor import SAMAudioJudgeProcessor
     from sam_audio_amd.ranking import JudgeRanker
     from sam_audio_amd.synthetic import init_judge_state_dict
-    jcfg = SAMAudioJudgeConfig(audio_codec=vars(cfg.audio_codec), text_model=dict(vocab_size=30522 + 8))
+    jcfg = SAMAudioJudgeConfig(audio_codec=vars(cfg.audio_codec))  # text tower: ModernBertConfig defaults (base)
     judge = SAMAudioJudgeModel(jcfg, precision=precision, device=str(dev))
     judge.load_state_dict(init_judge_state_dict(jcfg, seed=1, device=dev), strict=False)
     proc = SAMAudioJudgeProcessor(jcfg.audio_codec.hop_length, jcfg.audio_codec.sample_rate, tokenizer=_HashTokenizer())
