@@ -23,5 +23,6 @@ pids+=($!)
 hipcc $FLAGS -x hip -c emu_hip.cpp -o $OUT/emu_hip.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-hipcc -shared -fPIC -fopenmp $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/emu_kernels.o $OUT/emu_hip.o -o $OUT/libsamaudio_emu.so
+hipcc -shared -fPIC -fopenmp $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/emu_kernels.o $OUT/emu_hip.o -o $OUT/libsamaudio_emu.so.tmp
+mv -f $OUT/libsamaudio_emu.so.tmp $OUT/libsamaudio_emu.so   # atomic: a process that has the old library mapped keeps its inode
 echo "built $OUT/libsamaudio_emu.so"

@@ -221,13 +221,17 @@ inline simt::v4f __builtin_amdgcn_mfma_f32_16x16x32_bf16(simt::v8bf a, simt::v8b
   std::memcpy(m.b, &b, 16);
   const unsigned char* x = simt::wave_publish(&m, sizeof(m));
   const int l = simt::cur->lane, j = l & 15;
+  float bcol[32];
+  for (int kk = 0; kk < 4; ++kk) {
+    const simt::AB16* pb = (const simt::AB16*)(x + (size_t)(j + 16 * kk) * simt::XBYTES);
+    for (int e = 0; e < 8; ++e) bcol[8 * kk + e] = simt::bf(pb->b[e]);
+  }
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * (l >> 4) + r;
     float s = 0.f;
-    for (int k = 0; k < 32; ++k) {
-      const simt::AB16* pa = (const simt::AB16*)(x + (size_t)(i + 16 * (k >> 3)) * simt::XBYTES);
-      const simt::AB16* pb = (const simt::AB16*)(x + (size_t)(j + 16 * (k >> 3)) * simt::XBYTES);
-      s += simt::bf(pa->a[k & 7]) * simt::bf(pb->b[k & 7]);
+    for (int kk = 0; kk < 4; ++kk) {
+      const simt::AB16* pa = (const simt::AB16*)(x + (size_t)(i + 16 * kk) * simt::XBYTES);
+      for (int e = 0; e < 8; ++e) s += simt::bf(pa->a[e]) * bcol[8 * kk + e];
     }
     c[r] += s;
   }
@@ -241,13 +245,17 @@ inline simt::v16f __builtin_amdgcn_mfma_f32_32x32x16_bf16(simt::v8bf a, simt::v8
   std::memcpy(m.b, &b, 16);
   const unsigned char* x = simt::wave_publish(&m, sizeof(m));
   const int l = simt::cur->lane, j = l & 31;
+  float bcol[16];
+  for (int kk = 0; kk < 2; ++kk) {
+    const simt::AB16* pb = (const simt::AB16*)(x + (size_t)(j + 32 * kk) * simt::XBYTES);
+    for (int e = 0; e < 8; ++e) bcol[8 * kk + e] = simt::bf(pb->b[e]);
+  }
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
     float s = 0.f;
-    for (int k = 0; k < 16; ++k) {
-      const simt::AB16* pa = (const simt::AB16*)(x + (size_t)(i + 32 * (k >> 3)) * simt::XBYTES);
-      const simt::AB16* pb = (const simt::AB16*)(x + (size_t)(j + 32 * (k >> 3)) * simt::XBYTES);
-      s += simt::bf(pa->a[k & 7]) * simt::bf(pb->b[k & 7]);
+    for (int kk = 0; kk < 2; ++kk) {
+      const simt::AB16* pa = (const simt::AB16*)(x + (size_t)(i + 32 * kk) * simt::XBYTES);
+      for (int e = 0; e < 8; ++e) s += simt::bf(pa->a[e]) * bcol[8 * kk + e];
     }
     c[r] += s;
   }

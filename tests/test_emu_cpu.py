@@ -279,3 +279,31 @@ def test_frame_logits_on_the_emulation_match_the_oracle(emu):
                                           hip.ptr(out), None))
     assert ((out - want).abs() * pad).max() < 1e-4
     emu.samaudio_frame_destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------ host classes
+def _dryrun(args, timeout):
+    """The `-m gpu` tests themselves, with the product's Python host classes bound to the emulation library
+    (tests/conftest.py, SAMAUDIO_EMU_DRYRUN=1)."""
+    import sys
+    env = dict(os.environ, SAMAUDIO_EMU_DRYRUN="1", OMP_NUM_THREADS="8")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + args,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0, tail
+    return tail
+
+
+def test_samaudio_host_class_on_the_emulation(emu):
+    """SAMAudio.forward against the reference-minted goldens and with optional inputs - the GPU tests of
+    test_path_gpu.py, host Python included (the codec-heavy separate() tests take minutes on the emulation and are
+    dry-run by hand: SAMAUDIO_EMU_DRYRUN=1 python -m pytest tests/test_path_gpu.py -m gpu)."""
+    out = _dryrun(["tests/test_path_gpu.py", "-k", "forward"], 900)
+    assert "6 passed" in out
+
+
+def test_judge_host_classes_on_the_emulation(emu):
+    """SAMAudioJudgeModel.forward / score_candidates (fp32 mode; bf16 and the separate(reranking_candidates=2) test are
+    part of the by-hand dry run)."""
+    out = _dryrun(["tests/test_zz_next_rows_gpu.py", "-k", "(judge_forward or dedup) and fp32"], 900)
+    assert "2 passed" in out
