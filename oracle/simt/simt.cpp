@@ -149,6 +149,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   if (cur) { std::fprintf(stderr, "simt: nested launch\n"); std::abort(); }
   const int nthreads = (int)(block.x * block.y * block.z);
   const int nwaves = (nthreads + WAVE - 1) / WAVE;
+  static const bool reverse = [] { const char* e = std::getenv("SAMAUDIO_SIMT_ORDER"); return e && std::string(e) == "reverse"; }();
   g_body = &body;
   std::vector<Fiber> fibers((size_t)nthreads);
   std::vector<Wave>* waves = new std::vector<Wave>((size_t)nwaves);
@@ -188,7 +189,12 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         int remaining = nthreads;
         while (remaining > 0) {
           bool progress = false;
-          for (int i = 0; i < nthreads; ++i) {
+          for (int ii = 0; ii < nwaves * WAVE; ++ii) {
+            // SAMAUDIO_SIMT_ORDER=reverse runs the waves of a workgroup in the opposite order between barriers, so that
+            // a hazard between two waves inside one barrier interval is seen from both sides (with the early DMA mode: a
+            // wave staging over data another wave of the same interval still has to read)
+            const int i = reverse ? (nwaves - 1 - ii / WAVE) * WAVE + ii % WAVE : ii;
+            if (i >= nthreads) continue;
             Fiber& f = fibers[i];
             if (f.done) continue;
             if (f.waiting == 1 && f.wave->gen == f.wgen) continue;

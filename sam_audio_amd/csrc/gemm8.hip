@@ -1,0 +1,306 @@
+// gemm8: 256x256 bf16 GEMM with the "8-phase" K loop of the CDNA4 guide (cdna_hip_programming.md section 5, "The 256^2
+// 8-phase template": 16x16x32 MFMA, 8 waves as 2 (M) x 4 (N), 128 KiB of LDS as 2 K-tile buffers x 4 half-tiles, one
+// half-tile staged per phase, counted vmcnt - never 0 in the steady state -, two wave groups one barrier apart so that
+// one group's MFMA cluster overlaps the other's LDS reads on every SIMD).
+//
+// EXPERIMENTAL, force-only (variant 22, no policy selects it): written in the GPU-less tail of round 1 after the
+// ablation of the shipped kernels (profiles/r1_gemm_ablation.log) showed their LDS side - not the wave schedule variants
+// tried so far - as the limiter, and the guide reports 62 % MfmaUtil for exactly this structure.  Functionally verified
+// on the SIMT simulator (oracle/simt, both DMA modes); never timed.  Epilogue = the full GemmParams contract, operands
+// swapped (W fragment as the MFMA's A operand) so that a lane owns 4 consecutive output columns of one row.
+//
+// Geometry.  Tile 256 x 256, BK = 64.  Wave w: wr = w >> 2 (M half), wc = w & 3 (N quarter) -> output 128 x 64 =
+// acc[8 m-fragments][4 n-fragments] of 16 x 16.  A K-tile in LDS = 4 half-tiles of 128 rows x 128 B:
+// HA0 / HA1 (activation rows 0-127 / 128-255: exactly what the waves with wr = 0 / 1 read), HB0 / HB1 (weight rows =
+// output columns 0-127 / 128-255: waves with wc>>1 = 0 / 1).  16-byte chunks XOR-swizzled with (row>>1)&7 - applied to
+// the DMA's per-lane SOURCE address (the LDS image of global_load_lds is lane-linear) and again on the ds_read_b128.
+//
+// Phases of K-tile t (buffer t&1; "R" = reads + stage, then barrier, lgkmcnt(0), 16 MFMAs under s_setprio 1, barrier):
+//   P1  R: Bs0 (4 reads), As0 (8)      stage HA0(t+1)                       M: As0 x Bs0
+//   P2  R: Bs1 (4), lgkmcnt(0)         stage HA1(t+1)                       M: As0 x Bs1
+//   P3  R: As1 (8)                     stage HB0(t+2)   [HB(t) last read in P2, retired by its lgkmcnt(0)]
+//                                                                           M: As1 x Bs1
+//   P4  R: -                           stage HB1(t+2), vmcnt(4 | 0)         M: As1 x Bs0
+// (As = 64-row half of the wave's 128 rows, Bs = 32-column half of its 64 columns.)  HA(t) is last read in P3 and
+// restaged in P1 / P2 of tile t+1.  The wait in P4 leaves the 4 youngest loads (HB0, HB1 of t+2) in flight and retires
+// everything tile t+1 needs; its first read is one barrier later (two for the lagging group's loads: that group waits
+// in its own P4-R interval, one barrier before the leading group's P1-R of the next tile).
+#include "common.h"
+#include "kernels.h"
+
+namespace sa {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+namespace {
+
+__device__ __forceinline__ void dma16_8(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha) {
+  if (act == ACT_SILU) return silu_f(v);
+  if (act == ACT_TANH) return tanhf(v);
+  if (act == ACT_SNAKE) {
+    const float sn = __sinf(snake_alpha * v);
+    return v + sn * sn / (snake_alpha + 1e-9f);
+  }
+  return v;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: one of each group per SIMD
+  const int lr = lane & 15, lg = lane >> 4;
+
+  // ---- tile raster: contiguous run of tiles per XCD, GM M-tiles x all N-tiles per group (as gemm2.hip) ----
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int per_batch = tiles_m * tiles_n;
+  int b, tm, tn;
+  {
+    const int total = per_batch * p.nbatch;
+    const int bid = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    b = L / per_batch;
+    const int l2 = L - b * per_batch;
+    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
+    const int per_group = GM * tiles_n;
+    const int gi = l2 / per_group;
+    const int first_m = gi * GM;
+    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+    const int in_grp = l2 - gi * per_group;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging bookkeeping ---------------------------------------------------------------------------------
+  // A half-tile = 128 rows; wave w stages rows 16w .. 16w+15 as two wave-instructions of 8 rows (1 KiB each):
+  // lane -> row 16w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
+  const int r8 = lane >> 3;
+  const bf16_t* a_row[2][2];  // [half][q] activation row pointers (row clamped to M-1), without the k offset
+  const bf16_t* w_row[2][2];  // [half][q] weight row pointers incl. the lane's chunk
+  int chunk[2];
+  {
+    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = wave * 16 + q * 8 + r8;  // row inside a half-tile
+      chunk[q] = (lane & 7) ^ ((row >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int m = m0 + h * 128 + row;
+        m = m < p.M ? m : p.M - 1;
+        a_row[h][q] = A + (long)m * p.lda;
+        int n = n0 + h * 128 + row;
+        n = n < p.N ? n : p.N - 1;
+        w_row[h][q] = W + (long)n * p.K + chunk[q] * 8;
+      }
+    }
+  }
+  // position of the lane's chunk in the (tap, offset) structure of A's k axis, per q, for the K-tile being staged.
+  // HA0 and HA1 of a K-tile are staged in consecutive phases and share it; it advances once both are out.
+  int a_in[2];
+  long a_tap[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    a_in[q] = chunk[q] * 8;
+    a_tap[q] = 0;
+    while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+  }
+  const int nt = p.K / BK;
+  auto stage_a = [&](int h, int buf) {  // HA_h of the K-tile the a_in / a_tap state points at
+    char* dst = smem + buf * (4 * HT) + h * HT + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
+  };
+  auto advance_a = [&]() {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      a_in[q] += BK;
+      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+    }
+  };
+  auto stage_w = [&](int h, int buf, int kt) {  // HB_h of K-tile kt
+    char* dst = smem + buf * (4 * HT) + (2 + h) * HT + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
+  };
+
+  // ---- fragments --------------------------------------------------------------------------------------------
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4][2];      // activation fragments of the current 64-row half: [m-fragment][k-step]
+  bf16x8_t wf[2][2][2];   // weight fragments: [32-column half][n-fragment][k-step]
+
+  auto frag = [&](const char* half_base, int row, int ks) -> bf16x8_t {
+    return *(const bf16x8_t*)(half_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
+  };
+  auto read_a = [&](int buf, int sub) {  // rows 64*sub .. +63 of the wave's half-tile HA_wr
+    const char* base = smem + buf * (4 * HT) + wr * HT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = frag(base, sub * 64 + i * 16 + lr, ks);
+  };
+  // weight rows (output columns) 64*(wc&1) + 32*SUB .. +31 of HB_(wc>>1); SUB compile-time (static register index)
+#define SA_GEMM8_READ_W(BUF, SUB)                                                                                 \
+  do {                                                                                                            \
+    const char* base_ = smem + (BUF) * (4 * HT) + (2 + (wc >> 1)) * HT;                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+        wf[SUB][j][ks] = frag(base_, (wc & 1) * 64 + (SUB) * 32 + j * 16 + lr, ks);                               \
+  } while (0)
+  // one C quadrant x K = 64: 16 MFMAs.  ASUB / WSUB are compile-time so that acc[][] is indexed statically and stays in
+  // registers (a run-time quadrant index sends the whole accumulator to scratch).
+#define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
+  do {                                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+          acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
+              wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j], 0, 0, 0);                          \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+  } while (0)
+
+  // ---- prologue: K-tile 0 complete, HB0 / HB1 of K-tile 1 in flight (what the steady state expects) ----------
+  stage_w(0, 0, 0);
+  stage_w(1, 0, 0);
+  stage_a(0, 0);
+  stage_a(1, 0);
+  advance_a();
+  if (nt > 1) {
+    stage_w(0, 1, 1);
+    stage_w(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  for (int t = 0; t < nt; ++t) {
+    const int cb = t & 1, nb = cb ^ 1;
+    const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
+    // P1
+    SA_GEMM8_READ_W(cb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(cb, 0);
+    if (s1) stage_a(0, nb);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SA_GEMM8_MMA(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // P2
+    SA_GEMM8_READ_W(cb, 1);
+    if (s1) { stage_a(1, nb); advance_a(); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // HB(t) is restaged in the next phase: its reads end here
+    __builtin_amdgcn_s_barrier();
+    SA_GEMM8_MMA(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // P3
+    read_a(cb, 1);
+    if (s2) stage_w(0, cb, t + 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SA_GEMM8_MMA(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // P4
+    if (s2) {
+      stage_w(1, cb, t + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // HB0 / HB1 of t+2 stay in flight; K-tile t+1 has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    SA_GEMM8_MMA(1, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
+#undef SA_GEMM8_MMA
+#undef SA_GEMM8_READ_W
+
+  // ---- epilogue (contract of GemmParams, common.h) -------------------------------------------------------------
+  // swapped operands: D[n][m]; a lane holds row m = lr of fragment i and columns 4*lg .. 4*lg+3 of fragment j
+  const long bM = (long)b * p.M;
+  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
+             has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
+  const int n_out = p.swiglu ? p.N >> 1 : p.N;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + lr;
+    const bool m_ok = m < p.M;
+    const int mc = m_ok ? m : p.M - 1;
+    const float* grow = has_gate ? p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld : nullptr;
+    const float* rrow = has_res ? p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld : nullptr;
+    float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld : nullptr;
+    bf16_t* arow = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (p.swiglu && (j & 1)) continue;  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
+      const int nf = n0 + wc * 64 + j * 16;  // first GEMM column of the fragment
+      const int n = (p.swiglu ? nf >> 1 : nf) + 4 * lg;
+      const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = p.swiglu ? silu_f(acc[i][j][e]) * acc[i][j | 1][e] : acc[i][j][e];
+      if (has_bias) {
+        const float4 bb = *(const float4*)(p.bias + ch);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (has_gate) {
+        float4 q = *(const float4*)(grow + nc);
+        if (has_tab) {
+          const float4 tt = *(const float4*)(p.gate_tab + nc);
+          q.x += tt.x; q.y += tt.y; q.z += tt.z; q.w += tt.w;
+        }
+        v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (has_res) {
+        const float4 rr = *(const float4*)(rrow + nc);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      }
+      float4 sa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
+      const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
+                  a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
+      bool ok = m_ok && n < n_out;
+      if (p.c_ld_rel) {
+        const long erel = (long)m * p.c_ld_rel + n;
+        ok = ok && erel >= p.c_lo && erel < p.c_hi;
+      }
+      if (ok) {
+        if (frow) *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+        if (arow) store4<bf16_t>(arow + n, a0, a1, a2, a3);
+      }
+    }
+  }
+}
+
+// eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
+hipError_t launch_gemm8(const GemmParams& p, hipStream_t st) {
+  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+  hipLaunchKernelGGL(gemm8_kernel, dim3((unsigned)tiles), dim3(512), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace sa

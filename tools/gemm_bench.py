@@ -23,7 +23,7 @@ RASTER = [0]
 VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256"}
 # force-only kernels (gemm2.hip "gemm5" family: 4 loader waves + 8 compute waves; and the BK-32 two-workgroup tile)
 EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 256x256 h4", 17: "ld 256x128 s3",
-                18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist"}
+                18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist", 22: "8-phase 256x256"}
 
 
 def interleave16(w1, w3):
@@ -129,6 +129,10 @@ def main():
         run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
         run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
         return
+    if args.experimental:  # the guide's reference shapes (cdna_hip_programming.md section 5: 8-phase template ~1320-1340 TF
+        # at 4096^3 and ~1470 TF at 8192^3 on random operands) - calibrates this box / these kernels against that ladder
+        run_case("square 4096", 4096, 4096, 4096, "plain", dev, args.iters)
+        run_case("square 8192", 8192, 8192, 8192, "plain", dev, max(2, args.iters // 3))
     run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
     run_case("wo/c_wo (gate+res)", M, D, D, "gated", dev, args.iters)
     run_case("c_wq", M, D, D, "plain", dev, args.iters)
