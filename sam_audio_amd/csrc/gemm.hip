@@ -236,12 +236,13 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   static const char* names[2][kGemmVariants] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
        "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma",
        "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
        "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
-       "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase"}};
+       "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_nostagger",
+       "gemm8_bf16_256x256_8phase_noprio"}};
   if (v < 0 || v >= kGemmVariants) return "";
   const char* n = names[is_bf16 ? 1 : 0][v];
   return n ? n : "";

@@ -747,7 +747,9 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
     case 16: return launch5<256, 128, 4, 2, 3, 64, true>(p, st);  // 14 + register-prefetched fragments
     case 17: return launch5<256, 128, 4, 2, 3, 64, true, true>(p, st);  // 16 + persistent tile walk
     case 18: return launch5<256, 256, 2, 4, 2, 64, false, true>(p, st); // 12 + persistent tile walk
-    case 19: return launch_gemm8(p, st);  // gemm8.hip: the guide's 8-phase K loop, 16x16x32 MFMA
+    case 19: return launch_gemm8(p, 0, st);  // gemm8.hip: the guide's 8-phase K loop, 16x16x32 MFMA
+    case 20: return launch_gemm8(p, 1, st);  // ... A/B: wave groups not staggered
+    case 21: return launch_gemm8(p, 2, st);  // ... A/B: no s_setprio around the MFMA clusters
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
     case 3: return launch2<256, 192, 4, 2, 2, 64>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);

@@ -51,6 +51,9 @@ __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha)
 
 }  // namespace
 
+// STAGGER: the two wave groups run one barrier apart (off: all 8 waves read together, then multiply together);
+// PRIO: s_setprio 1 around each MFMA cluster.  Both on = the guide's template; the others are A/B builds.
+template <bool STAGGER, bool PRIO>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
@@ -170,13 +173,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
   // registers (a run-time quadrant index sends the whole accumulator to scratch).
 #define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
   do {                                                                                                            \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
+    if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
           acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
               wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j], 0, 0, 0);                          \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
+    if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 
   // ---- prologue: K-tile 0 complete, HB0 / HB1 of K-tile 1 in flight (what the steady state expects) ----------
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
 
   for (int t = 0; t < nt; ++t) {
     const int cb = t & 1, nb = cb ^ 1;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
     SA_GEMM8_MMA(1, 0);
     __builtin_amdgcn_s_barrier();
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
 #undef SA_GEMM8_MMA
 #undef SA_GEMM8_READ_W
 
@@ -297,9 +300,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
 }
 
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
-hipError_t launch_gemm8(const GemmParams& p, hipStream_t st) {
+hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
-  hipLaunchKernelGGL(gemm8_kernel, dim3((unsigned)tiles), dim3(512), 0, st, p);
+  const dim3 grid((unsigned)tiles), block(512);
+  if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p);        // no stagger
+  else if (mode == 2) hipLaunchKernelGGL((gemm8_kernel<true, false>), grid, block, 0, st, p);   // no setprio
+  else hipLaunchKernelGGL((gemm8_kernel<true, true>), grid, block, 0, st, p);
   return hipGetLastError();
 }
 

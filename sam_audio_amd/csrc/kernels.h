@@ -18,12 +18,13 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 23;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant (15..22 experimental, force-only)
+constexpr int kGemmVariants = 25;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant (15..24 experimental, force-only)
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
 bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
-// gemm8.hip: experimental 256x256 8-phase kernel (force-only variant 22 = gemm2 variant 19); needs gemm2_ok(p)
-hipError_t launch_gemm8(const GemmParams& p, hipStream_t st);
+// gemm8.hip: experimental 256x256 8-phase kernel (force-only variants 22..24 = gemm2 variants 19..21: template, no
+// stagger, no setprio); needs gemm2_ok(p)
+hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
 // test / tuning hook: force a variant for every eligible bf16 GEMM (-1 = automatic, 0..2 = gemm.hip tiles only,
 // 3.. = gemm2 variant when gemm2_ok)
 void gemm_force_variant(int v);

@@ -18,9 +18,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 # 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 6 = 256x192 2-stage ring,
 # 9 = 256x256 role-split.  15..22 = experimental kernels (loader-wave "gemm5" family, BK-32 two-workgroup tile,
-# 22 = gemm8.hip: the guide's 8-phase K loop) that
+# 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
 # no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
-EXPERIMENTAL = list(range(15, 23)) if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
+EXPERIMENTAL = list(range(15, 25)) if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
 VARIANTS = [3, 4, 5, 6, 9] + EXPERIMENTAL
 
 

@@ -23,7 +23,7 @@ RASTER = [0]
 VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256"}
 # force-only kernels (gemm2.hip "gemm5" family: 4 loader waves + 8 compute waves; and the BK-32 two-workgroup tile)
 EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 256x256 h4", 17: "ld 256x128 s3",
-                18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist", 22: "8-phase 256x256"}
+                18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist", 22: "8-phase 256x256", 23: "8-phase no stagger", 24: "8-phase no setprio"}
 
 
 def interleave16(w1, w3):
