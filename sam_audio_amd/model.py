@@ -466,7 +466,10 @@ class SAMAudio:
     def predict_spans(self, batch: Batch, audio_features: torch.Tensor, audio_pad_mask: torch.Tensor) -> Batch:
         """reference model.py:231-245: PE-A-Frame on the first 128 feature channels (the codec mean latent) and the
         descriptions -> spans -> "+" anchors -> batch.process_anchors."""
-        inputs = self.span_predictor_transform(text=batch.descriptions) if self.span_predictor_transform else {}
+        if self.span_predictor_transform is None:
+            raise RuntimeError("predict_spans needs model.span_predictor_transform (descriptions -> the span predictor's "
+                               "text inputs: input_ids / attention_mask, or text_pooled)")
+        inputs = self.span_predictor_transform(text=batch.descriptions)
         inputs = {k: v for k, v in dict(inputs).items() if k in ("input_ids", "attention_mask", "text_pooled")}
         half = self.cfg.audio_codec.codebook_dim
         output = self.span_predictor(input_features=audio_features[:, :, :half].contiguous(),

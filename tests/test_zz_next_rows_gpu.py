@@ -235,3 +235,47 @@ def test_frame_logits_and_spans_match_oracle(gpu, prec):
                                        pad, 1920, 48000)
         ids_g, al_g = O.anchors_to_ids([[("+", s, e) for s, e in r] for r in out.spans], pad, 1920, 48000)
         assert torch.equal((al_w >= 2) & margin, (al_g >= 2) & margin), "span frames differ away from the threshold"
+
+
+def test_predict_spans_reproduces_quirk_q13_and_the_opt_in_fix(gpu):
+    """reference model.py:257 builds the forward args BEFORE predict_spans rebinds the batch's anchor tensors
+    (:259-268, processor.py:122-123), so in the reference snapshot predicted spans never reach the ODE: the output
+    equals predict_spans=False while batch.anchors is filled in.  fix_span_order=True feeds them to the ODE, which must
+    equal a run with the same anchors given explicitly."""
+    from sam_audio_amd import SAMAudio, SAMAudioProcessor, preset_config
+    from sam_audio_amd.judge import PEAudioFrameOutput
+    from sam_audio_amd.synthetic import init_state_dict, synthetic_noise, synthetic_text_features
+    cfg = preset_config("tiny")
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 5 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 3)
+    proc = SAMAudioProcessor.from_config(cfg)
+    spans = [[[0.04 - 1e-6, 0.12 - 1e-6]], [[0.0, 0.08 - 1e-6], [0.16 - 1e-6, 0.2 - 1e-6]]]
+    seen = {}
+
+    def predictor(input_features, padding_mask=None, return_spans=False, **kw):
+        seen.update(shape=tuple(input_features.shape), return_spans=return_spans, keys=sorted(kw))
+        return PEAudioFrameOutput(logits=torch.zeros(input_features.shape[:2]), spans=spans)
+
+    model = SAMAudio(cfg, precision="fp32", device=str(gpu))
+    model.load_state_dict(init_state_dict(cfg, seed=3))
+    noise = synthetic_noise(2, 5).to(gpu)
+
+    def run(**kw):
+        batch = proc(descriptions=["a", "b"], audios=clips, text_features=text, text_mask=tmask,
+                     anchors=kw.pop("anchors", None)).to(gpu)
+        res = model.separate(batch, noise=noise, **kw)
+        return batch, model.last_latent.clone(), res
+
+    _, base, _ = run()
+    model.span_predictor = predictor
+    model.span_predictor_transform = lambda text: {"input_ids": torch.ones(len(text), 2, dtype=torch.long), "extra": 1}
+    batch, q13, _ = run(predict_spans=True)
+    assert seen["shape"] == (2, 5, 128) and seen["return_spans"] and seen["keys"] == ["input_ids"]
+    assert batch.anchors == [[("+", s, e) for s, e in row] for row in spans] and int(batch.anchor_alignment.max()) >= 2
+    assert torch.equal(q13, base), "quirk Q13: predicted spans must not reach the ODE by default"
+    model.fix_span_order = True
+    _, fixed, _ = run(predict_spans=True)
+    model.span_predictor = None
+    _, explicit, _ = run(anchors=[[("+", s, e) for s, e in row] for row in spans])
+    assert torch.equal(fixed, explicit) and not torch.equal(fixed, base)
