@@ -160,6 +160,12 @@ class SAMAudio:
         model = cls(SAMAudioConfig(**config), precision=precision, device=device)
         sd = torch.load(os.path.join(model_id, "checkpoint.pt"), weights_only=True, map_location=map_location)
         model.load_state_dict(sd, strict=strict)
+        # the reference builds its T5 encoder and rankers in __init__ from hub ids (model.py:82,94-95); offline they
+        # can only come from local directories - attach what is reachable, leave the rest to the caller
+        if os.path.isdir(model.cfg.text_encoder.name):
+            from .text_encoder import T5TextEncoder
+            model.text_encoder = T5TextEncoder(model.cfg.text_encoder, device=model.device)
+        model.attach_rankers(precision=precision)
         return model
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
@@ -490,7 +496,10 @@ class SAMAudio:
             if path is not None and not os.path.isdir(path):
                 warnings.warn(f"{name}: {path!r} is not a local directory (no hub access offline); not attached")
                 continue
-            setattr(self, name, create_ranker(rc, device=str(self.device) if self.device else None, **kwargs))
+            try:
+                setattr(self, name, create_ranker(rc, device=str(self.device) if self.device else None, **kwargs))
+            except NotImplementedError as exc:  # CLAP / ImageBind / ... wrap third-party models this build does not ship
+                warnings.warn(f"{name} not attached: {exc}")
 
     def unbatch(self, wavs: torch.Tensor, sizes: torch.Tensor, time_dim: int = -1):
         """reference model.py:340-344"""
