@@ -8,7 +8,7 @@ SRC=../../sam_audio_amd/csrc
 OUT=../_simt
 mkdir -p $OUT
 CXX=/opt/rocm/lib/llvm/bin/clang++
-FLAGS="-x c++ -std=c++17 -O2 -fPIC -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
 pids=()
 for f in gemm gemm2 gemm8 kernels attention peav_kernels engine peav api; do
   src=$SRC/$f.hip
@@ -29,6 +29,6 @@ done
 $CXX $FLAGS -c simt.cpp -o $OUT/simt.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$CXX -shared -fPIC $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/simt.o -o $OUT/libsamaudio_simt.so.tmp
+$CXX -shared -fPIC -fopenmp $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/simt.o -o $OUT/libsamaudio_simt.so.tmp
 mv -f $OUT/libsamaudio_simt.so.tmp $OUT/libsamaudio_simt.so   # atomic: a process that has the old library mapped keeps its inode
 echo "built $OUT/libsamaudio_simt.so"

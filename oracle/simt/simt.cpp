@@ -13,11 +13,11 @@
 
 namespace simt {
 
-Fiber* cur = nullptr;
+thread_local Fiber* cur = nullptr;
 
 namespace {
-void* g_sched_sp = nullptr;
-const std::function<void()>* g_body = nullptr;
+thread_local void* g_sched_sp = nullptr;
+const std::function<void()>* g_body = nullptr;  // shared, read-only during a launch
 constexpr size_t STACK_BYTES = 512 * 1024;
 
 extern "C" void simt_switch(void** save_sp, void* load_sp);
@@ -56,6 +56,7 @@ void yield() {
 }
 
 struct StackPool {
+  ~StackPool() { for (void* p : free_) munmap(p, STACK_BYTES); }
   std::vector<void*> free_;
   void* get() {
     if (!free_.empty()) { void* p = free_.back(); free_.pop_back(); return p; }
@@ -64,7 +65,8 @@ struct StackPool {
     return p;
   }
   void put(void* p) { free_.push_back(p); }
-} g_stacks;
+};
+thread_local StackPool g_stacks;
 }  // namespace
 
 void wave_sync() {
@@ -151,70 +153,76 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   const int nwaves = (nthreads + WAVE - 1) / WAVE;
   static const bool reverse = [] { const char* e = std::getenv("SAMAUDIO_SIMT_ORDER"); return e && std::string(e) == "reverse"; }();
   g_body = &body;
-  std::vector<Fiber> fibers((size_t)nthreads);
-  std::vector<Wave>* waves = new std::vector<Wave>((size_t)nwaves);
-  for (int i = 0; i < nthreads; ++i) fibers[i].stack = g_stacks.get();
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        Block blk;
-        blk.live = nthreads;
-        for (int w = 0; w < nwaves; ++w) {
-          (*waves)[w].live = std::min(WAVE, nthreads - w * WAVE);
-          (*waves)[w].arrived = 0;
-          (*waves)[w].gen = 0;
-          for (int r = 0; r < 4; ++r) { (*waves)[w].row_arrived[r] = 0; (*waves)[w].row_gen[r] = 0; }
-          (*waves)[w].pending.clear();  // DMAs still in flight when a workgroup ends are dropped
-          (*waves)[w].dma_first = 0;
-        }
-        for (int i = 0; i < nthreads; ++i) {
+  const long nblocks = (long)grid.x * grid.y * grid.z;
+  // Workgroups are independent (no kernel of this library communicates between workgroups), so they are simulated
+  // concurrently: one OS thread = one scheduler + its own LDS image (thread_local `static` arrays) + its own fibers.
+#pragma omp parallel
+  {
+    std::vector<Fiber> fibers((size_t)nthreads);
+    std::vector<Wave> waves((size_t)nwaves);
+    for (int i = 0; i < nthreads; ++i) fibers[i].stack = g_stacks.get();
+#pragma omp for schedule(dynamic, 1)
+    for (long blk_id = 0; blk_id < nblocks; ++blk_id) {
+      const unsigned bx = (unsigned)(blk_id % grid.x), by = (unsigned)((blk_id / grid.x) % grid.y),
+                     bz = (unsigned)(blk_id / ((long)grid.x * grid.y));
+      Block blk;
+      blk.live = nthreads;
+      for (int w = 0; w < nwaves; ++w) {
+        waves[w].live = std::min(WAVE, nthreads - w * WAVE);
+        waves[w].arrived = 0;
+        waves[w].gen = 0;
+        for (int r = 0; r < 4; ++r) { waves[w].row_arrived[r] = 0; waves[w].row_gen[r] = 0; }
+        waves[w].pending.clear();  // DMAs still in flight when a workgroup ends are dropped
+        waves[w].dma_first = 0;
+      }
+      for (int i = 0; i < nthreads; ++i) {
+        Fiber& f = fibers[i];
+        void* stack = f.stack;
+        f = Fiber{};
+        f.stack = stack;
+        f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
+        f.bid = dim3(bx, by, bz);
+        f.bdim = block;
+        f.gdim = grid;
+        f.lane = i % WAVE;
+        f.wave = &waves[i / WAVE];
+        f.block = &blk;
+        // initial frame: six callee-saved slots, then the entry address; rsp is 16-byte aligned + 8 at entry
+        uintptr_t top = ((uintptr_t)stack + STACK_BYTES) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 8);
+        *--sp = (void*)&simt_fiber_main;
+        for (int k = 0; k < 6; ++k) *--sp = nullptr;
+        f.sp = sp;
+      }
+      int remaining = nthreads;
+      while (remaining > 0) {
+        bool progress = false;
+        for (int ii = 0; ii < nwaves * WAVE; ++ii) {
+          // SAMAUDIO_SIMT_ORDER=reverse runs the waves of a workgroup in the opposite order between barriers, so that
+          // a hazard between two waves inside one barrier interval is seen from both sides (with the early DMA mode: a
+          // wave staging over data another wave of the same interval still has to read)
+          const int i = reverse ? (nwaves - 1 - ii / WAVE) * WAVE + ii % WAVE : ii;
+          if (i >= nthreads) continue;
           Fiber& f = fibers[i];
-          void* stack = f.stack;
-          f = Fiber{};
-          f.stack = stack;
-          f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-          f.bid = dim3(bx, by, bz);
-          f.bdim = block;
-          f.gdim = grid;
-          f.lane = i % WAVE;
-          f.wave = &(*waves)[i / WAVE];
-          f.block = &blk;
-          // initial frame: six callee-saved slots, then the entry address; rsp is 16-byte aligned + 8 at entry
-          uintptr_t top = ((uintptr_t)stack + STACK_BYTES) & ~(uintptr_t)15;
-          void** sp = (void**)(top - 8);
-          *--sp = (void*)&simt_fiber_main;
-          for (int k = 0; k < 6; ++k) *--sp = nullptr;
-          f.sp = sp;
+          if (f.done) continue;
+          if (f.waiting == 1 && f.wave->gen == f.wgen) continue;
+          if (f.waiting == 2 && f.block->gen == f.bgen) continue;
+          if (f.waiting == 3 && f.wave->row_gen[f.lane >> 4] == f.rgen) continue;
+          cur = &f;
+          simt_switch(&g_sched_sp, f.sp);
+          cur = nullptr;
+          progress = true;
+          if (f.done) --remaining;
         }
-        int remaining = nthreads;
-        while (remaining > 0) {
-          bool progress = false;
-          for (int ii = 0; ii < nwaves * WAVE; ++ii) {
-            // SAMAUDIO_SIMT_ORDER=reverse runs the waves of a workgroup in the opposite order between barriers, so that
-            // a hazard between two waves inside one barrier interval is seen from both sides (with the early DMA mode: a
-            // wave staging over data another wave of the same interval still has to read)
-            const int i = reverse ? (nwaves - 1 - ii / WAVE) * WAVE + ii % WAVE : ii;
-            if (i >= nthreads) continue;
-            Fiber& f = fibers[i];
-            if (f.done) continue;
-            if (f.waiting == 1 && f.wave->gen == f.wgen) continue;
-            if (f.waiting == 2 && f.block->gen == f.bgen) continue;
-            if (f.waiting == 3 && f.wave->row_gen[f.lane >> 4] == f.rgen) continue;
-            cur = &f;
-            simt_switch(&g_sched_sp, f.sp);
-            cur = nullptr;
-            progress = true;
-            if (f.done) --remaining;
-          }
-          if (!progress) {
-            std::fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d threads wait at a barrier / collective the "
-                                 "others never reach\n", bx, by, bz, remaining);
-            std::abort();
-          }
+        if (!progress) {
+          std::fprintf(stderr, "simt: deadlock in block (%u,%u,%u): %d threads wait at a barrier / collective the "
+                               "others never reach\n", bx, by, bz, remaining);
+          std::abort();
         }
       }
-  for (int i = 0; i < nthreads; ++i) g_stacks.put(fibers[i].stack);
-  delete waves;
+    }
+    for (int i = 0; i < nthreads; ++i) g_stacks.put(fibers[i].stack);
+  }
   g_body = nullptr;
 }
 

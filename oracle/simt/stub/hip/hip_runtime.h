@@ -84,7 +84,7 @@ struct Fiber {
   int waiting = 0;
   unsigned wgen = 0, bgen = 0, rgen = 0;
 };
-extern Fiber* cur;
+extern thread_local Fiber* cur;  // the workgroups of a launch run on several OS threads (OpenMP), one scheduler each
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void wave_sync();
 void block_sync();
@@ -111,7 +111,7 @@ void asm_stmt(const char* text);
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local   // one LDS image per OS thread = per concurrently simulated workgroup
 #define threadIdx (simt::cur->tid)
 #define blockIdx (simt::cur->bid)
 #define blockDim (simt::cur->bdim)
