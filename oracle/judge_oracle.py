@@ -28,7 +28,7 @@ reference for everything judge.py itself owns (`data_proj`, `cat_audio_proj`, `t
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.nn.functional as F

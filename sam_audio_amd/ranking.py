@@ -5,7 +5,7 @@ models that are not part of this build's environment: their configs are reported
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 
