@@ -542,8 +542,69 @@ hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* k
   return hipGetLastError();
 }
 
+// Candidate replacement (debug flag 3, never on by default - not yet timed).  The kernel above writes 8 bytes per
+// (batch, n) with a stride of KP*2 bytes between lanes: every store opens its own 64-byte segment.  Here the 4 waves of a
+// workgroup take 4 CONSECUTIVE heads for the same 16 output channels, stage their results in LDS as
+// [batch item][n][4 heads x LtP tokens] and the workgroup writes each (batch, n) row as one contiguous 8*LtP-byte run.
+// grid (D/16, ceil(H/4)); heads >= H contribute the zeros the K padding of U must hold.
+__global__ __launch_bounds__(256) void cross_attn_fold2_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
+                                                               long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
+                                                               int LtP, int H) {
+  __shared__ __attribute__((aligned(16))) unsigned short stage[4 * 16 * 4 * 16];  // [bb][n][head][token <= 16]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int D = H * 128;
+  const int h = blockIdx.y * 4 + wave;
+  const bool head_ok = h < H;
+  const int hc = head_ok ? h : H - 1;
+  const int n0 = blockIdx.x * 16;
+  bf16x8_t wf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)(n0 + r) * D + hc * 128 + ks * 32 + g * 8);
+  const int row_el = 4 * LtP;              // elements per (batch, n) row of the staging tile / contiguous global run
+  const int segs = row_el / 8;             // 16-byte segments per row: 4 (LtP = 8) or 8 (LtP = 16)
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    uint4 v[4][4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int b = b0 + bb < B ? b0 + bb : B - 1;
+      const bf16_t* vrow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + D + hc * 128 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) v[bb][ks] = *(const uint4*)(vrow + ks * 32);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 x = v[bb][ks];
+        if (r >= Lt || !head_ok) x = make_uint4(0u, 0u, 0u, 0u);
+        u = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&x, wf[ks], u, 0, 0, 0);
+      }
+      // lane: tokens g*4 .. g*4+3 of column n = r
+      if (g * 4 < LtP) {
+        unsigned short* d = stage + ((bb * 16 + r) * 4 + wave) * LtP + g * 4;
+        d[0] = f2bf(u[0]); d[1] = f2bf(u[1]); d[2] = f2bf(u[2]); d[3] = f2bf(u[3]);
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * 16 * segs; idx += 256) {
+      const int seg = idx % segs, n = (idx / segs) & 15, bb = idx / (segs * 16);
+      if (b0 + bb < B)
+        *(uint4*)(UT + ((long)(b0 + bb) * D + n0 + n) * KP + (long)blockIdx.y * row_el + seg * 8) =
+            *(const uint4*)(stage + (bb * 16 + n) * row_el + seg * 8);
+    }
+    __syncthreads();
+  }
+}
+
 hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
                                   int H, hipStream_t st) {
+  if (debug_flag(3) && ((H + 3) / 4) * 4 * LtP <= KP) {  // A/B candidate, see cross_attn_fold2_kernel
+    hipLaunchKernelGGL(cross_attn_fold2_kernel, dim3(H * 128 / 16, (H + 3) / 4), dim3(256), 0, st, (const bf16_t*)wo,
+                       (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H), dim3(256), 0, st, (const bf16_t*)wo,
                      (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
   return hipGetLastError();

@@ -10,6 +10,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
+//   flag 2: rmsnorm_mod keeps the row in registers between its two passes (candidate, not yet timed)
+//   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (candidate, not yet timed)
 //   flag 4: N = 192 GEMMs use two 128-wide tiles instead of the 256x192 tile
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);

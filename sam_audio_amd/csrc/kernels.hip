@@ -53,10 +53,64 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
   }
 }
 
+// Candidate replacement (debug flag 2, never on by default - not yet timed): the row stays in registers between the
+// statistics pass and the output pass (MAXV float4 per lane, D <= 256 * MAXV), so x is read from memory once instead of
+// twice.  Same arithmetic order per lane as the kernel above, so results are bit-identical.
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_mod_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ shift_tab,
+                                                              const float* __restrict__ scale_tab,
+                                                              const float* __restrict__ tvec, long tvec_ld, int shift_off,
+                                                              int scale_off, TO* __restrict__ out, int M, int D,
+                                                              int rows_per_b, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + (long)row * D);
+  const int n4 = D >> 2;
+  float4 v[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss / (float)D + eps);
+  const float* trow = tvec ? tvec + (long)(row / rows_per_b) * tvec_ld : nullptr;
+  TO* orow = out + (long)row * D;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i >= n4) continue;
+    float4 g = ((const float4*)w)[i];
+    float o0 = v[k].x * inv * g.x, o1 = v[k].y * inv * g.y, o2 = v[k].z * inv * g.z, o3 = v[k].w * inv * g.w;
+    if (trow) {
+      float4 st = ((const float4*)shift_tab)[i], ct = ((const float4*)scale_tab)[i];
+      float4 sv = *(const float4*)(trow + shift_off + 4 * i), cv = *(const float4*)(trow + scale_off + 4 * i);
+      o0 = o0 * (1.f + (ct.x + cv.x)) + (st.x + sv.x);
+      o1 = o1 * (1.f + (ct.y + cv.y)) + (st.y + sv.y);
+      o2 = o2 * (1.f + (ct.z + cv.z)) + (st.z + sv.z);
+      o3 = o3 * (1.f + (ct.w + cv.w)) + (st.w + sv.w);
+    }
+    store4<TO>(orow + 4 * i, o0, o1, o2, o3);
+  }
+}
+
 hipError_t launch_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
                               const float* tvec, long tvec_ld, int shift_off, int scale_off, void* out, bool bf16,
                               int M, int D, int rows_per_b, float eps, hipStream_t st) {
   dim3 grid((M + 3) / 4), block(256);
+  if (debug_flag(2) && D <= 256 * 12) {  // A/B candidate, see rmsnorm_mod_reg_kernel
+    if (bf16)
+      hipLaunchKernelGGL((rmsnorm_mod_reg_kernel<bf16_t, 12>), grid, block, 0, st, x, w, shift_tab, scale_tab, tvec, tvec_ld,
+                         shift_off, scale_off, (bf16_t*)out, M, D, rows_per_b, eps);
+    else
+      hipLaunchKernelGGL((rmsnorm_mod_reg_kernel<float, 12>), grid, block, 0, st, x, w, shift_tab, scale_tab, tvec, tvec_ld,
+                         shift_off, scale_off, (float*)out, M, D, rows_per_b, eps);
+    return hipGetLastError();
+  }
   if (bf16)
     hipLaunchKernelGGL(rmsnorm_mod_kernel<bf16_t>, grid, block, 0, st, x, w, shift_tab, scale_tab, tvec, tvec_ld,
                        shift_off, scale_off, (bf16_t*)out, M, D, rows_per_b, eps);

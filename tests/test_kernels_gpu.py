@@ -37,8 +37,11 @@ def _mk(shape, seed, scale=1.0):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shared_time", [False, True])
-def test_rmsnorm_modulate(gpu, prec, shared_time):
-    B, T, D = 3, 37, 512
+@pytest.mark.parametrize("D,candidate", [(512, 0), (512, 1), (2816, 1)])
+def test_rmsnorm_modulate(gpu, debug_flag, prec, shared_time, D, candidate):
+    """candidate = 1: the register-resident kernel behind debug flag 2 (D = 2816: 11 of its 12 float4 slots per lane)."""
+    debug_flag(2, candidate)
+    B, T = 3, 37
     x, w = _mk((B * T, D), 1), _mk((D,), 2, 0.1) + 1
     tab = _mk((6, D), 3, 0.2)
     t0 = _mk((1 if shared_time else B, 6 * D), 4, 0.2)
@@ -161,15 +164,33 @@ def test_layernorm_accum(gpu):
     util.report("layernorm_accum", acc_d, want, 1e-5)
 
 
-@pytest.mark.parametrize("Lt,ltp", [(3, 8), (8, 8), (11, 16)])
-def test_cross_attn_fold_operand(gpu, Lt, ltp):
-    """U^T of the folded cross-attention output projection against an fp32 einsum."""
-    B, H = 3, 4
+@pytest.fixture
+def debug_flag():
+    """Switch an A/B kernel generation on for one test (samaudio_debug_set_flag) and back off afterwards."""
+    touched = []
+
+    def set_flag(flag, value):
+        hip.lib().samaudio_debug_set_flag(flag, value)
+        touched.append(flag)
+
+    yield set_flag
+    for flag in touched:
+        hip.lib().samaudio_debug_set_flag(flag, 0)
+
+
+@pytest.mark.parametrize("candidate", [0, 1])
+@pytest.mark.parametrize("Lt,ltp,B,H", [(3, 8, 3, 4), (8, 8, 3, 4), (11, 16, 3, 4), (8, 8, 6, 6), (16, 16, 5, 2)])
+def test_cross_attn_fold_operand(gpu, debug_flag, Lt, ltp, B, H, candidate):
+    """U^T of the folded cross-attention output projection against an fp32 einsum.  candidate = 1: the LDS-staged
+    kernel behind debug flag 3 (heads per workgroup = 4: H = 6 and H = 2 exercise the partial last head group, whose
+    missing heads must come out as the zeros the K padding of U holds)."""
+    debug_flag(3, candidate)
     D = H * 128
     kp = (H * ltp + 63) // 64 * 64
     wo = _mk((D, D), 30, 1 / math.sqrt(D)).to(torch.bfloat16)
     kv = _mk((B * Lt, 2 * D), 31).to(torch.bfloat16)
-    ut = torch.zeros(B, D, kp, device=gpu, dtype=torch.bfloat16)
+    ut = torch.full((B, D, kp), float("nan"), device=gpu, dtype=torch.bfloat16) if candidate and (H + 3) // 4 * 4 * ltp == kp \
+        else torch.zeros(B, D, kp, device=gpu, dtype=torch.bfloat16)   # the candidate rewrites the whole padded row
     hip.check(hip.lib().samaudio_op_cross_attn_fold(P(wo.to(gpu)), P(kv.to(gpu)), 2 * D, hip.ptr(ut), kp, B, Lt, ltp, H,
                                                     util.stream()))
     v = kv.float()[:, D:].reshape(B, Lt, H, 128)

@@ -59,9 +59,12 @@ w = torch.rand(D, device=dev)
 tab = torch.randn(6, D, device=dev)
 t0 = torch.randn(1, 6 * D, device=dev)
 xn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-timeit("rmsnorm_mod", lambda: hip.check(L.samaudio_op_rmsnorm_mod(
-    hip.ptr(x), hip.ptr(w), C.c_void_p(tab[0].data_ptr()), C.c_void_p(tab[1].data_ptr()), hip.ptr(t0), 0, 0, D, hip.ptr(xn),
-    hip.BF16, M, D, T, 1e-5, st())), M * D * 6)
+for flag, name in ((0, "rmsnorm_mod"), (1, "rmsnorm_mod (row in registers, candidate)")):
+    L.samaudio_debug_set_flag(2, flag)
+    timeit(name, lambda: hip.check(L.samaudio_op_rmsnorm_mod(
+        hip.ptr(x), hip.ptr(w), C.c_void_p(tab[0].data_ptr()), C.c_void_p(tab[1].data_ptr()), hip.ptr(t0), 0, 0, D,
+        hip.ptr(xn), hip.BF16, M, D, T, 1e-5, st())), M * D * 6)
+L.samaudio_debug_set_flag(2, 0)
 q = torch.randn(M, D, device=dev).to(torch.bfloat16)
 kv = torch.randn(B * Lt, 2 * D, device=dev).to(torch.bfloat16)
 tmask = torch.ones(B, Lt, dtype=torch.uint8, device=dev)
@@ -72,8 +75,11 @@ timeit("cross_attention (+k headnorm)", lambda: hip.check(L.samaudio_op_cross_at
 wo = (torch.randn(D, D, device=dev) / D ** 0.5).to(torch.bfloat16)
 KP = (H * 8 + 63) // 64 * 64
 ut = torch.zeros(B, D, KP, device=dev, dtype=torch.bfloat16)
-timeit("cross_attn_fold", lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
-                                                                         8, H, st())), B * D * KP * 2 + D * D * 2)
+for flag, name in ((0, "cross_attn_fold"), (1, "cross_attn_fold (LDS-staged rows, candidate)")):
+    L.samaudio_debug_set_flag(3, flag)
+    timeit(name, lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
+                                                                 8, H, st())), B * D * KP * 2 + D * D * 2)
+L.samaudio_debug_set_flag(3, 0)
 
 # DAC decoder stage with 192 channels: dilated k7 conv as implicit GEMM (N = 192, K = 1344), 8 waveforms
 from tests import util  # noqa: E402

@@ -14,6 +14,7 @@ mkdir -p $OUT
 (timeout 600 python -m pytest tests -m gpu -q -x) > $OUT/gpu_tests.log 2>&1; tail -3 $OUT/gpu_tests.log
 (SAMAUDIO_TEST_EXPERIMENTAL=1 timeout 300 python -m pytest tests/test_gemm2_gpu.py -m gpu -q) > $OUT/gpu_tests_experimental.log 2>&1; tail -2 $OUT/gpu_tests_experimental.log
 (timeout 300 python tools/gemm_bench.py --experimental) > $OUT/gemm_experimental.log 2>&1; tail -12 $OUT/gemm_experimental.log | cut -c1-600
+(timeout 200 python tools/op_bench.py) > $OUT/op_bench.log 2>&1; tail -14 $OUT/op_bench.log   # incl. the two flag-gated candidates
 if [ -x tools/cu_probe ]; then (timeout 120 tools/cu_probe) > $OUT/cu_probe.log 2>&1; tail -20 $OUT/cu_probe.log; fi
 (timeout 400 python bench.py) > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-400
 (timeout 400 python bench.py --batch 8 --candidates 8 --no-cpu-baseline --steps 2) > $OUT/bench_rerank.log 2>&1; tail -1 $OUT/bench_rerank.log | cut -c1-400
