@@ -2,13 +2,17 @@
 # Builds oracle/_simt/libsamaudio_simt.so: EVERY product source (kernels and host orchestration), compiled unchanged
 # as plain C++ against the stand-in <hip/hip_runtime.h> of oracle/simt/stub, so that each hipLaunchKernelGGL runs the
 # real kernel body on the functional SIMT simulator (simt.cpp).  TEST INFRASTRUCTURE ONLY.
+# `build.sh poison` builds the LDS-poisoning variant (libsamaudio_simt_poison.so, see stub/hip/hip_runtime.h).
 set -e
 cd "$(dirname "$0")"
 SRC=../../sam_audio_amd/csrc
 OUT=../_simt
+LIB=libsamaudio_simt.so
+POISON=""
+if [ "$1" = "poison" ]; then OUT=../_simt/poison; LIB=libsamaudio_simt_poison.so; POISON="-DSIMT_POISON"; fi
 mkdir -p $OUT
 CXX=/opt/rocm/lib/llvm/bin/clang++
-FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp $POISON -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
 pids=()
 for f in gemm gemm2 gemm8 kernels attention peav_kernels engine peav api; do
   src=$SRC/$f.hip
@@ -29,6 +33,6 @@ done
 $CXX $FLAGS -c simt.cpp -o $OUT/simt.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$CXX -shared -fPIC -fopenmp $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/simt.o -o $OUT/libsamaudio_simt.so.tmp
-mv -f $OUT/libsamaudio_simt.so.tmp $OUT/libsamaudio_simt.so   # atomic: a process that has the old library mapped keeps its inode
-echo "built $OUT/libsamaudio_simt.so"
+$CXX -shared -fPIC -fopenmp $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/engine.o $OUT/peav.o $OUT/api.o $OUT/simt.o -o ../_simt/$LIB.tmp
+mv -f ../_simt/$LIB.tmp ../_simt/$LIB   # atomic: a process that has the old library mapped keeps its inode
+echo "built ../_simt/$LIB"

@@ -11,6 +11,10 @@
 #undef asm
 #undef volatile
 
+#ifdef SIMT_POISON
+extern "C" char __start_simt_lds[], __stop_simt_lds[];  // bounds of the section all LDS arrays live in (GNU ld)
+#endif
+
 namespace simt {
 
 thread_local Fiber* cur = nullptr;
@@ -156,7 +160,11 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   const long nblocks = (long)grid.x * grid.y * grid.z;
   // Workgroups are independent (no kernel of this library communicates between workgroups), so they are simulated
   // concurrently: one OS thread = one scheduler + its own LDS image (thread_local `static` arrays) + its own fibers.
+#ifdef SIMT_POISON
+#pragma omp parallel num_threads(1)
+#else
 #pragma omp parallel
+#endif
   {
     std::vector<Fiber> fibers((size_t)nthreads);
     std::vector<Wave> waves((size_t)nwaves);
@@ -165,6 +173,9 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
     for (long blk_id = 0; blk_id < nblocks; ++blk_id) {
       const unsigned bx = (unsigned)(blk_id % grid.x), by = (unsigned)((blk_id / grid.x) % grid.y),
                      bz = (unsigned)(blk_id / ((long)grid.x * grid.y));
+#ifdef SIMT_POISON
+      std::memset(__start_simt_lds, 0xFF, (size_t)(__stop_simt_lds - __start_simt_lds));
+#endif
       Block blk;
       blk.live = nthreads;
       for (int w = 0; w < nwaves; ++w) {

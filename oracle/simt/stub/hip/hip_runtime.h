@@ -111,7 +111,15 @@ void asm_stmt(const char* text);
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#ifdef SIMT_POISON
+// poison build (libsamaudio_simt_poison.so): every LDS array lives in one linker section that the launcher fills with
+// 0xFF bytes (NaN as fp32 and bf16) before EACH workgroup - the LDS of a real CU is not cleared between workgroups or
+// kernels either, so a kernel that consumes LDS it never wrote (the stale-LDS NaN bug of DESIGN.md section 8) fails
+// deterministically here.  One workgroup at a time in this build (the section is shared).
+#define __shared__ static __attribute__((section("simt_lds")))
+#else
 #define __shared__ static thread_local   // one LDS image per OS thread = per concurrently simulated workgroup
+#endif
 #define threadIdx (simt::cur->tid)
 #define blockIdx (simt::cur->bid)
 #define blockDim (simt::cur->bdim)

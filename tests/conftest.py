@@ -40,9 +40,10 @@ def _enable_emu_dryrun():
     import torch
     from sam_audio_amd import hip
     which = "simt" if EMU_MODE == "simt" else "emu"
-    emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}.so")
+    poison = which == "simt" and os.environ.get("SAMAUDIO_SIMT_POISON") == "1"   # LDS poisoned before every workgroup
+    emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}{'_poison' if poison else ''}.so")
     if not os.environ.get("SAMAUDIO_EMU_NOBUILD"):
-        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")])
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")] + (["poison"] if poison else []))
     lib = C.CDLL(emu)
     for name, (res, args) in hip._PROTOS.items():
         fn = getattr(lib, name)

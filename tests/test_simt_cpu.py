@@ -16,8 +16,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, timeout):
-    env = dict(os.environ, SAMAUDIO_EMU_DRYRUN="simt")
+def _run(args, timeout, **extra):
+    env = dict(os.environ, SAMAUDIO_EMU_DRYRUN="simt", **extra)
     p = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + args,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     tail = (p.stdout + p.stderr)[-3000:]
@@ -27,6 +27,16 @@ def _run(args, timeout):
 
 def test_every_non_gemm_kernel_on_the_simulator():
     out = _run(["tests/test_kernels_gpu.py"], 600)
+    assert " passed" in out and "failed" not in out
+
+
+def test_no_kernel_consumes_lds_it_never_wrote():
+    """SAMAUDIO_SIMT_POISON=1: every LDS array is filled with 0xFF bytes (NaN as fp32 and bf16) before each workgroup,
+    as a real CU's LDS holds whatever ran there before - the class of bug behind DESIGN.md section 8 (an MFMA operand
+    of padding lanes read past the rows the kernel had written: 0 x NaN).  All non-GEMM kernels, both candidates and
+    the new streaming kernels; the GEMM sweep with poison is part of the by-hand run."""
+    out = _run(["tests/test_kernels_gpu.py", "tests/test_zz_next_rows_gpu.py", "-k",
+                "not (judge or separate or predict or frame_logits or peav_transformer)"], 900, SAMAUDIO_SIMT_POISON="1")
     assert " passed" in out and "failed" not in out
 
 
