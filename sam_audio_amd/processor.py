@@ -1,8 +1,9 @@
 """Host-side batching for SAMAudio.separate(): the reference's `SAMAudioProcessor` / `Batch` API
 (reference sam_audio/processor.py:39-124, 158-260) for tensor inputs.
 
-This is small integer / memcpy work and stays on the CPU.  File decoding needs
-torchaudio / torchcodec, which are not part of this build's environment: string paths raise.
+This is small integer / memcpy work and stays on the CPU.  File decoding in the reference goes
+through torchaudio / torchcodec, which are not part of this build's environment: audio paths are accepted for
+uncompressed PCM WAV at the model's sampling rate (standard library decoder), video paths raise.
 Bit-exact parity of ``anchor_ids`` / ``anchor_alignment`` / ``sizes`` with the reference is pinned
 by tests/golden/anchors.npz (minted from the reference's own Batch class).
 """
@@ -27,13 +28,43 @@ def mask_from_sizes(sizes: torch.Tensor) -> torch.Tensor:
     return steps.unsqueeze(0) < sizes.unsqueeze(1)
 
 
-def batch_audio(audios: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Mono mix-down + right zero-padding (reference processor.py:23-36, tensor branch)."""
+def load_wav(path: str, sampling_rate: int) -> torch.Tensor:
+    """PCM WAV file -> float32 [channels, samples] in [-1, 1) with torchaudio.load's integer normalisation
+    (reference processor.py:27-30 calls torchaudio.load + resample).  torchaudio / torchcodec are not part of this
+    build's environment, so only what the standard library decodes is accepted - uncompressed PCM (8 / 16 / 24 / 32
+    bit) - and only at the model's sampling rate: resampling would need torchaudio's sinc kernel, which cannot be
+    pinned offline."""
+    import wave
+    import numpy as np
+    try:
+        with wave.open(path, "rb") as f:
+            sr, ch, width, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
+            raw = f.readframes(n)
+    except (wave.Error, EOFError) as exc:
+        raise ValueError(f"{path}: only uncompressed PCM WAV files can be decoded without torchaudio ({exc})") from exc
+    if sr != sampling_rate:
+        raise ValueError(f"{path}: sampling rate {sr} != {sampling_rate}; resample first (torchaudio is not available here)")
+    if width == 1:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 3:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif width == 4:
+        x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
+    else:
+        raise ValueError(f"{path}: unsupported sample width {width}")
+    return torch.from_numpy(x.reshape(-1, ch).T.copy())
+
+
+def batch_audio(audios: Sequence[torch.Tensor], audio_sampling_rate: int = 48_000) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Mono mix-down + right zero-padding (reference processor.py:23-36)."""
     mono = []
     for a in audios:
         if isinstance(a, str):
-            raise ValueError("audio file paths need torchaudio, which this build does not ship; "
-                             "pass a (channels, samples) tensor at 48 kHz")
+            a = load_wav(a, audio_sampling_rate)
         if a.dim() != 2:
             raise ValueError(f"expected a (channels, samples) tensor, got shape {tuple(a.shape)}")
         mono.append(a.float().mean(0))
@@ -158,7 +189,7 @@ class SAMAudioProcessor:
         assert len(descriptions) == len(audios)
         assert anchors is None or len(descriptions) == len(anchors)
         assert masked_videos is None or len(descriptions) == len(masked_videos)
-        wavs, wav_sizes = batch_audio(audios)
+        wavs, wav_sizes = batch_audio(audios, self.audio_sampling_rate)
         sizes = self.wav_to_feature_idx(wav_sizes)
         pad_mask = mask_from_sizes(sizes)
         video = None if masked_videos is None else sample_video_frames(sizes, masked_videos)

@@ -128,7 +128,7 @@ def test_processor_batching_matches_reference_semantics():
     assert short.anchor_alignment.tolist() == [[0, 1, 1], [0, 0, 0]]
     with pytest.raises(AssertionError):
         proc(descriptions=["a"], audios=[a, b])
-    with pytest.raises(ValueError):
+    with pytest.raises(FileNotFoundError):  # paths are decoded (PCM WAV, see test_wav_paths_...); a missing file is just that
         proc(descriptions=["a"], audios=["file.wav"])
     masked = proc.mask_videos([torch.ones(2, 3, 4, 4)], [torch.tensor([[[[1.0]]]]).expand(2, 3, 4, 4)])
     assert float(masked[0].abs().max()) == 0
@@ -168,3 +168,34 @@ def test_bench_core_detection_and_gemm_params_mirror():
     assert rc == hip.ERR_ARG and b"size mismatch" not in hip.lib().samaudio_last_error()
     rc = hip.lib().samaudio_op_gemm(C.byref(p), C.sizeof(p) - 8, hip.BF16, None)
     assert rc == hip.ERR_ARG and b"size mismatch" in hip.lib().samaudio_last_error()
+
+
+def test_wav_paths_are_decoded_like_torchaudio_load(tmp_path):
+    """PCM WAV at the model rate -> the tensor torchaudio.load would return (int16 / 32768 etc.); anything that would
+    need torchaudio (other rates, compressed formats) raises instead of guessing."""
+    import wave
+    import numpy as np
+    from sam_audio_amd.processor import batch_audio, load_wav
+    rng = np.random.default_rng(0)
+    pcm = rng.integers(-32768, 32767, size=(1000, 2), dtype=np.int16)
+    p16 = str(tmp_path / "a.wav")
+    with wave.open(p16, "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(48000); f.writeframes(pcm.tobytes())
+    x = load_wav(p16, 48000)
+    assert x.shape == (2, 1000) and x.dtype == torch.float32
+    assert torch.equal(x, torch.from_numpy(pcm.T.astype(np.float32) / 32768.0))
+    v24 = rng.integers(-(1 << 23), (1 << 23) - 1, size=500, dtype=np.int32)
+    p24 = str(tmp_path / "b.wav")
+    with wave.open(p24, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(3); f.setframerate(48000)
+        f.writeframes(b"".join(int(s).to_bytes(3, "little", signed=True) for s in v24))
+    assert torch.equal(load_wav(p24, 48000)[0], torch.from_numpy(v24.astype(np.float32) / 8388608.0))
+    wavs, sizes = batch_audio([p16, torch.zeros(1, 1200)], 48000)
+    assert wavs.shape == (2, 1, 1200) and sizes.tolist() == [1000, 1200]
+    assert torch.allclose(wavs[0, 0, :1000], x.mean(0))
+    with pytest.raises(ValueError, match="sampling rate"):
+        load_wav(p16, 44100)
+    bad = tmp_path / "c.wav"
+    bad.write_bytes(b"not a wav file")
+    with pytest.raises(ValueError, match="PCM WAV"):
+        load_wav(str(bad), 48000)
