@@ -279,3 +279,43 @@ def test_predict_spans_reproduces_quirk_q13_and_the_opt_in_fix(gpu):
     model.span_predictor = None
     _, explicit, _ = run(anchors=[[("+", s, e) for s, e in row] for row in spans])
     assert torch.equal(fixed, explicit) and not torch.equal(fixed, base)
+
+
+def test_visual_prompt_features_reach_the_ode(gpu):
+    """Row a4: separate() with masked videos - processor frame sampling (processor.py:147-153) -> PerceptionEncoder
+    wrapper (transform, chunking, time padding; vision_encoder.py:47-113) around an injected tower -> the video term of
+    align_inputs (align.py:41-50) inside the HIP prepare step, against the oracle fed with the same features."""
+    from sam_audio_amd import SAMAudio, SAMAudioProcessor, preset_config
+    from sam_audio_amd.config import PerceptionEncoderConfig
+    from sam_audio_amd.synthetic import init_state_dict, synthetic_noise, synthetic_text_features
+    from sam_audio_amd.vision_encoder import PerceptionEncoder
+    cfg = preset_config("tiny")
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 4 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 3)
+    g = torch.Generator().manual_seed(12)
+    videos = [torch.randint(0, 256, (7, 3, 10, 12), generator=g, dtype=torch.uint8),
+              torch.randint(0, 256, (5, 3, 8, 8), generator=g, dtype=torch.uint8)]
+    wproj = torch.randn(3, cfg.vision_encoder.dim, generator=g)
+
+    def tower(frames, normalize=True):
+        f = frames.float().mean(dim=(2, 3)).cpu() @ wproj                       # [N, 1024]
+        return torch.nn.functional.normalize(f, dim=-1) if normalize else f
+
+    enc = PerceptionEncoder(PerceptionEncoderConfig(image_size=8, batch_size=3), tower)
+    proc = SAMAudioProcessor.from_config(cfg)
+    batch = proc(descriptions=["a", "b"], audios=clips, masked_videos=videos, text_features=text, text_mask=tmask)
+    assert [tuple(v.shape) for v in batch.masked_video] == [(4, 3, 10, 12), (4, 3, 8, 8)]   # one frame per latent step
+    feats_v = enc(batch.masked_video)                                            # [B, T, 1024]
+    noise = synthetic_noise(2, 4)
+    sd = init_state_dict(cfg, seed=3)
+    with torch.inference_mode():
+        _, _, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise,
+                                   video=feats_v.transpose(1, 2), decode=False)
+        _, _, lat_novid = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise, decode=False)
+    assert (lat_ref - lat_novid).abs().max() > 1e-3, "the video term must matter for this check to mean anything"
+    model = SAMAudio(cfg, precision="fp32", device=str(gpu))
+    model.load_state_dict(sd)
+    model.vision_encoder = enc
+    model.separate(batch.to(gpu), noise=noise.to(gpu))
+    util.report("latent with visual prompt", model.last_latent, lat_ref, 1e-3)
