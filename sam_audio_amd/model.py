@@ -430,7 +430,7 @@ class SAMAudio:
             if noise is None:
                 noise = torch.randn_like(feats_r)                                # model.py:274-275
             assert noise.shape == feats_r.shape, "noise must be [B*candidates, T, 256]"
-            cond = [feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), video,
+            cond = [feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), self._repeat(video, cand),
                     self._repeat(anchor_ids, cand), self._repeat(anchor_alignment, cand),
                     self._repeat(batch.audio_pad_mask, cand)]
             groups = min(self.streams, feats_r.size(0))

@@ -319,3 +319,11 @@ def test_visual_prompt_features_reach_the_ode(gpu):
     model.vision_encoder = enc
     model.separate(batch.to(gpu), noise=noise.to(gpu))
     util.report("latent with visual prompt", model.last_latent, lat_ref, 1e-3)
+    # with reranking candidates the video features are repeated sample-major like every other conditioning tensor
+    # (reference model.py:193-229)
+    noise2 = synthetic_noise(4, 4, seed=5)
+    with torch.inference_mode():
+        _, _, lat2 = O.separate(sd, cfg, batch.audios.cpu(), batch.sizes.long().cpu(), text, tmask, noise2,
+                                video=feats_v.transpose(1, 2), candidates=2, decode=False)
+    model.separate(batch, noise=noise2.to(gpu), reranking_candidates=2)
+    util.report("latent with visual prompt, 2 candidates", model.last_latent, lat2, 1e-3)
