@@ -1,31 +1,45 @@
 #!/usr/bin/env python
 """bench.py - throughput of the SAMAudio.separate() hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) and as a plain `python bench.py --gpus N`, which re-executes
+itself under torch.distributed.run on 127.0.0.1 (one process per GPU, RCCL over xGMI).
 
 One "step" = one `model.separate(batch)` over one batch of synthetic 10 s / 48 kHz mono clips that is already
 resident in HBM: DAC-VAE encode -> 32 DiT evaluations of the 16-step midpoint ODE -> DAC-VAE decode of target
 and residual -> unbatch (reference sam_audio/model/model.py:247-338).  Metric (BASELINE.json):
-seconds of audio separated per second per node = N * B * 10 s * K / wall.
+seconds of audio separated per second per node = (clips processed by all ranks) * 10 s * K / wall.
 
 Workload: BASELINE.json configs[2] - the configuration the metric is quoted on ("sam-audio-large bf16,
 batch=32x10 s clips, text prompt"); it fits one GPU.  The checkpoint's real config.json is not reachable
 offline, so the dims are the labelled stand-in `large*` (D=2816, H=22, L=22, F=7552);
-weights are seeded random, text features are synthetic T5-shaped tensors (no tokenizer offline).  Each rank
-processes its own batch of B clips (the path shards over clips with no data-path collective: "weak").
-Rank 0 creates the weights and broadcasts them over RCCL/xGMI before the timed region.
+weights are seeded random, text features are synthetic T5-shaped tensors (no tokenizer offline).
+Rank 0 creates the weights and broadcasts them over RCCL/xGMI before the timed region; the steady state has no collective.
+
+Scaling.  `--scaling weak` (default, the line's `value`): every rank processes its own batch of --batch clips.
+`--scaling strong`: ONE global batch of --batch clips is split contiguously over the ranks (32 -> 8 x 4, SURVEY.md section
+8e).  With N > 1 the weak run also times the strong configuration and reports it under "strong_scaling", so one driver
+invocation per N yields both curves.
 
 The JSON line also carries
-  roofline     - bf16 MFMA roofline of the dominant kernel (the 128x128-tile GEMM): algorithmic flops of its
-                 launches / their HIP-event time, measured on the launch stream in one extra instrumented step;
-  cpu_baseline - the CPU oracle (oracle/samaudio_oracle.py, a torch fp32 restatement of the reference
-                 algorithm) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+  roofline       - bf16 MFMA roofline of the dominant DiT GEMM kernel symbol: algorithmic flops of its launches / their
+                   HIP-event time, measured on the launch stream in one extra instrumented step; plus the aggregate over
+                   every DiT GEMM launch ("dit_gemm_all") and the per-kernel table;
+  roofline_hbm   - the DAC-VAE convolutions (their own kernel symbols) and the streaming kernels of the DiT against
+                   max(flops / MFMA peak, algorithmic bytes / HBM peak);
+  cpu_baseline   - the CPU oracle (oracle/samaudio_oracle.py, a torch fp32 restatement of the reference algorithm)
+                   timed on this box's host cores on a bounded sample (rank 0, N=1 only);
+  parity_check   - the same sample (2 clips, fixed noise, ONE midpoint step) run through the HIP path in the benchmarked
+                   precision and compared with the oracle's result: encode latent, ODE latent and waveform max-abs error.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -33,35 +47,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 CLIP_SECONDS = 10.0
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0      # HBM3E peak, same table (6.29 TB/s measured achievable)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", default="large*", help="dims preset (sam_audio_amd.config.SIZE_PRESETS)")
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (weak) / global batch (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-strong", action="store_true", help="N > 1, weak: skip the extra strong-scaling measurement")
     ap.add_argument("--text-len", type=int, default=8)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip parity_check (it shares the oracle run with cpu_baseline)")
+    ap.add_argument("--verify", action="store_true", help="run parity_check even with --no-cpu-baseline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--streams", type=int, default=1, help="row groups of the batch solved concurrently on separate HIP streams")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="capture the ODE solve in a hipGraph: 1 on, 0 off, -1 auto (on when rows per GPU <= 8)")
     ap.add_argument("--candidates", type=int, default=1,
                     help="> 1: BASELINE.json configs[3] - reranking_candidates per clip, scored by the HIP Judge "
                          "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
-    return ap.parse_args()
+    ap.add_argument("--predict-spans", action="store_true",
+                    help="configs[3]: run the PE-A-Frame span predictor first (random weights, stand-in dims)")
+    ap.add_argument("--selftest-spawn", action="store_true",
+                    help="CPU-only: exercise the self-launch + sharding + gather plumbing on gloo (tests/test_bench_spawn_cpu.py)")
+    return ap.parse_args(argv)
 
 
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_self_launch(args) -> None:
+    """`python bench.py --gpus N` outside a torchrun environment: become `python -m torch.distributed.run ... bench.py`
+    (exec, so stdout / stderr / the exit code are this process's)."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def usable_cores() -> int:
@@ -84,42 +126,98 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(cfg, sd_cpu, clip, text, tmask, noise, threads):
-    """The oracle on the host cores, bounded: one 10 s clip; DAC encode, ONE of the 16 midpoint steps (2 of the
-    32 DiT evaluations) and DAC decode are each timed once; ODE time is scaled x16."""
+def selftest_spawn(args) -> None:
+    """No GPU: every rank joins a gloo group, takes its shard of the global batch exactly as the strong-scaling run
+    does, all-reduces a fake timing with MAX and rank 0 prints one JSON line.  Covers maybe_self_launch(), the env
+    contract and the collectives bench.py uses, with world_size > 1 on CPU."""
+    import torch
+    import torch.distributed as dist
+    from sam_audio_amd.dist import shard_range
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    rows = list(shard_range(args.batch, rank, world))
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    n = torch.tensor([len(rows)], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "spawn", "n_gpus": world, "clips_total": int(n.item()), "max_time": float(t.item()),
+                          "rank0_rows": rows}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def oracle_sample(cfg, sd_cpu, clips, text, tmask, noise, threads):
+    """The oracle on the host cores, bounded: R clips of 10 s; DAC encode, ONE of the 16 midpoint steps (2 of the
+    32 DiT evaluations) and DAC decode are each timed once; ODE time is scaled x16.  Returns (cpu_baseline dict, the
+    oracle's tensors for parity_check)."""
+    import torch
     from oracle import samaudio_oracle as O
     torch.set_num_threads(threads)
     codec = cfg.audio_codec
+    R = clips.size(0)
     with torch.inference_mode():
         t0 = time.perf_counter()
-        z = O.dac_encode(sd_cpu, codec, clip).transpose(1, 2)
+        z = O.dac_encode(sd_cpu, codec, clips).transpose(1, 2)
         t_enc = time.perf_counter() - t0
-        log(f"cpu baseline: DAC encode {t_enc:.2f} s on {threads} threads")
+        log(f"cpu baseline: DAC encode of {R} clips {t_enc:.2f} s on {threads} threads")
         feats = torch.cat([z, z], dim=2)
         T = feats.shape[1]
-        pad = torch.ones(1, T, dtype=torch.bool)
+        pad = torch.ones(R, T, dtype=torch.bool)
         ids, align = O.anchors_to_ids(None, pad, codec.hop_length, codec.sample_rate)
-        video = feats.new_zeros(1, cfg.vision_encoder.dim, T)
+        video = feats.new_zeros(R, cfg.vision_encoder.dim, T)
 
         def field(t, y):
-            return O.samaudio_forward(sd_cpu, cfg, y, feats, text, t.expand(1), video=video, text_mask=tmask,
+            return O.samaudio_forward(sd_cpu, cfg, y, feats, text, t.expand(R), video=video, text_mask=tmask,
                                       anchor_ids=ids, anchor_alignment=align, pad_mask=pad)
 
         t0 = time.perf_counter()
         lat = O.ode_fixed_grid(field, noise, method="midpoint", step_size=1.0)  # one step = 2 evaluations
         t_step = time.perf_counter() - t0
         log(f"cpu baseline: one midpoint step {t_step:.2f} s")
-        gen = lat.transpose(1, 2).reshape(2, lat.shape[2] // 2, T)
+        gen = lat.transpose(1, 2).reshape(2 * R, lat.shape[2] // 2, T)
         t0 = time.perf_counter()
-        O.dac_decode(sd_cpu, codec, gen)
+        wav = O.dac_decode(sd_cpu, codec, gen)
         t_dec = time.perf_counter() - t0
-        log(f"cpu baseline: DAC decode x2 {t_dec:.2f} s")
-    per_clip = t_enc + 16 * t_step + t_dec
-    return {
+        log(f"cpu baseline: DAC decode x{2 * R} {t_dec:.2f} s")
+    per_clip = (t_enc + 16 * t_step + t_dec) / R
+    base = {
         "value": CLIP_SECONDS / per_clip, "unit": "s-audio/s", "cores": threads, "kind": "port",
-        "sample": (f"1 clip x 10 s, same dims, fp32 torch oracle: DAC encode {t_enc:.2f} s + 1 of 16 midpoint steps "
-                   f"(2 of 32 DiT evals) {t_step:.2f} s (scaled x16) + DAC decode x2 {t_dec:.2f} s "
-                   f"=> {per_clip:.1f} s per clip"),
+        "sample": (f"{R} clips x 10 s, same dims, fp32 torch oracle (restatement of the reference, pinned to its own "
+                   f"classes; the reference package itself cannot be imported on the GPU box), one run: DAC encode "
+                   f"{t_enc:.2f} s + 1 of 16 midpoint steps (2 of 32 DiT evals) {t_step:.2f} s (scaled x16) + DAC decode "
+                   f"x{2 * R} {t_dec:.2f} s => {per_clip:.1f} s per clip"),
+    }
+    return base, {"z": z, "lat": lat, "wav": wav.reshape(R, 2, -1)}
+
+
+def parity_check(model, sub, noise, ref, R, dev, precision):
+    """The oracle's sample (`sub`: the same R clips as a device batch) through the HIP path in the benchmarked precision."""
+    import torch
+    with torch.inference_mode():
+        z = model.encode_audio(sub.audios)
+        model.separate(sub, noise=noise.to(dev), ode_opt={"method": "midpoint", "options": {"step_size": 1.0}})
+        lat = model.last_latent
+        half = lat.size(2) // 2
+        gen = lat.reshape(R, lat.size(1), 2, half).permute(0, 2, 1, 3).reshape(2 * R, lat.size(1), half).contiguous()
+        wav = model.decode_audio(gen).view(R, 2, -1)
+        torch.cuda.synchronize()
+
+    def err(a, b):
+        return float((a.float().cpu() - b).abs().max())
+
+    return {
+        "precision": precision, "rows": R,
+        "what": "DAC encode -> ONE midpoint step (2 DiT evaluations, step_size 1.0) on fixed CPU noise -> DAC decode of "
+                "target+residual; HIP path vs the fp32 CPU oracle, max-abs",
+        "encode_latent_err": err(z, ref["z"]), "encode_latent_ref_max": float(ref["z"].abs().max()),
+        "ode_latent_err": err(lat, ref["lat"]), "ode_latent_ref_max": float(ref["lat"].abs().max()),
+        "waveform_err": err(wav, ref["wav"]), "waveform_ref_max": float(ref["wav"].abs().max()),
     }
 
 
@@ -127,6 +225,7 @@ class _HashTokenizer:
     """Stand-in for the Judge's ModernBERT tokenizer (no tokenizer files offline): word hashes -> ids, pad-to-longest."""
 
     def __call__(self, text, return_tensors="pt", padding="longest", max_length=512, truncation=True):
+        import torch
         rows = [[1] + [3 + (hash(w) % 30000) for w in t.split()][: max_length - 1] for t in text]
         width = max(len(r) for r in rows)
         ids = torch.zeros(len(rows), width, dtype=torch.long)
@@ -152,13 +251,108 @@ def build_judge_ranker(cfg, precision, dev):
     return JudgeRanker(model=judge, processor=proc)
 
 
+def build_span_predictor(cfg, precision, dev):
+    """PE-A-Frame with the pe-a-frame-large stand-in dims (PEAudioFrameConfig defaults: PE-AV audio tower 1792 x 6 layers,
+    ModernBERT-large-shaped text tower, random init; reference model.py:96-102) + the hash tokenizer as its transform."""
+    from sam_audio_amd.config import PEAudioFrameConfig
+    from sam_audio_amd.judge import PEAudioFrame
+    from sam_audio_amd.synthetic import init_frame_state_dict
+    fcfg = PEAudioFrameConfig(codebook_dim=cfg.audio_codec.codebook_dim)
+    predictor = PEAudioFrame(fcfg, precision=precision, device=str(dev), hop_length=cfg.audio_codec.hop_length,
+                             sample_rate=cfg.audio_codec.sample_rate)
+    predictor.load_state_dict(init_frame_state_dict(fcfg, seed=2, device=dev), strict=False)
+    tok = _HashTokenizer()
+    return predictor, (lambda text: tok(text))
+
+
+# rocprofv3 kernel symbols of the profile names (profiles/r2_traffic.json is keyed by symbol)
+SYMBOLS = {
+    "gemm8_bf16_256x256_8phase": "sa::gemm8_kernel<true, true",
+    "gemm5_bf16_256x128_ld_s3_pf_persist": "sa::gemm5_kernel<256, 128, 4, 2, 3, 64, true, true, 0>",
+    "gemm2_bf16_256x128_s2": "sa::gemm2_kernel<256, 128, 4, 2, 2, 64, 0>",
+    "gemm3_bf16_256x256_pp2": "sa::gemm3_kernel<256, 256, 2, 4, 2, 2, 0>",
+}
+
+
+def traffic_of(kernel: str):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh -> tools/pmc_traffic.py);
+    they cannot be collected inside a timed run."""
+    for fname in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
+        except (OSError, KeyError, ValueError):
+            continue
+        key = SYMBOLS.get(kernel.split("/")[-1], "")
+        hit = [v for k, v in table.items() if key and k.startswith(key)]
+        if hit:
+            return round(hit[0]["traffic_bytes_per_launch"]), f"HBM bytes per launch, rocprofv3 PMC passes (profiles/{fname})"
+    return None, None
+
+
+def rooflines(stats):
+    """stats: [{name 'class/kernel', launches, flops, bytes, ms}] of ONE instrumented step."""
+    rows = []
+    for k in stats:
+        if k["ms"] <= 0:
+            continue
+        sec = k["ms"] * 1e-3
+        tf, gbs = k["flops"] / sec / 1e12, k["bytes"] / sec / 1e9
+        t_mfma, t_hbm = k["flops"] / (PEAK_BF16_TFLOPS * 1e12), k["bytes"] / (PEAK_HBM_GBS * 1e9)
+        rows.append({"kernel": k["name"], "launches": k["launches"], "ms": round(k["ms"], 3), "tflops": round(tf, 2),
+                     "gbs": round(gbs, 1), "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                     "frac": round(max(t_mfma, t_hbm) / sec, 4), "_flops": k["flops"], "_bytes": k["bytes"]})
+    rows.sort(key=lambda r: -r["ms"])
+    dit_gemm = [r for r in rows if r["kernel"].startswith("dit/gemm")]
+    out = {"roofline": None, "roofline_hbm": None}
+    if dit_gemm:
+        dom = dit_gemm[0]
+        ms_all = sum(r["ms"] for r in dit_gemm)
+        fl_all = sum(r["_flops"] for r in dit_gemm)
+        traffic, note = traffic_of(dom["kernel"])
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "launches_per_step": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+            "flops_per_step": dom["_flops"],
+            "dit_gemm_all": {"achieved": round(fl_all / (ms_all * 1e-3) / 1e12, 2),
+                             "frac": round(fl_all / (ms_all * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                             "ms_per_step": round(ms_all, 2), "flops_per_step": fl_all,
+                             "launches_per_step": sum(r["launches"] for r in dit_gemm)},
+        }
+        if note:
+            out["roofline"]["traffic_note"] = note
+    groups = []
+    codec = [r for r in rows if r["kernel"].startswith("codec/")]
+    if codec:
+        ms, fl, by = sum(r["ms"] for r in codec), sum(r["_flops"] for r in codec), sum(r["_bytes"] for r in codec)
+        t_mfma, t_hbm = fl / (PEAK_BF16_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)
+        groups.append({"kernel": "codec/* (DAC-VAE convolutions, all symbols)", "ms": round(ms, 2),
+                       "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "achieved": round(by / (ms * 1e-3) / 1e9, 1),
+                       "peak": PEAK_HBM_GBS, "unit": "GB/s", "bound": "mfma" if t_mfma >= t_hbm else "hbm",
+                       "frac": round(max(t_mfma, t_hbm) / (ms * 1e-3), 4), "algorithmic_bytes": by})
+    for r in rows:
+        if r["kernel"].startswith("dit/") and not r["kernel"].startswith("dit/gemm"):
+            groups.append({"kernel": r["kernel"], "ms": r["ms"], "launches": r["launches"], "achieved": r["gbs"],
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "bound": r["bound"], "frac": r["frac"],
+                           "algorithmic_bytes": r["_bytes"]})
+    out["roofline_hbm"] = groups or None
+    out["kernels"] = [{k: v for k, v in r.items() if not k.startswith("_")} for r in rows]
+    return out
+
+
 def main():
     args = parse()
+    maybe_self_launch(args)
+    if args.selftest_spawn:
+        return selftest_spawn(args)
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the hot path has no CPU fallback)"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -166,39 +360,45 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from sam_audio_amd import SAMAudio, SAMAudioProcessor, preset_config
-    from sam_audio_amd.dist import broadcast_state_dict
+    from sam_audio_amd.dist import broadcast_state_dict, shard_range
     from sam_audio_amd.synthetic import init_state_dict, synthetic_clip, synthetic_text_features
 
     cfg = preset_config(args.size)
     tcfg = cfg.transformer
-    B = args.batch
+    for kv in filter(None, os.environ.get("SAMAUDIO_DEBUG_FLAGS", "").split(",")):   # A/B switches, e.g. "5=1"
+        from sam_audio_amd import hip
+        k, v = kv.split("=")
+        hip.lib().samaudio_debug_set_flag(int(k), int(v))
+        log(f"debug flag {k} = {v}")
 
     # ---- weights: rank 0 creates them, RCCL broadcast over xGMI to the other ranks -----------------------
-    log(f"world {world}, preset {args.size}, {B} clips per GPU, usable host cores {usable_cores()}")
+    log(f"world {world} (backend {'nccl/RCCL' if world > 1 else 'none'}), preset {args.size}, scaling {args.scaling}, "
+        f"batch {args.batch}, usable host cores {usable_cores()}")
     sd = init_state_dict(cfg, seed=0, device=dev) if rank == 0 else None
     sd = broadcast_state_dict(sd, src=0, device=dev)
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    sd_cpu = {k: v.cpu() for k, v in sd.items()} if want_cpu else None
+    want_verify = rank == 0 and world == 1 and not args.no_verify and (want_cpu or args.verify)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()} if (want_cpu or want_verify) else None
     model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=args.streams)
     model.load_state_dict(sd, strict=False)
     del sd
     torch.cuda.empty_cache()
     log("weights loaded")
-
-    # ---- inputs: this rank's B synthetic clips, resident in HBM before the timed region ------------------
-    n_samples = int(CLIP_SECONDS * cfg.audio_codec.sample_rate)
-    clips = [synthetic_clip(rank * B + i, n_samples) for i in range(B)]
-    text, tmask = synthetic_text_features(B, args.text_len, seed=7 + rank)
-    proc = SAMAudioProcessor.from_config(cfg)
-    batch = proc(descriptions=["sound"] * B, audios=clips, text_features=text, text_mask=tmask).to(dev)
     os.environ.setdefault("SAMAUDIO_CODEC_CHUNK", "32")
+    n_samples = int(CLIP_SECONDS * cfg.audio_codec.sample_rate)
+    proc = SAMAudioProcessor.from_config(cfg)
+
+    def make_batch(clip_ids):
+        """This rank's synthetic clips, resident in HBM before the timed region."""
+        clips = [synthetic_clip(i, n_samples) for i in clip_ids]
+        text, tmask = synthetic_text_features(len(clip_ids), args.text_len, seed=7 + rank)
+        b = proc(descriptions=["sound"] * len(clip_ids), audios=clips, text_features=text, text_mask=tmask)
+        return b.to(dev), clips, text, tmask
 
     if args.candidates > 1:
         model.text_ranker = build_judge_ranker(cfg, args.precision, dev)
-
-    def step():
-        # noise=None: drawn on device inside, like the reference (model.py:274-275)
-        return model.separate(batch, reranking_candidates=args.candidates)
+    if args.predict_spans:
+        model.span_predictor, model.span_predictor_transform = build_span_predictor(cfg, args.precision, dev)
 
     def fence():
         torch.cuda.synchronize()
@@ -206,85 +406,103 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("inputs resident; warm-up")
-    for i in range(args.warmup):
+    def timed(batch, steps, warmup, label):
+        rows = len(batch.descriptions) * args.candidates
+        use_graph = args.graph == 1 or (args.graph < 0 and rows <= 8)
+        model.use_graph = bool(use_graph)
+
+        def step():
+            # noise=None: drawn on device inside, like the reference (model.py:274-275)
+            return model.separate(batch, reranking_candidates=args.candidates, predict_spans=args.predict_spans)
+
+        for i in range(warmup):
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            log(f"{label}: warm-up step {i}: {time.perf_counter() - t0:.3f} s")
+        fence()
         t0 = time.perf_counter()
-        step()
-        torch.cuda.synchronize()
-        log(f"warm-up step {i}: {time.perf_counter() - t0:.3f} s")
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert all(torch.isfinite(w).all() for w in res.target), "non-finite output"
-    value = world * B * CLIP_SECONDS * args.steps / elapsed
+        for _ in range(steps):
+            res = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert all(torch.isfinite(w).all() for w in res.target), "non-finite output"
+        return elapsed, step, model.use_graph
+
+    # ---- the timed run ------------------------------------------------------------------------------------
+    if args.scaling == "weak":
+        my_ids = list(range(rank * args.batch, (rank + 1) * args.batch))
+        clips_total = world * args.batch
+    else:
+        my_ids = list(shard_range(args.batch, rank, world))
+        clips_total = args.batch
+        assert my_ids, f"strong scaling: rank {rank} got no clip (global batch {args.batch} < {world} ranks)"
+    batch, clips, text, tmask = make_batch(my_ids)
+    log(f"inputs resident ({len(my_ids)} clips on this rank); warm-up")
+    elapsed, step, graphed = timed(batch, args.steps, args.warmup, args.scaling)
+    value = clips_total * CLIP_SECONDS * args.steps / elapsed
     log(f"timed {args.steps} steps in {elapsed:.3f} s -> {value:.2f} s-audio/s")
 
-    # ---- roofline of the dominant kernel: one extra, instrumented step (HIP events on the launch stream) --
-    roofline = None
+    # ---- N > 1, weak: the strong-scaling configuration of BASELINE configs[2] in the same invocation -----------
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong and args.batch >= world:
+        s_ids = list(shard_range(args.batch, rank, world))
+        s_batch = make_batch(s_ids)[0]
+        s_steps = max(2, min(args.steps, 5))
+        s_elapsed, _, s_graphed = timed(s_batch, s_steps, 1, "strong")
+        strong = {"scaling": "strong", "global_batch": args.batch, "clips_per_gpu": len(s_ids), "steps": s_steps,
+                  "ms_per_step": round(1e3 * s_elapsed / s_steps, 2), "hip_graph": bool(s_graphed),
+                  "value": round(args.batch * CLIP_SECONDS * s_steps / s_elapsed, 3), "unit": "s-audio/s"}
+        log(f"strong: {s_steps} steps in {s_elapsed:.3f} s -> {strong['value']:.2f} s-audio/s")
+        model.use_graph = graphed
+
+    # ---- rooflines: one extra, instrumented step (HIP events on the launch stream) ----------------------------
+    roof = {"roofline": None, "roofline_hbm": None, "kernels": None}
     if rank == 0 and not args.no_roofline:
         model.streams = 1  # events bracket single launches: keep the GPU to one stream while they are recorded
+        model.use_graph = False  # events cannot be recorded inside a captured graph
         model.profile_begin()
         step()
-        stats = model.profile_end()
+        roof = rooflines(model.profile_end())
         model.streams = args.streams
-        dom = max(stats, key=lambda k: k["ms"])
-        if dom["ms"] > 0:
-            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roofline = {
-                "bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                "launches_per_step": dom["launches"], "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-                "flops_per_step": dom["flops"],
-                "other_gemm_variants": [
-                    {"kernel": k["name"], "launches": k["launches"], "ms": round(k["ms"], 3),
-                     "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else None}
-                    for k in stats if k is not dom],
-                "gemm_ms_per_step": round(sum(k["ms"] for k in stats), 2),
-            }
 
-    # HBM traffic of the dominant kernel: PMC numbers come from separate profiled runs (tools/profile_bench.sh ->
-    # tools/pmc_traffic.py -> profiles/r1_traffic.json); they cannot be collected inside a timed run.
-    if roofline is not None:
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["kernels"]
-            key = {"gemm2_bf16_256x128_s2": "gemm2_kernel<256, 128, 4, 2, 2, 64, 0>",
-                   "gemm3_bf16_256x256_pp2": "gemm3_kernel<256, 256, 2, 4, 2, 2, 0>"}.get(roofline["kernel"], "")
-            hit = [v for k, v in traffic.items() if key and key in k]
-            if hit:
-                roofline["traffic"] = round(hit[0]["traffic_bytes_per_launch"])
-                roofline["traffic_note"] = "HBM bytes per launch, rocprofv3 PMC passes (profiles/r1_traffic.json)"
-        except (OSError, KeyError, ValueError):
-            pass
-
-    cpu = None
-    if want_cpu:
+    cpu = parity = None
+    if want_cpu or want_verify:
+        R = min(2, len(my_ids))
         threads = args.cpu_threads or usable_cores()
         g = torch.Generator().manual_seed(99)
-        noise = torch.randn(1, n_samples // cfg.audio_codec.hop_length, tcfg.out_channels, generator=g)
-        cpu = cpu_baseline(cfg, sd_cpu, clips[0].unsqueeze(0), text[:1], tmask[:1], noise, threads)
+        noise = torch.randn(R, n_samples // cfg.audio_codec.hop_length, tcfg.out_channels, generator=g)
+        cpu, ref = oracle_sample(cfg, sd_cpu, torch.stack(clips[:R]), text[:R], tmask[:R], noise, threads)
+        if want_verify:
+            model.use_graph = False
+            sub = proc(descriptions=["sound"] * R, audios=clips[:R], text_features=text[:R], text_mask=tmask[:R]).to(dev)
+            parity = parity_check(model, sub, noise, ref, R, dev, args.precision)
+            log(f"parity_check: {parity}")
+        if not want_cpu:
+            cpu = None
 
     if rank == 0:
         line = {
             "metric": "seconds-of-audio separated/sec/node", "value": round(value, 3), "unit": "s-audio/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (seeded random weights, synthetic 10 s/48 kHz clips, synthetic T5-shaped text features)",
             "config": {
                 "workload": (f"sam-audio-{args.size} (stand-in dims D={tcfg.dim} H={tcfg.n_heads} L={tcfg.n_layers} "
-                             f"F={tcfg.ffn_hidden}) {args.precision}, batch={B}x10 s clips per GPU, text prompt "
+                             f"F={tcfg.ffn_hidden}) {args.precision}, batch={args.batch}x10 s clips "
+                             f"{'per GPU' if args.scaling == 'weak' else 'global, split over the GPUs'}, text prompt "
                              f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"),
-                "clips_per_gpu": B, "global_batch": B * world, "parallelism": f"clip-sharded x{world}",
-                "streams_per_gpu": args.streams, "reranking_candidates": args.candidates,
+                "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}",
+                "streams_per_gpu": args.streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
+                "predict_spans": bool(args.predict_spans), "world_size_seen": world,
             },
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,
+            "parity_check": parity, "strong_scaling": strong, "kernels": roof.get("kernels"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

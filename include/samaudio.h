@@ -196,7 +196,8 @@ int samaudio_frame_logits(samaudio_frame* f, const float* codec_features, const 
 typedef struct {
   char name[64];
   int64_t launches;
-  double flops;
+  double flops; /* algorithmic flops of the launches (2*M*N*K for a contraction; 0 for pure streaming kernels) */
+  double bytes; /* algorithmic bytes of the launches: every operand, output and residual element counted once */
   double ms;
 } samaudio_kernel_stat;
 int samaudio_profile_begin(samaudio_ctx* ctx);

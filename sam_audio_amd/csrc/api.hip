@@ -132,6 +132,7 @@ int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capac
     std::strncpy(out[n].name, k.name.c_str(), sizeof(out[n].name) - 1);
     out[n].launches = k.launches;
     out[n].flops = k.flops;
+    out[n].bytes = k.bytes;
     out[n].ms = k.ms;
     ++n;
   }

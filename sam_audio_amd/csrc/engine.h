@@ -60,10 +60,12 @@ class Engine {
 
   // Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg): between begin and end
   // every GEMM launch is bracketed by an event pair; end synchronises and folds them per tile variant.
+  // name = "<class>/<kernel>": class dit | codec | prep (conditioning hoisted out of the ODE); GEMM launches carry their
+  // algorithmic flops AND bytes (operands + outputs + residual, each counted once), the streaming kernels their bytes.
   struct KernelStat {
     std::string name;
     long launches = 0;
-    double flops = 0, ms = 0;
+    double flops = 0, bytes = 0, ms = 0;
   };
   Status profile_begin();
   Status profile_end(std::vector<KernelStat>& out);
@@ -81,10 +83,14 @@ class Engine {
   // alg_flops < 0: 2*M*N*K*nbatch (exact unless K carries zero padding, then the caller passes the true count)
   Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0);
   struct ProfRec {
-    int variant;
-    double flops;
+    std::string key;
+    double flops, bytes;
     hipEvent_t e0, e1;
   };
+  const char* prof_cls_ = "dit";
+  // non-GEMM launch, event-bracketed while profiling
+  template <class F>
+  Status op(const char* name, double alg_bytes, double alg_flops, hipStream_t st, F&& launch);
   bool prof_on_ = false;
   std::vector<ProfRec> prof_;
   std::vector<hipEvent_t> ev_pool_;

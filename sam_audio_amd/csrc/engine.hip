@@ -317,19 +317,53 @@ Status Engine::set_workspace(void* p, size_t bytes) {
   return Status{};
 }
 
-Status Engine::gemm(const GemmParams& p, hipStream_t st, double alg_flops) {
+// algorithmic bytes of one GEMM / implicit-convolution launch: every operand, output and residual element once
+static double gemm_alg_bytes(const GemmParams& p, size_t esz) {
+  const double rows = (double)p.M * p.nbatch;
+  const double n_out = p.swiglu ? p.N / 2 : p.N;
+  const long a_row = p.lda > 0 && p.lda < p.K ? p.lda : p.K;  // implicit convolutions re-read a row once per tap
+  double b = rows * (double)a_row * esz + (double)p.N * p.K * esz * (p.w_bstride ? p.nbatch : 1);
+  if (p.out_f32) b += rows * n_out * 4;
+  if (p.out_act) b += rows * n_out * esz;
+  if (p.res) b += (p.res_ld ? rows : 1.0) * n_out * 4;
+  return b;
+}
+
+Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops) {
+  GemmParams p = p_in;
+  p.tag = prof_cls_[0] == 'c' ? 1 : 0;  // codec launches run under their own kernel symbols
   if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
   if (!prof_on_) {
     SA_HIP(launch_gemm(p, bf16_, st));
     return Status{};
   }
   ProfRec r;
-  r.variant = gemm_variant(p, bf16_);
+  r.key = std::string(prof_cls_) + "/" + gemm_variant_name(gemm_variant(p, bf16_), bf16_);
   r.flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
+  r.bytes = gemm_alg_bytes(p, esz_);
   SA_TRY(prof_event(&r.e0));
   SA_TRY(prof_event(&r.e1));
   SA_HIP(hipEventRecord(r.e0, st));
   SA_HIP(launch_gemm(p, bf16_, st));
+  SA_HIP(hipEventRecord(r.e1, st));
+  prof_.push_back(r);
+  return Status{};
+}
+
+template <class F>
+Status Engine::op(const char* name, double alg_bytes, double alg_flops, hipStream_t st, F&& launch) {
+  if (!prof_on_) {
+    SA_HIP(launch());
+    return Status{};
+  }
+  ProfRec r;
+  r.key = std::string(prof_cls_) + "/" + name;
+  r.flops = alg_flops;
+  r.bytes = alg_bytes;
+  SA_TRY(prof_event(&r.e0));
+  SA_TRY(prof_event(&r.e1));
+  SA_HIP(hipEventRecord(r.e0, st));
+  SA_HIP(launch());
   SA_HIP(hipEventRecord(r.e1, st));
   prof_.push_back(r);
   return Status{};
@@ -354,15 +388,22 @@ Status Engine::profile_begin() {
 
 Status Engine::profile_end(std::vector<KernelStat>& out) {
   prof_on_ = false;
-  out.assign(kGemmVariants, KernelStat{});
-  for (int v = 0; v < kGemmVariants; ++v) out[v].name = gemm_variant_name(v, bf16_);
+  out.clear();
+  std::map<std::string, size_t> index;
   for (const ProfRec& r : prof_) {
     SA_HIP(hipEventSynchronize(r.e1));
     float ms = 0.f;
     SA_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
-    KernelStat& k = out[r.variant];
+    auto it = index.find(r.key);
+    if (it == index.end()) {
+      it = index.emplace(r.key, out.size()).first;
+      out.push_back(KernelStat{});
+      out.back().name = r.key;
+    }
+    KernelStat& k = out[it->second];
     k.launches += 1;
     k.flops += r.flops;
+    k.bytes += r.bytes;
     k.ms += ms;
   }
   prof_.clear();
@@ -397,6 +438,7 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   if (text && Lt <= 0) return fail(SAMAUDIO_ERR_ARG, "prepare: text_len must be positive");
   if (!text) Lt = 1;
   if (anchor_ids && (!anchor_alignment || n_ids <= 0)) return fail(SAMAUDIO_ERR_ARG, "prepare: anchors incomplete");
+  prof_cls_ = "prep";
   Bump b(ws_, ws_bytes_);
   plan_dit(b, rows, T, Lt, true);
   if (!ws_ || !b.fits())
@@ -474,6 +516,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   const long M = (long)rows * T, Mt = (long)rows * Lt;
   const float eps = cfg_.norm_eps;
   const long t6 = nt == 1 ? 0 : 6L * D, t1 = nt == 1 ? 0 : (long)D;
+  prof_cls_ = "dit";
+  const double MD = (double)M * D;
 
   // aligned = noisy @ Wy^T + cond                                   (model.py:116-125, columns 0..255)
   SA_HIP(launch_to_act(noisy, 0, C2, 0, d_.ybf, 0, bf16_, 1, M, C2, C2, 0, st));
@@ -495,9 +539,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   };
   trace("cond", d_.cond, (size_t)M * D, false, st);
   trace("aligned", d_.aligned, (size_t)M * D, false, st);
-  SA_HIP(launch_groupnorm_silu(d_.aligned, g_.gn1_w, g_.gn1_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st));
+  SA_TRY(op("groupnorm_silu", MD * (4 + esz_), 0, st, [&] {
+    return launch_groupnorm_silu(d_.aligned, g_.gn1_w, g_.gn1_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st);
+  }));
   SA_TRY(patch_conv(g_.pw1, g_.pb1, nullptr, d_.hp1));
-  SA_HIP(launch_groupnorm_silu(d_.hp1, g_.gn2_w, g_.gn2_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st));
+  SA_TRY(op("groupnorm_silu", MD * (4 + esz_), 0, st, [&] {
+    return launch_groupnorm_silu(d_.hp1, g_.gn2_w, g_.gn2_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st);
+  }));
   SA_TRY(patch_conv(g_.pw2, g_.pb2, d_.aligned, d_.h));
 
   // timestep embeddings                                             (transformer.py:490-493, model.py:170)
@@ -543,21 +591,27 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     const LayerW& w = layers_[l];
     const float* tab = w.mod_table;
     // self-attention branch
-    SA_HIP(launch_rmsnorm_mod(d_.h, w.attn_norm, tab + 0 * D, tab + 1 * D, d_.t0, t6, 0 * D, 1 * D, d_.xn, bf16_,
-                              (int)M, D, T, eps, st));
+    SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
+      return launch_rmsnorm_mod(d_.h, w.attn_norm, tab + 0 * D, tab + 1 * D, d_.t0, t6, 0 * D, 1 * D, d_.xn, bf16_, (int)M, D,
+                                T, eps, st);
+    }));
     {
       GemmParams p = lin(d_.xn, D, w.wqkv, M, 3 * D, D);
       out_act(p, d_.qkv, 3L * D);
       SA_TRY(gemm(p, st));
     }
-    SA_HIP(launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp,
-                           H, eps, st));
+    SA_TRY(op("qkv_prep", 2 * 3 * MD * esz_, 0, st, [&] {
+      return launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp, H,
+                             eps, st);
+    }));
     trace("  xn", d_.xn, (size_t)M * D, bf16_, st);
     trace("  qkv", d_.qkv, (size_t)M * 3 * D, bf16_, st);
     trace("  Q", d_.Q, (size_t)rows * H * Tp * 128, bf16_, st);
     trace("  K", d_.K, (size_t)rows * H * Tp * 128, bf16_, st);
     trace("  Vt", d_.Vt, (size_t)rows * H * Tp * 128, bf16_, st);
-    SA_HIP(launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st));
+    SA_TRY(op("self_attention", 4 * MD * esz_, 4.0 * T * T * 128 * H * rows, st, [&] {
+      return launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st);
+    }));
     trace("  attn", d_.attn, (size_t)M * D, bf16_, st);
     {
       GemmParams p = lin(d_.attn, D, w.wo, M, D, D);  // h = x + gate_msa * attn
@@ -577,9 +631,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     const void* kv_l = (const char*)d_.kvc + (size_t)l * 2 * D * esz_;
     if (fold_ltp_) {
       // h += P . U with U = Wo V folded per (batch, head, token): K = H*Lt instead of D (see attention.hip)
-      SA_HIP(launch_cross_attn_probs(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.probs, fold_kp_, rows, T, Lt,
-                                     fold_ltp_, H, eps, st));
-      SA_HIP(launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st));
+      SA_TRY(op("cross_attn_probs", (MD + (double)M * fold_kp_ + (double)Mt * 2 * D) * esz_, 0, st, [&] {
+        return launch_cross_attn_probs(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.probs, fold_kp_, rows, T, Lt,
+                                       fold_ltp_, H, eps, st);
+      }));
+      SA_TRY(op("cross_attn_fold", ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_, 0, st, [&] {
+        return launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st);
+      }));
       GemmParams p = lin(d_.probs, fold_kp_, d_.ut, T, D, fold_kp_);
       p.nbatch = rows;
       p.a_bstride = (long)T * fold_kp_;
@@ -599,8 +657,10 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
     trace("  h after cross", d_.h, (size_t)M * D, false, st);
     // feed-forward branch
-    SA_HIP(launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_,
-                              (int)M, D, T, eps, st));
+    SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
+      return launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_, (int)M, D,
+                                T, eps, st);
+    }));
     {
       GemmParams p = lin(d_.xn, D, w.w13, M, 2 * F, D);
       p.swiglu = 1;
@@ -696,6 +756,7 @@ Status Engine::codec_encode(const float* wav, int items, int64_t S, float* laten
   if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_encode: workspace too small");
   if (chunk > items) chunk = items;
   prepared_ = false;  // the codec scratch aliases the DiT scratch
+  prof_cls_ = "codec";
   long encT[5], decT[5];
   int encC[5], decC[5];
   codec_stage_dims(cfg_, S, encT, encC, decT, decC);
@@ -776,6 +837,7 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
   if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_decode: workspace too small");
   if (chunk > items) chunk = items;
   prepared_ = false;
+  prof_cls_ = "codec";
   long encT[5], decT[5];
   int encC[5], decC[5];
   codec_stage_dims(cfg_, S, encT, encC, decT, decC);

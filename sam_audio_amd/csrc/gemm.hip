@@ -229,9 +229,17 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
     return g2 && known ? g_force : gemm1_variant(p);
   }
   if (g_force >= 0) return gemm1_variant(p);
-  // measured (tools/gemm_bench.py, profiles/r1_gemm_variants_*.log): 256x256 ping-pong for the widest outputs,
-  // 256x128 elsewhere; codec convolutions with >= 96 output channels ride the same kernels
-  if (g2 && p.N >= 96 && p.K >= 128) return p.N >= 12288 ? 9 : (p.N == 192 && !debug_flag(4) ? 6 : 4);
+  if (g2 && p.N >= 96 && p.K >= 128) {
+    // round-1 policy (A/B switch, flag 5): 256x256 ping-pong for the widest outputs, 256x128 2-stage ring elsewhere
+    if (debug_flag(5)) return p.N >= 12288 ? 9 : (p.N == 192 && !debug_flag(4) ? 6 : 4);
+    // round 2, measured on MI355X (profiles/r2_gemm_variants.log, M = 8000): the 8-phase 256x256 kernel (16x16x32 MFMA)
+    // for wide outputs - w13 1082 vs 953 TF/s, qkv 871 vs 678 -; it loses to tile quantisation at N = D (352 tiles on
+    // 256 CUs), where the loader-wave 256x128 kernel with its persistent tile walk is best (c_wq 845, w2 820, wo 601
+    // vs 818 / 767 / 583 for the 2-stage ring).  Codec convolutions with >= 96 output channels ride the same kernels.
+    if (p.N >= 4096) return 22;
+    if (p.N == 192 && !debug_flag(4)) return 6;
+    return 20;
+  }
   return gemm1_variant(p);
 }
 const char* gemm_variant_name(int v, bool is_bf16) {

@@ -139,7 +139,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
 // swizzle (row>>2)&3 - both make the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte bank slots).
 // 4-wave configurations (BK = 32, <= 80 KiB LDS) run TWO workgroups per CU: the two are not barrier-coupled, so
 // one's MFMAs cover the other's barrier / LDS-latency / epilogue time.
-template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
+// TAG: 0 = DiT / generic, 1 = DAC-VAE launches (identical code under a second symbol so that rocprofv3 and bench.py can
+// attribute the MFMA-bound DiT contractions and the codec convolutions separately; GemmParams.tag selects it).
+template <int BM, int BN, int WM_, int WN_, int STAGES, int BK, int TAG = 0>
 __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 256 ? 1 : (WM_ * WN_ == 8 && BK == 32 ? 4 : 2)))
     void gemm2_kernel(
     const GemmParams p) {
@@ -509,7 +511,7 @@ struct TileRaster {
   }
 };
 
-template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false>
+template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false, int TAG = 0>
 __global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
   constexpr int NC = 8, NL = 4;  // compute / loader waves
   static_assert(WM_ * WN_ == NC, "8 compute waves");
@@ -685,11 +687,14 @@ static int persistent_grid(long tiles) {  // one workgroup per CU, a multiple of
   return (int)(want < cus ? want : cus);
 }
 
-template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false>
+template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false, bool TAGGED = false>
 static hipError_t launch5(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
   const unsigned grid = PERSIST ? (unsigned)persistent_grid(tiles) : (unsigned)tiles;
-  hipLaunchKernelGGL((gemm5_kernel<BM, BN, WM_, WN_, NS, BK, PF, PERSIST>), dim3(grid), dim3(768), 0, st, p);
+  if (TAGGED && p.tag == 1)
+    hipLaunchKernelGGL((gemm5_kernel<BM, BN, WM_, WN_, NS, BK, PF, PERSIST, TAGGED ? 1 : 0>), dim3(grid), dim3(768), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm5_kernel<BM, BN, WM_, WN_, NS, BK, PF, PERSIST, 0>), dim3(grid), dim3(768), 0, st, p);
   return hipGetLastError();
 }
 
@@ -700,11 +705,15 @@ static hipError_t launch3(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int BM, int BN, int WM_, int WN_, int STAGES, int BK>
+template <int BM, int BN, int WM_, int WN_, int STAGES, int BK, bool TAGGED = false>
 static hipError_t launch2(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES, BK>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0,
-                     st, p);
+  if (TAGGED && p.tag == 1)
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES, BK, TAGGED ? 1 : 0>), dim3((unsigned)tiles),
+                       dim3(WM_ * WN_ * 64), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WM_, WN_, STAGES, BK, 0>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0,
+                       st, p);
   return hipGetLastError();
 }
 
@@ -745,16 +754,16 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
     case 14: return launch5<256, 128, 4, 2, 3, 64>(p, st);  // loader waves, 3 x 48 KiB stages
     case 15: return launch2<256, 128, 4, 2, 3, 32>(p, st);  // 8 waves, BK 32, 72 KiB => two workgroups per CU
     case 16: return launch5<256, 128, 4, 2, 3, 64, true>(p, st);  // 14 + register-prefetched fragments
-    case 17: return launch5<256, 128, 4, 2, 3, 64, true, true>(p, st);  // 16 + persistent tile walk
+    case 17: return launch5<256, 128, 4, 2, 3, 64, true, true, true>(p, st);  // 16 + persistent tile walk
     case 18: return launch5<256, 256, 2, 4, 2, 64, false, true>(p, st); // 12 + persistent tile walk
     case 19: return launch_gemm8(p, 0, st);  // gemm8.hip: the guide's 8-phase K loop, 16x16x32 MFMA
     case 20: return launch_gemm8(p, 1, st);  // ... A/B: wave groups not staggered
     case 21: return launch_gemm8(p, 2, st);  // ... A/B: no s_setprio around the MFMA clusters
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
-    case 3: return launch2<256, 192, 4, 2, 2, 64>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
+    case 3: return launch2<256, 192, 4, 2, 2, 64, true>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);
     case 0: return launch2<256, 128, 4, 2, 3, 64>(p, st);
-    default: return launch2<256, 128, 4, 2, 2, 64>(p, st);
+    default: return launch2<256, 128, 4, 2, 2, 64, true>(p, st);
   }
 }
 

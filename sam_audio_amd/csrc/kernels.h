@@ -10,9 +10,10 @@ hipError_t launch_poison_lds(hipStream_t st);
 
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
-//   flag 2: rmsnorm_mod keeps the row in registers between its two passes (candidate, not yet timed)
-//   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (candidate, not yet timed)
+//   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
+//   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)
 //   flag 4: N = 192 GEMMs use two 128-wide tiles instead of the 256x192 tile
+//   flag 5: round-1 GEMM tile policy (256x128 2-stage ring, 256x256 ping-pong for N >= 12288)
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);
 

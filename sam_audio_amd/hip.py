@@ -51,7 +51,7 @@ class GemmParams(C.Structure):
         ("out_act", C.c_void_p), ("act_bstride", C.c_long), ("act_ld", C.c_long), ("act_off", C.c_long),
         ("act", C.c_int), ("f32_act", C.c_int), ("act_alpha", C.c_void_p),
         ("c_lo", C.c_long), ("c_hi", C.c_long), ("c_ld_rel", C.c_long),
-        ("w_bstride", C.c_long), ("raster_gm", C.c_int),
+        ("w_bstride", C.c_long), ("raster_gm", C.c_int), ("tag", C.c_int),
     ]
 
 
@@ -74,7 +74,8 @@ class FrameConfig(C.Structure):
 
 class KernelStat(C.Structure):
     """Mirror of `samaudio_kernel_stat`."""
-    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("flops", C.c_double), ("ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("flops", C.c_double), ("bytes", C.c_double),
+                ("ms", C.c_double)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -291,7 +291,11 @@ class SAMAudioJudgeModel:
         canon = lambda k: re.sub(r"\.(weight_g|weight_v|parametrizations\.weight\.original[01])$", ".weight", k)  # noqa: E731
         have = {canon(k) for k in state_dict}
         want = set(self.expected_keys())
-        missing, unexpected = sorted(want - have), sorted(k for k in state_dict if canon(k) not in want)
+        # the reference DACVAEEncoder keeps the WHOLE quantizer of the dacvae model (codec.py:62-63: in_proj, out_proj, ...),
+        # and a checkpoint saved from a full DACVAE also carries the decoder: present in a genuine checkpoint, unused here
+        unused = re.compile(r"^audio_codec\.(quantizer\.(?!in_proj\.)|decoder\.)")
+        missing = sorted(want - have)
+        unexpected = sorted(k for k in state_dict if canon(k) not in want and not unused.search(k))
         if strict and (missing or unexpected):
             raise RuntimeError(f"Missing keys: {missing}, unexpected_keys: {unexpected}")
         text_sd = {k[len("text_model."):]: v for k, v in state_dict.items() if k.startswith("text_model.")}

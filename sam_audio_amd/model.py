@@ -104,6 +104,7 @@ class SAMAudio:
             # measured on MI355X: 2 groups +3 %, 3-4 groups no further gain
             raise ValueError("streams must be 1 or 2 (set SAMAUDIO_ALLOW_STREAMS=1 to experiment with more)")
         self.streams = int(streams)           # row groups solved concurrently on separate HIP streams
+        self.use_graph = False                # replay the ODE solve from a captured hipGraph (small per-GPU batches)
         self._lanes: List[_Lane] = []
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
@@ -179,6 +180,9 @@ class SAMAudio:
         dit_missing = [k for k in missing if not k.startswith("audio_codec.")]
         if strict and (missing or unexpected):
             raise RuntimeError(f"Missing keys: {missing}, unexpected_keys: {unexpected}")
+        vis = {k[len("vision_encoder."):]: v for k, v in state_dict.items() if k.startswith("vision_encoder.")}
+        if vis and hasattr(self.vision_encoder, "load_state_dict"):   # reference model.py:83: the checkpoint's PE-Core tower
+            self.vision_encoder.load_state_dict(vis, strict=strict)
         with torch.cuda.device(self.device):
             if not dit_missing:
                 self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device))
@@ -206,12 +210,13 @@ class SAMAudio:
         hip.check(self._lib.samaudio_profile_begin(self._ctx))
 
     def profile_end(self) -> List[Dict[str, Any]]:
-        """[{name, launches, flops, ms}] per GEMM tile variant since profile_begin() (synchronises)."""
-        buf = (hip.KernelStat * 16)()
+        """[{name, launches, flops, bytes, ms}] per (class, kernel) since profile_begin() (synchronises).  name =
+        "dit/<kernel>" | "codec/<kernel>" | "prep/<kernel>"; flops / bytes are algorithmic (see include/samaudio.h)."""
+        buf = (hip.KernelStat * 64)()
         n = C.c_int(0)
-        hip.check(self._lib.samaudio_profile_end(self._ctx, buf, 16, C.byref(n)))
+        hip.check(self._lib.samaudio_profile_end(self._ctx, buf, 64, C.byref(n)))
         return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), flops=float(buf[i].flops),
-                     ms=float(buf[i].ms)) for i in range(n.value)]
+                     bytes=float(buf[i].bytes), ms=float(buf[i].ms)) for i in range(n.value)]
 
     # ------------------------------------------------------------------ workspace
     def _ensure_workspace(self, rows: int, frames: int, text_len: int, codec_items: int, samples: int,

@@ -31,6 +31,12 @@ from .config import SAMAudioConfig
 
 # keys the reference checkpoint does not carry (reference model.py:351-355)
 OPTIONAL_KEY_RE = re.compile(r"(^text_encoder|^visual_ranker|^text_ranker|^span_predictor)")
+# keys a genuine reference checkpoint DOES carry but the separate() engine does not consume: the reference SAMAudio owns
+# `self.vision_encoder = PerceptionEncoder(...)` (model.py:83, a pe.CLIP under `vision_encoder.model.*`) and its strict
+# load forgives only the four prefixes above, so checkpoint.pt holds those tensors.  They are routed to
+# `model.vision_encoder.load_state_dict` when a tower with that method is attached and are otherwise ignored - never
+# reported as unexpected.
+IGNORED_KEY_RE = re.compile(r"^vision_encoder\.")
 
 
 def _head_major(w: torch.Tensor, n_heads: int) -> torch.Tensor:
@@ -228,5 +234,6 @@ def split_missing_unexpected(sd_keys, cfg: SAMAudioConfig) -> Tuple[List[str], L
 
     have_c = {canon(k) for k in have}
     missing = sorted(k for k in want if k not in have_c and not OPTIONAL_KEY_RE.search(k))
-    unexpected = sorted(k for k in have if canon(k) not in want and not OPTIONAL_KEY_RE.search(k))
+    unexpected = sorted(k for k in have if canon(k) not in want and not OPTIONAL_KEY_RE.search(k)
+                        and not IGNORED_KEY_RE.search(k))
     return missing, unexpected

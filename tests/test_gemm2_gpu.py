@@ -20,8 +20,10 @@ pytestmark = pytest.mark.gpu
 # 9 = 256x256 role-split.  15..22 = experimental kernels (loader-wave "gemm5" family, BK-32 two-workgroup tile,
 # 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
 # no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
-EXPERIMENTAL = list(range(15, 25)) if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
-VARIANTS = [3, 4, 5, 6, 9] + EXPERIMENTAL
+# Round 2 ships 20 (loader-wave 256x128, persistent tile walk) and 22 (8-phase 256x256): they are always in the sweep.
+SHIPPED_R2 = [20, 22]
+EXPERIMENTAL = [v for v in range(15, 25) if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
+VARIANTS = [3, 4, 5, 6, 9] + SHIPPED_R2 + EXPERIMENTAL
 
 
 def _mk(shape, seed, scale=1.0):
@@ -89,7 +91,7 @@ def test_gate_residual_dual_output_and_swiglu(gpu, variant):
     util.report(f"swiglu v{variant}", u, want_u, 3.2e-2)
 
 
-@pytest.mark.parametrize("variant", [3, 4, 9] + EXPERIMENTAL)
+@pytest.mark.parametrize("variant", [3, 4, 9] + SHIPPED_R2 + EXPERIMENTAL)
 def test_conv_forms(gpu, variant):
     """The codec's implicit-convolution forms on the 256-row kernels: dilated k7 conv with snake epilogue into a
     halo-padded buffer, and a stride-4 transposed conv (phase-major columns, chan_mod bias, output window mask)."""

@@ -36,7 +36,8 @@ def test_no_kernel_consumes_lds_it_never_wrote():
     of padding lanes read past the rows the kernel had written: 0 x NaN).  All non-GEMM kernels, both candidates and
     the new streaming kernels; the GEMM sweep with poison is part of the by-hand run."""
     out = _run(["tests/test_kernels_gpu.py", "tests/test_zz_next_rows_gpu.py", "-k",
-                "not (judge or separate or predict or frame_logits or peav_transformer)"], 900, SAMAUDIO_SIMT_POISON="1")
+                "not (judge or separate or predict or frame_logits or peav_transformer or visual_prompt)"], 900,
+               SAMAUDIO_SIMT_POISON="1")
     assert " passed" in out and "failed" not in out
 
 

@@ -59,7 +59,7 @@ w = torch.rand(D, device=dev)
 tab = torch.randn(6, D, device=dev)
 t0 = torch.randn(1, 6 * D, device=dev)
 xn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-for flag, name in ((0, "rmsnorm_mod"), (1, "rmsnorm_mod (row in registers, candidate)")):
+for flag, name in ((1, "rmsnorm_mod (two-pass, round 1)"), (0, "rmsnorm_mod (row in registers)")):
     L.samaudio_debug_set_flag(2, flag)
     timeit(name, lambda: hip.check(L.samaudio_op_rmsnorm_mod(
         hip.ptr(x), hip.ptr(w), C.c_void_p(tab[0].data_ptr()), C.c_void_p(tab[1].data_ptr()), hip.ptr(t0), 0, 0, D,
