@@ -17,9 +17,9 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X (profiles/r2_parity_large.log): forward bf16 ~1.1e-2 on |out| <= ~4, fp16 ~1.5e-3;
-# 2-step midpoint latent bf16 ~8e-3, fp16 ~1e-3
-BOUND = {"fp32": 1e-3, "bf16": 3e-2, "fp16": 5e-3}
+# measured on MI355X (profiles/r2_gpu_tests_call2_measured_errors.log): forward fp32 5.7e-6, bf16 8.8e-3 on |out| <= 2.7;
+# 2-step midpoint latent fp32 4.3e-6, bf16 7.6e-3 on |latent| <= 5.6.  bf16 bound = 2 x measured.
+BOUND = {"fp32": 1e-3, "bf16": 1.8e-2}
 
 
 @pytest.fixture(scope="module")

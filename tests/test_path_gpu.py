@@ -20,7 +20,9 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-TOL = {"fp32": 1e-3, "bf16": 1.5e-1}
+# bf16 bounds = 2 x the error measured on MI355X (profiles/r2_gpu_tests_call2_measured_errors.log): single DiT evaluation
+# 7.3e-3 .. 9.0e-3 on |out| <= 2.7 -> 2e-2
+TOL = {"fp32": 1e-3, "bf16": 2e-2}
 
 
 def _model(cfg, sd, prec, gpu):
@@ -76,8 +78,8 @@ def test_codec_roundtrip_pieces(gpu, prec):
     model = _model(cfg, sd, prec, gpu)
     z = model.encode_audio(wav)
     w = model.decode_audio(lat)
-    util.report(f"codec encode {prec}", z, z_ref, 1e-3 if prec == "fp32" else 1e-1)
-    util.report(f"codec decode {prec}", w, w_ref, 1e-3 if prec == "fp32" else 1e-1)
+    util.report(f"codec encode {prec}", z, z_ref, 1e-3 if prec == "fp32" else 3e-3)   # measured 1.25e-3 on |z| <= 0.26
+    util.report(f"codec decode {prec}", w, w_ref, 1e-3 if prec == "fp32" else 2e-3)   # measured 6.8e-4 on |w| <= 0.13
 
 
 def test_codec_chunked_equals_unchunked(gpu, monkeypatch):
@@ -134,7 +136,7 @@ def test_separate_bf16_error_is_reported_and_bounded(gpu):
     print(f"full 16-step midpoint ODE, 'mini' dims: latent max-abs err fp32 {errs['fp32']:.3e}, bf16 {errs['bf16']:.3e}"
           f" (latent max {lat_ref.abs().max().item():.2f})")
     assert errs["fp32"] < 1e-3
-    assert errs["bf16"] < 0.25
+    assert errs["bf16"] < 1.5e-2   # measured 6.1e-3 on |latent| <= 5.0
 
 
 def test_candidates_repeat_is_sample_major(gpu):

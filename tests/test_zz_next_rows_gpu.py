@@ -24,7 +24,8 @@ from sam_audio_amd.synthetic import init_frame_state_dict, init_judge_state_dict
 from tests import util
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp32": 1e-3, "bf16": 1.5e-1}
+# bf16 bounds = 2 x measured on MI355X (profiles/r2_gpu_tests_call2_measured_errors.log): PE-AV hidden 1.07e-2 on |x| <= 2.4
+TOL = {"fp32": 1e-3, "bf16": 2.5e-2}
 TINY_TEXT = dict(G.TINY_TEXT)
 
 
@@ -136,7 +137,7 @@ def test_judge_forward_matches_oracle(gpu, prec):
     m = _judge(cfg, sd, prec, gpu, text_model=tm)
     out = m(**{k: v.to(gpu) for k, v in inp.items()})
     got = torch.cat([out.overall, out.recall, out.precision, out.faithfulness], dim=1)
-    util.report(f"judge scores {prec}", got, want, 1e-3 if prec == "fp32" else 5e-2)
+    util.report(f"judge scores {prec}", got, want, 1e-3 if prec == "fp32" else 1e-2)   # measured 3.5e-3
     assert out.overall.shape == (2, 1)
 
 
@@ -163,7 +164,7 @@ def test_judge_candidate_dedup_equals_the_expanded_batch(gpu, prec):
     with torch.inference_mode():
         want = J.judge_forward(sd, cfg, pooled, inp["input_values"].repeat_interleave(cand, 0), inp["separated_values"],
                                inp["padding_mask"].repeat_interleave(cand, 0))
-    util.report(f"dedup vs oracle {prec}", scores.reshape(-1), want[:, 0], 1e-3 if prec == "fp32" else 5e-2)
+    util.report(f"dedup vs oracle {prec}", scores.reshape(-1), want[:, 0], 1e-3 if prec == "fp32" else 1e-2)   # measured 2.2e-3
 
 
 def test_separate_with_judge_reranking_picks_the_argmax(gpu):
@@ -228,7 +229,7 @@ def test_frame_logits_and_spans_match_oracle(gpu, prec):
     fp.load_state_dict(sd, strict=False)
     out = fp(input_features=feats.to(gpu), padding_mask=pad.to(gpu), return_spans=True, text_pooled=pooled.to(gpu))
     scale = max(1.0, want.abs().max().item())
-    util.report(f"frame logits {prec}", out.logits.cpu() * pad, want * pad, (1e-3 if prec == "fp32" else 5e-2) * scale)
+    util.report(f"frame logits {prec}", out.logits.cpu() * pad, want * pad, (1e-3 if prec == "fp32" else 1e-2) * scale)   # bf16 measured 4.4e-3 * scale
     if prec == "fp32":
         margin = (want.abs() > 1e-2) | ~pad                                     # frames not sitting on the threshold
         ids_w, al_w = O.anchors_to_ids([[("+", s, e) for s, e in r] for r in J.spans_from_logits(want, pad, 1920, 48000)],
