@@ -69,8 +69,9 @@ def parse(argv=None):
     ap.add_argument("--verify", action="store_true", help="run parity_check even with --no-cpu-baseline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--streams", type=int, default=1, help="row groups of the batch solved concurrently on separate HIP streams")
-    ap.add_argument("--graph", type=int, default=-1,
-                    help="capture the ODE solve in a hipGraph: 1 on, 0 off, -1 auto (on when rows per GPU <= 8)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="replay the ODE solve from a captured hipGraph: 1 on, 0 off (default: kernels at >= 4 clips per "
+                         "GPU average > 40 us, the host launch path is not the limiter - profiles/r2_bench_batch4_*.log)")
     ap.add_argument("--candidates", type=int, default=1,
                     help="> 1: BASELINE.json configs[3] - reranking_candidates per clip, scored by the HIP Judge "
                          "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
@@ -407,9 +408,7 @@ def main():
         torch.cuda.synchronize()
 
     def timed(batch, steps, warmup, label):
-        rows = len(batch.descriptions) * args.candidates
-        use_graph = args.graph == 1 or (args.graph < 0 and rows <= 8)
-        model.use_graph = bool(use_graph)
+        model.use_graph = args.graph == 1
 
         def step():
             # noise=None: drawn on device inside, like the reference (model.py:274-275)

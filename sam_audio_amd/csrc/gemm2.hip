@@ -759,6 +759,8 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
     case 19: return launch_gemm8(p, 0, st);  // gemm8.hip: the guide's 8-phase K loop, 16x16x32 MFMA
     case 20: return launch_gemm8(p, 1, st);  // ... A/B: wave groups not staggered
     case 21: return launch_gemm8(p, 2, st);  // ... A/B: no s_setprio around the MFMA clusters
+    case 22: return launch2<128, 128, 2, 2, 2, 64>(p, st);  // small M: 4 waves, 64 KiB => two workgroups per CU
+    case 23: return launch2<64, 128, 1, 4, 3, 64>(p, st);   // smaller M: 4 waves, 72 KiB => two workgroups per CU
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
     case 3: return launch2<256, 192, 4, 2, 2, 64, true>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);

@@ -14,6 +14,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)
 //   flag 4: N = 192 GEMMs use two 128-wide tiles instead of the 256x192 tile
 //   flag 5: round-1 GEMM tile policy (256x128 2-stage ring, 256x256 ping-pong for N >= 12288)
+//   flag 6: M-blind tile policy (no 128- / 64-row tiles for launches with few rows)
+//   flag 7: the 8-phase 256x256 kernel also for 2048 <= N < 4096 (A/B with concurrent streams filling its tile tails)
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);
 
@@ -21,7 +23,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 25;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant (15..24 experimental, force-only)
+constexpr int kGemmVariants = 27;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
 bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 # 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
 # no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
 # Round 2 ships 20 (loader-wave 256x128, persistent tile walk) and 22 (8-phase 256x256): they are always in the sweep.
-SHIPPED_R2 = [20, 22]
+SHIPPED_R2 = [20, 22, 25, 26]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows
 EXPERIMENTAL = [v for v in range(15, 25) if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
 VARIANTS = [3, 4, 5, 6, 9] + SHIPPED_R2 + EXPERIMENTAL
 
@@ -135,3 +135,25 @@ def test_conv_forms(gpu, variant):
     want_t = F.conv_transpose1d(util.rounded(xt, "bf16"), util.rounded(wt, "bf16"), bt, stride=s, padding=pad).transpose(1, 2)
     util.report(f"convT v{variant}", raw[:, halo:halo + Tout], want_t, 5e-4)
     assert float(raw[:, :halo].abs().max()) == 0 and float(raw[:, halo + Tout:].abs().max()) == 0
+
+
+def test_row_tile_variants_are_bitwise_identical(gpu):
+    """The M-aware policy may pick 256-, 128- or 64-row tiles of the 32x32x16-MFMA family for the SAME (N, K) depending on
+    how many rows a launch has (sam_audio_amd/csrc/gemm.hip gemm_variant).  Batch sharding stays bitwise invariant
+     only if every one of them accumulates an output element in the same order: same MFMA shape,
+    K walked slab by slab.  Gated-residual epilogue, fp32 + bf16 outputs, ragged M."""
+    B, T, N, K = 3, 90, 384, 448
+    M = B * T
+    A, W = _mk((M, K), 21), _mk((N, K), 22, 1 / math.sqrt(K))
+    tab, gate, res = _mk((N,), 23), _mk((B, N), 24), _mk((M, N), 25)
+    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
+    outs = {}
+    for variant in (4, 3, 5, 9, 20, 25, 26):
+        hip.lib().samaudio_debug_force_gemm_variant(variant)
+        out = torch.full((M, N), float("nan"), device=gpu)
+        out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
+        util.gemm("bf16", keep[0], keep[1], M, N, K, gate_tab=keep[2], gate=keep[3], gate_ld=N, rows_per_gate=T, res=keep[4],
+                  res_geom=(0, N, 0), out_f32=out, f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
+        outs[variant] = (out.cpu(), out_act.cpu())
+    for variant, (o, a) in outs.items():
+        assert torch.equal(o, outs[4][0]) and torch.equal(a.view(torch.int16), outs[4][1].view(torch.int16)), variant
