@@ -366,11 +366,8 @@ def main():
 
     cfg = preset_config(args.size)
     tcfg = cfg.transformer
-    for kv in filter(None, os.environ.get("SAMAUDIO_DEBUG_FLAGS", "").split(",")):   # A/B switches, e.g. "5=1"
-        from sam_audio_amd import hip
-        k, v = kv.split("=")
-        hip.lib().samaudio_debug_set_flag(int(k), int(v))
-        log(f"debug flag {k} = {v}")
+    if os.environ.get("SAMAUDIO_DEBUG_FLAGS"):   # A/B switches, applied by sam_audio_amd.hip.lib() at load
+        log(f"debug flags {os.environ['SAMAUDIO_DEBUG_FLAGS']}")
 
     # ---- weights: rank 0 creates them, RCCL broadcast over xGMI to the other ranks -----------------------
     log(f"world {world} (backend {'nccl/RCCL' if world > 1 else 'none'}), preset {args.size}, scaling {args.scaling}, "

@@ -130,6 +130,7 @@ struct GemmParams {
   long c_ld_rel;
   long w_bstride;          // per-batch offset of W in elements (0: one weight matrix for every batch)
   int raster_gm;           // gemm2/gemm3 tile raster: M-tiles per group (0 = default 8)
+  int flags;               // kernel-internal switches, set by the launcher (bit 0: accumulator-layout epilogue)
   int tag;                 // 1: DAC-VAE launch - same code under its own kernel symbol (rocprofv3 / roofline attribution)
 };
 

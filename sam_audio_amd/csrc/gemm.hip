@@ -243,11 +243,11 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
     // slab by slab), so the choice may depend on M without breaking bitwise batch-sharding invariance.
     if (!debug_flag(6)) {
       const long tn = (p.N + 127) / 128;
-      if ((long)((p.M + 255) / 256) * tn * p.nbatch >= 192) return 20;
+      if ((long)((p.M + 255) / 256) * tn * p.nbatch >= 192) return debug_flag(9) ? 19 : 20;
       if ((long)((p.M + 127) / 128) * tn * p.nbatch >= 192) return 25;
       return 26;
     }
-    return 20;
+    return debug_flag(9) ? 19 : 20;
   }
   return gemm1_variant(p);
 }

@@ -135,6 +135,98 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   }
 }
 
+// ---- LDS-staged variant of the same epilogue ----------------------------------------------------------------------
+// In the accumulator layout above one store instruction covers 32 different rows for 32 contiguous bytes each: 32 cache
+// lines per instruction, for the fp32 residual read, the fp32 write and the bf16 write alike - the three residual GEMMs
+// of a DiT layer spend 30-60 us of their 150-420 us in it (profiles/r2_gemm_variants.log: wo 601 vs c_wq 845 TF/s on the
+// same shape).  Here every 32-row slice of the wave's tile goes through a PRIVATE LDS region of the wave (FN x 4 KiB,
+// free after the K loop; 16-byte chunks XOR-swizzled with row & 7) and comes back with 4 consecutive columns per lane
+// and FN*8 lanes per row, so all global traffic of the epilogue moves whole 128-/256-/512-byte row segments.
+// Wave-private: only wave-level ordering (s_waitcnt lgkmcnt) is needed between the two phases.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16_t (&acc)[FM][FN], int b, int m_first,
+                                                  int n_first, int lane, char* stg) {
+  const int l31 = lane & 31, lh = lane >> 5;
+  const long bM = (long)b * p.M;
+  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
+             has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
+  const int n_out = p.swiglu ? p.N >> 1 : p.N;
+  const int cpr = p.swiglu ? FN * 4 : FN * 8;                   // 4-column chunks per staged row
+  const int rb = cpr * 16;                                      // bytes per staged row
+  const int col0 = p.swiglu ? n_first >> 1 : n_first;
+  const int units = 32 * cpr;                                   // (row, chunk) pairs of one 32-row slice
+  const int smask = (cpr & 7) ? 3 : 7;                          // the XOR must stay inside the row: cpr = 4 / 12 -> groups of 4
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    // write phase: fragment row l31, columns j*32 + 8g + 4lh .. +3
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        int chunk;
+        if (p.swiglu) {  // groups 0,1 = w1 rows of the 32-row block, groups 2,3 = the matching w3 rows
+          if (g >= 2) continue;
+          v = make_float4(silu_f(acc[i][j][4 * g + 0]) * acc[i][j][4 * (g + 2) + 0],
+                          silu_f(acc[i][j][4 * g + 1]) * acc[i][j][4 * (g + 2) + 1],
+                          silu_f(acc[i][j][4 * g + 2]) * acc[i][j][4 * (g + 2) + 2],
+                          silu_f(acc[i][j][4 * g + 3]) * acc[i][j][4 * (g + 2) + 3]);
+          chunk = j * 4 + 2 * g + lh;
+        } else {
+          v = make_float4(acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          chunk = j * 8 + 2 * g + lh;
+        }
+        *(float4*)(stg + l31 * rb + ((chunk ^ (l31 & smask)) << 4)) = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // read phase
+    for (int u = lane; u < units; u += 64) {
+      const int row = u / cpr, chunk = u - row * cpr;
+      const float4 sv = *(const float4*)(stg + row * rb + ((chunk ^ (row & smask)) << 4));
+      const int m = m_first + i * 32 + row;
+      const int n = col0 + chunk * 4;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : p.M - 1;
+      const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
+      float v[4] = {sv.x, sv.y, sv.z, sv.w};
+      float4 bb, gg, tt, rr, sa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_bias) bb = *(const float4*)(p.bias + ch);
+      if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
+      if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
+      if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
+      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
+      if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+      if (has_gate) {
+        if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
+        v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+      const float a0 = act_apply(v[0], p.act, sa.x), a1 = act_apply(v[1], p.act, sa.y),
+                  a2 = act_apply(v[2], p.act, sa.z), a3 = act_apply(v[3], p.act, sa.w);
+      bool ok = m_ok && n < n_out;
+      if (p.c_ld_rel) {  // transposed conv: keep only the (row, phase) pairs that fall inside the output
+        const long erel = (long)m * p.c_ld_rel + n;
+        ok = ok && erel >= p.c_lo && erel < p.c_hi;
+      }
+      if (ok) {
+        if (p.out_f32) {
+          float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
+          *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (p.out_act) {
+          bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
+          store4<bf16_t>(arow + n, a0, a1, a2, a3);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this slice's reads precede the next slice's writes
+  }
+}
+
 // BK = k-elements per LDS slab (64: 128-byte rows, 8 chunks, swizzle (row>>1)&7;  32: 64-byte rows, 4 chunks,
 // swizzle (row>>2)&3 - both make the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte bank slots).
 // 4-wave configurations (BK = 32, <= 80 KiB LDS) run TWO workgroups per CU: the two are not barrier-coupled, so
@@ -278,7 +370,13 @@ __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 
     st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
   }
 
-  gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
+  if (p.flags & 1) {  // A/B: the round-1 epilogue straight from the accumulator layout
+    gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
+  } else {
+    static_assert(NW * FN * 4096 <= STAGES * STAGE, "epilogue staging fits the ring");
+    __syncthreads();  // every wave is done with the last slab (no DMA is in flight any more)
+    gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (FN * 4096));
+  }
 }
 
 // ---- gemm3: role-split ("ping-pong") main loop ---------------------------------------------------------------
@@ -461,7 +559,13 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
   }
   if (grp == 0) phase_barrier();
 
-  gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
+  if (p.flags & 1) {
+    gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
+  } else {
+    static_assert(NW * FN * 4096 <= NS * STAGE, "epilogue staging fits the stages");
+    phase_barrier();  // both groups are past their last fragment reads
+    gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (FN * 4096));
+  }
 }
 
 // ---- gemm5: dedicated loader waves (EXPERIMENTAL - reachable only through samaudio_debug_force_gemm_variant) ----
@@ -606,6 +710,10 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
       if (g + NS - 1 < total_slabs) issue(st_i);
       st_i = st_i + 1 == NS ? 0 : st_i + 1;
     }
+    if (!PERSIST) {  // B_end: tells the compute waves that every one of them is done with the ring (LDS-staged epilogue)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
     return;
   }
 
@@ -670,7 +778,18 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
     }
     int b, tm, tn;
     ras.locate(p, base + idx0 + tk * stride, b, tm, tn);
-    gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
+    if (PERSIST) {  // the loaders are already filling the ring with the next tile: no LDS to stage through
+      gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
+    } else {
+      static_assert(PERSIST || NC * FN * 4096 <= NS * STAGE, "epilogue staging fits the ring");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();  // B_end (all 12 waves)
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.flags & 1)
+        gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
+      else
+        gemm_epilogue_lds<FM, FN>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, lane, smem + wave * (FN * 4096));
+    }
   }
 }
 
@@ -741,7 +860,9 @@ bool gemm2_ok(const GemmParams& p) {
 // 256x128 role-split with 3 stages (7, 8), 256x256 with one 512-register wave per SIMD (12), hand-pipelined asm
 // fragment reads (13, 14) - all within +-3 % of the kept kernels or slower.  Ablation builds (9-11: no DMA / no MFMA /
 // no LDS reads; wrong results, timing only) compile with -DSAMAUDIO_GEMM_ABLATIONS.
-hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
+hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
+  GemmParams p = p_in;
+  p.flags = debug_flag(8) ? 1 : 0;  // bit 0: epilogue straight from the accumulator layout (round-1 path, A/B)
   switch (variant) {
 #ifdef SAMAUDIO_GEMM_ABLATIONS
     case 11: return launch3<256, 256, 2, 4, 2, 2, 3>(p, st);

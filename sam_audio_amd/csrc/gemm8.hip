@@ -240,50 +240,69 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
 #undef SA_GEMM8_READ_W
 
   // ---- epilogue (contract of GemmParams, common.h) -------------------------------------------------------------
-  // swapped operands: D[n][m]; a lane holds row m = lr of fragment i and columns 4*lg .. 4*lg+3 of fragment j
+  // Swapped operands give D[n][m]: a lane holds row m = lr of fragment i and columns 4*lg .. 4*lg+3 of fragment j, i.e.
+  // one accumulator register group covers 16 rows x 64 B - a store instruction straight from that layout touches 16
+  // different cache lines for 32 B each.  The tile is therefore re-laid through LDS (free after the K loop; 16 KiB per
+  // wave, rows of 64 fp32 columns, 16-byte chunks XOR-swizzled with the row): after it a lane owns 4 consecutive columns
+  // and the 16 lanes of a row group cover 256 contiguous bytes, so residual / gate loads and fp32 / bf16 stores move
+  // whole cache lines per row (MI355X_MICROARCH.md "store-ISSUE-bound" epilogues, cdna_hip_programming.md T21).
+  __syncthreads();
+  char* const stg = smem + wave * 16384;
   const long bM = (long)b * p.M;
   const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
              has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
   const int n_out = p.swiglu ? p.N >> 1 : p.N;
+  const int cpr = p.swiglu ? 8 : 16;                                  // 4-column chunks per staged row
+  const int col0 = p.swiglu ? (n0 + wc * 64) >> 1 : n0 + wc * 64;     // first output column of this wave
+  const int rsub = p.swiglu ? lane >> 3 : lane >> 4, csub = p.swiglu ? lane & 7 : lane & 15;
+  const int rows_per_it = 64 / cpr;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wr * 128 + i * 16 + lr;
-    const bool m_ok = m < p.M;
-    const int mc = m_ok ? m : p.M - 1;
-    const float* grow = has_gate ? p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld : nullptr;
-    const float* rrow = has_res ? p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld : nullptr;
-    float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld : nullptr;
-    bf16_t* arow = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld : nullptr;
+  for (int half = 0; half < 2; ++half) {
+    // write phase: rows half*64 + i*16 + lr of the wave's 128
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (p.swiglu && (j & 1)) continue;  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
-      const int nf = n0 + wc * 64 + j * 16;  // first GEMM column of the fragment
-      const int n = (p.swiglu ? nf >> 1 : nf) + 4 * lg;
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t a = acc[half * 4 + i][j];
+        if (p.swiglu) {  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
+          if (j & 1) continue;
+          const f32x4_t g = acc[half * 4 + i][j | 1];
+          const int chunk = (j >> 1) * 4 + lg;
+          *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) =
+              make_float4(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1], silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
+        } else {
+          const int chunk = j * 4 + lg;
+          *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+      }
+    }
+    __syncthreads();
+    // read phase: rows_per_it rows x cpr chunks per wave instruction
+    for (int r0 = 0; r0 < 64; r0 += rows_per_it) {
+      const int row = r0 + rsub;
+      const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
+      const int m = m0 + wr * 128 + half * 64 + row;
+      const int n = col0 + csub * 4;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : p.M - 1;
       const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
       const int ch = p.chan_mod ? nc % p.chan_mod : nc;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = p.swiglu ? silu_f(acc[i][j][e]) * acc[i][j | 1][e] : acc[i][j][e];
-      if (has_bias) {
-        const float4 bb = *(const float4*)(p.bias + ch);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
+      float v[4] = {sv.x, sv.y, sv.z, sv.w};
+      float4 bb, gg, tt, rr, sa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_bias) bb = *(const float4*)(p.bias + ch);
+      if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
+      if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
+      if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
+      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
+      if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
       if (has_gate) {
-        float4 q = *(const float4*)(grow + nc);
-        if (has_tab) {
-          const float4 tt = *(const float4*)(p.gate_tab + nc);
-          q.x += tt.x; q.y += tt.y; q.z += tt.z; q.w += tt.w;
-        }
-        v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
+        if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
+        v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (has_res) {
-        const float4 rr = *(const float4*)(rrow + nc);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-      }
-      float4 sa = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
+      if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
       const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
                   a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
       bool ok = m_ok && n < n_out;
@@ -292,10 +311,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
         ok = ok && erel >= p.c_lo && erel < p.c_hi;
       }
       if (ok) {
-        if (frow) *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
-        if (arow) store4<bf16_t>(arow + n, a0, a1, a2, a3);
+        if (p.out_f32) {
+          float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
+          *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (p.out_act) {
+          bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
+          store4<bf16_t>(arow + n, a0, a1, a2, a3);
+        }
       }
     }
+    if (half == 0) __syncthreads();  // the reads of this half precede the next half's writes
   }
 }
 

@@ -15,6 +15,9 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 4: N = 192 GEMMs use two 128-wide tiles instead of the 256x192 tile
 //   flag 5: round-1 GEMM tile policy (256x128 2-stage ring, 256x256 ping-pong for N >= 12288)
 //   flag 6: M-blind tile policy (no 128- / 64-row tiles for launches with few rows)
+//   flag 8: GEMM epilogues straight from the accumulator layout (round 1) instead of the LDS-staged coalesced form
+//   flag 9: loader-wave 256x128 kernel WITHOUT the persistent tile walk (its ring is free after the K loop, so it can use
+//           the LDS-staged epilogue; the persistent walk keeps the accumulator-layout epilogue)
 //   flag 7: the 8-phase 256x256 kernel also for 2048 <= N < 4096 (A/B with concurrent streams filling its tile tails)
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);

@@ -51,7 +51,7 @@ class GemmParams(C.Structure):
         ("out_act", C.c_void_p), ("act_bstride", C.c_long), ("act_ld", C.c_long), ("act_off", C.c_long),
         ("act", C.c_int), ("f32_act", C.c_int), ("act_alpha", C.c_void_p),
         ("c_lo", C.c_long), ("c_hi", C.c_long), ("c_ld_rel", C.c_long),
-        ("w_bstride", C.c_long), ("raster_gm", C.c_int), ("tag", C.c_int),
+        ("w_bstride", C.c_long), ("raster_gm", C.c_int), ("flags", C.c_int), ("tag", C.c_int),
     ]
 
 
@@ -149,6 +149,10 @@ def lib() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        # tuning only: A/B switches between kernel generations (sam_audio_amd/csrc/kernels.h), e.g. "8=1,9=1"
+        for kv in filter(None, os.environ.get("SAMAUDIO_DEBUG_FLAGS", "").split(",")):
+            k, v = kv.split("=")
+            handle.samaudio_debug_set_flag(int(k), int(v))
     return _lib
 
 
