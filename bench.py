@@ -25,8 +25,9 @@ invocation per N yields both curves.
 
 The JSON line also carries
   roofline       - bf16 MFMA roofline of the dominant DiT GEMM kernel symbol: algorithmic flops of its launches / their
-                   HIP-event time, measured on the launch stream in one extra instrumented step; plus the aggregate over
-                   every DiT GEMM launch ("dit_gemm_all") and the per-kernel table;
+                   HIP-event time, measured on the launch stream in one extra instrumented step (single stream); plus the
+                   aggregate over every DiT GEMM launch ("dit_gemm_all"), the whole-step figure ("whole_step": executed
+                   flops of all kernels / the TIMED step, concurrent streams included) and the per-kernel table;
   roofline_hbm   - the DAC-VAE convolutions (their own kernel symbols) and the streaming kernels of the DiT against
                    max(flops / MFMA peak, algorithmic bytes / HBM peak);
   cpu_baseline   - the CPU oracle (oracle/samaudio_oracle.py, a torch fp32 restatement of the reference algorithm)
@@ -68,7 +69,11 @@ def parse(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip parity_check (it shares the oracle run with cpu_baseline)")
     ap.add_argument("--verify", action="store_true", help="run parity_check even with --no-cpu-baseline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
-    ap.add_argument("--streams", type=int, default=1, help="row groups of the batch solved concurrently on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="row groups of the batch solved concurrently on separate HIP streams (default 0 = auto: 2 with >= 16 "
+                         "clips on the rank, else 1; with 2, one group's GEMM "
+                         "tile tails - 352 tiles of 256x256 on 256 CUs at N = D - and epilogues are filled by the other's "
+                         "workgroups; bitwise equal to 1 stream; 200.5 vs 181.1 s-audio/s, profiles/r2_call3/)")
     ap.add_argument("--graph", type=int, default=0,
                     help="replay the ODE solve from a captured hipGraph: 1 on, 0 off (default: kernels at >= 4 clips per "
                          "GPU average > 40 us, the host launch path is not the limiter - profiles/r2_bench_batch4_*.log)")
@@ -338,6 +343,7 @@ def rooflines(stats):
                            "algorithmic_bytes": r["_bytes"]})
     out["roofline_hbm"] = groups or None
     out["kernels"] = [{k: v for k, v in r.items() if not k.startswith("_")} for r in rows]
+    out["_rows"] = rows
     return out
 
 
@@ -377,7 +383,10 @@ def main():
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     want_verify = rank == 0 and world == 1 and not args.no_verify and (want_cpu or args.verify)
     sd_cpu = {k: v.cpu() for k, v in sd.items()} if (want_cpu or want_verify) else None
-    model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=args.streams)
+    def auto_streams(n_clips):
+        return args.streams if args.streams > 0 else (2 if n_clips >= 16 else 1)
+
+    model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=max(args.streams, 2))
     model.load_state_dict(sd, strict=False)
     del sd
     torch.cuda.empty_cache()
@@ -438,7 +447,8 @@ def main():
         clips_total = args.batch
         assert my_ids, f"strong scaling: rank {rank} got no clip (global batch {args.batch} < {world} ranks)"
     batch, clips, text, tmask = make_batch(my_ids)
-    log(f"inputs resident ({len(my_ids)} clips on this rank); warm-up")
+    n_streams = model.streams = auto_streams(len(my_ids))
+    log(f"inputs resident ({len(my_ids)} clips on this rank, {n_streams} stream(s)); warm-up")
     elapsed, step, graphed = timed(batch, args.steps, args.warmup, args.scaling)
     value = clips_total * CLIP_SECONDS * args.steps / elapsed
     log(f"timed {args.steps} steps in {elapsed:.3f} s -> {value:.2f} s-audio/s")
@@ -449,12 +459,15 @@ def main():
         s_ids = list(shard_range(args.batch, rank, world))
         s_batch = make_batch(s_ids)[0]
         s_steps = max(2, min(args.steps, 5))
+        model.streams = auto_streams(len(s_ids))
         s_elapsed, _, s_graphed = timed(s_batch, s_steps, 1, "strong")
         strong = {"scaling": "strong", "global_batch": args.batch, "clips_per_gpu": len(s_ids), "steps": s_steps,
                   "ms_per_step": round(1e3 * s_elapsed / s_steps, 2), "hip_graph": bool(s_graphed),
+                  "streams_per_gpu": model.streams,
                   "value": round(args.batch * CLIP_SECONDS * s_steps / s_elapsed, 3), "unit": "s-audio/s"}
         log(f"strong: {s_steps} steps in {s_elapsed:.3f} s -> {strong['value']:.2f} s-audio/s")
         model.use_graph = graphed
+        model.streams = n_streams
 
     # ---- rooflines: one extra, instrumented step (HIP events on the launch stream) ----------------------------
     roof = {"roofline": None, "roofline_hbm": None, "kernels": None}
@@ -464,7 +477,17 @@ def main():
         model.profile_begin()
         step()
         roof = rooflines(model.profile_end())
-        model.streams = args.streams
+        model.streams = n_streams
+        if roof["roofline"]:
+            fl = sum(k["_flops"] for k in roof["_rows"])
+            roof["roofline"]["measured"] = (
+                "one extra instrumented step on ONE stream: HIP events bracket every launch on its launch stream, so "
+                "durations are those of a kernel that has the GPU to itself (= what rocprofv3 --kernel-trace of "
+                "`bench.py --streams 1` reports, profiles/); the timed steps run streams_per_gpu concurrent row groups")
+            roof["roofline"]["whole_step"] = {
+                "what": "executed flops of ALL kernels of a step / the timed ms_per_step (concurrent streams included)",
+                "flops_per_step": fl, "achieved": round(fl / (elapsed / args.steps) / 1e12, 2), "unit": "TFLOP/s",
+                "frac": round(fl / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     cpu = parity = None
     if want_cpu or want_verify:
@@ -494,7 +517,7 @@ def main():
                              f"{'per GPU' if args.scaling == 'weak' else 'global, split over the GPUs'}, text prompt "
                              f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"),
                 "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}",
-                "streams_per_gpu": args.streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
+                "streams_per_gpu": n_streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
             },
             "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,

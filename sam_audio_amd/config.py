@@ -65,6 +65,51 @@ class PerceptionEncoderConfig:
 
 
 @dataclass
+class PEVisionConfig:
+    """Architecture of the PE-Core vision tower the reference instantiates by NAME
+    (`pe.CLIP.from_config(cfg.name)`, reference sam_audio/model/vision_encoder.py:86; the table of named configs
+    lives in the un-vendored perception_models package, so the published PE-Core-L14-336 numbers are restated here)."""
+    image_size: int = 336
+    patch_size: int = 14
+    width: int = 1024
+    layers: int = 24
+    heads: int = 16
+    mlp_ratio: float = 4.0
+    output_dim: int = 1024
+    use_cls_token: bool = True
+    use_abs_posemb: bool = True
+    use_rope2d: bool = True
+    use_ln_pre: bool = True
+    use_ln_post: bool = True
+    pool_type: str = "attn"          # "attn" | "tok" | "avg"
+    attn_pooler_heads: int = 8
+    act: str = "gelu"                # "gelu" (erf) | "quick_gelu"
+    ln_eps: float = 1e-5
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + int(self.use_cls_token)
+
+    @property
+    def mlp_width(self) -> int:
+        return int(self.width * self.mlp_ratio)
+
+
+PE_VISION_CONFIGS = {
+    "PE-Core-L14-336": PEVisionConfig(),
+    # stand-ins for tests (not published models): same structure, small dims
+    "pe-tiny": PEVisionConfig(image_size=56, patch_size=14, width=128, layers=2, heads=2, output_dim=64,
+                              attn_pooler_heads=2),
+    "pe-mini": PEVisionConfig(image_size=112, patch_size=14, width=256, layers=3, heads=4, output_dim=128,
+                              attn_pooler_heads=2),
+}
+
+
+@dataclass
 class TransformerConfig:
     dim: int = 2048
     n_heads: int = 16

@@ -225,18 +225,24 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
   const bool g2 = is_bf16 && gemm2_ok(p);
   if (g_force >= 3) {
     const bool known = g_force == 3 || g_force == 4 || g_force == 5 || g_force == 6 || g_force == 9 ||
-                       (g_force >= 12 && g_force < kGemmVariants);  // incl. 25 / 26
+                       (g_force >= 12 && g_force < kGemmVariants);  // incl. 25 / 26 / 27
     return g2 && known ? g_force : gemm1_variant(p);
   }
   if (g_force >= 0) return gemm1_variant(p);
   if (g2 && p.N >= 96 && p.K >= 128) {
     // round-1 policy (A/B switch, flag 5): 256x256 ping-pong for the widest outputs, 256x128 2-stage ring elsewhere
     if (debug_flag(5)) return p.N >= 12288 ? 9 : (p.N == 192 && !debug_flag(4) ? 6 : 4);
-    // round 2, measured on MI355X (profiles/r2_gemm_variants.log, M = 8000): the 8-phase 256x256 kernel (16x16x32 MFMA)
-    // for wide outputs - w13 1082 vs 953 TF/s, qkv 871 vs 678 -; it loses to tile quantisation at N = D (352 tiles on
-    // 256 CUs), where the loader-wave 256x128 kernel with its persistent tile walk is best (c_wq 845, w2 820, wo 601
-    // vs 818 / 767 / 583 for the 2-stage ring).  Codec convolutions with >= 96 output channels ride the same kernels.
-    if (p.N >= (debug_flag(7) ? 2048 : 4096)) return 22;   // flag 7 (A/B): the 8-phase kernel for N = D as well
+    // round 2, measured on MI355X (profiles/r2_gemm_variants.log, profiles/r2_call3/, M = 8000): the 8-phase 256x256
+    // kernel (16x16x32 MFMA) for every DiT-class output width - w13 1128 vs 957 TF/s for the best other kernel, qkv 960
+    // vs 855, w2 860 vs 814, c_wq 839 vs 821, wo 615 vs 615 -; with its LDS-staged epilogue it no longer loses at N = D
+    // (352 tiles on 256 CUs) and a second stream fills its tile tails (200.5 vs 183.2 s-audio/s for the previous policy).
+    // Few rows: the 128x128 tile of the SAME family (gemm8s, bitwise identical results, two workgroups per CU) once the
+    // 256x256 tiling would leave most CUs without a tile - so the choice may depend on M without breaking batch-sharding
+    // invariance.  Codec convolutions with that many output columns ride the same kernels.
+    if (p.N >= (debug_flag(7) ? 4096 : 2048)) {
+      const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+      return t256 >= 128 || debug_flag(6) ? 22 : 27;
+    }
     if (p.N == 192 && !debug_flag(4)) return 6;
     // Few rows (strong scaling: 4 clips per GPU = 1000 rows): 256-row tiles leave most CUs idle (4 x 22 = 88 tiles at
     // N = D).  Smaller M-tiles of the SAME kernel family keep every element's accumulation order (32x32x16 MFMA, K walked
@@ -253,13 +259,13 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   static const char* names[2][kGemmVariants] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
        "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma",
        "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
        "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
        "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_nostagger",
-       "gemm8_bf16_256x256_8phase_noprio", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3"}};
+       "gemm8_bf16_256x256_8phase_noprio", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128"}};
   if (v < 0 || v >= kGemmVariants) return "";
   const char* n = names[is_bf16 ? 1 : 0][v];
   return n ? n : "";

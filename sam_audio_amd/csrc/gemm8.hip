@@ -49,6 +49,117 @@ __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha)
   return v;
 }
 
+// Epilogue of the 16x16x32 family (contract of GemmParams, common.h).  A wave owns NH x 64 rows x 64 columns as
+// acc[NH * 4 m-fragments][4 n-fragments]; `stg` = 16 KiB of LDS private to the wave (free after the K loop).
+// Swapped operands give D[n][m]: a lane holds row m = lr of fragment i and columns 4*lg .. 4*lg+3 of fragment j, i.e.
+// one accumulator register group covers 16 rows x 64 B - a store instruction straight from that layout touches 16
+// different cache lines for 32 B each.  The tile is therefore re-laid through LDS (rows of 64 fp32 columns, 16-byte
+// chunks XOR-swizzled with the row): after it a lane owns 4 consecutive columns and the 16 lanes of a row group cover
+// 256 contiguous bytes, so residual / gate loads and fp32 / bf16 stores move whole cache lines per row
+// (MI355X_MICROARCH.md "store-ISSUE-bound" epilogues, cdna_hip_programming.md T21).
+template <int NH>
+__device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH * 4][4], char* const stg, const int b,
+                                          const int m_wave0, const int n_wave0, const int lane) {
+  const int lr = lane & 15, lg = lane >> 4;
+  const long bM = (long)b * p.M;
+  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
+             has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
+  const int n_out = p.swiglu ? p.N >> 1 : p.N;
+  const int cpr = p.swiglu ? 8 : 16;                                  // 4-column chunks per staged row
+  const int col0 = p.swiglu ? n_wave0 >> 1 : n_wave0;                 // first output column of this wave
+  const int rsub = p.swiglu ? lane >> 3 : lane >> 4, csub = p.swiglu ? lane & 7 : lane & 15;
+  const int rows_per_it = 64 / cpr;
+#pragma unroll
+  for (int half = 0; half < NH; ++half) {
+    // write phase: rows half*64 + i*16 + lr of the wave's rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t a = acc[half * 4 + i][j];
+        if (p.swiglu) {  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
+          if (j & 1) continue;
+          const f32x4_t g = acc[half * 4 + i][j | 1];
+          const int chunk = (j >> 1) * 4 + lg;
+          *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) =
+              make_float4(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1], silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
+        } else {
+          const int chunk = j * 4 + lg;
+          *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+      }
+    }
+    __syncthreads();
+    // read phase: rows_per_it rows x cpr chunks per wave instruction
+    for (int r0 = 0; r0 < 64; r0 += rows_per_it) {
+      const int row = r0 + rsub;
+      const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
+      const int m = m_wave0 + half * 64 + row;
+      const int n = col0 + csub * 4;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : p.M - 1;
+      const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
+      float v[4] = {sv.x, sv.y, sv.z, sv.w};
+      float4 bb, gg, tt, rr, sa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_bias) bb = *(const float4*)(p.bias + ch);
+      if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
+      if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
+      if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
+      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
+      if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+      if (has_gate) {
+        if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
+        v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+      const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
+                  a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
+      bool ok = m_ok && n < n_out;
+      if (p.c_ld_rel) {
+        const long erel = (long)m * p.c_ld_rel + n;
+        ok = ok && erel >= p.c_lo && erel < p.c_hi;
+      }
+      if (ok) {
+        if (p.out_f32) {
+          float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
+          *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (p.out_act) {
+          bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
+          store4<bf16_t>(arow + n, a0, a1, a2, a3);
+        }
+      }
+    }
+    if (half + 1 < NH) __syncthreads();  // the reads of this half precede the next half's writes
+  }
+}
+
+// workgroup -> tile: contiguous run of tiles per XCD, GM M-tiles x all N-tiles per group (as gemm2.hip)
+__device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, const int BN, int& b, int& tm, int& tn) {
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int per_batch = tiles_m * tiles_n;
+  const int total = per_batch * p.nbatch;
+  const int bid = blockIdx.x;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  b = L / per_batch;
+  const int l2 = L - b * per_batch;
+  const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
+  const int per_group = GM * tiles_n;
+  const int gi = l2 / per_group;
+  const int first_m = gi * GM;
+  const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+  const int in_grp = l2 - gi * per_group;
+  tm = first_m + in_grp % gsz;
+  tn = in_grp / gsz;
+}
+
 }  // namespace
 
 // STAGGER: the two wave groups run one barrier apart (off: all 8 waves read together, then multiply together);
@@ -64,28 +175,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: one of each group per SIMD
   const int lr = lane & 15, lg = lane >> 4;
 
-  // ---- tile raster: contiguous run of tiles per XCD, GM M-tiles x all N-tiles per group (as gemm2.hip) ----
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int per_batch = tiles_m * tiles_n;
   int b, tm, tn;
-  {
-    const int total = per_batch * p.nbatch;
-    const int bid = blockIdx.x;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    b = L / per_batch;
-    const int l2 = L - b * per_batch;
-    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
-    const int per_group = GM * tiles_n;
-    const int gi = l2 / per_group;
-    const int first_m = gi * GM;
-    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
-    const int in_grp = l2 - gi * per_group;
-    tm = first_m + in_grp % gsz;
-    tn = in_grp / gsz;
-  }
+  tile_raster8(p, BM, BN, b, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging bookkeeping ---------------------------------------------------------------------------------
@@ -239,93 +330,122 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
 #undef SA_GEMM8_MMA
 #undef SA_GEMM8_READ_W
 
-  // ---- epilogue (contract of GemmParams, common.h) -------------------------------------------------------------
-  // Swapped operands give D[n][m]: a lane holds row m = lr of fragment i and columns 4*lg .. 4*lg+3 of fragment j, i.e.
-  // one accumulator register group covers 16 rows x 64 B - a store instruction straight from that layout touches 16
-  // different cache lines for 32 B each.  The tile is therefore re-laid through LDS (free after the K loop; 16 KiB per
-  // wave, rows of 64 fp32 columns, 16-byte chunks XOR-swizzled with the row): after it a lane owns 4 consecutive columns
-  // and the 16 lanes of a row group cover 256 contiguous bytes, so residual / gate loads and fp32 / bf16 stores move
-  // whole cache lines per row (MI355X_MICROARCH.md "store-ISSUE-bound" epilogues, cdna_hip_programming.md T21).
+  // ---- epilogue (contract of GemmParams, common.h): shared with gemm8s_kernel below ----------------------------
   __syncthreads();
-  char* const stg = smem + wave * 16384;
-  const long bM = (long)b * p.M;
-  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
-             has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
-  const int n_out = p.swiglu ? p.N >> 1 : p.N;
-  const int cpr = p.swiglu ? 8 : 16;                                  // 4-column chunks per staged row
-  const int col0 = p.swiglu ? (n0 + wc * 64) >> 1 : n0 + wc * 64;     // first output column of this wave
-  const int rsub = p.swiglu ? lane >> 3 : lane >> 4, csub = p.swiglu ? lane & 7 : lane & 15;
-  const int rows_per_it = 64 / cpr;
+  epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+// gemm8s: the SAME arithmetic as gemm8_kernel on a 128 x 128 tile - 16x16x32 MFMA with swapped operands, identical
+// fragment <-> k mapping, K walked in slabs of 64 with the two k-steps of a slab in the same order - so an output element
+// is accumulated bit for bit as the 256 x 256 kernel accumulates it.  The tile policy (gemm.hip gemm_variant) may
+// therefore switch between the two with the number of rows of a launch (few rows: strong scaling at 4 clips per GPU,
+// the Judge's and the vision tower's small batches) without breaking batch-sharding invariance.
+// 4 waves as 2 (M) x 2 (N), 64 x 64 outputs each; two 32 KiB stages (A tile | W tile) = 64 KiB of LDS and 256 threads, so
+// two workgroups share a CU and one's barriers / epilogue are covered by the other's K loop; a plain double buffer: the
+// DMA of K-tile t+1 is issued before the reads of K-tile t, one counted vmcnt and two barriers per K-tile.
+__global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p) {
+  constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];  // [stage][A tile, W tile]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  int b, tm, tn;
+  tile_raster8(p, BM, BN, b, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // staging: wave w moves rows 32w .. 32w+31 of both tiles as 4 + 4 wave instructions of 8 rows (1 KiB each):
+  // lane -> row 32w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
+  const int r8 = lane >> 3;
+  const bf16_t* a_row[4];
+  const bf16_t* w_row[4];
+  int a_in[4];
+  long a_tap[4];
+  {
+    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    // write phase: rows half*64 + i*16 + lr of the wave's 128
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i * 16 + lr;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4_t a = acc[half * 4 + i][j];
-        if (p.swiglu) {  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
-          if (j & 1) continue;
-          const f32x4_t g = acc[half * 4 + i][j | 1];
-          const int chunk = (j >> 1) * 4 + lg;
-          *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) =
-              make_float4(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1], silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
-        } else {
-          const int chunk = j * 4 + lg;
-          *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) = make_float4(a[0], a[1], a[2], a[3]);
-        }
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int row = wave * 32 + q * 8 + r8;
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      a_row[q] = A + (long)m * p.lda;
+      int n = n0 + row;
+      n = n < p.N ? n : p.N - 1;
+      w_row[q] = W + (long)n * p.K + chunk * 8;
+      a_in[q] = chunk * 8;
+      a_tap[q] = 0;
+      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
     }
-    __syncthreads();
-    // read phase: rows_per_it rows x cpr chunks per wave instruction
-    for (int r0 = 0; r0 < 64; r0 += rows_per_it) {
-      const int row = r0 + rsub;
-      const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
-      const int m = m0 + wr * 128 + half * 64 + row;
-      const int n = col0 + csub * 4;
-      const bool m_ok = m < p.M;
-      const int mc = m_ok ? m : p.M - 1;
-      const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
-      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
-      float v[4] = {sv.x, sv.y, sv.z, sv.w};
-      float4 bb, gg, tt, rr, sa = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_bias) bb = *(const float4*)(p.bias + ch);
-      if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
-      if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
-      if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
-      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
-      if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-      if (has_gate) {
-        if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
-        v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-      const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
-                  a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
-      bool ok = m_ok && n < n_out;
-      if (p.c_ld_rel) {
-        const long erel = (long)m * p.c_ld_rel + n;
-        ok = ok && erel >= p.c_lo && erel < p.c_hi;
-      }
-      if (ok) {
-        if (p.out_f32) {
-          float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
-          *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
-        }
-        if (p.out_act) {
-          bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
-          store4<bf16_t>(arow + n, a0, a1, a2, a3);
-        }
-      }
-    }
-    if (half == 0) __syncthreads();  // the reads of this half precede the next half's writes
   }
+  const int nt = p.K / BK;
+  auto stage = [&](int buf, int kt) {  // K-tile kt (the a_in / a_tap state points at it) -> stage buf
+    char* dst = smem + buf * (2 * TB) + wave * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma16_8(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma16_8(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a_in[q] += BK;
+      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto frag = [&](const char* tile_base, int row, int ks) -> bf16x8_t {
+    return *(const bf16x8_t*)(tile_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
+  };
+
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int cb = t & 1;
+    if (t + 1 < nt) {
+      stage(cb ^ 1, t + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 loads just issued stay in flight; K-tile t has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* At = smem + cb * (2 * TB);
+    const char* Wt = At + TB;
+    bf16x8_t af[4][2], wf[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        af[i][ks] = frag(At, wr * 64 + i * 16 + lr, ks);
+        wf[i][ks] = frag(Wt, wc * 64 + i * 16 + lr, ks);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave holds its fragments: stage cb may be overwritten by K-tile t+2
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+  }
+  __syncthreads();
+  epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
+hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
+  const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
+  hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const dim3 grid((unsigned)tiles), block(512);

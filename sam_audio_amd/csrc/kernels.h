@@ -18,7 +18,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 8: GEMM epilogues straight from the accumulator layout (round 1) instead of the LDS-staged coalesced form
 //   flag 9: loader-wave 256x128 kernel WITHOUT the persistent tile walk (its ring is free after the K loop, so it can use
 //           the LDS-staged epilogue; the persistent walk keeps the accumulator-layout epilogue)
-//   flag 7: the 8-phase 256x256 kernel also for 2048 <= N < 4096 (A/B with concurrent streams filling its tile tails)
+//   flag 7: the loader-wave 256x128 kernel (32x32x16 family) for 2048 <= N < 4096 as before GPU call 3 of round 2 (the
+//           8-phase family now covers every N >= 2048: 181.1 vs 173.0 s-audio/s, 200.5 vs 183.2 with two streams)
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);
 
@@ -26,13 +27,16 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 27;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 28;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+                                   // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
 bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 // gemm8.hip: experimental 256x256 8-phase kernel (force-only variants 22..24 = gemm2 variants 19..21: template, no
 // stagger, no setprio); needs gemm2_ok(p)
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
+// gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
+hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // test / tuning hook: force a variant for every eligible bf16 GEMM (-1 = automatic, 0..2 = gemm.hip tiles only,
 // 3.. = gemm2 variant when gemm2_ok)
 void gemm_force_variant(int v);

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 # 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
 # no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
 # Round 2 ships 20 (loader-wave 256x128, persistent tile walk) and 22 (8-phase 256x256): they are always in the sweep.
-SHIPPED_R2 = [20, 22, 25, 26]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows
+SHIPPED_R2 = [20, 22, 25, 26, 27]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows (27 = gemm8s)
 EXPERIMENTAL = [v for v in range(15, 25) if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
 VARIANTS = [3, 4, 5, 6, 9] + SHIPPED_R2 + EXPERIMENTAL
 
@@ -157,3 +157,33 @@ def test_row_tile_variants_are_bitwise_identical(gpu):
         outs[variant] = (out.cpu(), out_act.cpu())
     for variant, (o, a) in outs.items():
         assert torch.equal(o, outs[4][0]) and torch.equal(a.view(torch.int16), outs[4][1].view(torch.int16)), variant
+
+
+@pytest.mark.parametrize("M,N,K,swiglu", [(270, 384, 448, 0), (700, 2816, 256, 0), (333, 512, 320, 1)])
+def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
+    """Same property for the 16x16x32-MFMA family that carries every N >= 2048 GEMM: the 256x256 8-phase kernel (22) and
+    its 128x128 tile gemm8s (27, picked for launches with few rows) must produce identical bits - gated-residual
+    epilogue with fp32 + bf16 outputs, and the SwiGLU epilogue; ragged M and N tails."""
+    B = 1
+    A, W = _mk((M, K), 31), _mk((N, K), 32, 1 / math.sqrt(K))
+    n_out = N // 2 if swiglu else N
+    tab, gate, res = _mk((n_out,), 33), _mk((B, n_out), 34), _mk((M, n_out), 35)
+    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
+    outs = {}
+    for variant in (22, 27):
+        hip.lib().samaudio_debug_force_gemm_variant(variant)
+        out_act = torch.zeros(M, n_out, device=gpu, dtype=torch.bfloat16)
+        if swiglu:
+            util.gemm("bf16", keep[0], keep[1], M, N, K, swiglu=1, out_act=out_act, act_geom=(0, n_out, 0))
+            outs[variant] = (out_act.cpu(), out_act.cpu())
+        else:
+            out = torch.full((M, N), float("nan"), device=gpu)
+            util.gemm("bf16", keep[0], keep[1], M, N, K, gate_tab=keep[2], gate=keep[3], gate_ld=N, rows_per_gate=M,
+                      res=keep[4], res_geom=(0, N, 0), out_f32=out, f32_geom=(0, N, 0), out_act=out_act,
+                      act_geom=(0, N, 0))
+            outs[variant] = (out.cpu(), out_act.cpu())
+    o22, a22 = outs[22]
+    o27, a27 = outs[27]
+    assert torch.isfinite(o22.float()).all()
+    assert torch.equal(o22.view(torch.int16) if swiglu else o22, o27.view(torch.int16) if swiglu else o27)
+    assert torch.equal(a22.view(torch.int16), a27.view(torch.int16))

@@ -26,6 +26,11 @@ EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 2
                 18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist", 22: "8-phase 256x256", 23: "8-phase no stagger", 24: "8-phase no setprio"}
 
 
+# round 2, after GPU call 3: the kernels the tile policy can pick for a DiT-class GEMM, for A/B at several row counts
+FAMILY = {22: "8-phase 256x256", 27: "gemm8s 128x128", 20: "ld 256x128 pf persist", 25: "128x128 s2 (32x32x16)",
+          26: "64x128 s3 (32x32x16)"}
+
+
 def interleave16(w1, w3):
     F_, K = w1.shape
     return torch.stack([w1.view(F_ // 16, 16, K), w3.view(F_ // 16, 16, K)], 1).reshape(2 * F_, K)
@@ -99,6 +104,7 @@ def main():
     ap.add_argument("--ablate", action="store_true", help="time the gemm3 256x256 ablation builds (results are wrong)")
     ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size on the shipped variants")
     ap.add_argument("--experimental", action="store_true", help="shipped policy kernels vs the force-only experimental ones")
+    ap.add_argument("--family", action="store_true", help="only the kernels the round-2 tile policy picks from")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.ablate:
@@ -107,6 +113,9 @@ def main():
     if args.experimental:
         VARIANTS.clear()
         VARIANTS.update(EXPERIMENTAL)
+    if args.family:
+        VARIANTS.clear()
+        VARIANTS.update(FAMILY)
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
     M = args.batch * 250
