@@ -19,48 +19,52 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // bf16 MFMA self-attention.  grid (Tp/64, H, B), 256 threads (4 waves x 16 query rows).
 // ---------------------------------------------------------------------------------------------------
 // NW waves x 16 query rows per workgroup: NW = 8 (128 rows) halves the K / V^T staging traffic and barrier count per
-// query row; it needs Tp % 128 == 0 (the launcher falls back to NW = 4 otherwise).
-template <int NW>
+// query row; it needs Tp % 128 == 0 (the launcher falls back to NW = 4 otherwise).  HD = head dim: 128 (DiT, PE-AV
+// transformers, the vision tower's pooling head) or 64 (PE-Core vision tower blocks); scale = HD^-0.5.
+template <int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt,
                                                                  const unsigned char* __restrict__ key_mask,
                                                                  bf16_t* __restrict__ out, int T, int Tp, int H) {
-  __shared__ __attribute__((aligned(16))) char Ks[64 * 256];   // [key][128 d] bf16, chunk ^= key & 15
-  __shared__ __attribute__((aligned(16))) char Vs[128 * 128];  // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
+  constexpr int CH = HD / 8;       // 16-byte chunks per K row
+  constexpr int KS = HD / 32;      // k-steps of the S = Q K^T contraction
+  constexpr int NF = HD / 16;      // output fragments (16 head channels each)
+  __shared__ __attribute__((aligned(16))) char Ks[64 * HD * 2];   // [key][HD d] bf16, chunk ^= key & (CH - 1)
+  __shared__ __attribute__((aligned(16))) char Vs[HD * 128];      // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
   __shared__ __attribute__((aligned(16))) char Ps[NW * 16 * 128];  // per wave [16 q][64 keys] bf16
   const int q0 = blockIdx.x * (16 * NW), h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const long bh = (long)b * H + h;
-  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(HD)
 
-  bf16x8_t qf[4];
+  bf16x8_t qf[KS];
   {
-    const bf16_t* qrow = Q + (bh * Tp + q0 + wave * 16 + lr) * 128;
+    const bf16_t* qrow = Q + (bh * Tp + q0 + wave * 16 + lr) * HD;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
   }
   float m_i[4], l_i[4];
-  f32x4_t o[8];
+  f32x4_t o[NF];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { m_i[r] = -INFINITY; l_i[r] = 0.f; }
 #pragma unroll
-  for (int n = 0; n < 8; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < NF; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   char* Pw = Ps + wave * 2048;
 
   for (int kt = 0; kt < Tp; kt += 64) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 16 / NW; ++it) {
+    for (int it = 0; it < HD / (8 * NW); ++it) {
       const int idx = tid + 64 * NW * it;
       {
-        const int row = idx >> 4, c = idx & 15;
-        const uint4 v = *(const uint4*)(K + (bh * Tp + kt + row) * 128 + c * 8);
-        *(uint4*)(Ks + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+        const int row = idx / CH, c = idx % CH;
+        const uint4 v = *(const uint4*)(K + (bh * Tp + kt + row) * HD + c * 8);
+        *(uint4*)(Ks + row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4)) = v;
       }
       {
         const int d = idx >> 3, c = idx & 7;
-        const uint4 v = *(const uint4*)(Vt + (bh * 128 + d) * Tp + kt + c * 8);
+        const uint4 v = *(const uint4*)(Vt + (bh * HD + d) * Tp + kt + c * 8);
         *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = v;
       }
     }
@@ -72,8 +76,8 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       s[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       const int row = nb * 16 + lr;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + row * 256 + (((ks * 4 + lg) ^ (row & 15)) << 4));
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4));
         s[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[nb], 0, 0, 0);
       }
     }
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       l_i[r] = l_i[r] * alpha + rs;
       m_i[r] = m_new;
 #pragma unroll
-      for (int n = 0; n < 8; ++n) o[n][r] *= alpha;
+      for (int n = 0; n < NF; ++n) o[n][r] *= alpha;
       // P -> LDS as an A operand image: row q = lg*4 + r, key = nb*16 + lr
       const int q = lg * 4 + r;
 #pragma unroll
@@ -122,61 +126,62 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       const int c = ks * 4 + lg;
       const bf16x8_t pf = *(const bf16x8_t*)(Pw + lr * 128 + ((c ^ ((lr >> 1) & 7)) << 4));
 #pragma unroll
-      for (int n = 0; n < 8; ++n) {
+      for (int n = 0; n < NF; ++n) {
         const int d = n * 16 + lr;
         const bf16x8_t vf = *(const bf16x8_t*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
         o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
       }
     }
   }
-  const int D = H * 128;
+  const int D = H * HD;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int q = q0 + wave * 16 + lg * 4 + r;
     if (q >= T) continue;
     const float inv = 1.f / l_i[r];
-    bf16_t* orow = out + ((long)b * T + q) * D + h * 128;
+    bf16_t* orow = out + ((long)b * T + q) * D + h * HD;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) orow[n * 16 + lr].v = f2bf(o[n][r] * inv);
+    for (int n = 0; n < NF; ++n) orow[n * 16 + lr].v = f2bf(o[n][r] * inv);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // fp32 self-attention (parity path).  grid (ceil(T/32), H, B), 256 threads: thread = (query qi, lane-in-8 sub).
 // ---------------------------------------------------------------------------------------------------
+template <int HD>
 __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                             const float* __restrict__ Vt,
                                                             const unsigned char* __restrict__ key_mask,
                                                             float* __restrict__ out, int T, int Tp, int H) {
-  __shared__ float Qs[32][129];
-  __shared__ float KV[128 * 65];  // K tile as [64][129] (8256 floats) or V^T tile as [128][65] (8320 floats)
+  __shared__ float Qs[32][HD + 1];
+  __shared__ float KV[HD * 65];  // K tile as [64][HD + 1] or V^T tile as [HD][65]
   __shared__ float Ss[32][65];
   const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, qi = tid >> 3, sub = tid & 7;
   const long bh = (long)b * H + h;
-  const float scale = 0.08838834764831845f;
-  for (int idx = tid; idx < 32 * 128; idx += 256) {
-    const int r = idx >> 7, d = idx & 127;
+  const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;
+  for (int idx = tid; idx < 32 * HD; idx += 256) {
+    const int r = idx / HD, d = idx % HD;
     const int q = q0 + r;
-    Qs[r][d] = q < Tp ? Q[(bh * Tp + q) * 128 + d] : 0.f;
+    Qs[r][d] = q < Tp ? Q[(bh * Tp + q) * HD + d] : 0.f;
   }
-  float m_i = -INFINITY, l_i = 0.f, o[16];
+  float m_i = -INFINITY, l_i = 0.f, o[HD / 8];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) o[i] = 0.f;
+  for (int i = 0; i < HD / 8; ++i) o[i] = 0.f;
   for (int kt = 0; kt < Tp; kt += 64) {
     __syncthreads();
-    for (int idx = tid; idx < 64 * 128; idx += 256) {
-      const int r = idx >> 7, d = idx & 127;
-      KV[r * 129 + d] = K[(bh * Tp + kt + r) * 128 + d];
+    for (int idx = tid; idx < 64 * HD; idx += 256) {
+      const int r = idx / HD, d = idx % HD;
+      KV[r * (HD + 1) + d] = K[(bh * Tp + kt + r) * HD + d];
     }
     __syncthreads();
     float sc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) sc[u] = 0.f;
-    for (int d = 0; d < 128; ++d) {
+    for (int d = 0; d < HD; ++d) {
       const float qv = Qs[qi][d];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sc[u] = fmaf(qv, KV[(sub + 8 * u) * 129 + d], sc[u]);
+      for (int u = 0; u < 8; ++u) sc[u] = fmaf(qv, KV[(sub + 8 * u) * (HD + 1) + d], sc[u]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -203,40 +208,52 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
     l_i = l_i * alpha + rs;
     m_i = m_new;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[i] *= alpha;
+    for (int i = 0; i < HD / 8; ++i) o[i] *= alpha;
     __syncthreads();  // scores written, K tile no longer needed
-    for (int idx = tid; idx < 128 * 64; idx += 256) {
+    for (int idx = tid; idx < HD * 64; idx += 256) {
       const int d = idx >> 6, kk = idx & 63;
-      KV[d * 65 + kk] = Vt[(bh * 128 + d) * Tp + kt + kk];
+      KV[d * 65 + kk] = Vt[(bh * HD + d) * Tp + kt + kk];
     }
     __syncthreads();
     for (int kk = 0; kk < 64; ++kk) {
       const float pv = Ss[qi][kk];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[i] = fmaf(pv, KV[(sub + 8 * i) * 65 + kk], o[i]);
+      for (int i = 0; i < HD / 8; ++i) o[i] = fmaf(pv, KV[(sub + 8 * i) * 65 + kk], o[i]);
     }
   }
   const int q = q0 + qi;
   if (q < T) {
     const float inv = 1.f / l_i;
-    float* orow = out + ((long)b * T + q) * (H * 128) + h * 128;
+    float* orow = out + ((long)b * T + q) * (H * HD) + h * HD;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) orow[sub + 8 * i] = o[i] * inv;
+    for (int i = 0; i < HD / 8; ++i) orow[sub + 8 * i] = o[i] * inv;
   }
+}
+
+template <int HD>
+static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
+                                          void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
+  if (bf16 && Tp % 128 == 0)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<8, HD>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else if (bf16)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<4, HD>), dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q,
+                       (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else
+    hipLaunchKernelGGL(self_attn_f32_kernel<HD>, dim3((T + 31) / 32, H, B), dim3(256), 0, st, (const float*)Q,
+                       (const float*)K, (const float*)Vt, key_mask, (float*)out, T, Tp, H);
+  return hipGetLastError();
 }
 
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                  void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
-  if (bf16 && Tp % 128 == 0)
-    hipLaunchKernelGGL(self_attn_bf16_kernel<8>, dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
-  else if (bf16)
-    hipLaunchKernelGGL(self_attn_bf16_kernel<4>, dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q,
-                       (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
-  else
-    hipLaunchKernelGGL(self_attn_f32_kernel, dim3((T + 31) / 32, H, B), dim3(256), 0, st, (const float*)Q,
-                       (const float*)K, (const float*)Vt, key_mask, (float*)out, T, Tp, H);
-  return hipGetLastError();
+  return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st);
+}
+hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
+                                    void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st) {
+  if (head_dim == 64) return launch_self_attention_t<64>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st);
+  if (head_dim == 128) return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st);
+  return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -51,6 +51,9 @@ template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, f
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// nn.GELU() (erf form) and CLIP's x * sigmoid(1.702 x): the vision tower's MLP activations
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float snake_f(float x, float a) {
   float s = sinf(a * x);
   return x + s * s / (a + 1e-9f);
@@ -90,7 +93,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- epilogue activation codes --------------------------------------------------------------
-enum : int { ACT_NONE = 0, ACT_SNAKE = 1, ACT_TANH = 2, ACT_SILU = 3 };
+enum : int { ACT_NONE = 0, ACT_SNAKE = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_GELU = 4, ACT_QUICK_GELU = 5 };
 
 // ---- generalised (implicit-convolution) GEMM ---------------------------------------------------
 // C[b][m][n] = sum_k A(b, m, k) * W[n][k]

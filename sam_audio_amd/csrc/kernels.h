@@ -65,6 +65,10 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                  void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st);
 
+// the same with head_dim 64 or 128 (Q, K [B,H,Tp,hd], Vt [B,H,hd,Tp], out [B*T, H*hd]; scale hd^-0.5)
+hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
+                                    void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st);
+
 // in-place per-(row, head) RMSNorm of x[rows, ld] columns [col0, col0 + H*128)
 hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
                            hipStream_t st);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsamaudio_hip.so")
 F32, BF16 = 0, 1
 DT_F32, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3
 ODE_EULER, ODE_MIDPOINT = 0, 1
-ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU = 0, 1, 2, 3
+ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
 
 ERR_ARG, ERR_WEIGHT, ERR_WORKSPACE, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5
 

@@ -289,3 +289,58 @@ def init_frame_state_dict(cfg, seed: int = 0, device="cpu") -> Dict[str, torch.T
     sd["text_audio_logit_scale"] = torch.full((1,), 4.0, device=dev)
     sd["text_audio_logit_bias"] = torch.full((1,), -0.5, device=dev)
     return sd
+
+
+def init_vision_state_dict(cfg, seed: int = 0, device="cpu", prefix: str = "") -> Dict[str, torch.Tensor]:
+    """Random weights of the PE-Core vision tower (config.PEVisionConfig) under the key names `pe.CLIP`'s vision tower
+    uses below `visual.` (reference sam_audio/model/vision_encoder.py:86: `self.model = pe.CLIP.from_config(name)`, so a
+    reference checkpoint carries them as `vision_encoder.model.visual.*`).  Scales: width**-0.5 for the class / position
+    tables and `proj` (the published init), U(+-1/sqrt(fan_in)) for linear layers, LayerNorm weights around 1."""
+    dev = torch.device(device)
+    gen = None
+    if dev.type != "meta":
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+    W, Fw = cfg.width, cfg.mlp_width
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out_f, in_f):
+        b = 1.0 / math.sqrt(in_f)
+        sd[name + ".weight"] = _uniform(gen, (out_f, in_f), b, dev)
+        sd[name + ".bias"] = _uniform(gen, (out_f,), b, dev)
+
+    def ln(name):
+        sd[name + ".weight"] = 1.0 + _normal(gen, (W,), 0.1, dev)
+        sd[name + ".bias"] = _normal(gen, (W,), 0.1, dev)
+
+    def mha_block(name):
+        b = 1.0 / math.sqrt(W)
+        sd[name + ".in_proj_weight"] = _uniform(gen, (3 * W, W), b, dev)
+        sd[name + ".in_proj_bias"] = _uniform(gen, (3 * W,), b, dev)
+        lin(name + ".out_proj", W, W)
+
+    kk = 3 * cfg.patch_size * cfg.patch_size
+    sd["conv1.weight"] = _uniform(gen, (W, 3, cfg.patch_size, cfg.patch_size), 1.0 / math.sqrt(kk), dev)
+    if cfg.use_cls_token:
+        sd["class_embedding"] = _normal(gen, (W,), W ** -0.5, dev)
+    if cfg.use_abs_posemb:
+        sd["positional_embedding"] = _normal(gen, (cfg.tokens, W), W ** -0.5, dev)
+    if cfg.use_ln_pre:
+        ln("ln_pre")
+    for i in range(cfg.layers):
+        p = f"transformer.resblocks.{i}."
+        ln(p + "ln_1")
+        mha_block(p + "attn")
+        ln(p + "ln_2")
+        lin(p + "mlp.c_fc", Fw, W)
+        lin(p + "mlp.c_proj", W, Fw)
+    if cfg.use_ln_post:
+        ln("ln_post")
+    if cfg.pool_type == "attn":
+        sd["attn_pool.probe"] = _normal(gen, (1, 1, W), 1.0, dev)
+        mha_block("attn_pool.attn")
+        ln("attn_pool.layernorm")
+        lin("attn_pool.mlp.c_fc", Fw, W)
+        lin("attn_pool.mlp.c_proj", W, Fw)
+    sd["proj"] = _normal(gen, (W, cfg.output_dim), W ** -0.5, dev)
+    return {prefix + k: v for k, v in sd.items()}
