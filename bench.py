@@ -82,6 +82,10 @@ def parse(argv=None):
                          "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
     ap.add_argument("--predict-spans", action="store_true",
                     help="configs[3]: run the PE-A-Frame span predictor first (random weights, stand-in dims)")
+    ap.add_argument("--visual", action="store_true",
+                    help="BASELINE.json configs[4]: visual prompting - every clip comes with a 250-frame 336x336 uint8 video "
+                         "(left half masked out), encoded by the PE-Core-L14-336 tower on the HIP library inside the step "
+                         "(random weights); use with --batch 4")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU-only: exercise the self-launch + sharding + gather plumbing on gloo (tests/test_bench_spawn_cpu.py)")
     return ap.parse_args(argv)
@@ -399,8 +403,32 @@ def main():
         """This rank's synthetic clips, resident in HBM before the timed region."""
         clips = [synthetic_clip(i, n_samples) for i in clip_ids]
         text, tmask = synthetic_text_features(len(clip_ids), args.text_len, seed=7 + rank)
-        b = proc(descriptions=["sound"] * len(clip_ids), audios=clips, text_features=text, text_mask=tmask)
+        videos = None
+        if args.visual:  # SURVEY.md section 8d: uint8 video [250, 3, 336, 336] uniform random, mask = left half
+            S = cfg.vision_encoder.image_size
+            vids, masks = [], []
+            for i in clip_ids:
+                g = torch.Generator().manual_seed(4321 + i)
+                vids.append(torch.randint(0, 256, (250, 3, S, S), generator=g, dtype=torch.uint8))
+                m = torch.zeros(250, 1, S, S, dtype=torch.uint8)
+                m[..., : S // 2] = 1
+                masks.append(m)
+            videos = proc.mask_videos(vids, masks)
+        b = proc(descriptions=["sound"] * len(clip_ids), audios=clips, masked_videos=videos, text_features=text,
+                 text_mask=tmask)
         return b.to(dev), clips, text, tmask
+
+    vision = None
+    if args.visual:
+        from sam_audio_amd.config import PE_VISION_CONFIGS
+        from sam_audio_amd.synthetic import init_vision_state_dict
+        from sam_audio_amd.vision_encoder import PerceptionEncoder
+        pe_cfg = PE_VISION_CONFIGS[cfg.vision_encoder.name]
+        model.vision_encoder = PerceptionEncoder(cfg.vision_encoder, device=dev, precision=args.precision)
+        model.vision_encoder.load_state_dict(
+            {"model.visual." + k: v for k, v in init_vision_state_dict(pe_cfg, seed=5, device=dev).items()})
+        log(f"vision tower {cfg.vision_encoder.name} attached ({pe_cfg.layers} layers, width {pe_cfg.width}, "
+            f"{pe_cfg.tokens} tokens per frame)")
 
     if args.candidates > 1:
         model.text_ranker = build_judge_ranker(cfg, args.precision, dev)
@@ -489,6 +517,27 @@ def main():
                 "flops_per_step": fl, "achieved": round(fl / (elapsed / args.steps) / 1e12, 2), "unit": "TFLOP/s",
                 "frac": round(fl / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
+    # ---- visual prompting: the tower alone, HIP events around the frames of ONE video (250 frames) ---------------
+    if rank == 0 and args.visual:
+        from sam_audio_amd.vision_tower import tower_flops
+        frames = model.vision_encoder.transform(batch.masked_video[0])
+        model.vision_encoder.encode(frames)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            model.vision_encoder.encode(frames)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        fl = tower_flops(pe_cfg, frames.shape[0])
+        vision = {"tower": cfg.vision_encoder.name, "frames": int(frames.shape[0]), "ms": round(ms, 2),
+                  "flops": fl, "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                  "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "bound": "mfma",
+                  "frames_per_s": round(frames.shape[0] / (ms * 1e-3), 1),
+                  "what": "encode_image of one 250-frame video after resize/normalise: algorithmic flops of the tower "
+                          "(all GEMMs + attention) / HIP-event time on the current stream"}
+        log(f"vision tower: {vision['ms']} ms per 250 frames, {vision['achieved']} TFLOP/s")
+
     cpu = parity = None
     if want_cpu or want_verify:
         R = min(2, len(my_ids))
@@ -515,11 +564,16 @@ def main():
                 "workload": (f"sam-audio-{args.size} (stand-in dims D={tcfg.dim} H={tcfg.n_heads} L={tcfg.n_layers} "
                              f"F={tcfg.ffn_hidden}) {args.precision}, batch={args.batch}x10 s clips "
                              f"{'per GPU' if args.scaling == 'weak' else 'global, split over the GPUs'}, text prompt "
-                             f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"),
+                             f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"
+                             + (", visual prompt: 250 masked video frames per clip through the PE-Core tower" if args.visual
+                                else "")),
                 "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}",
                 "streams_per_gpu": n_streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
+                "visual_prompt": (f"{cfg.vision_encoder.name} tower, 250 frames x 336x336 per clip, encoded inside the step"
+                                  if args.visual else None),
             },
+            "vision_tower": vision,
             "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,
             "parity_check": parity, "strong_scaling": strong, "kernels": roof.get("kernels"),
         }

@@ -186,6 +186,38 @@ int samaudio_frame_set_workspace(samaudio_frame* f, void* workspace, size_t byte
 int samaudio_frame_logits(samaudio_frame* f, const float* codec_features, const float* text_pooled,
                           const uint8_t* pad_mask, int rows, int frames, float* logits, samaudio_stream stream);
 
+/* ---- visual-prompt tower -------------------------------------------------------
+ * PE-Core vision tower behind `PerceptionEncoder.encode` (reference sam_audio/model/vision_encoder.py:80-89:
+ * `pe.CLIP.from_config("PE-Core-L14-336")`, `encode_image(x, normalize=...)`).  Resize / scaling / normalisation of the
+ * frames (vision_encoder.py:91-113) stay with the caller; everything from the patch embedding to the L2-normalised
+ * feature runs here.  Engine tensor names: sam_audio_amd/vision_tower.py documents the mapping from the `visual.*`
+ * state_dict keys. */
+typedef struct {
+  int32_t precision;                          /* SAMAUDIO_F32 | SAMAUDIO_BF16 */
+  int32_t image_size, patch_size;             /* 336, 14 */
+  int32_t width, layers, heads, mlp_width;    /* 1024, 24, 16 (head dim 64 or 128), 4096 */
+  int32_t output_dim;                         /* 1024 */
+  int32_t use_cls_token, use_rope2d, use_ln_pre, use_ln_post;
+  int32_t pool_type;                          /* 0 = class token, 1 = token mean, 2 = attention pooling */
+  int32_t pool_heads;                         /* heads of the pooling attention (8; head dim 64 or 128) */
+  int32_t act;                                /* 4 = GELU (erf), 5 = quick GELU */
+  float ln_eps;
+} samaudio_vit_config;
+
+typedef struct samaudio_vit samaudio_vit;
+int samaudio_vit_create(const samaudio_vit_config* cfg, samaudio_vit** out);
+void samaudio_vit_destroy(samaudio_vit* v);
+int samaudio_vit_set_tensor(samaudio_vit* v, const char* name, const void* data, int dtype, int ndim,
+                            const int64_t* shape);
+int samaudio_vit_finalize(samaudio_vit* v);
+size_t samaudio_vit_workspace_bytes(samaudio_vit* v, int frames);
+int samaudio_vit_set_workspace(samaudio_vit* v, void* workspace, size_t bytes);
+/* frames [n, 3, image_size, image_size] f32 (resized, scaled, normalised) -> features [n, output_dim] f32, L2-normalised
+ * when `normalize` != 0.  tokens_out (nullable, parity hook): the residual stream after the last block,
+ * [n, tokens, width] f32 (before ln_post). */
+int samaudio_vit_encode(samaudio_vit* v, const float* frames, int n, int normalize, float* features, float* tokens_out,
+                        samaudio_stream stream);
+
 /* ---- measurement ----------------------------------------------------------------------------------- */
 
 /* Live per-kernel timing for bench.py's roofline leg (the reference has no counterpart: it publishes no

@@ -17,6 +17,11 @@ struct samaudio_frame {
 
 namespace {
 thread_local std::string g_err;
+}  // namespace
+namespace sa {
+void set_last_error(const std::string& msg) { g_err = msg; }  // for the C entry points that live in other files (vit.hip)
+}  // namespace sa
+namespace {
 int ret(const sa::Status& s) {
   if (!s.ok()) g_err = s.msg;
   return s.code;

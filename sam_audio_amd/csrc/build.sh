@@ -7,8 +7,8 @@ OUT=../libsamaudio_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in gemm gemm2 gemm8 kernels attention peav_kernels engine peav api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ peav.h -nt build/$f.o ] || [ ../../include/samaudio.h -nt build/$f.o ]; then
+for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels engine peav vit api; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ peav.h -nt build/$f.o ] || [ vit.h -nt build/$f.o ] || [ ../../include/samaudio.h -nt build/$f.o ]; then
     EXTRA=""
     # gemm2.hip: the fully unrolled 4x4-fragment epilogue exceeds clang's default pragma-unroll budget; without the
     # full unroll the accumulator array is indexed dynamically and lands in scratch memory.
@@ -18,5 +18,5 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels engine peav api; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/gemm2.o build/gemm8.o build/kernels.o build/attention.o build/peav_kernels.o build/engine.o build/peav.o build/api.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/gemm2.o build/gemm8.o build/kernels.o build/attention.o build/peav_kernels.o build/vit_kernels.o build/engine.o build/peav.o build/vit.o build/api.o -o $OUT
 echo "built $OUT"

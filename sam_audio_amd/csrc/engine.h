@@ -21,6 +21,8 @@ struct Status {
   bool ok() const { return code == 0; }
 };
 
+void set_last_error(const std::string& msg);  // api.hip: the thread-local string behind samaudio_last_error()
+
 constexpr int HALO = 40;  // zero rows either side of codec activations (>= 4 * max dilation 9)
 
 class Bump {  // workspace carving (also used dry to size the workspace)

@@ -131,4 +131,18 @@ hipError_t launch_judge_pool_head(const float* hidden, const unsigned char* mask
 hipError_t launch_frame_logits(const float* audio, long a_bstride, long a_off, const float* text, const float* scale,
                                const float* bias, float* out, int B, int T, int E, hipStream_t st);
 
+// ---- PE-Core vision tower (vit_kernels.hip) ---------------------------------------------------------------------
+// im2col of the k = stride = P patch convolution: frames [n,3,S,S] f32 -> rows [n*(S/P)^2, Kp], column c*P*P + py*P + px
+hipError_t launch_patchify(const float* frames, void* out, bool bf16, int n, int S, int P, int Kp, hipStream_t st);
+// q|k|v rows [n*T, 3*H*hd] -> Q, K [n,H,Tp,hd] (adjacent-pair rotation by rc / rs [T, hd/2]; null = none), V^T [n,H,hd,Tp]
+hipError_t launch_rope2d_split(const void* qkv, const float* rc, const float* rs, void* Q, void* K, void* Vt, bool bf16,
+                               int n, int T, int Tp, int H, int head_dim, hipStream_t st);
+// one query per head over all tokens: q [H*hd] f32, kv rows [n*T, 2*H*hd] = (k | v) -> out [n, H*hd]
+hipError_t launch_pool_attention(const float* q, const void* kv, void* out, bool bf16, int n, int T, int H, int head_dim,
+                                 hipStream_t st);
+hipError_t launch_l2_normalize(float* x, int rows, int D, hipStream_t st);
+// out[f, :] = mean over the T tokens of x[f, t, :]
+hipError_t launch_token_mean(const float* x, long x_ld, float* out_f32, void* out_act, bool bf16, int n, int T, int D,
+                             hipStream_t st);
+
 }  // namespace sa

@@ -72,6 +72,15 @@ class FrameConfig(C.Structure):
     _fields_ = [("precision", C.c_int32), ("audio", PeavDims), ("codec_dim", C.c_int32), ("embed_dim", C.c_int32)]
 
 
+class VitConfig(C.Structure):
+    """Mirror of `samaudio_vit_config`."""
+    _fields_ = [("precision", C.c_int32), ("image_size", C.c_int32), ("patch_size", C.c_int32), ("width", C.c_int32),
+                ("layers", C.c_int32), ("heads", C.c_int32), ("mlp_width", C.c_int32), ("output_dim", C.c_int32),
+                ("use_cls_token", C.c_int32), ("use_rope2d", C.c_int32), ("use_ln_pre", C.c_int32),
+                ("use_ln_post", C.c_int32), ("pool_type", C.c_int32), ("pool_heads", C.c_int32), ("act", C.c_int32),
+                ("ln_eps", C.c_float)]
+
+
 class KernelStat(C.Structure):
     """Mirror of `samaudio_kernel_stat`."""
     _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("flops", C.c_double), ("bytes", C.c_double),
@@ -130,6 +139,13 @@ _PROTOS = {
     "samaudio_frame_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "samaudio_frame_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
+    "samaudio_vit_create": (C.c_int, [C.POINTER(VitConfig), C.POINTER(C.c_void_p)]),
+    "samaudio_vit_destroy": (None, [C.c_void_p]),
+    "samaudio_vit_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "samaudio_vit_finalize": (C.c_int, [C.c_void_p]),
+    "samaudio_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "samaudio_vit_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "samaudio_vit_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -181,7 +181,12 @@ class SAMAudio:
         if strict and (missing or unexpected):
             raise RuntimeError(f"Missing keys: {missing}, unexpected_keys: {unexpected}")
         vis = {k[len("vision_encoder."):]: v for k, v in state_dict.items() if k.startswith("vision_encoder.")}
-        if vis and hasattr(self.vision_encoder, "load_state_dict"):   # reference model.py:83: the checkpoint's PE-Core tower
+        if vis and self.vision_encoder is None and self._covers_vision_tower(vis):
+            # reference model.py:83: SAMAudio owns `PerceptionEncoder(cfg.vision_encoder)`; build it when the checkpoint
+            # really carries the PE-Core tower (a text-only deployment pays nothing for it)
+            from .vision_encoder import PerceptionEncoder
+            self.vision_encoder = PerceptionEncoder(self.cfg.vision_encoder, device=self.device, precision=self.precision)
+        if vis and hasattr(self.vision_encoder, "load_state_dict"):
             self.vision_encoder.load_state_dict(vis, strict=strict)
         with torch.cuda.device(self.device):
             if not dit_missing:
@@ -193,6 +198,12 @@ class SAMAudio:
                 hip.check(self._lib.samaudio_finalize(self._ctx, 1))
                 self._has_codec = True
         return missing, unexpected
+
+    def _covers_vision_tower(self, vis: Dict[str, torch.Tensor]) -> bool:
+        from .config import PE_VISION_CONFIGS
+        from .vision_tower import expected_keys
+        pe = PE_VISION_CONFIGS.get(self.cfg.vision_encoder.name)
+        return pe is not None and all(("model.visual." + k) in vis for k in expected_keys(pe))
 
     def _register(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():

@@ -1,12 +1,12 @@
 """`PerceptionEncoder` - host wrapper with the interface of the reference's visual-prompt encoder
 (reference sam_audio/model/vision_encoder.py:40-113; SURVEY.md section 8 row a4 / "next" row f3).
 
-The tower itself is `pe.CLIP.from_config("PE-Core-L14-336")` of the un-vendored perception_models package; neither
-that package nor `timm` (which carries the only other implementation of the PE-Core ViT) is part of this build's
-environment, so there is nothing in the container to restate the network from or to pin it against.  This wrapper
-therefore owns what the reference file owns - resize, scaling, normalisation, chunking by `batch_size`, time padding -
-and takes the tower as an injected callable `encode_image(frames [N,3,S,S] float, normalize=bool) -> [N, dim]`.
-`SAMAudio.vision_encoder = PerceptionEncoder(cfg.vision_encoder, tower)` enables `separate()` with `masked_videos`.
+This wrapper owns what the reference file owns - resize, scaling, normalisation, chunking by `batch_size`, time
+padding.  The tower is `pe.CLIP.from_config(cfg.name)` in the reference (un-vendored perception_models); here it is
+`sam_audio_amd.vision_tower.PEVisionTower`, the same network on the HIP library (built by default for the config
+names in `config.PE_VISION_CONFIGS`), or any injected callable `encode_image(frames [N,3,S,S] float, normalize=bool)
+-> [N, dim]`.  `SAMAudio.vision_encoder = PerceptionEncoder(cfg.vision_encoder, device=...)` + `load_state_dict`
+enables `separate()` with `masked_videos`.
 """
 from __future__ import annotations
 
@@ -20,7 +20,8 @@ _MODES = {"NEAREST": "nearest", "BILINEAR": "bilinear", "BICUBIC": "bicubic"}
 
 
 class PerceptionEncoder:
-    def __init__(self, cfg: Optional[PerceptionEncoderConfig] = None, tower: Optional[Callable] = None, device=None):
+    def __init__(self, cfg: Optional[PerceptionEncoderConfig] = None, tower: Optional[Callable] = None, device=None,
+                 precision: str = "bf16"):
         self.cfg = cfg or PerceptionEncoderConfig()
         self.batch_size, self.dim = self.cfg.batch_size, self.cfg.dim
         self.normalize_feature, self.image_size = self.cfg.normalize_feature, self.cfg.image_size
@@ -28,8 +29,23 @@ class PerceptionEncoder:
         if mode not in _MODES:  # reference vision_encoder.py:93-99
             raise ValueError(f"Unsupported interpolation_mode: {self.cfg.interpolation_mode}")
         self.mode = _MODES[mode]
-        self.tower = tower
         self.device = device
+        if tower is None:
+            from .config import PE_VISION_CONFIGS
+            if self.cfg.name in PE_VISION_CONFIGS:   # reference vision_encoder.py:86: pe.CLIP.from_config(cfg.name)
+                from .vision_tower import PEVisionTower
+                tower = PEVisionTower(name=self.cfg.name, precision=precision, device=device)
+                assert tower.cfg.output_dim == self.dim and tower.cfg.image_size == self.image_size, \
+                    "vision_encoder.dim / image_size do not match the named PE config"
+        self.tower = tower
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """The `vision_encoder.*` tensors of a SAMAudio checkpoint (`model.visual.*` = the PE-Core tower)."""
+        if not hasattr(self.tower, "load_state_dict"):
+            raise NotImplementedError("the attached tower takes no weights")
+        if self.device is not None and getattr(self.tower, "device", None) is None:
+            self.tower.to(self.device)
+        return self.tower.load_state_dict(state_dict, strict=strict)
 
     def transform(self, video: torch.Tensor) -> torch.Tensor:
         """uint8 / float frames [T, 3, H, W] -> normalised float [T, 3, S, S] (reference vision_encoder.py:91-113:
@@ -39,13 +55,20 @@ class PerceptionEncoder:
         if x.shape[-2:] != (self.image_size, self.image_size):
             kw = {"antialias": True, "align_corners": False} if self.mode != "nearest" else {}
             x = torch.nn.functional.interpolate(x, size=(self.image_size, self.image_size), mode=self.mode, **kw)
+            if not video.is_floating_point():
+                # torchvision's tensor Resize interpolates integer frames in float and casts back (round; uint8 is
+                # clamped to 0..255, which also removes bicubic overshoot) before the `/ 255`
+                x = x.round()
+                if video.dtype == torch.uint8:
+                    x = x.clamp(0, 255)
         return (x / 255.0 - 0.5) / 0.5
 
     def encode(self, frames: torch.Tensor) -> torch.Tensor:
         if self.tower is None:
             raise NotImplementedError(
-                "no PE-Core tower attached: perception_models / timm are not part of this build's environment; pass "
-                "`tower=` (a callable encode_image(frames, normalize=...) -> [N, dim])")
+                f"no vision tower for config name {self.cfg.name!r}: known PE configs are built on the HIP library "
+                "(sam_audio_amd.vision_tower), anything else needs `tower=` (a callable encode_image(frames, "
+                "normalize=...) -> [N, dim])")
         return self.tower(frames, normalize=self.normalize_feature)
 
     @torch.no_grad()
