@@ -34,9 +34,11 @@ class PerceptionEncoder:
             from .config import PE_VISION_CONFIGS
             if self.cfg.name in PE_VISION_CONFIGS:   # reference vision_encoder.py:86: pe.CLIP.from_config(cfg.name)
                 from .vision_tower import PEVisionTower
+                pe = PE_VISION_CONFIGS[self.cfg.name]
+                if pe.output_dim != self.dim or pe.image_size != self.image_size:
+                    raise ValueError(f"vision_encoder dim / image_size ({self.dim}, {self.image_size}) do not match the "
+                                     f"named PE config {self.cfg.name!r} ({pe.output_dim}, {pe.image_size})")
                 tower = PEVisionTower(name=self.cfg.name, precision=precision, device=device)
-                assert tower.cfg.output_dim == self.dim and tower.cfg.image_size == self.image_size, \
-                    "vision_encoder.dim / image_size do not match the named PE config"
         self.tower = tower
 
     def load_state_dict(self, state_dict, strict: bool = True):

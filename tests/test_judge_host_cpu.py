@@ -255,8 +255,10 @@ def test_perception_encoder_wrapper_transform_chunking_and_padding():
     assert torch.equal(out[1, 3:], torch.zeros(7, 8))                                   # time padding
     with pytest.raises(ValueError):
         PerceptionEncoder(PerceptionEncoderConfig(interpolation_mode="lanczos"))
-    with pytest.raises(NotImplementedError):
-        PerceptionEncoder(PerceptionEncoderConfig(image_size=6))([vids[0]])
+    with pytest.raises(NotImplementedError):                                              # no tower for an unknown config name
+        PerceptionEncoder(PerceptionEncoderConfig(name="PE-Core-unknown", image_size=6))([vids[0]])
+    with pytest.raises(ValueError):                                                       # known name, inconsistent geometry
+        PerceptionEncoder(PerceptionEncoderConfig(image_size=6))
 
 
 def test_attach_rankers_skips_what_cannot_be_built_offline():
