@@ -12,7 +12,7 @@
 
 namespace sa {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef h16x8_t bf16x8_t;  // 8 x 16-bit operand words (bf16, or fp16 with -DSA_OPERAND_FP16: common.h)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // ---------------------------------------------------------------------------------------------------
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8_t kf = *(const bf16x8_t*)(Ks + row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4));
-        s[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[nb], 0, 0, 0);
+        s[nb] = SA_MFMA_16x16x32(qf[ks], kf, s[nb]);
       }
     }
     bool valid[4];
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       for (int n = 0; n < NF; ++n) {
         const int d = n * 16 + lr;
         const bf16x8_t vf = *(const bf16x8_t*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[n], 0, 0, 0);
+        o[n] = SA_MFMA_16x16x32(pf, vf, o[n]);
       }
     }
   }
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
       const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        qv[ks][2 * e] = __uint_as_float(w4[e] << 16);
-        qv[ks][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+        qv[ks][2 * e] = h16_lo(w4[e]);
+        qv[ks][2 * e + 1] = h16_hi(w4[e]);
         ss += qv[ks][2 * e] * qv[ks][2 * e] + qv[ks][2 * e + 1] * qv[ks][2 * e + 1];
       }
     }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
     for (int e = 0; e < 4; ++e)
       pk[e] = (unsigned)f2bf(qv[ks][2 * e] * inv * wv[2 * e]) | ((unsigned)f2bf(qv[ks][2 * e + 1] * inv * wv[2 * e + 1]) << 16);
     const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], *(const bf16x8_t*)&pv, sT, 0, 0, 0);
+    sT = SA_MFMA_16x16x32(kf[ks], *(const bf16x8_t*)&pv, sT);
   }
   // softmax over the tokens of row r: lane holds tokens g*4 + e
   const float scale = 0.08838834764831845f;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
       vf = *(const bf16x8_t*)&z;
     }
     f32x4_t o = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pB, o, 0, 0, 0);
+    o = SA_MFMA_16x16x32(vf, pB, o);
     if (t < T) store4<bf16_t>(orow + n * 16, o[0] * il, o[1] * il, o[2] * il, o[3] * il);
   }
 }
@@ -466,8 +466,8 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
       const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        qv[ks][2 * e] = __uint_as_float(w4[e] << 16);
-        qv[ks][2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+        qv[ks][2 * e] = h16_lo(w4[e]);
+        qv[ks][2 * e + 1] = h16_hi(w4[e]);
         ss += qv[ks][2 * e] * qv[ks][2 * e] + qv[ks][2 * e + 1] * qv[ks][2 * e + 1];
       }
     }
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
     for (int e = 0; e < 4; ++e)
       pk[e] = (unsigned)f2bf(qv[ks][2 * e] * inv * wv[2 * e]) | ((unsigned)f2bf(qv[ks][2 * e + 1] * inv * wv[2 * e + 1]) << 16);
     const uint4 pv = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], *(const bf16x8_t*)&pv, sT, 0, 0, 0);
+    sT = SA_MFMA_16x16x32(kf[ks], *(const bf16x8_t*)&pv, sT);
   }
   const float scale = 0.08838834764831845f;
   float p[4], mx = -INFINITY;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
       for (int ks = 0; ks < 4; ++ks) {
         uint4 x = v[bb][ks];
         if (r >= Lt) x = make_uint4(0u, 0u, 0u, 0u);
-        u = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&x, wf[ks], u, 0, 0, 0);
+        u = SA_MFMA_16x16x32(*(const bf16x8_t*)&x, wf[ks], u);
       }
       // lane: tokens g*4 .. g*4+3 of column n
       if (b0 + bb < B && g * 4 < LtP)
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void cross_attn_fold2_kernel(const bf16_t* __r
       for (int ks = 0; ks < 4; ++ks) {
         uint4 x = v[bb][ks];
         if (r >= Lt || !head_ok) x = make_uint4(0u, 0u, 0u, 0u);
-        u = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&x, wf[ks], u, 0, 0, 0);
+        u = SA_MFMA_16x16x32(*(const bf16x8_t*)&x, wf[ks], u);
       }
       // lane: tokens g*4 .. g*4+3 of column n = r
       if (g * 4 < LtP) {

@@ -6,17 +6,39 @@
 namespace sa {
 
 // ---- activation element types -------------------------------------------------------------
-// bf16 is stored as raw 16-bit words (bit-compatible with torch.bfloat16); all arithmetic is fp32.
+// The 16-bit GEMM-operand type is stored as raw 16-bit words; all arithmetic is fp32.  Default build: bfloat16
+// (bit-compatible with torch.bfloat16).  -DSA_OPERAND_FP16 builds libsamaudio_hip_f16.so, in which the SAME type and the
+// same kernels carry IEEE fp16 (torch.float16): identical MFMA rate on gfx950 (v_mfma_*_f16 vs *_bf16), 10 instead of 7
+// mantissa bits per operand rounding - the precision="fp16" mode of the host classes.  Only the two
+// conversions, the packed-word unpackers and the MFMA builtins below depend on the format.
 struct bf16_t {
   unsigned short v;
 };
 
+#ifdef SA_OPERAND_FP16
+__device__ __forceinline__ float bf2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // v_cvt_f16_f32: round-to-nearest-even, overflow -> inf
+  return __builtin_bit_cast(unsigned short, (_Float16)f);
+}
+// the two halves of a packed 32-bit word
+__device__ __forceinline__ float h16_lo(unsigned w) { return bf2f((unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return bf2f((unsigned short)(w >> 16)); }
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_t;
+#define SA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define SA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
   unsigned u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+__device__ __forceinline__ float h16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+typedef __attribute__((ext_vector_type(8))) __bf16 h16x8_t;
+#define SA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define SA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

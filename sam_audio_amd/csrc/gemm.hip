@@ -23,14 +23,14 @@
 
 namespace sa {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef h16x8_t bf16x8_t;  // 8 x 16-bit operand words (bf16, or fp16 with -DSA_OPERAND_FP16: common.h)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
   typedef bf16x8_t frag_t;
   static __device__ __forceinline__ f32x4_t run(const frag_t& a, const frag_t& b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    return SA_MFMA_16x16x32(a, b, c);
   }
 };
 template <> struct Mma<float> {
@@ -241,7 +241,9 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
     // Few rows: the 128x128 tile of the SAME family (gemm8s, bitwise identical results, two workgroups per CU) once the
     // 256x256 tiling would leave most CUs without a tile - so the choice may depend on M without breaking batch-sharding
     // invariance.  Codec convolutions with that many output columns ride the same kernels.
-    if (p.N >= (debug_flag(7) ? 4096 : 2048)) {
+    // N >= 1024 since GPU call 5: the vision tower's out_proj / c_proj (N = 1024, M = 144 000) ran at 624 TF/s on the
+    // loader-wave kernel, small* (D = 1536) at 264 TF/s on the 128x128 tile of the other family
+    if (p.N >= (debug_flag(7) ? 4096 : 1024)) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
       return t256 >= 128 || debug_flag(6) ? 22 : 27;
     }

@@ -22,7 +22,7 @@
 
 namespace sa {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef h16x8_t bf16x8_t;  // 8 x 16-bit operand words (bf16, or fp16 with -DSA_OPERAND_FP16: common.h)
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = SA_MFMA_32x32x16(wf[j], af[i], acc[i][j]);
     }
     st_c = st_c + 1 == STAGES ? 0 : st_c + 1;
     st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = SA_MFMA_32x32x16(wf[kk][j], af[kk][i], acc[i][j]);
       }
       __builtin_amdgcn_s_setprio(0);
       if (hh == HPS - 1 && grp == 0) drain(s);             // group 0: this is global phase 2*HPS*(s+1)-1
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = SA_MFMA_32x32x16(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
           for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = SA_MFMA_32x32x16(wf[j], af[i], acc[i][j]);
         }
       }
       st_c = st_c + 1 == NS ? 0 : st_c + 1;

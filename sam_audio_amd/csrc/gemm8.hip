@@ -30,7 +30,7 @@
 
 namespace sa {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef h16x8_t bf16x8_t;  // 8 x 16-bit operand words (bf16, or fp16 with -DSA_OPERAND_FP16: common.h)
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 namespace {
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-          acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                          \
-              wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j], 0, 0, 0);                          \
+          acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = SA_MFMA_16x16x32(                          \
+              wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                          \
     if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[i][j], 0, 0, 0);
+          acc[i][j] = SA_MFMA_16x16x32(wf[j][ks], af[i][ks], acc[i][j]);
   }
   __syncthreads();
   epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);

@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void rope2d_split_bf16_kernel(const bf16_t* __
     const unsigned w4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      x[2 * e] = __uint_as_float(w4[e] << 16);
-      x[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+      x[2 * e] = h16_lo(w4[e]);
+      x[2 * e + 1] = h16_hi(w4[e]);
     }
   };
   auto pack = [](const float (&x)[8]) {

@@ -74,7 +74,10 @@ def test_head_dim_128_blocks_fp32_and_bf16(gpu):
     assert (got - want).abs().max().item() < BF16_FEATURE_BOUND
 
 
-BF16_FEATURE_BOUND = 2.5e-2   # L2-normalised features (|f_i| <= 1, typical 1/sqrt(dim)): 2x the error measured on MI355X
+# L2-normalised features (|f_i| <= 1): measured on MI355X (profiles/r2_call5/gpu_tests.log) pe-tiny 1.7e-3, pe-mini 1.6e-3,
+# PE-Core-L14-336 6.8e-4 max-abs; residual-stream tokens 2.1e-3 .. 3.3e-3 relative.  Bounds = 2x the largest.
+BF16_FEATURE_BOUND = 3.5e-3
+BF16_TOKEN_BOUND = 7e-3
 
 
 @pytest.mark.parametrize("name", ["pe-tiny", "pe-mini"])
@@ -85,7 +88,7 @@ def test_tower_bf16_matches_oracle(gpu, name):
     e = (got - want).abs().max().item()
     cos = torch.nn.functional.cosine_similarity(got, want, dim=-1).min().item()
     print(f"vit {name} bf16: tokens rel {e_tok:.2e}, normalised features abs {e:.2e}, min cosine {cos:.5f}")
-    assert e < BF16_FEATURE_BOUND and cos > 0.995 and e_tok < 5e-2
+    assert e < BF16_FEATURE_BOUND and cos > 0.9999 and e_tok < BF16_TOKEN_BOUND
 
 
 def test_ragged_frame_counts_share_one_workspace(gpu):
@@ -145,7 +148,7 @@ def test_pe_core_l14_336_dims(gpu, precision, bound):
     e = (got - want).abs().max().item()
     cos = torch.nn.functional.cosine_similarity(got, want, dim=-1).min().item()
     print(f"PE-Core-L14-336 {precision}: tokens rel {e_tok:.2e}, normalised features abs {e:.2e}, min cosine {cos:.6f}")
-    assert e < bound and cos > 0.99
+    assert e < bound and cos > 0.9999 and e_tok < (BF16_TOKEN_BOUND if precision == "bf16" else 1e-4)
 
 
 def test_separate_with_the_hip_tower_from_a_checkpoint(gpu):
