@@ -63,7 +63,8 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-strong", action="store_true", help="N > 1, weak: skip the extra strong-scaling measurement")
     ap.add_argument("--text-len", type=int, default=8)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16 (default) | fp16 = the same kernels on IEEE fp16 operands (libsamaudio_hip_f16.so) | fp32 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip parity_check (it shares the oracle run with cpu_baseline)")

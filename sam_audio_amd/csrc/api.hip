@@ -40,7 +40,11 @@ int bad(const char* msg) {
 extern "C" {
 
 const char* samaudio_last_error(void) { return g_err.c_str(); }
+#ifdef SA_OPERAND_FP16
+const char* samaudio_version(void) { return "samaudio-hip 0.1 (gfx950, fp16 operands)"; }
+#else
 const char* samaudio_version(void) { return "samaudio-hip 0.1 (gfx950)"; }
+#endif
 
 int samaudio_create(const samaudio_config* cfg, samaudio_ctx** out) {
   if (!cfg || !out) return bad("samaudio_create: null argument");

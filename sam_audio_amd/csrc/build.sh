@@ -1,22 +1,32 @@
 #!/bin/bash
-# Builds libsamaudio_hip.so for gfx950 (hipcc cross-compiles without a GPU).  In-tree output so the
-# .so travels with the repo snapshot to the GPU box.
+# Builds libsamaudio_hip.so (16-bit operands = bf16) and libsamaudio_hip_f16.so (the same sources with -DSA_OPERAND_FP16:
+# 16-bit operands = IEEE fp16, the precision="fp16" mode) for gfx950; hipcc cross-compiles without a GPU.  In-tree output
+# so the .so files travel with the repo snapshot to the GPU box.
 set -e
 cd "$(dirname "$0")"
-OUT=../libsamaudio_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
-mkdir -p build
-pids=()
-for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels engine peav vit api; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ kernels.h -nt build/$f.o ] || [ engine.h -nt build/$f.o ] || [ peav.h -nt build/$f.o ] || [ vit.h -nt build/$f.o ] || [ ../../include/samaudio.h -nt build/$f.o ]; then
-    EXTRA=""
-    # gemm2.hip: the fully unrolled 4x4-fragment epilogue exceeds clang's default pragma-unroll budget; without the
-    # full unroll the accumulator array is indexed dynamically and lands in scratch memory.
-    if [ $f = gemm2 ] || [ $f = gemm8 ]; then EXTRA="-mllvm -pragma-unroll-threshold=262144"; fi
-    hipcc $FLAGS $EXTRA -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/gemm.o build/gemm2.o build/gemm8.o build/kernels.o build/attention.o build/peav_kernels.o build/vit_kernels.o build/engine.o build/peav.o build/vit.o build/api.o -o $OUT
-echo "built $OUT"
+SRCS="gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels engine peav vit api"
+build_one() {  # $1 = object dir, $2 = extra flags, $3 = output
+  local dir=$1 extra_all=$2 out=$3 pids=() objs=""
+  mkdir -p $dir
+  for f in $SRCS; do
+    objs="$objs $dir/$f.o"
+    if [ ! -f $dir/$f.o ] || [ $f.hip -nt $dir/$f.o ] || [ common.h -nt $dir/$f.o ] || [ kernels.h -nt $dir/$f.o ] || [ engine.h -nt $dir/$f.o ] || [ peav.h -nt $dir/$f.o ] || [ vit.h -nt $dir/$f.o ] || [ ../../include/samaudio.h -nt $dir/$f.o ] || [ build.sh -nt $dir/$f.o ]; then
+      EXTRA=""
+      # gemm2.hip / gemm8.hip: the fully unrolled 4x4-fragment epilogues exceed clang's default pragma-unroll budget; without
+      # the full unroll the accumulator array is indexed dynamically and lands in scratch memory.
+      if [ $f = gemm2 ] || [ $f = gemm8 ]; then EXTRA="-mllvm -pragma-unroll-threshold=262144"; fi
+      hipcc $FLAGS $extra_all $EXTRA -c $f.hip -o $dir/$f.o &
+      pids+=($!)
+    fi
+  done
+  for p in "${pids[@]}"; do wait $p; done
+  hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out
+  echo "built $out"
+}
+build_one build "" ../libsamaudio_hip.so &
+B1=$!
+build_one build_f16 "-DSA_OPERAND_FP16" ../libsamaudio_hip_f16.so &
+B2=$!
+wait $B1
+wait $B2

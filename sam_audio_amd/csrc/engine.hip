@@ -39,8 +39,15 @@ static void trace(const char* name, const void* dev, size_t count, bool is_bf16,
   for (size_t i = 0; i < count; ++i) {
     float v;
     if (is_bf16) {
+#ifdef SA_OPERAND_FP16
+      const unsigned short hw = ((const unsigned short*)host.data())[i];
+      const int e = (hw >> 10) & 31, m = hw & 1023;
+      const float mag = e == 31 ? (m ? NAN : INFINITY) : (e ? std::ldexp(1.f + m / 1024.f, e - 15) : std::ldexp(m / 1024.f, -14));
+      v = (hw & 0x8000) ? -mag : mag;
+#else
       const unsigned u = (unsigned)((const unsigned short*)host.data())[i] << 16;
       std::memcpy(&v, &u, 4);
+#endif
     } else {
       v = ((const float*)host.data())[i];
     }

@@ -12,9 +12,36 @@ from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsamaudio_hip.so")
+# the same sources built with -DSA_OPERAND_FP16: the 16-bit GEMM-operand format is IEEE fp16 instead of bfloat16
+LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libsamaudio_hip_f16.so")}
 
-F32, BF16 = 0, 1
-DT_F32, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3
+F32, BF16 = 0, 1             # precision codes of the C ABI: fp32 parity mode | 16-bit GEMM operands (bf16 or fp16 by library)
+DT_F32, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3   # DT_BF16 = "the library's 16-bit operand format"
+PRECISIONS = ("bf16", "fp16", "fp32")
+
+
+def check_precision(precision: str) -> None:
+    if precision not in PRECISIONS:
+        raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+
+
+def precision_code(precision: str) -> int:
+    return F32 if precision == "fp32" else BF16
+
+
+def operands_for(precision: str) -> str:
+    """Which build of the library a host object of this precision talks to (fp32 mode lives in both; use the default)."""
+    return "fp16" if precision == "fp16" else "bf16"
+
+
+def act_dtype(precision: str):
+    import torch
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
+
+
+def dtype_code(dtype) -> int:
+    import torch
+    return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
 ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
 
@@ -87,7 +114,27 @@ class KernelStat(C.Structure):
                 ("ms", C.c_double)]
 
 
-_lib: Optional[C.CDLL] = None
+_lib = None     # the default (bf16-operand) library; tests/conftest.py swaps it for its CPU dry-run builds
+_libs = {}      # operand format -> loaded library
+_last = None    # library of the most recent call: check() reads samaudio_last_error() from the one that reported
+
+
+class _Handle:
+    """CDLL proxy that remembers which library was called last (two builds of the library can be loaded side by side)."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+
+        def call(*args, _fn=fn, _self=self):
+            global _last
+            _last = _self
+            return _fn(*args)
+        object.__setattr__(self, name, call)
+        return call
+
 
 _PROTOS = {
     "samaudio_last_error": (C.c_char_p, []),
@@ -151,25 +198,32 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
-def lib() -> C.CDLL:
-    """Load (once) and return the shared library; raises if it is not there."""
+def lib(operands: str = "bf16"):
+    """Load (once) and return the shared library for a 16-bit operand format; raises if it is not there."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise SamAudioHipError(
-                f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or sam_audio_amd/csrc/build.sh.  There is no CPU fallback for the separate() hot path.")
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in _PROTOS.items():
-            fn = getattr(handle, name)  # AttributeError if the .so does not export it
-            fn.restype = res
-            fn.argtypes = args
+    if operands == "bf16" and _lib is not None:
+        return _lib
+    if operands in _libs:
+        return _libs[operands]
+    path = LIB_PATHS[operands]
+    if not os.path.exists(path):
+        raise SamAudioHipError(
+            f"{path} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or sam_audio_amd/csrc/build.sh.  There is no CPU fallback for the separate() hot path.")
+    cdll = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(cdll, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    handle = _Handle(cdll)
+    _libs[operands] = handle
+    if operands == "bf16":
         _lib = handle
-        # tuning only: A/B switches between kernel generations (sam_audio_amd/csrc/kernels.h), e.g. "8=1,9=1"
-        for kv in filter(None, os.environ.get("SAMAUDIO_DEBUG_FLAGS", "").split(",")):
-            k, v = kv.split("=")
-            handle.samaudio_debug_set_flag(int(k), int(v))
-    return _lib
+    # tuning only: A/B switches between kernel generations (sam_audio_amd/csrc/kernels.h), e.g. "8=1,9=1"
+    for kv in filter(None, os.environ.get("SAMAUDIO_DEBUG_FLAGS", "").split(",")):
+        k, v = kv.split("=")
+        cdll.samaudio_debug_set_flag(int(k), int(v))
+    return handle
 
 
 def check(code: int) -> None:
@@ -177,7 +231,8 @@ def check(code: int) -> None:
     (SURVEY.md §8b 'Errors')."""
     if code == 0:
         return
-    msg = lib().samaudio_last_error().decode()
+    src = _last if _last is not None else lib()
+    msg = src.samaudio_last_error().decode()
     if code == ERR_ARG:
         raise AssertionError(msg)
     if code == ERR_WEIGHT:

@@ -136,10 +136,10 @@ class _CodecEncoder:
 
     def __init__(self, codec_cfg, precision: str, device: torch.device):
         self.cfg, self.device = codec_cfg, device
-        self._lib = hip.lib()
+        self._lib = hip.lib(hip.operands_for(precision))
         self._ctx = C.c_void_p()
         hc = hip.Config(
-            precision=hip.BF16 if precision == "bf16" else hip.F32, dim=256, n_heads=2, n_layers=0, ffn_hidden=64,
+            precision=hip.precision_code(precision), dim=256, n_heads=2, n_layers=0, ffn_hidden=64,
             latent_channels=2 * codec_cfg.codebook_dim, text_dim=64, video_dim=64, freq_dim=64, anchor_dim=64,
             anchor_vocab=4, max_positions=64, norm_eps=1e-5, codec_dim=codec_cfg.codebook_dim,
             codec_latent=codec_cfg.latent_dim, enc_dim=codec_cfg.encoder_dim, dec_dim=codec_cfg.decoder_dim,
@@ -155,7 +155,7 @@ class _CodecEncoder:
 
     def load(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
-            dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+            dt = hip.dtype_code(t.dtype)
             self._tensors[name] = t
             hip.check(self._lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                     hip.shape_array(t.shape)))
@@ -193,7 +193,7 @@ def _ensure_ws(owner, need: int, setter) -> None:
 
 def _register(lib_set, handle, store: Dict[str, torch.Tensor], tensors: Dict[str, torch.Tensor]) -> None:
     for name, t in tensors.items():
-        dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+        dt = hip.dtype_code(t.dtype)
         store[name] = t  # keep alive: the library borrows the pointer
         hip.check(lib_set(handle, name.encode(), hip.ptr(t), dt, t.dim(), hip.shape_array(t.shape)))
 
@@ -212,20 +212,19 @@ class SAMAudioJudgeModel:
     def __init__(self, config: SAMAudioJudgeConfig, precision: str = "bf16", device: Optional[str] = None,
                  text_model=None):
         config.check_supported()
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        hip.check_precision(precision)
         self.config = config
         self.precision = precision
         self.device = torch.device(device) if device is not None else None
         self.text_model = text_model if text_model is not None else _text_tower(config.text_model)  # judge.py:48
-        self._lib = hip.lib()
+        self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self._codec: Optional[_CodecEncoder] = None
         self._loaded = False
         jc = hip.JudgeConfig(
-            precision=hip.BF16 if precision == "bf16" else hip.F32,
+            precision=hip.precision_code(precision),
             transformer=peav_dims(config.transformer, config.audio_codec.codebook_dim),
             finetune_transformer=peav_dims(config.finetune_transformer, config.bottleneck_dim),
             codec_dim=config.audio_codec.codebook_dim, text_hidden=config.text_hidden,
@@ -239,7 +238,7 @@ class SAMAudioJudgeModel:
 
     @property
     def act_dtype(self) -> torch.dtype:
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return hip.act_dtype(self.precision)
 
     def eval(self):
         return self
@@ -448,12 +447,12 @@ class PEAudioFrame:
         self.device = torch.device(device) if device is not None else None
         self.hop_length, self.sample_rate = hop_length, sample_rate
         self.text_model = text_model if text_model is not None else _text_tower(config.text_model)
-        self._lib = hip.lib()
+        self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self._loaded = False
-        fc = hip.FrameConfig(precision=hip.BF16 if precision == "bf16" else hip.F32,
+        fc = hip.FrameConfig(precision=hip.precision_code(precision),
                              audio=peav_dims(config.audio, config.codebook_dim), codec_dim=config.codebook_dim,
                              embed_dim=config.text_hidden)
         hip.check(self._lib.samaudio_frame_create(C.byref(fc), C.byref(self._h)))
@@ -465,7 +464,7 @@ class PEAudioFrame:
 
     @property
     def act_dtype(self) -> torch.dtype:
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return hip.act_dtype(self.precision)
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         if self.device is None:

@@ -58,7 +58,7 @@ class _Lane:
         self._ctx = C.c_void_p()
         hip.check(self.lib.samaudio_create(C.byref(model._hc), C.byref(self._ctx)))
         for name, t in model._tensors.items():
-            dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+            dt = hip.dtype_code(t.dtype)
             hip.check(self.lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                    hip.shape_array(t.shape)))
         hip.check(self.lib.samaudio_finalize(self._ctx, 0))
@@ -78,8 +78,7 @@ class SAMAudio:
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
                  text_encoder: Optional[Callable] = None, streams: int = 1):
         cfg.check_supported()
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        hip.check_precision(precision)
         self.cfg = cfg
         self.precision = precision
         self.device = torch.device(device) if device is not None else None
@@ -95,7 +94,7 @@ class SAMAudio:
         self.span_predictor_transform = None
         self.vision_encoder = None            # callable: list of [T,3,H,W] videos -> [B, T, vision_encoder.dim]
         self.fix_span_order = False           # quirk Q13, see separate()
-        self._lib = hip.lib()                 # raises if the HIP library is not built
+        self._lib = hip.lib(hip.operands_for(precision))   # raises if the HIP library is not built
         self._ctx = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
@@ -108,7 +107,7 @@ class SAMAudio:
         self._lanes: List[_Lane] = []
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
-            precision=hip.BF16 if precision == "bf16" else hip.F32, dim=t.dim, n_heads=t.n_heads,
+            precision=hip.precision_code(precision), dim=t.dim, n_heads=t.n_heads,
             n_layers=t.n_layers, ffn_hidden=t.ffn_hidden, latent_channels=t.out_channels,
             text_dim=cfg.text_encoder.dim, video_dim=cfg.vision_encoder.dim, freq_dim=t.frequency_embedding_dim,
             anchor_dim=cfg.anchor_embedding_dim, anchor_vocab=cfg.num_anchors + 1, max_positions=t.max_positions,
@@ -127,7 +126,7 @@ class SAMAudio:
     # ------------------------------------------------------------------ nn.Module-ish surface
     @property
     def act_dtype(self) -> torch.dtype:
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return hip.act_dtype(self.precision)
 
     @property
     def sample_rate(self) -> int:  # reference model.py:104-106
@@ -207,7 +206,7 @@ class SAMAudio:
 
     def _register(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
-            dt = {torch.float32: hip.DT_F32, torch.bfloat16: hip.DT_BF16}[t.dtype]
+            dt = hip.dtype_code(t.dtype)
             self._tensors[name] = t  # keep alive: the library borrows the pointer
             hip.check(self._lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                     hip.shape_array(t.shape)))

@@ -141,8 +141,7 @@ class PEVisionTower:
 
     def __init__(self, cfg: Optional[PEVisionConfig] = None, precision: str = "bf16", device: Optional[str] = None,
                  name: str = "PE-Core-L14-336"):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        hip.check_precision(precision)
         if cfg is None:
             if name not in PE_VISION_CONFIGS:
                 raise ValueError(f"unknown PE vision config {name!r}; known: {sorted(PE_VISION_CONFIGS)}")
@@ -152,13 +151,13 @@ class PEVisionTower:
         self.cfg = cfg
         self.precision = precision
         self.device = torch.device(device) if device is not None else None
-        self._lib = hip.lib()
+        self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
         self._loaded = False
         vc = hip.VitConfig(
-            precision=hip.BF16 if precision == "bf16" else hip.F32, image_size=cfg.image_size, patch_size=cfg.patch_size,
+            precision=hip.precision_code(precision), image_size=cfg.image_size, patch_size=cfg.patch_size,
             width=cfg.width, layers=cfg.layers, heads=cfg.heads, mlp_width=cfg.mlp_width, output_dim=cfg.output_dim,
             use_cls_token=int(cfg.use_cls_token), use_rope2d=int(cfg.use_rope2d), use_ln_pre=int(cfg.use_ln_pre),
             use_ln_post=int(cfg.use_ln_post), pool_type=POOL_TYPES[cfg.pool_type], pool_heads=cfg.attn_pooler_heads,
@@ -172,7 +171,7 @@ class PEVisionTower:
 
     @property
     def act_dtype(self) -> torch.dtype:
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return hip.act_dtype(self.precision)
 
     def eval(self):
         return self

@@ -163,7 +163,7 @@ def convert_codec(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: t
     """`cfg` needs an `.audio_codec` DACVAEConfig.  with_decoder=False converts the encoder + quantizer.in_proj only
     (the Judge's DACVAEEncoder, reference codec.py:42-78)."""
     c = cfg.audio_codec
-    slab = 64 if act_dtype == torch.bfloat16 else 32
+    slab = 64 if act_dtype != torch.float32 else 32
     out: Dict[str, torch.Tensor] = {}
 
     def f32(x):

@@ -20,11 +20,13 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "samaudio.h")).read()
     declared = set(re.findall(r"\b(samaudio_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
-    lib = hip.lib()
-    for name in sorted(declared):
-        assert hasattr(lib, name), f"libsamaudio_hip.so does not export {name}"
+    for operands in ("bf16", "fp16"):          # the two builds of the library (16-bit operand format), same C ABI
+        lib = hip.lib(operands)
+        for name in sorted(declared):
+            assert hasattr(lib, name), f"{hip.LIB_PATHS[operands]} does not export {name}"
+        assert b"gfx950" in lib.samaudio_version()
+        assert (b"fp16" in lib.samaudio_version()) == (operands == "fp16")
     assert declared == set(hip.EXPORTED_SYMBOLS)
-    assert b"gfx950" in lib.samaudio_version()
 
 
 def test_config_defaults_match_reference_rule():

@@ -19,7 +19,9 @@ pytestmark = pytest.mark.gpu
 
 # measured on MI355X (profiles/r2_gpu_tests_call2_measured_errors.log): forward fp32 5.7e-6, bf16 8.8e-3 on |out| <= 2.7;
 # 2-step midpoint latent fp32 4.3e-6, bf16 7.6e-3 on |latent| <= 5.6.  bf16 bound = 2 x measured.
-BOUND = {"fp32": 1e-3, "bf16": 1.8e-2}
+# fp16 operands (libsamaudio_hip_f16.so, same kernels / same MFMA rate): bound = 2 x measured, see FP16_NOTE below
+BOUND = {"fp32": 1e-3, "bf16": 1.8e-2, "fp16": 4e-3}
+FP16_NOTE = "first measured in GPU call 6 of round 2 (profiles/r2_call6/): the bound above is tightened to 2x that value"
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +61,7 @@ def _model(large, prec, gpu):
     return m
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_forward_large_dims(gpu, large, prec):
     c = large["cond"]
     model = _model(large, prec, gpu)
@@ -69,7 +71,7 @@ def test_forward_large_dims(gpu, large, prec):
     util.report(f"large* forward {prec}", out, large["want_fwd"], BOUND[prec])
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_two_step_midpoint_large_dims(gpu, large, prec):
     c = large["cond"]
     model = _model(large, prec, gpu)

@@ -5,8 +5,8 @@ import torch
 
 from sam_audio_amd import hip
 
-PREC = {"fp32": hip.F32, "bf16": hip.BF16}
-ACT_DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+PREC = {"fp32": hip.F32, "bf16": hip.BF16, "fp16": hip.BF16}   # fp16: the 16-bit mode of libsamaudio_hip_f16.so
+ACT_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def stream():
@@ -46,7 +46,7 @@ def gemm(prec: str, A, W, M, N, K, *, nbatch=1, a_off=0, a_bstride=0, lda=None, 
     p.act_alpha = 0 if act_alpha is None else act_alpha.data_ptr()
     p.c_lo, p.c_hi, p.c_ld_rel = c_lo, c_hi, c_ld_rel
     p.w_bstride, p.raster_gm = w_bstride, raster_gm
-    hip.check(hip.lib().samaudio_op_gemm(C.byref(p), C.sizeof(p), PREC[prec], stream()))
+    hip.check(hip.lib(hip.operands_for(prec)).samaudio_op_gemm(C.byref(p), C.sizeof(p), PREC[prec], stream()))
 
 
 def report(name, got, want, tol):
