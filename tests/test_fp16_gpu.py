@@ -50,7 +50,7 @@ def test_gemm_kernels_on_fp16_operands(gpu, variant):
     base = util.rounded(A, "fp16") @ util.rounded(W, "fp16").T + bias
     want = base * (tab[None] + gate.repeat_interleave(T, 0)) + res
     util.report(f"fp16 gemm v{variant} f32", out, want, 5e-4)
-    util.report(f"fp16 gemm v{variant} act", out_act, torch.nn.functional.silu(want), 4e-3)
+    util.report(f"fp16 gemm v{variant} act", out_act, torch.nn.functional.silu(want), 8.5e-3)  # half an fp16 ulp at |v| in [16, 32)
 
 
 def test_separate_fp16_error_next_to_bf16(gpu):
