@@ -57,6 +57,8 @@ const char* gemm_variant_name(int v, bool) { return v == 0 ? "emu_gemm" : ""; }
 bool gemm2_ok(const GemmParams&) { return false; }
 hipError_t launch_gemm2(const GemmParams&, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_gemm8(const GemmParams&, int, hipStream_t) { return hipErrorNotSupported; }
+int gemm_tail_split(const GemmParams&, bool) { return 0; }
+hipError_t launch_gemm_part(const GemmParams&, bool, int, hipStream_t) { return hipErrorNotSupported; }
 
 // same argument checks as the product (gemm.hip gemm_check): the orchestration must satisfy them on the GPU too
 const char* gemm_check(const GemmParams& p, bool is_bf16) {

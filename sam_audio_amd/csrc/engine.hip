@@ -344,16 +344,25 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops) {
     SA_HIP(launch_gemm(p, bf16_, st));
     return Status{};
   }
-  ProfRec r;
-  r.key = std::string(prof_cls_) + "/" + gemm_variant_name(gemm_variant(p, bf16_), bf16_);
-  r.flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
-  r.bytes = gemm_alg_bytes(p, esz_);
-  SA_TRY(prof_event(&r.e0));
-  SA_TRY(prof_event(&r.e1));
-  SA_HIP(hipEventRecord(r.e0, st));
-  SA_HIP(launch_gemm(p, bf16_, st));
-  SA_HIP(hipEventRecord(r.e1, st));
-  prof_.push_back(r);
+  const double flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
+  const double bytes = gemm_alg_bytes(p, esz_);
+  const int full = gemm_tail_split(p, bf16_);
+  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+  for (int part = 0; part < (full ? 2 : 1); ++part) {
+    // a split launch (gemm.hip gemm_tail_split) is two kernels: each gets its own record, flops / bytes by tile share
+    const double share = !full ? 1.0 : (part == 0 ? (double)full / tiles : 1.0 - (double)full / tiles);
+    ProfRec r;
+    r.key = std::string(prof_cls_) + "/" + (part ? "gemm8s_bf16_128x128_tail" : gemm_variant_name(gemm_variant(p, bf16_), bf16_));
+    r.flops = flops * share;
+    r.bytes = bytes * share;
+    SA_TRY(prof_event(&r.e0));
+    SA_TRY(prof_event(&r.e1));
+    SA_HIP(hipEventRecord(r.e0, st));
+    if (full) SA_HIP(launch_gemm_part(p, bf16_, part, st));
+    else SA_HIP(launch_gemm(p, bf16_, st));
+    SA_HIP(hipEventRecord(r.e1, st));
+    prof_.push_back(r);
+  }
   return Status{};
 }
 

@@ -284,8 +284,25 @@ static hipError_t launch_t(const GemmParams& p, int variant, hipStream_t st) {
   }
 }
 
+// 8-phase launches whose last round of 256x256 tiles would be mostly empty are split (gemm8.hip launch_gemm8_split):
+// returns the number of tiles the main launch keeps, 0 = one launch.  Only when the policy (not a forced variant) chose
+// the kernel; the tail must be worth a launch (>= 16 tiles) and the last round must be at most 3/4 full.
+int gemm_tail_split(const GemmParams& p, bool is_bf16) {
+  if (g_force >= 0 || debug_flag(10) || gemm_variant(p, is_bf16) != 22) return 0;
+  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+  const long full = tiles / 256 * 256, rem = tiles - full;
+  return full >= 256 && rem >= 16 && rem <= 192 ? (int)full : 0;
+}
+hipError_t launch_gemm_part(const GemmParams& p, bool is_bf16, int part, hipStream_t st) {
+  return launch_gemm8_split(p, gemm_tail_split(p, is_bf16), part, st);
+}
+
 // host entry used by the engine and by the C-ABI test hook; is_bf16 selects the element type
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st) {
+  if (const int full = gemm_tail_split(p, is_bf16)) {
+    const hipError_t e = launch_gemm8_split(p, full, 0, st);
+    return e != hipSuccess ? e : launch_gemm8_split(p, full, 1, st);
+  }
   const int v = gemm_variant(p, is_bf16);
   if (v >= 3) return launch_gemm2(p, v - 3, st);
   return is_bf16 ? launch_t<bf16_t>(p, v, st) : launch_t<float>(p, v, st);

@@ -140,16 +140,12 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
   }
 }
 
-// workgroup -> tile: contiguous run of tiles per XCD, GM M-tiles x all N-tiles per group (as gemm2.hip)
-__device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, const int BN, int& b, int& tm, int& tn) {
+// workgroup -> tile: contiguous run of tiles per XCD, GM M-tiles x all N-tiles per group (as gemm2.hip).
+// `L` = position in the linear raster order; tile_of() maps it to (batch, M-tile, N-tile).
+__device__ __forceinline__ void tile_of(const GemmParams& p, const int BM, const int BN, const int L, int& b, int& tm, int& tn) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int per_batch = tiles_m * tiles_n;
-  const int total = per_batch * p.nbatch;
-  const int bid = blockIdx.x;
-  const int q = total >> 3, r = total & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   b = L / per_batch;
   const int l2 = L - b * per_batch;
   const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
@@ -161,13 +157,24 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
   tm = first_m + in_grp % gsz;
   tn = in_grp / gsz;
 }
+// blockIdx.x -> position in a run of `total` units dealt to the 8 XCDs as contiguous sub-runs
+__device__ __forceinline__ int xcd_run_pos(const int total) {
+  const int bid = blockIdx.x;
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+__device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, const int BN, int& b, int& tm, int& tn) {
+  const int total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  tile_of(p, BM, BN, xcd_run_pos(total), b, tm, tn);
+}
 
 }  // namespace
 
 // STAGGER: the two wave groups run one barrier apart (off: all 8 waves read together, then multiply together);
 // PRIO: s_setprio 1 around each MFMA cluster.  Both on = the guide's template; the others are A/B builds.
 template <bool STAGGER, bool PRIO>
-__global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
 
@@ -177,8 +184,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
   const int wr = wave >> 2, wc = wave & 3;  // waves w and w+4 share a SIMD: one of each group per SIMD
   const int lr = lane & 15, lg = lane >> 4;
 
+  // tile_count > 0: this launch covers only the first tile_count tiles of the raster order (the full rounds of the chip);
+  // the rest runs as 128x128 tiles of gemm8s_kernel (launch_gemm8_split below)
   int b, tm, tn;
-  tile_raster8(p, BM, BN, b, tm, tn);
+  if (tile_count > 0) tile_of(p, BM, BN, xcd_run_pos(tile_count), b, tm, tn);
+  else tile_raster8(p, BM, BN, b, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging bookkeeping ---------------------------------------------------------------------------------
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p) {
 // 4 waves as 2 (M) x 2 (N), 64 x 64 outputs each; two 32 KiB stages (A tile | W tile) = 64 KiB of LDS and 256 threads, so
 // two workgroups share a CU and one's barriers / epilogue are covered by the other's K loop; a plain double buffer: the
 // DMA of K-tile t+1 is issued before the reads of K-tile t, one counted vmcnt and two barriers per K-tile.
-__global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];  // [stage][A tile, W tile]
 
@@ -355,9 +365,22 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p) {
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lg = lane >> 4;
 
-  int b, tm, tn;
-  tile_raster8(p, BM, BN, b, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  // skip256 >= 0 ("tail" mode): the first skip256 tiles of the 256x256 raster order were computed by gemm8_kernel; this
+  // launch covers the remaining ones as 4 quadrants each - consecutive workgroups of an XCD's run share a 256-tile's
+  // operand panels.  Same arithmetic either way, so the split is invisible in the results.
+  int b, tm, tn, m0, n0;
+  if (skip256 >= 0) {
+    const int total256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+    const int pos = xcd_run_pos((total256 - skip256) * 4);
+    tile_of(p, 256, 256, skip256 + (pos >> 2), b, tm, tn);
+    m0 = tm * 256 + ((pos >> 1) & 1) * 128;
+    n0 = tn * 256 + (pos & 1) * 128;
+    if (m0 >= p.M || n0 >= p.N) return;  // quadrant outside the problem (uniform for the workgroup)
+  } else {
+    tile_raster8(p, BM, BN, b, tm, tn);
+    m0 = tm * BM;
+    n0 = tn * BN;
+  }
 
   // staging: wave w moves rows 32w .. 32w+31 of both tiles as 4 + 4 wave instructions of 8 rows (1 KiB each):
   // lane -> row 32w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
@@ -444,16 +467,28 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p) {
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
-  hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
   return hipGetLastError();
 }
 
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const dim3 grid((unsigned)tiles), block(512);
-  if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p);        // no stagger
-  else if (mode == 2) hipLaunchKernelGGL((gemm8_kernel<true, false>), grid, block, 0, st, p);   // no setprio
-  else hipLaunchKernelGGL((gemm8_kernel<true, true>), grid, block, 0, st, p);
+  if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, 0);        // no stagger
+  else if (mode == 2) hipLaunchKernelGGL((gemm8_kernel<true, false>), grid, block, 0, st, p, 0);   // no setprio
+  else hipLaunchKernelGGL((gemm8_kernel<true, true>), grid, block, 0, st, p, 0);
+  return hipGetLastError();
+}
+
+// Tile-quantisation split: 256x256 tiles fill the chip only in whole rounds of 256 workgroups (one per CU); the last,
+// partial round of a launch leaves CUs idle for a full tile time (352 tiles at N = D: 2 rounds for 1.375 rounds of
+// work).  part 0 = the 8-phase kernel on the first `full` tiles of the raster order, part 1 = the remaining tiles as
+// 128x128 quadrants on gemm8s_kernel (two workgroups per CU, 4x finer granularity).  Bitwise the same results.
+hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st) {
+  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+  if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
+  if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  else hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
   return hipGetLastError();
 }
 

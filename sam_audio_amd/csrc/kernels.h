@@ -18,6 +18,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 8: GEMM epilogues straight from the accumulator layout (round 1) instead of the LDS-staged coalesced form
 //   flag 9: loader-wave 256x128 kernel WITHOUT the persistent tile walk (its ring is free after the K loop, so it can use
 //           the LDS-staged epilogue; the persistent walk keeps the accumulator-layout epilogue)
+//   flag 10: no tail split of 8-phase launches (every 256x256 tile on gemm8_kernel, as before GPU call 7 of round 2)
 //   flag 7: the loader-wave 256x128 kernel (32x32x16 family) for 2048 <= N < 4096 as before GPU call 3 of round 2 (the
 //           8-phase family now covers every N >= 2048: 181.1 vs 173.0 s-audio/s, 200.5 vs 183.2 with two streams)
 void set_debug_flag(int flag, int value);
@@ -37,6 +38,11 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
+// gemm8.hip: one GEMM as two launches - part 0: gemm8 on the first `full` 256x256 tiles (whole rounds of the chip),
+// part 1: the rest as 128x128 quadrants on gemm8s.  gemm_tail_split() = `full` for a launch (0: no split).
+hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st);
+int gemm_tail_split(const GemmParams& p, bool is_bf16);
+hipError_t launch_gemm_part(const GemmParams& p, bool is_bf16, int part, hipStream_t st);
 // test / tuning hook: force a variant for every eligible bf16 GEMM (-1 = automatic, 0..2 = gemm.hip tiles only,
 // 3.. = gemm2 variant when gemm2_ok)
 void gemm_force_variant(int v);

@@ -187,3 +187,29 @@ def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
     assert torch.isfinite(o22.float()).all()
     assert torch.equal(o22.view(torch.int16) if swiglu else o22, o27.view(torch.int16) if swiglu else o27)
     assert torch.equal(a22.view(torch.int16), a27.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10)])
+def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
+    """8-phase launches whose last round of 256x256 tiles is mostly empty run as two kernels (gemm.hip gemm_tail_split:
+    whole rounds on gemm8, the rest as 128x128 quadrants on gemm8s).  272 / 280 tiles here -> 256 + 16 / 24; ragged M and N
+    put quadrants partly and wholly outside the problem.  The automatic (split) result must equal the forced single-kernel
+    one bit for bit - gated residual epilogue, fp32 + bf16 outputs, per-batch strides."""
+    if os.environ.get("SAMAUDIO_EMU_DRYRUN") == "simt" and os.environ.get("SAMAUDIO_SIMT_POLICY", "r1") == "r1":
+        pytest.skip("the simulator's default policy is the round-1 one (tests/conftest.py); run with SAMAUDIO_SIMT_POLICY=r2")
+    A, W = _mk((nbatch, M, K), 41), _mk((N, K), 42, 1 / math.sqrt(K))
+    tab, gate, res = _mk((N,), 43), _mk((nbatch, N), 44), _mk((nbatch, M, N), 45)
+    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
+    outs = {}
+    for variant in (-1, 22):
+        hip.lib().samaudio_debug_force_gemm_variant(variant)
+        out = torch.full((nbatch, M, N), float("nan"), device=gpu)
+        out_act = torch.zeros(nbatch, M, N, device=gpu, dtype=torch.bfloat16)
+        util.gemm("bf16", keep[0], keep[1], M, N, K, nbatch=nbatch, a_bstride=M * K, gate_tab=keep[2], gate=keep[3],
+                  gate_ld=N, rows_per_gate=M, res=keep[4], res_geom=(M * N, N, 0), out_f32=out, f32_geom=(M * N, N, 0),
+                  out_act=out_act, act_geom=(M * N, N, 0))
+        outs[variant] = (out.cpu(), out_act.cpu())
+    want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None, None] + gate[:, None, :]) + res
+    util.report(f"tail split {M}x{N}x{K}x{nbatch}", outs[-1][0], want, 5e-4)
+    assert torch.equal(outs[-1][0], outs[22][0])
+    assert torch.equal(outs[-1][1].view(torch.int16), outs[22][1].view(torch.int16))

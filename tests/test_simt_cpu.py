@@ -70,3 +70,12 @@ def test_new_streaming_kernels_and_the_peav_transformer_on_the_simulator():
     out = _run(["tests/test_zz_next_rows_gpu.py", "-k",
                 "masked_groupnorm or layernorm_rows or peav_transformer or frame_logits"], 900)
     assert "10 passed" in out
+
+
+def test_round2_policy_tail_split_and_vision_tower_on_the_simulator():
+    """The shipped (round-2) tile policy end to end on small shapes: the 8-phase launch split into whole rounds + 128x128
+    quadrant tail must be bitwise invisible, and the PE-Core vision tower (tests/test_vit_gpu.py: every structural switch,
+    fp32 and bf16, uint8 video -> resize -> tower) must match its oracle with the real kernel code."""
+    out = _run(["tests/test_gemm2_gpu.py", "tests/test_vit_gpu.py", "-k",
+                "tail_split or 8phase_family or (test_vit_gpu and not checkpoint)"], 900, SAMAUDIO_SIMT_POLICY="r2")
+    assert " passed" in out and "failed" not in out

@@ -27,7 +27,7 @@ EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 2
 
 
 # round 2, after GPU call 3: the kernels the tile policy can pick for a DiT-class GEMM, for A/B at several row counts
-FAMILY = {22: "8-phase 256x256", 27: "gemm8s 128x128", 20: "ld 256x128 pf persist", 25: "128x128 s2 (32x32x16)",
+FAMILY = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128", 20: "ld 256x128 pf persist", 25: "128x128 s2 (32x32x16)",
           26: "64x128 s3 (32x32x16)"}
 
 
