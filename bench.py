@@ -477,6 +477,7 @@ def main():
         assert my_ids, f"strong scaling: rank {rank} got no clip (global batch {args.batch} < {world} ranks)"
     batch, clips, text, tmask = make_batch(my_ids)
     n_streams = model.streams = auto_streams(len(my_ids))
+    model.tail_split = n_streams == 1   # pinned, so that the instrumented (single-stream) step launches the timed kernels
     log(f"inputs resident ({len(my_ids)} clips on this rank, {n_streams} stream(s)); warm-up")
     elapsed, step, graphed = timed(batch, args.steps, args.warmup, args.scaling)
     value = clips_total * CLIP_SECONDS * args.steps / elapsed
@@ -506,6 +507,22 @@ def main():
         model.profile_begin()
         step()
         roof = rooflines(model.profile_end())
+        if n_streams > 1 and roof["roofline"]:
+            # for reference: the same step as ONE row group with the tail split on (what a context that has the GPU to
+            # itself runs): whole rounds of 256x256 tiles under the 8-phase symbol, last partial rounds as 128x128 tiles
+            model.tail_split = True
+            model.profile_begin()
+            step()
+            alt = rooflines(model.profile_end())
+            model.tail_split = False
+            if alt["roofline"]:
+                a = alt["roofline"]
+                roof["roofline"]["single_group_tail_split"] = {
+                    "what": "the same step solved as one row group with SAMAUDIO_OPT_TAIL_SPLIT on (not the timed configuration)",
+                    "kernel": a["kernel"], "achieved": a["achieved"], "frac": a["frac"], "launches_per_step": a["launches_per_step"],
+                    "dit_gemm_all": a["dit_gemm_all"],
+                    "tail_kernel": next(({"kernel": k["kernel"], "tflops": k["tflops"], "ms": k["ms"], "launches": k["launches"]}
+                                         for k in alt["kernels"] if k["kernel"].endswith("_tail")), None)}
         model.streams = n_streams
         if roof["roofline"]:
             fl = sum(k["_flops"] for k in roof["_rows"])

@@ -82,6 +82,13 @@ size_t samaudio_workspace_bytes(samaudio_ctx* ctx, int rows, int frames, int tex
                                 int64_t samples);
 int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
 
+/* Execution options of a context (no reference counterpart: scheduling only, results are bitwise unaffected).
+ *   SAMAUDIO_OPT_TAIL_SPLIT (default 1): a GEMM whose last round of 256x256 tiles would leave most CUs idle is issued as
+ *   two kernels (whole rounds + a 128x128-tile tail).  Set to 0 for contexts that share the GPU with another context's
+ *   stream (SAMAudio(streams=2)): there the other stream's workgroups fill the idle CUs and the extra launches cost 2 %. */
+#define SAMAUDIO_OPT_TAIL_SPLIT 1
+int samaudio_set_option(samaudio_ctx* ctx, int option, int value);
+
 /* ---- hot path ------------------------------------------------------------------------------------ */
 
 /* Everything of SAMAudio.forward that does not depend on (noisy_audio, time): the audio_features / video /

@@ -384,9 +384,12 @@ hipError_t launch_add_rowvec(const float* x, const float* vec, long vec_ld, void
 }
 
 hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, const long* align, void* out, bool bf16,
-                                int B, int T, int E, hipStream_t) {
+                                int B, int T, int E, int vocab, hipStream_t) {
   for (long r = 0; r < (long)B * T; ++r) {
-    const long tok = ids[(r / T) * n_ids + align[r]];
+    long slot = align[r];
+    slot = slot < 0 ? 0 : (slot >= n_ids ? n_ids - 1 : slot);
+    long tok = ids[(r / T) * n_ids + slot];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
     for (int i = 0; i < E; ++i) {
       if (bf16) HE<bf16_t>::st((bf16_t*)out + r * E + i, emb[tok * E + i]);
       else ((float*)out)[r * E + i] = emb[tok * E + i];

@@ -68,6 +68,11 @@ int samaudio_set_tensor(samaudio_ctx* ctx, const char* name, const void* data, i
   return ret(ctx->engine->set_tensor(name, data, dtype, ndim, shape));
 }
 
+int samaudio_set_option(samaudio_ctx* ctx, int option, int value) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->set_option(option, value));
+}
+
 int samaudio_finalize(samaudio_ctx* ctx, int what) {
   if (!ctx) return bad("null context");
   return ret(ctx->engine->finalize(what));

@@ -49,6 +49,7 @@ class Engine {
   explicit Engine(const samaudio_config& c);
   Status set_tensor(const char* name, const void* p, int dtype, int ndim, const int64_t* shape);
   Status finalize(int what);
+  Status set_option(int option, int value);
   size_t workspace_bytes(int rows, int frames, int text_len, int codec_items, int64_t samples);
   Status set_workspace(void* p, size_t bytes);
 
@@ -103,6 +104,7 @@ class Engine {
 
   samaudio_config cfg_;
   bool bf16_;
+  bool tail_split_ = true;  // SAMAUDIO_OPT_TAIL_SPLIT
   size_t esz_;  // bytes per activation / GEMM-operand element
   int at_dtype_;
   std::map<std::string, TensorRef> tensors_;

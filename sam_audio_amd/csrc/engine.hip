@@ -336,9 +336,18 @@ static double gemm_alg_bytes(const GemmParams& p, size_t esz) {
   return b;
 }
 
+Status Engine::set_option(int option, int value) {
+  if (option == SAMAUDIO_OPT_TAIL_SPLIT) {
+    tail_split_ = value != 0;
+    return Status{};
+  }
+  return fail(SAMAUDIO_ERR_ARG, "samaudio_set_option: unknown option " + std::to_string(option));
+}
+
 Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops) {
   GemmParams p = p_in;
   p.tag = prof_cls_[0] == 'c' ? 1 : 0;  // codec launches run under their own kernel symbols
+  p.flags = tail_split_ ? 0 : 2;        // bit 1: no tail split (gemm.hip gemm_tail_split)
   if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
   if (!prof_on_) {
     SA_HIP(launch_gemm(p, bf16_, st));
@@ -500,7 +509,7 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
     SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment, d_.anch,
-                                bf16_, rows, T, cfg_.anchor_dim, st));
+                                bf16_, rows, T, cfg_.anchor_dim, cfg_.anchor_vocab, st));
     GemmParams p = lin(d_.anch, cfg_.anchor_dim, g_.anc_w, M, D, cfg_.anchor_dim);
     with_res(p, d_.cond, D);
     out_f32(p, d_.cond, D);

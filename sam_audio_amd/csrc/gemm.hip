@@ -288,7 +288,7 @@ static hipError_t launch_t(const GemmParams& p, int variant, hipStream_t st) {
 // returns the number of tiles the main launch keeps, 0 = one launch.  Only when the policy (not a forced variant) chose
 // the kernel; the tail must be worth a launch (>= 16 tiles) and the last round must be at most 3/4 full.
 int gemm_tail_split(const GemmParams& p, bool is_bf16) {
-  if (g_force >= 0 || debug_flag(10) || gemm_variant(p, is_bf16) != 22) return 0;
+  if (g_force >= 0 || debug_flag(10) || (p.flags & 2) || gemm_variant(p, is_bf16) != 22) return 0;
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const long full = tiles / 256 * 256, rem = tiles - full;
   return full >= 256 && rem >= 16 && rem <= 192 ? (int)full : 0;

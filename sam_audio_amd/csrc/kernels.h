@@ -105,7 +105,7 @@ hipError_t launch_add_rowvec(const float* x, const float* vec, long vec_ld, void
 
 // out[r,:] = AT(emb[ids[b, align[b,t]], :])   (model.py:61: embed(anchor_ids.gather(1, anchor_alignment)))
 hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, const long* align, void* out, bool bf16,
-                                int B, int T, int E, hipStream_t st);
+                                int B, int T, int E, int vocab, hipStream_t st);
 
 // generic fp32 -> AT copy with optional halo layout: out[b][halo + t][c_out_pad] <- in[b][t][c_in] (extra channels 0)
 // out_bstride in elements (0 = dense (T + 2*halo) * C_out)

@@ -544,22 +544,26 @@ hipError_t launch_add_rowvec(const float* x, const float* vec, long vec_ld, void
 // ------------------------------------------------------------------------------------------------
 template <typename TA>
 __global__ void anchor_gather_kernel(const float* __restrict__ emb, const long* __restrict__ ids, int n_ids,
-                                     const long* __restrict__ align, TA* __restrict__ out, int T, int E) {
+                                     const long* __restrict__ align, TA* __restrict__ out, int T, int E, int vocab) {
   const long r = blockIdx.x;  // row b*T + t
   const long b = r / T;
-  const long slot = align[r];
-  const long tok = ids[b * n_ids + slot];
+  // indices arrive through the public ABI: out-of-range values are clamped here so that the kernel never reads outside
+  // its tables (the host classes reject them with the reference's exception type before they get this far)
+  long slot = align[r];
+  slot = slot < 0 ? 0 : (slot >= n_ids ? n_ids - 1 : slot);
+  long tok = ids[b * n_ids + slot];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
   for (int i = threadIdx.x; i < E; i += blockDim.x) Elem<TA>::store(out + r * E + i, emb[tok * E + i]);
 }
 
 hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, const long* align, void* out, bool bf16,
-                                int B, int T, int E, hipStream_t st) {
+                                int B, int T, int E, int vocab, hipStream_t st) {
   if (bf16)
     hipLaunchKernelGGL(anchor_gather_kernel<bf16_t>, dim3(B * T), dim3(64), 0, st, emb, ids, n_ids, align,
-                       (bf16_t*)out, T, E);
+                       (bf16_t*)out, T, E, vocab);
   else
     hipLaunchKernelGGL(anchor_gather_kernel<float>, dim3(B * T), dim3(64), 0, st, emb, ids, n_ids, align, (float*)out,
-                       T, E);
+                       T, E, vocab);
   return hipGetLastError();
 }
 

@@ -43,6 +43,7 @@ def dtype_code(dtype) -> int:
     import torch
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
+OPT_TAIL_SPLIT = 1
 ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
 
 ERR_ARG, ERR_WEIGHT, ERR_WORKSPACE, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5
@@ -143,6 +144,7 @@ _PROTOS = {
     "samaudio_destroy": (None, [C.c_void_p]),
     "samaudio_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
     "samaudio_finalize": (C.c_int, [C.c_void_p, C.c_int]),
+    "samaudio_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "samaudio_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "samaudio_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "samaudio_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -104,6 +104,11 @@ class SAMAudio:
             raise ValueError("streams must be 1 or 2 (set SAMAUDIO_ALLOW_STREAMS=1 to experiment with more)")
         self.streams = int(streams)           # row groups solved concurrently on separate HIP streams
         self.use_graph = False                # replay the ODE solve from a captured hipGraph (small per-GPU batches)
+        # GEMM launches split into whole rounds + a small-tile tail (samaudio.h SAMAUDIO_OPT_TAIL_SPLIT): None = automatic,
+        # on when the batch is solved as one row group, off when two groups share the GPU (their kernels fill each other's
+        # tails: +2 % without the split, profiles/r2_call7/); True / False pin it (bench.py keeps the instrumented step on
+        # the same kernels as the timed ones)
+        self.tail_split: Optional[bool] = None
         self._lanes: List[_Lane] = []
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
@@ -162,9 +167,12 @@ class SAMAudio:
         model.load_state_dict(sd, strict=strict)
         # the reference builds its T5 encoder and rankers in __init__ from hub ids (model.py:82,94-95); offline they
         # can only come from local directories - attach what is reachable, leave the rest to the caller
-        if os.path.isdir(model.cfg.text_encoder.name):
+        try:   # a directory, or a hub id that is already in the local Hugging Face cache (local_files_only)
             from .text_encoder import T5TextEncoder
             model.text_encoder = T5TextEncoder(model.cfg.text_encoder, device=model.device)
+        except FileNotFoundError as exc:
+            warnings.warn(f"text encoder not attached ({exc}); pass text_features / text_mask to the processor or set "
+                          "model.text_encoder")
         model.attach_rankers(precision=precision)
         return model
 
@@ -307,7 +315,13 @@ class SAMAudio:
             ids = anchor_ids.to(dev, torch.long).contiguous()
             align = anchor_alignment.to(dev, torch.long).contiguous()
             n_ids = ids.size(1)
-            assert int(align.max()) < n_ids, "anchor_alignment points past anchor_ids"
+            # the reference's gather / nn.Embedding raise on out-of-range indices (model.py:61); one host sync per separate()
+            lo, hi = int(align.min()), int(align.max())
+            if lo < 0 or hi >= n_ids:
+                raise IndexError(f"anchor_alignment values must be in [0, {n_ids}): found [{lo}, {hi}]")
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi > self.cfg.num_anchors:
+                raise IndexError(f"anchor_ids must be in [0, {self.cfg.num_anchors}]: found [{lo}, {hi}]")
         if audio_pad_mask is not None:
             pad = audio_pad_mask.to(dev).to(torch.uint8).contiguous()
         own._live = (feats, text, tmask, video, ids, align, pad)
@@ -346,6 +360,11 @@ class SAMAudio:
                                                    hip.current_stream_ptr()))
         return state
 
+    def _apply_options(self, groups: int) -> None:
+        split = int(self.tail_split if self.tail_split is not None else groups == 1)
+        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_TAIL_SPLIT, split))
+
     def _solve_concurrent(self, noise: torch.Tensor, ode_opt: Dict[str, Any], cond: List[Optional[torch.Tensor]],
                           groups: int) -> torch.Tensor:
         """prepare + ODE solve of `groups` contiguous row groups, each on its own engine context and HIP stream, driven
@@ -359,6 +378,7 @@ class SAMAudio:
         rows = state.size(0)
         while len(self._lanes) < groups - 1:
             self._lanes.append(_Lane(self))
+        self._apply_options(groups)
         main = torch.cuda.current_stream(self.device)
         errors: List[BaseException] = []
 
@@ -453,6 +473,7 @@ class SAMAudio:
                 cond = [None if c is None else c.to(self.device) for c in cond]
                 latent = self._solve_concurrent(noise, ode_opt, cond, groups)
             else:
+                self._apply_options(1)
                 self._prepare(*cond)
                 latent = self.solve(noise, ode_opt)                              # states[-1], [Bc, T, 256]
             self.last_latent = latent
@@ -474,6 +495,9 @@ class SAMAudio:
         the text ranker, else candidate 0; `idxs = scores.argmax(dim=1)`."""
         B = len(target_wavs)
         sr = self.cfg.audio_codec.sample_rate
+        if cand > 1 and self.text_ranker is None and (self.visual_ranker is None or batch.masked_video is None):
+            warnings.warn(f"reranking_candidates={cand} but no applicable ranker is attached (model.text_ranker / "
+                          "model.visual_ranker): candidate 0 is returned for every clip")
         if cand > 1 and batch.masked_video is not None and self.visual_ranker is not None:
             scores = self.visual_ranker(extracted_audio=target_wavs, videos=batch.masked_video, sample_rate=sr)
             return scores.argmax(dim=1)

@@ -74,5 +74,7 @@ def test_separate_fp16_error_next_to_bf16(gpu):
     print(f"full 16-step midpoint ODE + decode, 'mini' dims (latent max {lat_ref.abs().max().item():.2f}): "
           f"bf16 latent {errs['bf16'][0]:.3e} waveform {errs['bf16'][1]:.3e} | "
           f"fp16 latent {errs['fp16'][0]:.3e} waveform {errs['fp16'][1]:.3e}")
-    assert errs["fp16"][0] < 2.5e-3 and errs["fp16"][1] < 1e-3   # bounds: 2 x measured (profiles/r2_call6/), see DESIGN section 4
+    # measured on MI355X (profiles/r2_call7/gpu_tests.log): fp16 latent 7.1e-4, waveform 1.6e-4 (bf16: 6.1e-3 / 1.5e-3);
+    # bounds = 2 x measured, both inside the north_star's 1e-3 ... and 8x below bf16
+    assert errs["fp16"][0] < 1.5e-3 and errs["fp16"][1] < 3.5e-4
     assert errs["fp16"][0] < errs["bf16"][0]
