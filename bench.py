@@ -83,6 +83,10 @@ def parse(argv=None):
                          "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
     ap.add_argument("--predict-spans", action="store_true",
                     help="configs[3]: run the PE-A-Frame span predictor first (random weights, stand-in dims)")
+    ap.add_argument("--t5", action="store_true",
+                    help="row a3 inside the step: descriptions go through a t5-base-shaped T5EncoderModel (transformers on "
+                         "PyTorch-ROCm, random init, hash tokenizer - no tokenizer files offline) instead of resident text "
+                         "features")
     ap.add_argument("--visual", action="store_true",
                     help="BASELINE.json configs[4]: visual prompting - every clip comes with a 250-frame 336x336 uint8 video "
                          "(left half masked out), encoded by the PE-Core-L14-336 tower on the HIP library inside the step "
@@ -232,10 +236,14 @@ def parity_check(model, sub, noise, ref, R, dev, precision):
     }
 
 
+PROMPTS = ["a dog barking", "man speaking", "rain on a tin roof", "acoustic guitar strumming chords", "car engine idling",
+           "glass breaking", "a woman singing softly over a piano", "birds"]
+
+
 class _HashTokenizer:
     """Stand-in for the Judge's ModernBERT tokenizer (no tokenizer files offline): word hashes -> ids, pad-to-longest."""
 
-    def __call__(self, text, return_tensors="pt", padding="longest", max_length=512, truncation=True):
+    def __call__(self, text, return_tensors="pt", padding="longest", max_length=512, truncation=True, **_):
         import torch
         rows = [[1] + [3 + (hash(w) % 30000) for w in t.split()][: max_length - 1] for t in text]
         width = max(len(r) for r in rows)
@@ -415,9 +423,22 @@ def main():
                 m[..., : S // 2] = 1
                 masks.append(m)
             videos = proc.mask_videos(vids, masks)
-        b = proc(descriptions=["sound"] * len(clip_ids), audios=clips, masked_videos=videos, text_features=text,
-                 text_mask=tmask)
+        if args.t5:   # the processor hands the descriptions through; SAMAudio.separate() calls model.text_encoder
+            b = proc(descriptions=[PROMPTS[i % len(PROMPTS)] for i in clip_ids], audios=clips, masked_videos=videos)
+        else:
+            b = proc(descriptions=["sound"] * len(clip_ids), audios=clips, masked_videos=videos, text_features=text,
+                     text_mask=tmask)
         return b.to(dev), clips, text, tmask
+
+    if args.t5:
+        import transformers
+        from sam_audio_amd.text_encoder import T5TextEncoder
+        t5cfg = transformers.T5Config(vocab_size=32128, d_model=768, d_kv=64, d_ff=3072, num_layers=12, num_heads=12,
+                                      feed_forward_proj="relu")   # t5-base (reference text_encoder.py:11-17)
+        torch.manual_seed(11)
+        model.text_encoder = T5TextEncoder(cfg.text_encoder, model=transformers.T5EncoderModel(t5cfg), tokenizer=_HashTokenizer(),
+                                           device=dev)
+        log("T5 text encoder attached (t5-base dims, random init, hash tokenizer)")
 
     vision = None
     if args.visual:
@@ -588,6 +609,7 @@ def main():
                 "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}",
                 "streams_per_gpu": n_streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
+                "text_encoder_in_step": "t5-base dims, random init (transformers on PyTorch-ROCm)" if args.t5 else None,
                 "visual_prompt": (f"{cfg.vision_encoder.name} tower, 250 frames x 336x336 per clip, encoded inside the step"
                                   if args.visual else None),
             },

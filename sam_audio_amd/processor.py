@@ -28,12 +28,44 @@ def mask_from_sizes(sizes: torch.Tensor) -> torch.Tensor:
     return steps.unsqueeze(0) < sizes.unsqueeze(1)
 
 
+def resample(wav: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+             rolloff: float = 0.99) -> torch.Tensor:
+    """Band-limited sinc resampling of [..., samples], the algorithm `torchaudio.functional.resample` documents for its
+    default method (reference processor.py:29-30 calls it for files whose rate differs from the model's 48 kHz):
+    rates reduced by their gcd; for each of the `new` output phases a Hann-windowed sinc low-pass (cut-off = rolloff x the
+    lower Nyquist rate, `lowpass_filter_width` zero crossings either side) sampled at the input positions; the filter bank is
+    applied as one strided convolution (stride = reduced input rate) and the result is trimmed to ceil(new * n / orig)
+    samples.  torchaudio is not part of this build's environment: restated from the published description, property-tested
+    (tests/test_host_cpu.py), UNPINNED against torchaudio's own output.  Host-side preprocessing, runs once per file."""
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq <= 0 or new_freq <= 0:
+        raise ValueError("sampling rates must be positive")
+    if orig_freq == new_freq:
+        return wav
+    g = math.gcd(orig_freq, new_freq)
+    o, n = orig_freq // g, new_freq // g
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    taps = torch.arange(-width, width + o, dtype=torch.float64)[None, :] / o          # input sample positions (in seconds * g)
+    phase = -torch.arange(n, dtype=torch.float64)[:, None] / n                       # output phase offsets
+    t = ((phase + taps) * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernel = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / o)    # [n phases, 2*width + o]
+    shape = wav.shape
+    x = wav.reshape(-1, shape[-1])
+    length = x.shape[-1]
+    x = torch.nn.functional.pad(x, (width, width + o))
+    y = torch.nn.functional.conv1d(x[:, None].to(torch.float64), kernel[:, None], stride=o)     # [rows, n, frames]
+    y = y.transpose(1, 2).reshape(x.shape[0], -1)[:, : math.ceil(n * length / o)]
+    return y.to(wav.dtype if wav.is_floating_point() else torch.float32).reshape(*shape[:-1], -1)
+
+
 def load_wav(path: str, sampling_rate: int) -> torch.Tensor:
-    """PCM WAV file -> float32 [channels, samples] in [-1, 1) with torchaudio.load's integer normalisation
-    (reference processor.py:27-30 calls torchaudio.load + resample).  torchaudio / torchcodec are not part of this
-    build's environment, so only what the standard library decodes is accepted - uncompressed PCM (8 / 16 / 24 / 32
-    bit) - and only at the model's sampling rate: resampling would need torchaudio's sinc kernel, which cannot be
-    pinned offline."""
+    """PCM WAV file -> float32 [channels, samples] in [-1, 1) with torchaudio.load's integer normalisation, resampled to
+    the model's rate when the file's differs (reference processor.py:27-30: torchaudio.load + functional.resample).
+    torchaudio / torchcodec are not part of this build's environment, so only what the standard library decodes is
+    accepted - uncompressed PCM (8 / 16 / 24 / 32 bit)."""
     import wave
     import numpy as np
     try:
@@ -42,8 +74,6 @@ def load_wav(path: str, sampling_rate: int) -> torch.Tensor:
             raw = f.readframes(n)
     except (wave.Error, EOFError) as exc:
         raise ValueError(f"{path}: only uncompressed PCM WAV files can be decoded without torchaudio ({exc})") from exc
-    if sr != sampling_rate:
-        raise ValueError(f"{path}: sampling rate {sr} != {sampling_rate}; resample first (torchaudio is not available here)")
     if width == 1:
         x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
     elif width == 2:
@@ -56,7 +86,8 @@ def load_wav(path: str, sampling_rate: int) -> torch.Tensor:
         x = (np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0).astype(np.float32)
     else:
         raise ValueError(f"{path}: unsupported sample width {width}")
-    return torch.from_numpy(x.reshape(-1, ch).T.copy())
+    wav = torch.from_numpy(x.reshape(-1, ch).T.copy())
+    return resample(wav, sr, sampling_rate) if sr != sampling_rate else wav
 
 
 def batch_audio(audios: Sequence[torch.Tensor], audio_sampling_rate: int = 48_000) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -195,9 +195,40 @@ def test_wav_paths_are_decoded_like_torchaudio_load(tmp_path):
     wavs, sizes = batch_audio([p16, torch.zeros(1, 1200)], 48000)
     assert wavs.shape == (2, 1, 1200) and sizes.tolist() == [1000, 1200]
     assert torch.allclose(wavs[0, 0, :1000], x.mean(0))
-    with pytest.raises(ValueError, match="sampling rate"):
-        load_wav(p16, 44100)
+    # a file at another rate is resampled to the model's (reference processor.py:29-30): 1000 samples at 48 kHz read as
+    # if the model ran at 44.1 kHz -> ceil(1000 * 441 / 480) samples
+    assert load_wav(p16, 44100).shape == (2, 919)
     bad = tmp_path / "c.wav"
     bad.write_bytes(b"not a wav file")
     with pytest.raises(ValueError, match="PCM WAV"):
         load_wav(str(bad), 48000)
+
+
+def test_sinc_resampler_properties():
+    """`processor.resample` (restated torchaudio.functional.resample, UNPINNED offline): output length
+    ceil(new * n / orig); identity at equal rates; a band-limited tone keeps frequency, phase and amplitude; DC gain 1;
+    content above the new Nyquist rate is removed when down-sampling; agrees with scipy's polyphase resampler on a
+    band-limited signal (different filter design, so only to ~1e-2)."""
+    import math
+    import numpy as np
+    import scipy.signal
+    from sam_audio_amd.processor import resample
+    x = torch.randn(2, 3, 4410)
+    assert resample(x, 44100, 44100) is x
+    for o, n in ((44100, 48000), (16000, 48000), (96000, 48000), (22050, 48000)):
+        y = resample(x, o, n)
+        assert y.shape == (2, 3, math.ceil(n * 4410 / o)) and y.dtype == x.dtype
+    t44 = torch.arange(44100, dtype=torch.float64) / 44100
+    tone = torch.sin(2 * math.pi * 1000 * t44 + 0.3).float()
+    y = resample(tone, 44100, 48000)
+    t48 = torch.arange(y.numel(), dtype=torch.float64) / 48000
+    want = torch.sin(2 * math.pi * 1000 * t48 + 0.3).float()
+    assert (y - want)[200:-200].abs().max().item() < 2e-3
+    assert (resample(torch.ones(1, 8000), 16000, 48000)[0, 100:-100] - 1).abs().max().item() < 2e-3
+    hi = torch.sin(2 * math.pi * 30000 * torch.arange(96000, dtype=torch.float64) / 96000).float()   # above 24 kHz
+    assert resample(hi, 96000, 48000)[200:-200].abs().max().item() < 2e-2
+    g = torch.Generator().manual_seed(0)
+    sig = sum(torch.sin(2 * math.pi * f * t44 + p) for f, p in ((220.0, 0.1), (1300.0, 1.0), (5200.0, 2.0))).float() / 3
+    ours = resample(sig, 44100, 48000).numpy()
+    ref = scipy.signal.resample_poly(sig.numpy().astype(np.float64), 160, 147)
+    assert np.abs(ours - ref[: ours.size])[500:-500].max() < 1e-2

@@ -328,3 +328,53 @@ def test_visual_prompt_features_reach_the_ode(gpu):
                                 video=feats_v.transpose(1, 2), candidates=2, decode=False)
     model.separate(batch, noise=noise2.to(gpu), reranking_candidates=2)
     util.report("latent with visual prompt, 2 candidates", model.last_latent, lat2, 1e-3)
+
+
+def test_t5_text_encoder_on_the_gpu_feeds_separate(gpu):
+    """Row a3 on the device: descriptions -> `T5TextEncoder` (transformers' T5EncoderModel on PyTorch-ROCm, random init at
+    the model's text width, whitespace-hash tokenizer - t5-base's files cannot be fetched offline) -> `[B, Lt, 768]`
+    features + bool mask -> the HIP prepare step (reference text_encoder.py:19-37, model.py:256-257).  separate() through
+    `model.text_encoder` must equal separate() fed with the same features explicitly (bitwise), and the oracle (1e-3)."""
+    import transformers
+    from sam_audio_amd import SAMAudio, SAMAudioProcessor, preset_config
+    from sam_audio_amd.synthetic import init_state_dict, synthetic_noise
+    from sam_audio_amd.text_encoder import T5TextEncoder
+    if gpu.type != "cuda":
+        pytest.skip("needs PyTorch-ROCm on a GPU (the dry-run builds replace torch's device plumbing)")
+
+    class Tok:
+        def __call__(self, texts, truncation=True, max_length=512, padding="longest", return_tensors="pt"):
+            rows = [[2 + (sum(map(ord, w)) % 90) for w in t.split()][: max_length - 1] + [1] for t in texts]
+            width = max(len(r) for r in rows)
+            ids = torch.zeros(len(rows), width, dtype=torch.long)
+            att = torch.zeros(len(rows), width, dtype=torch.long)
+            for i, r in enumerate(rows):
+                ids[i, : len(r)] = torch.tensor(r)
+                att[i, : len(r)] = 1
+            return {"input_ids": ids, "attention_mask": att}
+
+    cfg = preset_config("tiny")
+    torch.manual_seed(4)
+    t5 = transformers.T5EncoderModel(transformers.T5Config(vocab_size=100, d_model=cfg.text_encoder.dim, d_kv=32, d_ff=256,
+                                                           num_layers=2, num_heads=4))
+    enc = T5TextEncoder(cfg.text_encoder, model=t5, tokenizer=Tok(), device=gpu)
+    descriptions = ["a dog barking loudly", "rain"]
+    feats, mask = enc(descriptions)
+    assert feats.shape == (2, 5, cfg.text_encoder.dim) and feats.device.type == "cuda"
+    assert mask.tolist() == [[True] * 5, [True, True, False, False, False]]
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 5 * hop) for i in range(2)]
+    proc = SAMAudioProcessor.from_config(cfg)
+    noise = synthetic_noise(2, 5)
+    sd = init_state_dict(cfg, seed=3)
+    model = SAMAudio(cfg, precision="fp32", device=str(gpu), text_encoder=enc)
+    model.load_state_dict(sd)
+    res_a = model.separate(proc(descriptions=descriptions, audios=clips).to(gpu), noise=noise.to(gpu))
+    lat_a = model.last_latent.clone()
+    res_b = model.separate(proc(descriptions=descriptions, audios=clips, text_features=feats, text_mask=mask).to(gpu),
+                           noise=noise.to(gpu))
+    assert torch.equal(lat_a, model.last_latent) and all(torch.equal(x, y) for x, y in zip(res_a.target, res_b.target))
+    batch = proc(descriptions=descriptions, audios=clips)
+    with torch.inference_mode():
+        _, _, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), feats.cpu(), mask.cpu(), noise, decode=False)
+    util.report("latent with T5 features from the GPU", lat_a, lat_ref, 1e-3)
