@@ -526,9 +526,10 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
   bf16x8_t wf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
-  // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one
-  for (int b0 = 0; b0 < B; b0 += 4) {
-    uint4 v[4][4];
+  // four batch items per trip, and the NEXT trip's 16 loads are issued before this trip's stores: vmcnt retires in issue
+  // order, so loads issued after the stores could only be waited for together with them - every trip would pay the
+  // stores' round trip to L2 (that serialisation, not the store pattern, is what the round-1 kernel was bound by)
+  auto fetch = [&](const int b0, uint4 (&v)[4][4]) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       const int b = b0 + bb < B ? b0 + bb : B - 1;
@@ -536,6 +537,8 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) v[bb][ks] = *(const uint4*)(vrow + ks * 32);
     }
+  };
+  auto emit = [&](const int b0, const uint4 (&v)[4][4]) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -548,6 +551,16 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
       // lane: tokens g*4 .. g*4+3 of column n
       if (b0 + bb < B && g * 4 < LtP)
         store4<bf16_t>(UT + ((long)(b0 + bb) * D + n) * KP + h * LtP + g * 4, u[0], u[1], u[2], u[3]);
+    }
+  };
+  uint4 va[4][4], vb[4][4];
+  fetch(0, va);
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    if (b0 + 4 < B) fetch(b0 + 4, vb);
+    emit(b0, va);
+    if (b0 + 4 < B) {
+      if (b0 + 8 < B) fetch(b0 + 8, va);
+      emit(b0 + 4, vb);
     }
   }
 }

@@ -71,6 +71,15 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
   const int col0 = p.swiglu ? n_wave0 >> 1 : n_wave0;                 // first output column of this wave
   const int rsub = p.swiglu ? lane >> 3 : lane >> 4, csub = p.swiglu ? lane & 7 : lane & 15;
   const int rows_per_it = 64 / cpr;
+  const int nit = cpr;  // read-phase iterations per 64-row half (64 / rows_per_it)
+  // column-only operands of this lane (its 4 columns are the same in every iteration)
+  const int n = col0 + csub * 4;
+  const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+  const int ch = p.chan_mod ? nc % p.chan_mod : nc;
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), tt = bb, sa = bb;
+  if (has_bias) bb = *(const float4*)(p.bias + ch);
+  if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
+  if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
 #pragma unroll
   for (int half = 0; half < NH; ++half) {
     // write phase: rows half*64 + i*16 + lr of the wave's rows
@@ -93,46 +102,57 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
       }
     }
     __syncthreads();
-    // read phase: rows_per_it rows x cpr chunks per wave instruction
-    for (int r0 = 0; r0 < 64; r0 += rows_per_it) {
-      const int row = r0 + rsub;
-      const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
-      const int m = m_wave0 + half * 64 + row;
-      const int n = col0 + csub * 4;
-      const bool m_ok = m < p.M;
-      const int mc = m_ok ? m : p.M - 1;
-      const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
-      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
-      float v[4] = {sv.x, sv.y, sv.z, sv.w};
-      float4 bb, gg, tt, rr, sa = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (has_bias) bb = *(const float4*)(p.bias + ch);
-      if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
-      if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
+    // read phase: rows_per_it rows x cpr chunks per wave instruction.  The residual / gate operands of a row are loaded
+    // PD iterations ahead of their use: vmcnt retires in issue order, so a load issued AFTER the previous iteration's
+    // stores cannot be waited for without also waiting for those stores to reach L2 - every iteration would pay a full
+    // store round trip (measured: gated-residual tiles +28 us over plain ones).  Issued ahead, the loads overtake nothing.
+    constexpr int PD = 4;
+    float4 rq[PD], gq[PD];
+    auto issue = [&](const int it, float4& rr, float4& gg) {
+      const int m = m_wave0 + half * 64 + it * rows_per_it + rsub;
+      const int mc = m < p.M ? m : p.M - 1;
       if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
-      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
-      if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-      if (has_gate) {
-        if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
-        v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
-      }
+      if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
+    };
+    if (has_res || has_gate) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-      const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
-                  a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
-      bool ok = m_ok && n < n_out;
-      if (p.c_ld_rel) {
-        const long erel = (long)m * p.c_ld_rel + n;
-        ok = ok && erel >= p.c_lo && erel < p.c_hi;
-      }
-      if (ok) {
-        if (p.out_f32) {
-          float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
-          *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+      for (int k = 0; k < PD; ++k) issue(k, rq[k], gq[k]);  // nit >= 8 > PD
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (it < nit) {  // uniform: nit = 16, or 8 with the SwiGLU epilogue
+        const int row = it * rows_per_it + rsub;
+        const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
+        const int m = m_wave0 + half * 64 + row;
+        const bool m_ok = m < p.M;
+        const int mc = m_ok ? m : p.M - 1;
+        float v[4] = {sv.x, sv.y, sv.z, sv.w};
+        float4 rr = rq[it % PD], gg = gq[it % PD];
+        if ((has_res || has_gate) && it + PD < nit) issue(it + PD, rq[it % PD], gq[it % PD]);
+        if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+        if (has_gate) {
+          if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
+          v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
         }
-        if (p.out_act) {
-          bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
-          store4<bf16_t>(arow + n, a0, a1, a2, a3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+        const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
+                    a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
+        bool ok = m_ok && n < n_out;
+        if (p.c_ld_rel) {
+          const long erel = (long)m * p.c_ld_rel + n;
+          ok = ok && erel >= p.c_lo && erel < p.c_hi;
+        }
+        if (ok) {
+          if (p.out_f32) {
+            float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
+            *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+          }
+          if (p.out_act) {
+            bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
+            store4<bf16_t>(arow + n, a0, a1, a2, a3);
+          }
         }
       }
     }

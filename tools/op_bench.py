@@ -80,6 +80,11 @@ for flag, name in ((0, "cross_attn_fold"), (1, "cross_attn_fold (LDS-staged rows
     timeit(name, lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
                                                                  8, H, st())), B * D * KP * 2 + D * D * 2)
 L.samaudio_debug_set_flag(3, 0)
+# ... with the engine's real key/value layout: one [B*Lt, L*2D] tensor for all 22 layers (row stride 248 KB)
+kv_all = torch.randn(B * Lt, 22 * 2 * D, device=dev).to(torch.bfloat16)
+timeit("cross_attn_fold (kv_all layout)", lambda: hip.check(L.samaudio_op_cross_attn_fold(
+    hip.ptr(wo), C.c_void_p(kv_all.data_ptr() + 5 * 2 * D * 2), 22 * 2 * D, hip.ptr(ut), KP, B, Lt, 8, H, st())),
+    B * D * KP * 2 + D * D * 2)
 
 # DAC decoder stage with 192 channels: dilated k7 conv as implicit GEMM (N = 192, K = 1344), 8 waveforms
 from tests import util  # noqa: E402
@@ -95,3 +100,11 @@ for flag, name in ((1, "codec conv7 C=192 (2 x 128-wide tiles)"), (0, "codec con
                                    act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c),
            2 * items * Tc * Cc * 2, iters=5)
 L.samaudio_debug_set_flag(4, 0)
+
+# the k1 convolution that closes a residual unit: raw (fp32) += W x, bf16 copy snake(raw) for the next unit - HBM-bound
+raw = torch.randn(items, Tc + 80, Cc, device=dev)
+w1 = (torch.randn(Cc, Cc, device=dev) / Cc ** 0.5).to(torch.bfloat16)
+timeit("codec conv1 C=192 + in-place residual", lambda: util.gemm(
+    "bf16", xa, w1, Tc, Cc, Cc, nbatch=items, a_off=40 * Cc, a_bstride=(Tc + 80) * Cc, lda=Cc, bias=bias_c, res=raw,
+    res_geom=((Tc + 80) * Cc, Cc, 40 * Cc), out_f32=raw, f32_geom=((Tc + 80) * Cc, Cc, 40 * Cc), out_act=oc,
+    act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c), items * Tc * Cc * (2 + 4 + 4 + 2), iters=5)
