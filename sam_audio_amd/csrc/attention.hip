@@ -52,23 +52,35 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   for (int n = 0; n < NF; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   char* Pw = Ps + wave * 2048;
 
+  // The K / V^T tile of the NEXT iteration is fetched into registers right after this iteration's tile became visible,
+  // i.e. the global-load latency runs under the two MFMA contractions and the softmax instead of in front of them.
+  constexpr int IT = HD / (8 * NW);
+  uint4 kpre[IT], vpre[IT];
+  auto fetch = [&](const int kt) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int idx = tid + 64 * NW * it;
+      kpre[it] = *(const uint4*)(K + (bh * Tp + kt + idx / CH) * HD + (idx % CH) * 8);
+      vpre[it] = *(const uint4*)(Vt + (bh * HD + (idx >> 3)) * Tp + kt + (idx & 7) * 8);
+    }
+  };
+  fetch(0);
   for (int kt = 0; kt < Tp; kt += 64) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < HD / (8 * NW); ++it) {
+    for (int it = 0; it < IT; ++it) {
       const int idx = tid + 64 * NW * it;
       {
         const int row = idx / CH, c = idx % CH;
-        const uint4 v = *(const uint4*)(K + (bh * Tp + kt + row) * HD + c * 8);
-        *(uint4*)(Ks + row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4)) = v;
+        *(uint4*)(Ks + row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4)) = kpre[it];
       }
       {
         const int d = idx >> 3, c = idx & 7;
-        const uint4 v = *(const uint4*)(Vt + (bh * HD + d) * Tp + kt + c * 8);
-        *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = v;
+        *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vpre[it];
       }
     }
     __syncthreads();
+    if (kt + 64 < Tp) fetch(kt + 64);
     // S = Q K^T : s[nb][r] = S[q = lg*4 + r][key = nb*16 + lr]
     f32x4_t s[4];
 #pragma unroll

@@ -106,55 +106,67 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
     // PD iterations ahead of their use: vmcnt retires in issue order, so a load issued AFTER the previous iteration's
     // stores cannot be waited for without also waiting for those stores to reach L2 - every iteration would pay a full
     // store round trip (measured: gated-residual tiles +28 us over plain ones).  Issued ahead, the loads overtake nothing.
-    constexpr int PD = 4;
-    float4 rq[PD], gq[PD];
+    // Explicit modulo schedule of depth 4: four bodies per trip, each consuming ITS queue slot and refilling it for the
+    // row four iterations later (no register rotation, which would need the data at copy time).  Not unrolled further: fully
+    // unrolled the epilogue is 6x the kernel's code - five inlined activation functions x 4 elements x 16 iterations x 2
+    // halves - and the instruction fetch then costs more than the pipelining wins (798 -> 622 TF/s on a plain GEMM,
+    // profiles/r2_call8/).
+    float4 r0, r1, r2, r3, g0, g1, g2, g3;
     auto issue = [&](const int it, float4& rr, float4& gg) {
       const int m = m_wave0 + half * 64 + it * rows_per_it + rsub;
       const int mc = m < p.M ? m : p.M - 1;
       if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
       if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
     };
-    if (has_res || has_gate) {
+    const bool ahead = has_res || has_gate;
+    auto body = [&](const int it, float4& rslot, float4& gslot) {
+      const float4 rr = rslot;
+      float4 gg = gslot;
+      if (ahead && it + 4 < nit) issue(it + 4, rslot, gslot);
+      const int row = it * rows_per_it + rsub;
+      const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
+      const int m = m_wave0 + half * 64 + row;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : p.M - 1;
+      float v[4] = {sv.x, sv.y, sv.z, sv.w};
+      if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+      if (has_gate) {
+        if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
+        v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
+      }
 #pragma unroll
-      for (int k = 0; k < PD; ++k) issue(k, rq[k], gq[k]);  // nit >= 8 > PD
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      if (it < nit) {  // uniform: nit = 16, or 8 with the SwiGLU epilogue
-        const int row = it * rows_per_it + rsub;
-        const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
-        const int m = m_wave0 + half * 64 + row;
-        const bool m_ok = m < p.M;
-        const int mc = m_ok ? m : p.M - 1;
-        float v[4] = {sv.x, sv.y, sv.z, sv.w};
-        float4 rr = rq[it % PD], gg = gq[it % PD];
-        if ((has_res || has_gate) && it + PD < nit) issue(it + PD, rq[it % PD], gq[it % PD]);
-        if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-        if (has_gate) {
-          if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
-          v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
+      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+      if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+      const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
+                  a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
+      bool ok = m_ok && n < n_out;
+      if (p.c_ld_rel) {
+        const long erel = (long)m * p.c_ld_rel + n;
+        ok = ok && erel >= p.c_lo && erel < p.c_hi;
+      }
+      if (ok) {
+        if (p.out_f32) {
+          float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
+          *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-        if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-        const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
-                    a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
-        bool ok = m_ok && n < n_out;
-        if (p.c_ld_rel) {
-          const long erel = (long)m * p.c_ld_rel + n;
-          ok = ok && erel >= p.c_lo && erel < p.c_hi;
-        }
-        if (ok) {
-          if (p.out_f32) {
-            float* frow = p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld;
-            *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
-          }
-          if (p.out_act) {
-            bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
-            store4<bf16_t>(arow + n, a0, a1, a2, a3);
-          }
+        if (p.out_act) {
+          bf16_t* arow = (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld;
+          store4<bf16_t>(arow + n, a0, a1, a2, a3);
         }
       }
+    };
+    if (ahead) {  // nit is 8 or 16
+      issue(0, r0, g0);
+      issue(1, r1, g1);
+      issue(2, r2, g2);
+      issue(3, r3, g3);
+    }
+#pragma unroll 1
+    for (int it = 0; it < nit; it += 4) {
+      body(it, r0, g0);
+      body(it + 1, r1, g1);
+      body(it + 2, r2, g2);
+      body(it + 3, r3, g3);
     }
     if (half + 1 < NH) __syncthreads();  // the reads of this half precede the next half's writes
   }

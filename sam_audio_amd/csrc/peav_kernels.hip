@@ -178,9 +178,62 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
   }
 }
 
+// The same with the row held in registers between the passes (MAXV float4 per lane, D <= 256 * MAXV): x is read from
+// memory once instead of three times and no load sits behind a store.  Per-lane summation order is unchanged, so the
+// results are bit-identical to layernorm_rows_kernel.
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_rows_reg_kernel(const float* __restrict__ x, long x_ld,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 float* __restrict__ out_f32, TO* __restrict__ out_act,
+                                                                 long M, int D, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + row * x_ld);
+  const int n4 = D >> 2;
+  float4 v[MAXV], ww[MAXV], bb[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    const bool in = i < n4;
+    v[k] = in ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ww[k] = in ? ((const float4*)w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bb[k] = in ? ((const float4*)b)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) s += v[k].x + v[k].y + v[k].z + v[k].w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    if (lane + 64 * k >= n4) continue;
+    const float a = v[k].x - mean, c = v[k].y - mean, d = v[k].z - mean, e = v[k].w - mean;
+    q += a * a + c * c + d * d + e * e;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i >= n4) continue;
+    const float o0 = (v[k].x - mean) * rstd * ww[k].x + bb[k].x, o1 = (v[k].y - mean) * rstd * ww[k].y + bb[k].y,
+                o2 = (v[k].z - mean) * rstd * ww[k].z + bb[k].z, o3 = (v[k].w - mean) * rstd * ww[k].w + bb[k].w;
+    if (out_f32) *(float4*)(out_f32 + row * D + 4 * i) = make_float4(o0, o1, o2, o3);
+    if (out_act) store4<TO>(out_act + row * D + 4 * i, o0, o1, o2, o3);
+  }
+}
+
 hipError_t launch_layernorm_rows(const float* x, long x_ld, const float* w, const float* b, float* out_f32,
                                  void* out_act, bool bf16, long M, int D, float eps, hipStream_t st) {
   dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  if (D <= 256 * 4) {  // vision tower (1024) and smaller: 4 float4 per lane
+    if (bf16)
+      hipLaunchKernelGGL((layernorm_rows_reg_kernel<bf16_t, 4>), grid, block, 0, st, x, x_ld, w, b, out_f32, (bf16_t*)out_act,
+                         M, D, eps);
+    else
+      hipLaunchKernelGGL((layernorm_rows_reg_kernel<float, 4>), grid, block, 0, st, x, x_ld, w, b, out_f32, (float*)out_act, M,
+                         D, eps);
+    return hipGetLastError();
+  }
   if (bf16)
     hipLaunchKernelGGL(layernorm_rows_kernel<bf16_t>, grid, block, 0, st, x, x_ld, w, b, out_f32, (bf16_t*)out_act, M,
                        D, eps);

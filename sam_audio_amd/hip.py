@@ -208,6 +208,8 @@ def lib(operands: str = "bf16"):
     if operands in _libs:
         return _libs[operands]
     path = LIB_PATHS[operands]
+    if operands == "bf16" and os.environ.get("SAMAUDIO_LIB_AB"):   # tuning only: A/B an older build of the library
+        path = os.environ["SAMAUDIO_LIB_AB"]
     if not os.path.exists(path):
         raise SamAudioHipError(
             f"{path} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
