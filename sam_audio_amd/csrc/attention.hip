@@ -32,6 +32,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   __shared__ __attribute__((aligned(16))) char Ks[64 * HD * 2];   // [key][HD d] bf16, chunk ^= key & (CH - 1)
   __shared__ __attribute__((aligned(16))) char Vs[HD * 128];      // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
   __shared__ __attribute__((aligned(16))) char Ps[NW * 16 * 128];  // per wave [16 q][64 keys] bf16
+  __shared__ unsigned char Ms[64];                                 // key mask of the tile (0 = masked or beyond T)
   const int q0 = blockIdx.x * (16 * NW), h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -52,10 +53,14 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   for (int n = 0; n < NF; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   char* Pw = Ps + wave * 2048;
 
-  // The K / V^T tile of the NEXT iteration is fetched into registers right after this iteration's tile became visible,
-  // i.e. the global-load latency runs under the two MFMA contractions and the softmax instead of in front of them.
+  // The K / V^T tile (and the 64 key-mask bytes) of the NEXT iteration are fetched into registers right after this
+  // iteration's tile became visible, so the global-load latency runs under the two MFMA contractions and the softmax
+  // instead of in front of them.  The compiler fence keeps the loads where they are written (without it they are sunk
+  // to their use after the next barrier - and the four mask bytes of a lane, read straight from global memory behind a
+  // short-circuit `&&`, were four serialised round trips per key tile: profiles/r2_call9/ has the ISA finding).
   constexpr int IT = HD / (8 * NW);
   uint4 kpre[IT], vpre[IT];
+  unsigned char mpre = 0;
   auto fetch = [&](const int kt) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -63,6 +68,12 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       kpre[it] = *(const uint4*)(K + (bh * Tp + kt + idx / CH) * HD + (idx % CH) * 8);
       vpre[it] = *(const uint4*)(Vt + (bh * HD + (idx >> 3)) * Tp + kt + (idx & 7) * 8);
     }
+    if (tid < 64) {
+      const int key = kt + tid;
+      mpre = key_mask[(long)b * T + (key < T ? key : T - 1)];
+      if (key >= T) mpre = 0;
+    }
+    asm volatile("" ::: "memory");
   };
   fetch(0);
   for (int kt = 0; kt < Tp; kt += 64) {
@@ -79,6 +90,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
         *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vpre[it];
       }
     }
+    if (tid < 64) Ms[tid] = mpre;
     __syncthreads();
     if (kt + 64 < Tp) fetch(kt + 64);
     // S = Q K^T : s[nb][r] = S[q = lg*4 + r][key = nb*16 + lr]
@@ -95,10 +107,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
     }
     bool valid[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const int key = kt + nb * 16 + lr;
-      valid[nb] = key < T && key_mask[(long)b * T + key] != 0;
-    }
+    for (int nb = 0; nb < 4; ++nb) valid[nb] = Ms[nb * 16 + lr] != 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = -INFINITY;
@@ -538,10 +547,9 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
   bf16x8_t wf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
-  // four batch items per trip, and the NEXT trip's 16 loads are issued before this trip's stores: vmcnt retires in issue
-  // order, so loads issued after the stores could only be waited for together with them - every trip would pay the
-  // stores' round trip to L2 (that serialisation, not the store pattern, is what the round-1 kernel was bound by)
-  auto fetch = [&](const int b0, uint4 (&v)[4][4]) {
+  // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    uint4 v[4][4];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       const int b = b0 + bb < B ? b0 + bb : B - 1;
@@ -549,8 +557,6 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) v[bb][ks] = *(const uint4*)(vrow + ks * 32);
     }
-  };
-  auto emit = [&](const int b0, const uint4 (&v)[4][4]) {
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -563,16 +569,6 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
       // lane: tokens g*4 .. g*4+3 of column n
       if (b0 + bb < B && g * 4 < LtP)
         store4<bf16_t>(UT + ((long)(b0 + bb) * D + n) * KP + h * LtP + g * 4, u[0], u[1], u[2], u[3]);
-    }
-  };
-  uint4 va[4][4], vb[4][4];
-  fetch(0, va);
-  for (int b0 = 0; b0 < B; b0 += 8) {
-    if (b0 + 4 < B) fetch(b0 + 4, vb);
-    emit(b0, va);
-    if (b0 + 4 < B) {
-      if (b0 + 8 < B) fetch(b0 + 8, va);
-      emit(b0 + 4, vb);
     }
   }
 }

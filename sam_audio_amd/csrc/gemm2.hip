@@ -63,89 +63,77 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
              has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
   const int NG = p.swiglu ? 2 : 4;       // swiglu: groups 0,1 = w1 rows of the 32-row block, groups 2,3 = matching w3 rows
   const int n_out = p.swiglu ? p.N >> 1 : p.N;
-  // One "round" = U register groups (4 output columns per lane each) of fragment (i, j).  The operands of round r+1 are
-  // loaded BEFORE the stores of round r: vmcnt retires in issue order, so loads issued after a round's stores could only be
-  // waited for together with those stores' round trip to L2 - and with an in-place residual (res == out_f32) the compiler
-  // may not move them up by itself.  A lane reads and writes each element exactly once, so the early loads are safe.
-  // (gate / gate_tab - DiT-only operands, and the DiT runs on gemm8.hip - are loaded in place: they would cost 32 more
-  // registers in flight in kernels that run 12 waves per CU on a 168-register budget.)
-  struct Round { float4 bb[U], rr[U], sa[U]; };
-  constexpr int GR = 4 / U, R = FM * FN * GR;
-  auto fetch = [&](const int r, Round& o) {
-    const int i = r / (FN * GR), j = (r / GR) % FN, gp = (r % GR) * U;
-    if (gp >= NG) return;
-    const int m = m_first + i * 32 + l31;
-    const int mc = m < p.M ? m : p.M - 1;
-    const int nb = (p.swiglu ? (n_first + j * 32) >> 1 : n_first + j * 32) + 4 * lh;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int n = nb + 8 * (gp + u);
-      const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
-      const int ch = p.chan_mod ? nc % p.chan_mod : nc;  // channel of a (phase, channel) column: transposed conv
-      if (has_bias) o.bb[u] = *(const float4*)(p.bias + ch);
-      if (has_snake) o.sa[u] = *(const float4*)(p.act_alpha + ch);
-      if (has_res) o.rr[u] = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
-    }
-  };
-  auto finish = [&](const int r, const Round& o) {
-    const int i = r / (FN * GR), j = (r / GR) % FN, gp = (r % GR) * U;
-    if (gp >= NG) return;
+  for (int i = 0; i < FM; ++i) {
     const int m = m_first + i * 32 + l31;
     const bool m_ok = m < p.M;
     const int mc = m_ok ? m : p.M - 1;
+    const float* grow = has_gate ? p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld : nullptr;
+    const float* rrow = has_res ? p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld : nullptr;
     float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld : nullptr;
     bf16_t* arow = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld : nullptr;
-    const int nb = (p.swiglu ? (n_first + j * 32) >> 1 : n_first + j * 32) + 4 * lh;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int g = gp + u;
-      const int ncol = nb + 8 * g;
-      float v[4];
-      if (p.swiglu) {
+    for (int j = 0; j < FN; ++j) {
+      const int nf = n_first + j * 32;  // first GEMM column of this 32-wide fragment
+      const int nb = (p.swiglu ? nf >> 1 : nf) + 4 * lh;
+      // U register groups (4 output columns per lane each) per round trip: 16*U registers of loads in flight
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[i][j][4 * g + e]) * acc[i][j][4 * ((g + 2) & 3) + e];
-      } else {
+      for (int gp = 0; gp < 4; gp += U) {
+        if (gp >= NG) continue;
+        int ncol[U];
+        float4 bb[U], gg[U], tt[U], rr[U], sa[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-      }
-      if (has_bias) { v[0] += o.bb[u].x; v[1] += o.bb[u].y; v[2] += o.bb[u].z; v[3] += o.bb[u].w; }
-      if (has_gate) {
-        const int nc = ncol + 4 <= n_out ? ncol : n_out - 4;
-        float4 q = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
-        if (has_tab) {
-          const float4 t4 = *(const float4*)(p.gate_tab + nc);
-          q.x += t4.x; q.y += t4.y; q.z += t4.z; q.w += t4.w;
+        for (int u = 0; u < U; ++u) {
+          const int n = nb + 8 * (gp + u);
+          ncol[u] = n;
+          const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+          const int ch = p.chan_mod ? nc % p.chan_mod : nc;  // channel of a (phase, channel) column: transposed conv
+          if (has_bias) bb[u] = *(const float4*)(p.bias + ch);
+          if (has_snake) sa[u] = *(const float4*)(p.act_alpha + ch);
+          if (has_gate) gg[u] = *(const float4*)(grow + nc);
+          if (has_tab) tt[u] = *(const float4*)(p.gate_tab + nc);
+          if (has_res) rr[u] = *(const float4*)(rrow + nc);
         }
-        v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
-      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-      if (has_res) { v[0] += o.rr[u].x; v[1] += o.rr[u].y; v[2] += o.rr[u].z; v[3] += o.rr[u].w; }
-      float a[4];
-      a[0] = act_apply(v[0], p.act, has_snake ? o.sa[u].x : 0.f);
-      a[1] = act_apply(v[1], p.act, has_snake ? o.sa[u].y : 0.f);
-      a[2] = act_apply(v[2], p.act, has_snake ? o.sa[u].z : 0.f);
-      a[3] = act_apply(v[3], p.act, has_snake ? o.sa[u].w : 0.f);
-      bool ok = m_ok && ncol < n_out;
-      if (p.c_ld_rel) {  // transposed conv: keep only the (row, phase) pairs that fall inside the output
-        const long erel = (long)m * p.c_ld_rel + ncol;
-        ok = ok && erel >= p.c_lo && erel < p.c_hi;
-      }
-      if (ok) {
-        if (frow) {
-          if (p.f32_act) *(float4*)(frow + ncol) = make_float4(a[0], a[1], a[2], a[3]);
-          else *(float4*)(frow + ncol) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int u = 0; u < U; ++u) {
+          const int g = gp + u;
+          float v[4];
+          if (p.swiglu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[i][j][4 * g + e]) * acc[i][j][4 * ((g + 2) & 3) + e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+          }
+          if (has_bias) { v[0] += bb[u].x; v[1] += bb[u].y; v[2] += bb[u].z; v[3] += bb[u].w; }
+          if (has_gate) {
+            float4 q = gg[u];
+            if (has_tab) { q.x += tt[u].x; q.y += tt[u].y; q.z += tt[u].z; q.w += tt[u].w; }
+            v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+          if (has_res) { v[0] += rr[u].x; v[1] += rr[u].y; v[2] += rr[u].z; v[3] += rr[u].w; }
+          float a[4];
+          a[0] = act_apply(v[0], p.act, has_snake ? sa[u].x : 0.f);
+          a[1] = act_apply(v[1], p.act, has_snake ? sa[u].y : 0.f);
+          a[2] = act_apply(v[2], p.act, has_snake ? sa[u].z : 0.f);
+          a[3] = act_apply(v[3], p.act, has_snake ? sa[u].w : 0.f);
+          bool ok = m_ok && ncol[u] < n_out;
+          if (p.c_ld_rel) {  // transposed conv: keep only the (row, phase) pairs that fall inside the output
+            const long erel = (long)m * p.c_ld_rel + ncol[u];
+            ok = ok && erel >= p.c_lo && erel < p.c_hi;
+          }
+          if (ok) {
+            if (frow) {
+              if (p.f32_act) *(float4*)(frow + ncol[u]) = make_float4(a[0], a[1], a[2], a[3]);
+              else *(float4*)(frow + ncol[u]) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (arow) store4<bf16_t>(arow + ncol[u], a[0], a[1], a[2], a[3]);
+          }
         }
-        if (arow) store4<bf16_t>(arow + ncol, a[0], a[1], a[2], a[3]);
       }
     }
-  };
-  Round q[2];
-  fetch(0, q[0]);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (r + 1 < R) fetch(r + 1, q[(r + 1) & 1]);
-    finish(r, q[r & 1]);
   }
 }
 
@@ -194,32 +182,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16_t 
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // read phase.  Bias / Snake alpha / residual of a (row, chunk) unit are loaded PD units ahead of their use: vmcnt
-    // retires in issue order, so a load issued after the previous unit's stores could only be waited for together with
-    // those stores' round trip to L2 (gemm8.hip epilogue8 has the measurement).  The registers rotate; gate / gate_tab
-    // (DiT-only operands; the DiT runs on gemm8.hip) stay unpipelined.
-    struct Ahead { float4 bb, sa, rr; };
-    auto issue = [&](const int u, Ahead& o) {
-      const int row = u / cpr, chunk = u - row * cpr;
-      const int m = m_first + i * 32 + row;
-      const int n = col0 + chunk * 4;
-      const int mc = m < p.M ? m : p.M - 1;
-      const int nc = n + 4 <= n_out ? n : n_out - 4;
-      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
-      if (has_bias) o.bb = *(const float4*)(p.bias + ch);
-      if (has_snake) o.sa = *(const float4*)(p.act_alpha + ch);
-      if (has_res) o.rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
-    };
-    Ahead q0, q1, q2;
-    q0.sa = q1.sa = q2.sa = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < units) issue(lane, q0);
-    if (lane + 64 < units) issue(lane + 64, q1);
-    if (lane + 128 < units) issue(lane + 128, q2);
+    // read phase
     for (int u = lane; u < units; u += 64) {
-      const Ahead cur = q0;
-      q0 = q1;
-      q1 = q2;
-      if (u + 192 < units) issue(u + 192, q2);
       const int row = u / cpr, chunk = u - row * cpr;
       const float4 sv = *(const float4*)(stg + row * rb + ((chunk ^ (row & smask)) << 4));
       const int m = m_first + i * 32 + row;
@@ -227,11 +191,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x16_t 
       const bool m_ok = m < p.M;
       const int mc = m_ok ? m : p.M - 1;
       const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
+      const int ch = p.chan_mod ? nc % p.chan_mod : nc;
       float v[4] = {sv.x, sv.y, sv.z, sv.w};
-      float4 gg, tt;
-      const float4 bb = cur.bb, rr = cur.rr, sa = cur.sa;
+      float4 bb, gg, tt, rr, sa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_bias) bb = *(const float4*)(p.bias + ch);
       if (has_gate) gg = *(const float4*)(p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld + nc);
       if (has_tab) tt = *(const float4*)(p.gate_tab + nc);
+      if (has_res) rr = *(const float4*)(p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld + nc);
+      if (has_snake) sa = *(const float4*)(p.act_alpha + ch);
       if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
       if (has_gate) {
         if (has_tab) { gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
@@ -814,14 +781,14 @@ __global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
     int b, tm, tn;
     ras.locate(p, base + idx0 + tk * stride, b, tm, tn);
     if (PERSIST) {  // the loaders are already filling the ring with the next tile: no LDS to stage through
-      gemm_epilogue<FM, FN, 1>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);  // U = 1: 12 waves share the register file
+      gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
     } else {
       static_assert(PERSIST || NC * FN * 4096 <= NS * STAGE, "epilogue staging fits the ring");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();  // B_end (all 12 waves)
       __builtin_amdgcn_sched_barrier(0);
       if (p.flags & 1)
-        gemm_epilogue<FM, FN, 1>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);  // U = 1: 12 waves share the register file
+        gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
       else
         gemm_epilogue_lds<FM, FN>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, lane, smem + wave * (FN * 4096));
     }

@@ -62,6 +62,8 @@ class _Lane:
             hip.check(self.lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                    hip.shape_array(t.shape)))
         hip.check(self.lib.samaudio_finalize(self._ctx, 0))
+        if model._has_codec:   # the lane also decodes its own row group (SAMAudio._solve_concurrent)
+            hip.check(self.lib.samaudio_finalize(self._ctx, 1))
         self._workspace: Optional[torch.Tensor] = None
         self._live = None
         self.stream = torch.cuda.Stream(device=model.device)
@@ -278,17 +280,21 @@ class SAMAudio:
                                                       hip.current_stream_ptr()))
         return z
 
-    def decode_audio(self, latents: torch.Tensor) -> torch.Tensor:
-        """latents channels-last [N, T, codebook_dim] -> [N, T*hop] (reference codec.py:86-89)."""
+    def decode_audio(self, latents: torch.Tensor, lane: Optional[_Lane] = None,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """latents channels-last [N, T, codebook_dim] -> [N, T*hop] (reference codec.py:86-89).  `lane`: run on that
+        lane's context (and on the current stream); `out`: a contiguous [N, T*hop] fp32 destination."""
         if not self._has_codec:
             raise RuntimeError("audio_codec weights are not loaded")
         lat = latents.to(self.device, torch.float32).contiguous()
         items, frames, _ = lat.shape
         samples = frames * self.cfg.audio_codec.hop_length
-        wav = torch.empty(items, samples, device=self.device)
+        wav = out if out is not None else torch.empty(items, samples, device=self.device)
+        assert wav.shape == (items, samples) and wav.is_contiguous() and wav.dtype == torch.float32
         with torch.cuda.device(self.device):
-            self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples)
-            hip.check(self._lib.samaudio_codec_decode(self._ctx, hip.ptr(lat), items, frames, hip.ptr(wav),
+            self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples, lane=lane)
+            ctx = self._ctx if lane is None else lane._ctx
+            hip.check(self._lib.samaudio_codec_decode(ctx, hip.ptr(lat), items, frames, hip.ptr(wav),
                                                       hip.current_stream_ptr()))
         return wav
 
@@ -366,16 +372,19 @@ class SAMAudio:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_TAIL_SPLIT, split))
 
     def _solve_concurrent(self, noise: torch.Tensor, ode_opt: Dict[str, Any], cond: List[Optional[torch.Tensor]],
-                          groups: int) -> torch.Tensor:
-        """prepare + ODE solve of `groups` contiguous row groups, each on its own engine context and HIP stream, driven
-        by one host thread per group (the C calls release the GIL).  Rows are independent, so
-        the result equals the single-stream one bit for bit."""
+                          groups: int, decode: bool = False):
+        """prepare + ODE solve (+ DAC-VAE decode of target and residual when `decode`) of `groups` contiguous row groups,
+        each on its own engine context and HIP stream, driven by one host thread per group (the C calls release the GIL).
+        Rows are independent, so the result equals the single-stream one bit for bit.  Returns the
+        latent state, and with `decode` also the waveforms [rows, 2, samples] (model.py:291-295)."""
         import threading
         from .dist import shard_range
         method, grid = ode_grid(ode_opt)
         g = (C.c_float * len(grid))(*grid)
         state = noise.to(self.device, torch.float32).clone().contiguous()
-        rows = state.size(0)
+        rows, frames, C2 = state.shape
+        wavs = (torch.empty(rows * 2, frames * self.cfg.audio_codec.hop_length, device=self.device)
+                if decode else None)
         while len(self._lanes) < groups - 1:
             self._lanes.append(_Lane(self))
         self._apply_options(groups)
@@ -393,6 +402,10 @@ class SAMAudio:
                     ctx = self._ctx if lane is None else lane._ctx
                     hip.check(self._lib.samaudio_ode_solve(ctx, hip.ptr(state[sl]), method, g, len(grid),
                                                            hip.current_stream_ptr()))
+                    if decode:   # rows (2b, 2b+1) = (target, residual) latents of clip b, channels-last
+                        n = rr.stop - rr.start
+                        lat = state[sl].reshape(n, frames, 2, C2 // 2).permute(0, 2, 1, 3).reshape(2 * n, frames, C2 // 2)
+                        self.decode_audio(lat.contiguous(), lane=lane, out=wavs[2 * rr.start: 2 * rr.stop])
             except BaseException as exc:  # re-raised on the caller's thread
                 errors.append(exc)
 
@@ -407,7 +420,7 @@ class SAMAudio:
             main.wait_stream(lane.stream)
         if errors:
             raise errors[0]
-        return state
+        return (state, wavs.view(rows, 2, -1)) if decode else state
 
     # ------------------------------------------------------------------ separate()
     def _text(self, batch: Batch):
@@ -469,9 +482,12 @@ class SAMAudio:
                     self._repeat(anchor_ids, cand), self._repeat(anchor_alignment, cand),
                     self._repeat(batch.audio_pad_mask, cand)]
             groups = min(self.streams, feats_r.size(0))
+            wavs = None
             if groups > 1:
                 cond = [None if c is None else c.to(self.device) for c in cond]
-                latent = self._solve_concurrent(noise, ode_opt, cond, groups)
+                # each group also decodes its own rows on its stream: the codec's HBM-bound convolutions of one group run
+                # beside the other group's kernels instead of after both solves
+                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True)
             else:
                 self._apply_options(1)
                 self._prepare(*cond)
@@ -479,8 +495,9 @@ class SAMAudio:
             self.last_latent = latent
             # [Bc, T, 2C] -> rows (2b, 2b+1) = (target, residual) latents, channels-last (model.py:291-295)
             Bc, half = latent.size(0), C2 // 2
-            lat = latent.reshape(Bc, T, 2, half).permute(0, 2, 1, 3).reshape(2 * Bc, T, half).contiguous()
-            wavs = self.decode_audio(lat).view(Bc, 2, -1)
+            if wavs is None:
+                lat = latent.reshape(Bc, T, 2, half).permute(0, 2, 1, 3).reshape(2 * Bc, T, half).contiguous()
+                wavs = self.decode_audio(lat).view(Bc, 2, -1)
             sizes = (batch.sizes.to(self.device) * self.cfg.audio_codec.hop_length).int()  # codec.py:91-97
             target = self.unbatch(wavs[:, 0].view(B, cand, -1), sizes)
             residual = self.unbatch(wavs[:, 1].view(B, cand, -1), sizes)
