@@ -29,12 +29,20 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   constexpr int CH = HD / 8;       // 16-byte chunks per K row
   constexpr int KS = HD / 32;      // k-steps of the S = Q K^T contraction
   constexpr int NF = HD / 16;      // output fragments (16 head channels each)
-  __shared__ __attribute__((aligned(16))) char Ks[64 * HD * 2];   // [key][HD d] bf16, chunk ^= key & (CH - 1)
-  __shared__ __attribute__((aligned(16))) char Vs[HD * 128];      // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
+  constexpr int KB = 64 * HD * 2;  // bytes of a K tile  [key][HD d] bf16, chunk ^= key & (CH - 1)
+  constexpr int VB = HD * 128;     // bytes of a V^T tile [d][64 keys] bf16, chunk ^= (d >> 1) & 7
+  // Two K / V^T tile buffers filled by global_load_lds (1 KiB per wave instruction, no VGPR round trip; the XOR swizzle is
+  // applied to the per-lane SOURCE address because the LDS image of the DMA is lane-linear): the tile of iteration t+1 is
+  // in flight while iteration t computes - ONE barrier per key tile.  (Round 1 staged through registers behind two
+  // barriers, and read the key mask straight from global memory behind a short-circuit `&&`: four serialised round trips
+  // per tile, profiles/r2_call9/; a register prefetch is sunk back to its use by the compiler.)
+  __shared__ __attribute__((aligned(16))) char Ks[2 * KB];
+  __shared__ __attribute__((aligned(16))) char Vs[2 * VB];
   __shared__ __attribute__((aligned(16))) char Ps[NW * 16 * 128];  // per wave [16 q][64 keys] bf16
-  __shared__ unsigned char Ms[64];                                 // key mask of the tile (0 = masked or beyond T)
+  __shared__ unsigned char Ms[2 * 64];                             // key mask of a tile (0 = masked or beyond T)
   const int q0 = blockIdx.x * (16 * NW), h = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const long bh = (long)b * H + h;
   const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(HD)
@@ -45,6 +53,32 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
   }
+  constexpr int NI = HD / 8;        // wave instructions per tile (K and V^T alike: 1 KiB each)
+  constexpr int PW = NI / NW;       // ... per wave
+  constexpr int KR = 1024 / (HD * 2);  // K rows per wave instruction
+  unsigned char mnext = 0;
+  auto stage = [&](const int buf, const int kt) {
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int ins = wave * PW + i;
+      {
+        const int row = ins * KR + lane / CH, slot = lane % CH;
+        const bf16_t* src = K + (bh * Tp + kt + row) * HD + ((slot ^ (row & (CH - 1))) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Ks + buf * KB + ins * 1024), 16, 0, 0);
+      }
+      {
+        const int d = ins * 8 + (lane >> 3), slot = lane & 7;
+        const bf16_t* src = Vt + (bh * HD + d) * Tp + kt + ((slot ^ ((d >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(Vs + buf * VB + ins * 1024), 16, 0, 0);
+      }
+    }
+    if (tid < 64) {
+      const int key = kt + tid;
+      mnext = key < T ? key_mask[(long)b * T + key] : (unsigned char)0;
+    }
+  };
   float m_i[4], l_i[4];
   f32x4_t o[NF];
 #pragma unroll
@@ -53,46 +87,14 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   for (int n = 0; n < NF; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   char* Pw = Ps + wave * 2048;
 
-  // The K / V^T tile (and the 64 key-mask bytes) of the NEXT iteration are fetched into registers right after this
-  // iteration's tile became visible, so the global-load latency runs under the two MFMA contractions and the softmax
-  // instead of in front of them.  The compiler fence keeps the loads where they are written (without it they are sunk
-  // to their use after the next barrier - and the four mask bytes of a lane, read straight from global memory behind a
-  // short-circuit `&&`, were four serialised round trips per key tile: profiles/r2_call9/ has the ISA finding).
-  constexpr int IT = HD / (8 * NW);
-  uint4 kpre[IT], vpre[IT];
-  unsigned char mpre = 0;
-  auto fetch = [&](const int kt) {
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int idx = tid + 64 * NW * it;
-      kpre[it] = *(const uint4*)(K + (bh * Tp + kt + idx / CH) * HD + (idx % CH) * 8);
-      vpre[it] = *(const uint4*)(Vt + (bh * HD + (idx >> 3)) * Tp + kt + (idx & 7) * 8);
-    }
-    if (tid < 64) {
-      const int key = kt + tid;
-      mpre = key_mask[(long)b * T + (key < T ? key : T - 1)];
-      if (key >= T) mpre = 0;
-    }
-    asm volatile("" ::: "memory");
-  };
-  fetch(0);
-  for (int kt = 0; kt < Tp; kt += 64) {
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int idx = tid + 64 * NW * it;
-      {
-        const int row = idx / CH, c = idx % CH;
-        *(uint4*)(Ks + row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4)) = kpre[it];
-      }
-      {
-        const int d = idx >> 3, c = idx & 7;
-        *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vpre[it];
-      }
-    }
-    if (tid < 64) Ms[tid] = mpre;
-    __syncthreads();
-    if (kt + 64 < Tp) fetch(kt + 64);
+  stage(0, 0);
+  for (int kt = 0, buf = 0; kt < Tp; kt += 64, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt (and its mask byte) has landed
+    if (tid < 64) Ms[buf * 64 + tid] = mnext;
+    __syncthreads();                                  // ... everybody's has; everybody is done with the other buffer
+    if (kt + 64 < Tp) stage(buf ^ 1, kt + 64);
+    const char* Kt = Ks + buf * KB;
+    const char* Vb = Vs + buf * VB;
     // S = Q K^T : s[nb][r] = S[q = lg*4 + r][key = nb*16 + lr]
     f32x4_t s[4];
 #pragma unroll
@@ -101,13 +103,13 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       const int row = nb * 16 + lr;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Ks + row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4));
+        const bf16x8_t kf = *(const bf16x8_t*)(Kt + row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4));
         s[nb] = SA_MFMA_16x16x32(qf[ks], kf, s[nb]);
       }
     }
     bool valid[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) valid[nb] = Ms[nb * 16 + lr] != 0;
+    for (int nb = 0; nb < 4; ++nb) valid[nb] = Ms[buf * 64 + nb * 16 + lr] != 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = -INFINITY;
@@ -140,7 +142,8 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
         *(unsigned short*)(Pw + q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + (lr & 7) * 2) = f2bf(s[nb][r]);
       }
     }
-    __syncthreads();
+    // the P tile is private to the wave: LDS operations of one wave execute in order, no workgroup barrier needed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // O += P V : A = P[q = lr][key chunk], B = Vt[d = n*16 + lr][key chunk]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -149,10 +152,11 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const int d = n * 16 + lr;
-        const bf16x8_t vf = *(const bf16x8_t*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
+        const bf16x8_t vf = *(const bf16x8_t*)(Vb + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
         o[n] = SA_MFMA_16x16x32(pf, vf, o[n]);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's P reads precede the next tile's P writes
   }
   const int D = H * HD;
 #pragma unroll
