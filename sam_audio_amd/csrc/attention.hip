@@ -21,6 +21,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // NW waves x 16 query rows per workgroup: NW = 8 (128 rows) halves the K / V^T staging traffic and barrier count per
 // query row; it needs Tp % 128 == 0 (the launcher falls back to NW = 4 otherwise).  HD = head dim: 128 (DiT, PE-AV
 // transformers, the vision tower's pooling head) or 64 (PE-Core vision tower blocks); scale = HD^-0.5.
+// (Round 2 tried three restructurings of this kernel on hardware, all slower or flat, profiles/r2_call9/ and r2_call11/:
+// a register prefetch of the next K / V^T tile - the compiler sinks the loads back behind the barrier -, DMA double
+// buffering with one barrier per tile and the key mask staged through LDS (79 vs 68 us), and both together.  At T = 250
+// the kernel moves 275 MB for 23.6 GFLOP in 68 us = 4 TB/s: it is bandwidth-bound, not latency-bound.)
 template <int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt,
@@ -29,20 +33,11 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   constexpr int CH = HD / 8;       // 16-byte chunks per K row
   constexpr int KS = HD / 32;      // k-steps of the S = Q K^T contraction
   constexpr int NF = HD / 16;      // output fragments (16 head channels each)
-  constexpr int KB = 64 * HD * 2;  // bytes of a K tile  [key][HD d] bf16, chunk ^= key & (CH - 1)
-  constexpr int VB = HD * 128;     // bytes of a V^T tile [d][64 keys] bf16, chunk ^= (d >> 1) & 7
-  // Two K / V^T tile buffers filled by global_load_lds (1 KiB per wave instruction, no VGPR round trip; the XOR swizzle is
-  // applied to the per-lane SOURCE address because the LDS image of the DMA is lane-linear): the tile of iteration t+1 is
-  // in flight while iteration t computes - ONE barrier per key tile.  (Round 1 staged through registers behind two
-  // barriers, and read the key mask straight from global memory behind a short-circuit `&&`: four serialised round trips
-  // per tile, profiles/r2_call9/; a register prefetch is sunk back to its use by the compiler.)
-  __shared__ __attribute__((aligned(16))) char Ks[2 * KB];
-  __shared__ __attribute__((aligned(16))) char Vs[2 * VB];
+  __shared__ __attribute__((aligned(16))) char Ks[64 * HD * 2];   // [key][HD d] bf16, chunk ^= key & (CH - 1)
+  __shared__ __attribute__((aligned(16))) char Vs[HD * 128];      // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
   __shared__ __attribute__((aligned(16))) char Ps[NW * 16 * 128];  // per wave [16 q][64 keys] bf16
-  __shared__ unsigned char Ms[2 * 64];                             // key mask of a tile (0 = masked or beyond T)
   const int q0 = blockIdx.x * (16 * NW), h = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const long bh = (long)b * H + h;
   const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(HD)
@@ -53,32 +48,6 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
   }
-  constexpr int NI = HD / 8;        // wave instructions per tile (K and V^T alike: 1 KiB each)
-  constexpr int PW = NI / NW;       // ... per wave
-  constexpr int KR = 1024 / (HD * 2);  // K rows per wave instruction
-  unsigned char mnext = 0;
-  auto stage = [&](const int buf, const int kt) {
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-      const int ins = wave * PW + i;
-      {
-        const int row = ins * KR + lane / CH, slot = lane % CH;
-        const bf16_t* src = K + (bh * Tp + kt + row) * HD + ((slot ^ (row & (CH - 1))) << 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(Ks + buf * KB + ins * 1024), 16, 0, 0);
-      }
-      {
-        const int d = ins * 8 + (lane >> 3), slot = lane & 7;
-        const bf16_t* src = Vt + (bh * HD + d) * Tp + kt + ((slot ^ ((d >> 1) & 7)) << 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(Vs + buf * VB + ins * 1024), 16, 0, 0);
-      }
-    }
-    if (tid < 64) {
-      const int key = kt + tid;
-      mnext = key < T ? key_mask[(long)b * T + key] : (unsigned char)0;
-    }
-  };
   float m_i[4], l_i[4];
   f32x4_t o[NF];
 #pragma unroll
@@ -87,14 +56,23 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
   for (int n = 0; n < NF; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   char* Pw = Ps + wave * 2048;
 
-  stage(0, 0);
-  for (int kt = 0, buf = 0; kt < Tp; kt += 64, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt (and its mask byte) has landed
-    if (tid < 64) Ms[buf * 64 + tid] = mnext;
-    __syncthreads();                                  // ... everybody's has; everybody is done with the other buffer
-    if (kt + 64 < Tp) stage(buf ^ 1, kt + 64);
-    const char* Kt = Ks + buf * KB;
-    const char* Vb = Vs + buf * VB;
+  for (int kt = 0; kt < Tp; kt += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < HD / (8 * NW); ++it) {
+      const int idx = tid + 64 * NW * it;
+      {
+        const int row = idx / CH, c = idx % CH;
+        const uint4 v = *(const uint4*)(K + (bh * Tp + kt + row) * HD + c * 8);
+        *(uint4*)(Ks + row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4)) = v;
+      }
+      {
+        const int d = idx >> 3, c = idx & 7;
+        const uint4 v = *(const uint4*)(Vt + (bh * HD + d) * Tp + kt + c * 8);
+        *(uint4*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = v;
+      }
+    }
+    __syncthreads();
     // S = Q K^T : s[nb][r] = S[q = lg*4 + r][key = nb*16 + lr]
     f32x4_t s[4];
 #pragma unroll
@@ -103,13 +81,16 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       const int row = nb * 16 + lr;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(Kt + row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4));
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4));
         s[nb] = SA_MFMA_16x16x32(qf[ks], kf, s[nb]);
       }
     }
     bool valid[4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) valid[nb] = Ms[buf * 64 + nb * 16 + lr] != 0;
+    for (int nb = 0; nb < 4; ++nb) {
+      const int key = kt + nb * 16 + lr;
+      valid[nb] = key < T && key_mask[(long)b * T + key] != 0;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = -INFINITY;
@@ -142,8 +123,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
         *(unsigned short*)(Pw + q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + (lr & 7) * 2) = f2bf(s[nb][r]);
       }
     }
-    // the P tile is private to the wave: LDS operations of one wave execute in order, no workgroup barrier needed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
     // O += P V : A = P[q = lr][key chunk], B = Vt[d = n*16 + lr][key chunk]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -152,11 +132,10 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
       for (int n = 0; n < NF; ++n) {
         const int d = n * 16 + lr;
-        const bf16x8_t vf = *(const bf16x8_t*)(Vb + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
+        const bf16x8_t vf = *(const bf16x8_t*)(Vs + d * 128 + ((c ^ ((d >> 1) & 7)) << 4));
         o[n] = SA_MFMA_16x16x32(pf, vf, o[n]);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's P reads precede the next tile's P writes
   }
   const int D = H * HD;
 #pragma unroll
@@ -551,8 +530,12 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
   bf16x8_t wf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
-  // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one
-  for (int b0 = 0; b0 < B; b0 += 4) {
+  // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one.  A trip is one
+  // load + one store round trip (vmcnt retires in order), so the batch is also split over blockIdx.z: twice the waves,
+  // half the dependent trips each (the Wo fragment is re-read from L2 once per split).
+  const int bz = (((B + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3;
+  const int b_end = (int)(blockIdx.z + 1) * bz < B ? (int)(blockIdx.z + 1) * bz : B;
+  for (int b0 = blockIdx.z * bz; b0 < b_end; b0 += 4) {
     uint4 v[4][4];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
@@ -647,7 +630,8 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
                        (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H), dim3(256), 0, st, (const bf16_t*)wo,
+  const int zs = debug_flag(12) > 0 ? debug_flag(12) : (B >= 32 ? 4 : (B >= 8 ? 2 : 1));  // flag 12: A/B of the batch split
+  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H, zs), dim3(256), 0, st, (const bf16_t*)wo,
                      (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
   return hipGetLastError();
 }

@@ -80,6 +80,11 @@ for flag, name in ((0, "cross_attn_fold"), (1, "cross_attn_fold (LDS-staged rows
     timeit(name, lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
                                                                  8, H, st())), B * D * KP * 2 + D * D * 2)
 L.samaudio_debug_set_flag(3, 0)
+for zs in (1, 2, 4):
+    L.samaudio_debug_set_flag(12, zs)
+    timeit(f"cross_attn_fold, batch split {zs}", lambda: hip.check(L.samaudio_op_cross_attn_fold(
+        hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt, 8, H, st())), B * D * KP * 2 + D * D * 2)
+L.samaudio_debug_set_flag(12, 0)
 # ... with the engine's real key/value layout: one [B*Lt, L*2D] tensor for all 22 layers (row stride 248 KB)
 kv_all = torch.randn(B * Lt, 22 * 2 * D, device=dev).to(torch.bfloat16)
 timeit("cross_attn_fold (kv_all layout)", lambda: hip.check(L.samaudio_op_cross_attn_fold(
