@@ -237,6 +237,15 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
 template <int HD>
 static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                           void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
+  // HD = 128 and whole 256-row blocks (the DiT at T = 250): 16 waves per workgroup, so K / V^T of a (batch, head) are
+  // staged once instead of once per 128 query rows - the kernel is bandwidth-bound there (flag 13 = 1: the 8-wave form)
+  if constexpr (HD == 128) {
+    if (bf16 && Tp % 256 == 0 && !debug_flag(13)) {
+      hipLaunchKernelGGL((self_attn_bf16_kernel<16, HD>), dim3(Tp / 256, H, B), dim3(1024), 0, st, (const bf16_t*)Q,
+                         (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+      return hipGetLastError();
+    }
+  }
   if (bf16 && Tp % 128 == 0)
     hipLaunchKernelGGL((self_attn_bf16_kernel<8, HD>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q,
                        (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);

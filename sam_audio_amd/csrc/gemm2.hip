@@ -884,6 +884,7 @@ hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
     case 21: return launch_gemm8(p, 2, st);  // ... A/B: no s_setprio around the MFMA clusters
     case 22: return launch2<128, 128, 2, 2, 2, 64>(p, st);  // small M: 4 waves, 64 KiB => two workgroups per CU
     case 23: return launch2<64, 128, 1, 4, 3, 64>(p, st);   // smaller M: 4 waves, 72 KiB => two workgroups per CU
+    case 25: return launch2<256, 64, 8, 1, 2, 64, true>(p, st);  // N = 64 outputs (first DAC encoder stage) in one 64-wide tile
     case 24: return launch_gemm8s(p, st);  // gemm8.hip: 128x128 tile of the 8-phase kernel's MFMA family
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
     case 3: return launch2<256, 192, 4, 2, 2, 64, true>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
