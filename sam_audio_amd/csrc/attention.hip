@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
 template <int HD>
 static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                           void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
-  // HD = 128 and whole 256-row blocks (the DiT at T = 250): 16 waves per workgroup, so K / V^T of a (batch, head) are
-  // staged once instead of once per 128 query rows - the kernel is bandwidth-bound there (flag 13 = 1: the 8-wave form)
+  // flag 13 (A/B, off): HD = 128 and whole 256-row blocks with 16 waves per workgroup, so that K / V^T of a (batch, head)
+  // are staged once instead of once per 128 query rows - measured SLOWER (72.8 vs 66.4 us, profiles/r2_call12/)
   if constexpr (HD == 128) {
-    if (bf16 && Tp % 256 == 0 && !debug_flag(13)) {
+    if (bf16 && Tp % 256 == 0 && debug_flag(13)) {
       hipLaunchKernelGGL((self_attn_bf16_kernel<16, HD>), dim3(Tp / 256, H, B), dim3(1024), 0, st, (const bf16_t*)Q,
                          (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
       return hipGetLastError();
@@ -639,7 +639,7 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
                        (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
     return hipGetLastError();
   }
-  const int zs = debug_flag(12) > 0 ? debug_flag(12) : (B >= 32 ? 4 : (B >= 8 ? 2 : 1));  // flag 12: A/B of the batch split
+  const int zs = debug_flag(12) > 0 ? debug_flag(12) : 1;  // flag 12 (A/B): batch split - 48.8 / 50.3 / 53.3 us for 1 / 2 / 4
   hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H, zs), dim3(256), 0, st, (const bf16_t*)wo,
                      (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
   return hipGetLastError();

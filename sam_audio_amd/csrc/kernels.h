@@ -19,8 +19,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 9: loader-wave 256x128 kernel WITHOUT the persistent tile walk (its ring is free after the K loop, so it can use
 //           the LDS-staged epilogue; the persistent walk keeps the accumulator-layout epilogue)
 //   flag 14: 64-channel convolutions on gemm.hip's 128x64 tile instead of the 256x64 tile of the DMA-fed family (A/B)
-//   flag 13: self-attention with 8 waves (128 query rows) per workgroup even when 256-row blocks fit (A/B)
-//   flag 12: batch split (blockIdx.z) of cross_attn_fold: 1 / 2 / 4 (0 = automatic)
+//   flag 13: self-attention with 16 waves (256 query rows) per workgroup when 256-row blocks fit (A/B; measured slower)
+//   flag 12: batch split (blockIdx.z) of cross_attn_fold: 2 / 4 (A/B; measured no gain, default 1)
 //   flag 10: no tail split of 8-phase launches (every 256x256 tile on gemm8_kernel, as before GPU call 7 of round 2)
 //   flag 7: the loader-wave 256x128 kernel (32x32x16 family) for 2048 <= N < 4096 as before GPU call 3 of round 2 (the
 //           8-phase family now covers every N >= 2048: 181.1 vs 173.0 s-audio/s, 200.5 vs 183.2 with two streams)

@@ -52,7 +52,7 @@ for flag, name in ((1, "qkv_prep (first generation)"), (0, "qkv_prep (16-byte ac
     L.samaudio_debug_set_flag(1, flag)
     timeit(name, prep, 2 * M * 3 * D * 2)
 L.samaudio_debug_set_flag(1, 0)
-for flag, name in ((1, "self_attention (8 waves, 128 query rows)"), (0, "self_attention (16 waves, 256 query rows)")):
+for flag, name in ((0, "self_attention (8 waves, 128 query rows)"), (1, "self_attention (16 waves, 256 query rows)")):
     L.samaudio_debug_set_flag(13, flag)
     timeit(name, lambda: hip.check(L.samaudio_op_self_attention(
         hip.ptr(Q), hip.ptr(K), hip.ptr(Vt), hip.ptr(mask), hip.ptr(out), hip.BF16, B, T, Tp, H, st())), 4 * M * D * 2)
