@@ -234,6 +234,15 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
   // 64-channel convolutions (first DAC encoder stage: 7 launches per encode, 53 GB of activations at the benchmark
   // shape): one 64-wide tile of the DMA-fed family instead of gemm.hip's first-generation 128x64 tile (flag 14 = old path)
   if (g2 && p.N >= 64 && p.N < 96 && p.K >= 64 && !debug_flag(14) && (long)((p.M + 255) / 256) * p.nbatch >= 256) return 28;
+  // Narrow outputs with very many rows (the DAC stages with 96 / 128 / 192 channels at T = 240 000 .. 480 000): a K-tile
+  // of such a tile is ~0.4 us of MFMA work behind ~2 us of L2 latency, so what pays is MORE TILES IN FLIGHT per CU, not a
+  // deeper ring in one workgroup: BK 32, 36 - 60 KiB per workgroup, 2 - 4 workgroups per CU (op_bench on MI355X,
+  // profiles/r2_call13/: k7 C=96 1429 -> 1207 us, k1+residual C=96 1255 -> 1065, k1 C=192 1442 -> 1277, k7 C=192 1587 ->
+  // 1509 for 8 waveforms).  Same MFMA shape and K order as the rest of the family.  Flag 15 = previous choice.
+  if (g2 && !debug_flag(15) && p.N >= 96 && p.N <= 192 && p.K >= 64 && (long)((p.M + 127) / 128) * p.nbatch >= 1024) {
+    if (p.N <= 128) return p.K <= 256 ? 33 : 29;   // 64x128 k32 s3 (k1) | 128x128 k32 s3 (k7)
+    if (p.N == 192) return p.K <= 256 ? 29 : 34;   // 128x128 k32 s3 (k1) | 128x192 k32 s3 (k7)
+  }
   if (g2 && p.N >= 96 && p.K >= 128) {
     // round-1 policy (A/B switch, flag 5): 256x256 ping-pong for the widest outputs, 256x128 2-stage ring elsewhere
     if (debug_flag(5)) return p.N >= 12288 ? 9 : (p.N == 192 && !debug_flag(4) ? 6 : 4);
@@ -266,13 +275,14 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   static const char* names[2][kGemmVariants] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
        "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma",
        "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
        "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
        "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_nostagger",
-       "gemm8_bf16_256x256_8phase_noprio", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2"}};
+       "gemm8_bf16_256x256_8phase_noprio", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
+       "gemm2_bf16_128x128_k32_s2", "gemm2_bf16_128x64_k32_s2", "gemm2_bf16_64x128_k32_s3", "gemm2_bf16_128x192_k32_s3"}};
   if (v < 0 || v >= kGemmVariants) return "";
   const char* n = names[is_bf16 ? 1 : 0][v];
   return n ? n : "";

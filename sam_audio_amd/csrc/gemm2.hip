@@ -884,6 +884,13 @@ hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
     case 21: return launch_gemm8(p, 2, st);  // ... A/B: no s_setprio around the MFMA clusters
     case 22: return launch2<128, 128, 2, 2, 2, 64>(p, st);  // small M: 4 waves, 64 KiB => two workgroups per CU
     case 23: return launch2<64, 128, 1, 4, 3, 64>(p, st);   // smaller M: 4 waves, 72 KiB => two workgroups per CU
+    // experimental (GPU call 14): more K-tiles in flight per CU for narrow-N / short-K convolutions - BK 32, 4 waves
+    case 26: return launch2<128, 128, 2, 2, 3, 32>(p, st);  // 48 KiB => three workgroups per CU, 3 stages each
+    case 27: return launch2<128, 128, 2, 2, 4, 32>(p, st);  // 64 KiB => two workgroups per CU, 4 stages each
+    case 28: return launch2<128, 128, 2, 2, 2, 32>(p, st);  // 32 KiB => five workgroups per CU
+    case 29: return launch2<128, 64, 2, 2, 2, 32>(p, st);   // N <= 64: 24 KiB => six workgroups per CU
+    case 30: return launch2<64, 128, 1, 4, 3, 32>(p, st);   // 36 KiB => four workgroups per CU
+    case 31: return launch2<128, 192, 2, 2, 3, 32>(p, st);  // N = 192 in one tile, 60 KiB => two workgroups per CU
     case 25: return launch2<256, 64, 8, 1, 2, 64, true>(p, st);  // N = 64 outputs (first DAC encoder stage) in one 64-wide tile
     case 24: return launch_gemm8s(p, st);  // gemm8.hip: 128x128 tile of the 8-phase kernel's MFMA family
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);

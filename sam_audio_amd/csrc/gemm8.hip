@@ -3,11 +3,12 @@
 // half-tile staged per phase, counted vmcnt - never 0 in the steady state -, two wave groups one barrier apart so that
 // one group's MFMA cluster overlaps the other's LDS reads on every SIMD).
 //
-// EXPERIMENTAL, force-only (variant 22, no policy selects it): written in the GPU-less tail of round 1 after the
-// ablation of the shipped kernels (profiles/r1_gemm_ablation.log) showed their LDS side - not the wave schedule variants
-// tried so far - as the limiter, and the guide reports 62 % MfmaUtil for exactly this structure.  Functionally verified
-// on the SIMT simulator (oracle/simt, both DMA modes); never timed.  Epilogue = the full GemmParams contract, operands
-// swapped (W fragment as the MFMA's A operand) so that a lane owns 4 consecutive output columns of one row.
+// Shipped since round 2 for every GEMM with N >= 1024 (gemm.hip gemm_variant): measured on MI355X at 1 349 TF/s on 8192^3
+// and 860 - 1 134 TF/s on the DiT's shapes (the round-1 ablation, profiles/r1_gemm_ablation.log,
+// had shown the LDS side of the earlier kernels - not their wave schedules - as the limiter).  A/B builds of the template
+// (no wave-group stagger, no s_setprio) stay force-able as variants 23 / 24.  Epilogue = the full GemmParams contract,
+// operands swapped (W fragment as the MFMA's A operand) so that a lane owns 4 consecutive output columns of one row.
+// gemm8s_kernel below is the same arithmetic on a 128 x 128 tile (few rows; the tail of a split launch).
 //
 // Geometry.  Tile 256 x 256, BK = 64.  Wave w: wr = w >> 2 (M half), wc = w & 3 (N quarter) -> output 128 x 64 =
 // acc[8 m-fragments][4 n-fragments] of 16 x 16.  A K-tile in LDS = 4 half-tiles of 128 rows x 128 B:

@@ -18,6 +18,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 8: GEMM epilogues straight from the accumulator layout (round 1) instead of the LDS-staged coalesced form
 //   flag 9: loader-wave 256x128 kernel WITHOUT the persistent tile walk (its ring is free after the K loop, so it can use
 //           the LDS-staged epilogue; the persistent walk keeps the accumulator-layout epilogue)
+//   flag 15: DAC stages with 96 - 192 channels on the 256-row tiles of call 12 instead of the BK-32 multi-workgroup tiles (A/B)
 //   flag 14: 64-channel convolutions on gemm.hip's 128x64 tile instead of the 256x64 tile of the DMA-fed family (A/B)
 //   flag 13: self-attention with 16 waves (256 query rows) per workgroup when 256-row blocks fit (A/B; measured slower)
 //   flag 12: batch split (blockIdx.z) of cross_attn_fold: 2 / 4 (A/B; measured no gain, default 1)
@@ -31,7 +32,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 29;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 35;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
                                    // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family;
                                    // 28 = 256x64 tile of the 32x32x16 family for 64-channel convolutions
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)

@@ -21,8 +21,8 @@ pytestmark = pytest.mark.gpu
 # 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
 # no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
 # Round 2 ships 20 (loader-wave 256x128, persistent tile walk) and 22 (8-phase 256x256): they are always in the sweep.
-SHIPPED_R2 = [20, 22, 25, 26, 27, 28]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows (27 = gemm8s)
-EXPERIMENTAL = [v for v in range(15, 25) if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
+SHIPPED_R2 = [20, 22, 25, 26, 27, 28, 29, 33, 34]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows (27 = gemm8s)
+EXPERIMENTAL = [v for v in list(range(15, 25)) + [29, 30, 31, 32, 33, 34] if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
 VARIANTS = [3, 4, 5, 6, 9] + SHIPPED_R2 + EXPERIMENTAL
 
 
@@ -148,7 +148,7 @@ def test_row_tile_variants_are_bitwise_identical(gpu):
     tab, gate, res = _mk((N,), 23), _mk((B, N), 24), _mk((M, N), 25)
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
     outs = {}
-    for variant in (4, 3, 5, 9, 20, 25, 26, 28):
+    for variant in (4, 3, 5, 9, 20, 25, 26, 28, 29, 33, 34):
         hip.lib().samaudio_debug_force_gemm_variant(variant)
         out = torch.full((M, N), float("nan"), device=gpu)
         out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)

@@ -101,18 +101,56 @@ xa = torch.randn(items, Tc + 80, Cc, device=dev).to(torch.bfloat16)
 wc = (torch.randn(Cc, 7 * Cc, device=dev) / (7 * Cc) ** 0.5).to(torch.bfloat16)
 oc = torch.empty(items, Tc + 80, Cc, device=dev, dtype=torch.bfloat16)
 bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
-for flag, name in ((1, "codec conv7 C=192 (2 x 128-wide tiles)"), (0, "codec conv7 C=192 (256x192 tile)")):
-    L.samaudio_debug_set_flag(4, flag)
+for flag, name in ((1, "codec conv7 C=192 (2 x 128-wide tiles)"), (0, "codec conv7 C=192 (256x192 tile)"), (34, "codec conv7 C=192 (128x192 k32 s3, 2 wg/CU)"), (29, "codec conv7 C=192 (128x128 k32 s3)")):
+    L.samaudio_debug_set_flag(4, 1 if flag == 1 else 0)
+    L.samaudio_debug_force_gemm_variant(flag if flag > 1 else -1)
     timeit(name, lambda: util.gemm("bf16", xa, wc, Tc, Cc, 7 * Cc, nbatch=items, a_off=(40 - 9) * Cc, a_bstride=(Tc + 80) * Cc,
                                    lda=Cc, kc=Cc, tap_stride=3 * Cc, bias=bias_c, out_act=oc,
                                    act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c),
            2 * items * Tc * Cc * 2, iters=5)
 L.samaudio_debug_set_flag(4, 0)
+L.samaudio_debug_force_gemm_variant(-1)
 
 # the k1 convolution that closes a residual unit: raw (fp32) += W x, bf16 copy snake(raw) for the next unit - HBM-bound
 raw = torch.randn(items, Tc + 80, Cc, device=dev)
 w1 = (torch.randn(Cc, Cc, device=dev) / Cc ** 0.5).to(torch.bfloat16)
-timeit("codec conv1 C=192 + in-place residual", lambda: util.gemm(
+for v192 in (-1, 34, 29):
+  L.samaudio_debug_force_gemm_variant(v192)
+  timeit(f"codec conv1 C=192 + in-place residual [variant {v192}]", lambda: util.gemm(
     "bf16", xa, w1, Tc, Cc, Cc, nbatch=items, a_off=40 * Cc, a_bstride=(Tc + 80) * Cc, lda=Cc, bias=bias_c, res=raw,
     res_geom=((Tc + 80) * Cc, Cc, 40 * Cc), out_f32=raw, f32_geom=((Tc + 80) * Cc, Cc, 40 * Cc), out_act=oc,
     act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c), items * Tc * Cc * (2 + 4 + 4 + 2), iters=5)
+L.samaudio_debug_force_gemm_variant(-1)
+
+# the last decoder stage (96 channels, T = 480 000): which tile family suits a 96-wide output?  (8 waveforms)
+items, Tc, Cc = 8, 480000, 96
+xa = torch.randn(items, Tc + 80, Cc, device=dev).to(torch.bfloat16)
+Kp = (7 * Cc + 63) // 64 * 64
+wc = (torch.randn(Cc, Kp, device=dev) / (7 * Cc) ** 0.5).to(torch.bfloat16)
+oc = torch.empty(items, Tc + 80, Cc, device=dev, dtype=torch.bfloat16)
+raw = torch.randn(items, Tc + 80, Cc, device=dev)
+w1 = (torch.randn(Cc, 128, device=dev) / Cc ** 0.5).to(torch.bfloat16)   # K padded to 128
+bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+for v, vname in ((-1, "policy"), (29, "128x128 k32 s3 (3 wg/CU)"), (31, "128x128 k32 s2 (5 wg/CU)"), (33, "64x128 k32 s3 (4 wg/CU)")):
+    L.samaudio_debug_force_gemm_variant(v)
+    timeit(f"codec conv7 C=96 [{vname}]", lambda: util.gemm(
+        "bf16", xa, wc, Tc, Cc, Kp, nbatch=items, a_off=(40 - 3) * Cc, a_bstride=(Tc + 80) * Cc, lda=Cc, kc=Cc, tap_stride=Cc,
+        bias=bias_c, out_act=oc, act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c),
+        2 * items * Tc * Cc * 2, iters=5)
+    timeit(f"codec conv1 C=96 + residual [{vname}]", lambda: util.gemm(
+        "bf16", xa, w1, Tc, Cc, 128, nbatch=items, a_off=40 * Cc, a_bstride=(Tc + 80) * Cc, lda=Cc, kc=Cc, bias=bias_c, res=raw,
+        res_geom=((Tc + 80) * Cc, Cc, 40 * Cc), out_f32=raw, f32_geom=((Tc + 80) * Cc, Cc, 40 * Cc), out_act=oc,
+        act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c), items * Tc * Cc * (2 + 4 + 4 + 2), iters=5)
+L.samaudio_debug_force_gemm_variant(-1)
+
+# the same contraction as a PLAIN GEMM (dense A [M, 704]): separates the implicit-convolution addressing from the
+# narrow-N / short-K regime
+Mp = items * Tc
+Ad = torch.randn(Mp // 4, Kp, device=dev).to(torch.bfloat16)      # a quarter of the rows (5.4 GB would not fit the timing loop comfortably)
+od = torch.empty(Mp // 4, Cc, device=dev, dtype=torch.bfloat16)
+for v, vname in ((20, "ld 256x128 persist"), (25, "128x128 s2"), (4, "ring 256x128 s2")):
+    L.samaudio_debug_force_gemm_variant(v)
+    timeit(f"plain GEMM M={Mp // 4} N=96 K={Kp} [{vname}] (x4 = conv7 C=96)", lambda: util.gemm(
+        "bf16", Ad, wc, Mp // 4, Cc, Kp, bias=bias_c, out_act=od, act_geom=(0, Cc, 0), act=hip.ACT_SNAKE, act_alpha=alpha_c),
+        (Mp // 4) * (Kp + Cc) * 2, iters=5)
+L.samaudio_debug_force_gemm_variant(-1)
