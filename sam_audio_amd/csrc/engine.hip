@@ -776,8 +776,11 @@ Status Engine::codec_encode(const float* wav, int items, int64_t S, float* laten
   long hop = 1;
   for (int i = 0; i < 4; ++i) hop *= cfg_.enc_rates[i];
   if (!wav || !latent || items <= 0 || S <= 0 || S % hop) return fail(SAMAUDIO_ERR_ARG, "codec_encode: samples % hop != 0");
-  const size_t per_item = codec_bytes(1, S);
-  int chunk = (int)(ws_bytes_ / (per_item ? per_item : 1));
+  // codec_bytes(n) = n * per_item + a fixed 64 KiB: dividing the workspace by codec_bytes(1) would turn a workspace sized
+  // for exactly n waveforms into passes of n - 1 and 1 (and the stray single-waveform pass runs at a fraction of the rate)
+  const size_t fixed = (size_t)1 << 16;
+  const size_t per_item = codec_bytes(1, S) - fixed;
+  int chunk = ws_bytes_ > fixed ? (int)((ws_bytes_ - fixed) / (per_item ? per_item : 1)) : 0;
   if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_encode: workspace too small");
   if (chunk > items) chunk = items;
   prepared_ = false;  // the codec scratch aliases the DiT scratch
@@ -857,8 +860,11 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
   long hop = 1;
   for (int i = 0; i < 4; ++i) hop *= cfg_.enc_rates[i];
   const int64_t S = (int64_t)T0 * hop;
-  const size_t per_item = codec_bytes(1, S);
-  int chunk = (int)(ws_bytes_ / (per_item ? per_item : 1));
+  // codec_bytes(n) = n * per_item + a fixed 64 KiB: dividing the workspace by codec_bytes(1) would turn a workspace sized
+  // for exactly n waveforms into passes of n - 1 and 1 (and the stray single-waveform pass runs at a fraction of the rate)
+  const size_t fixed = (size_t)1 << 16;
+  const size_t per_item = codec_bytes(1, S) - fixed;
+  int chunk = ws_bytes_ > fixed ? (int)((ws_bytes_ - fixed) / (per_item ? per_item : 1)) : 0;
   if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_decode: workspace too small");
   if (chunk > items) chunk = items;
   prepared_ = false;

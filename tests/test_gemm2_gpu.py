@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 # 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
 # no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
 # Round 2 ships 20 (loader-wave 256x128, persistent tile walk) and 22 (8-phase 256x256): they are always in the sweep.
-SHIPPED_R2 = [20, 22, 25, 26, 27, 28, 29, 33, 34]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows (27 = gemm8s)
+SHIPPED_R2 = [20, 22, 25, 26, 27, 28, 29, 32, 33, 34]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows (27 = gemm8s)
 EXPERIMENTAL = [v for v in list(range(15, 25)) + [29, 30, 31, 32, 33, 34] if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
 VARIANTS = [3, 4, 5, 6, 9] + SHIPPED_R2 + EXPERIMENTAL
 
@@ -148,7 +148,7 @@ def test_row_tile_variants_are_bitwise_identical(gpu):
     tab, gate, res = _mk((N,), 23), _mk((B, N), 24), _mk((M, N), 25)
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
     outs = {}
-    for variant in (4, 3, 5, 9, 20, 25, 26, 28, 29, 33, 34):
+    for variant in (4, 3, 5, 9, 20, 25, 26, 28, 29, 32, 33, 34):
         hip.lib().samaudio_debug_force_gemm_variant(variant)
         out = torch.full((M, N), float("nan"), device=gpu)
         out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
@@ -213,3 +213,38 @@ def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
     util.report(f"tail split {M}x{N}x{K}x{nbatch}", outs[-1][0], want, 5e-4)
     assert torch.equal(outs[-1][0], outs[22][0])
     assert torch.equal(outs[-1][1].view(torch.int16), outs[22][1].view(torch.int16))
+
+
+def test_sixty_four_channel_tiles_are_bitwise_identical(gpu):
+    """N = 64 outputs (first DAC encoder stage): the 256x64 tile (28) and its few-rows fallback, the 128x64 BK-32 tile (32),
+    must agree bit for bit - the number of waveforms per codec pass (hence which of the two runs) depends on the caller's
+    workspace.  Dilated k7 convolution form with bias + Snake, and the k1 form with an in-place fp32 residual."""
+    items, T, C, dil, halo = 3, 700, 64, 3, 40
+    x = _mk((items, C, T), 51)
+    xb = torch.zeros(items, T + 2 * halo, C)
+    xb[:, halo:halo + T] = x.transpose(1, 2)
+    w7 = _mk((C, 7 * C), 52, 1 / math.sqrt(7 * C))
+    w1 = _mk((C, C), 53, 1 / math.sqrt(C))
+    bias, alpha = _mk((C,), 54, 0.1), (_mk((C,), 55, 0.2) + 1).clamp(0.3, 2)
+    raw0 = _mk((items, T + 2 * halo, C), 56)
+    keep = [util.as_act(xb, "bf16", gpu), util.as_act(w7, "bf16", gpu), util.as_act(w1, "bf16", gpu), bias.to(gpu), alpha.to(gpu)]
+    outs = {}
+    for variant in (28, 32):
+        hip.lib().samaudio_debug_force_gemm_variant(variant)
+        tmp = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+        util.gemm("bf16", keep[0], keep[1], T, C, 7 * C, nbatch=items, a_off=(halo - 3 * dil) * C, a_bstride=(T + 2 * halo) * C,
+                  lda=C, kc=C, tap_stride=dil * C, bias=keep[3], out_act=tmp, act_geom=((T + 2 * halo) * C, C, halo * C),
+                  act=hip.ACT_SNAKE, act_alpha=keep[4])
+        raw = raw0.to(gpu)
+        act = torch.zeros_like(tmp)
+        util.gemm("bf16", tmp, keep[2], T, C, C, nbatch=items, a_off=halo * C, a_bstride=(T + 2 * halo) * C, lda=C, bias=keep[3],
+                  res=raw, res_geom=((T + 2 * halo) * C, C, halo * C), out_f32=raw, f32_geom=((T + 2 * halo) * C, C, halo * C),
+                  out_act=act, act_geom=((T + 2 * halo) * C, C, halo * C), act=hip.ACT_SNAKE, act_alpha=keep[4])
+        outs[variant] = (tmp.cpu(), raw.cpu(), act.cpu())
+    for a, b_ in zip(outs[28], outs[32]):
+        assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b_.view(torch.int16) if b_.dtype == torch.bfloat16 else b_)
+    y = torch.nn.functional.conv1d(util.rounded(x, "bf16"), util.rounded(w7, "bf16").view(C, 7, C).permute(0, 2, 1), bias,
+                                   dilation=dil, padding=3 * dil)
+    a_ = alpha[None, :, None]
+    want = (y + torch.sin(a_ * y) ** 2 / (a_ + 1e-9)).transpose(1, 2)
+    util.report("k7 C=64 conv + snake (256x64 tile)", outs[28][0][:, halo:halo + T], want, 4e-2)
