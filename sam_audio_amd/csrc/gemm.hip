@@ -309,7 +309,10 @@ int gemm_tail_split(const GemmParams& p, bool is_bf16) {
   if (g_force >= 0 || debug_flag(10) || (p.flags & 2) || gemm_variant(p, is_bf16) != 22) return 0;
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const long full = tiles / 256 * 256, rem = tiles - full;
-  return full >= 256 && rem >= 16 && rem <= 192 ? (int)full : 0;
+  // ... and only for launches of a few rounds: with many rounds the idle part of the last one is a small share of the
+  // launch and the second kernel costs more than it recovers (vision tower, M = 144 250: qkv 749 -> 646 TF/s, out_proj
+  // 557 -> 500 with the split; profiles/r2_call15/)
+  return full >= 256 && full <= 1024 && rem >= 16 && rem <= 192 ? (int)full : 0;
 }
 hipError_t launch_gemm_part(const GemmParams& p, bool is_bf16, int part, hipStream_t st) {
   return launch_gemm8_split(p, gemm_tail_split(p, is_bf16), part, st);

@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size on the shipped variants")
     ap.add_argument("--experimental", action="store_true", help="shipped policy kernels vs the force-only experimental ones")
     ap.add_argument("--family", action="store_true", help="only the kernels the round-2 tile policy picks from")
+    ap.add_argument("--vit", action="store_true", help="the PE-Core-L14-336 tower's GEMM shapes (250 frames x 577 tokens)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.ablate:
@@ -116,6 +117,15 @@ def main():
     if args.family:
         VARIANTS.clear()
         VARIANTS.update(FAMILY)
+    if args.vit:
+        VARIANTS.clear()
+        VARIANTS.update({-1: "auto policy", 22: "8-phase 256x256", 27: "gemm8s 128x128", 20: "ld 256x128 pf persist"})
+        Mv = 250 * 577
+        run_case("vit qkv (bias)", Mv, 3072, 1024, "plain", dev, 5)
+        run_case("vit out_proj (bias+res)", Mv, 1024, 1024, "gated", dev, 5)
+        run_case("vit c_fc (bias+gelu)", Mv, 4096, 1024, "plain", dev, 5)
+        run_case("vit c_proj (bias+res)", Mv, 1024, 4096, "gated", dev, 5)
+        return
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
     M = args.batch * 250
