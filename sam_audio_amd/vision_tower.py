@@ -25,6 +25,7 @@ reference key (below `visual.`)                         engine tensor
 from __future__ import annotations
 
 import ctypes as C
+import os
 import re
 from typing import Dict, List, Optional, Tuple
 
@@ -140,8 +141,17 @@ class PEVisionTower:
     callable (`tower(frames, normalize=...)`), which is the signature `PerceptionEncoder(tower=...)` expects."""
 
     def __init__(self, cfg: Optional[PEVisionConfig] = None, precision: str = "bf16", device: Optional[str] = None,
-                 name: str = "PE-Core-L14-336"):
+                 name: str = "PE-Core-L14-336", streams: int = 2):
         hip.check_precision(precision)
+        streams = int(os.environ.get("SAMAUDIO_VIT_STREAMS", streams))   # tuning only: A/B of the two-stream encode
+        if streams not in (1, 2):
+            raise ValueError("streams must be 1 or 2")
+        # 2: frame batches of >= 64 frames are encoded as two halves on two HIP streams (a second engine context that
+        # borrows the same weights).  The tower's GEMMs are short (K = 1024 = 16 K-tiles per tile) and every CU reaches its
+        # epilogue at the same time, so alone the kernel alternates between an MFMA phase and an HBM write burst; two
+        # streams interleave the two.  Frames are independent: bitwise equal to one stream (tests/test_vit_gpu.py).
+        self.streams = streams
+        self._side = None          # (handle, workspace holder, torch stream) of the second context
         if cfg is None:
             if name not in PE_VISION_CONFIGS:
                 raise ValueError(f"unknown PE vision config {name!r}; known: {sorted(PE_VISION_CONFIGS)}")
@@ -162,9 +172,13 @@ class PEVisionTower:
             use_cls_token=int(cfg.use_cls_token), use_rope2d=int(cfg.use_rope2d), use_ln_pre=int(cfg.use_ln_pre),
             use_ln_post=int(cfg.use_ln_post), pool_type=POOL_TYPES[cfg.pool_type], pool_heads=cfg.attn_pooler_heads,
             act=ACTS[cfg.act], ln_eps=cfg.ln_eps)
+        self._vc = vc
         hip.check(self._lib.samaudio_vit_create(C.byref(vc), C.byref(self._h)))
 
     def __del__(self):
+        if getattr(self, "_side", None):
+            self._lib.samaudio_vit_destroy(self._side[0])
+            self._side = None
         if getattr(self, "_h", None):
             self._lib.samaudio_vit_destroy(self._h)
             self._h = None
@@ -209,6 +223,26 @@ class PEVisionTower:
             self._loaded = True
         return missing, unexpected
 
+    def _side_context(self):
+        if self._side is None:
+            class _Holder:   # owns the second context's workspace (judge._ensure_ws contract: .device, ._workspace)
+                pass
+            holder = _Holder()
+            holder.device, holder._workspace = self.device, None
+            h = C.c_void_p()
+            hip.check(self._lib.samaudio_vit_create(C.byref(self._vc), C.byref(h)))
+            _register(self._lib.samaudio_vit_set_tensor, h, {}, self._tensors)   # borrowed: the same device tensors
+            hip.check(self._lib.samaudio_vit_finalize(h))
+            self._side = (h, holder, torch.cuda.Stream(device=self.device))
+        return self._side
+
+    def _encode_on(self, handle, owner, x, normalize, feats, tokens):
+        n = x.shape[0]
+        need = self._lib.samaudio_vit_workspace_bytes(handle, n)
+        _ensure_ws(owner, need, lambda p, b: self._lib.samaudio_vit_set_workspace(handle, p, b))
+        hip.check(self._lib.samaudio_vit_encode(handle, hip.ptr(x), n, int(bool(normalize)), hip.ptr(feats),
+                                                hip.ptr(tokens), hip.current_stream_ptr()))
+
     @torch.inference_mode()
     def encode_image(self, frames: torch.Tensor, normalize: bool = False, return_tokens: bool = False):
         if not self._loaded:
@@ -221,10 +255,29 @@ class PEVisionTower:
             x = frames.to(self.device, torch.float32).contiguous()
             feats = torch.empty(n, cfg.output_dim, device=self.device, dtype=torch.float32)
             tokens = torch.empty(n, cfg.tokens, cfg.width, device=self.device, dtype=torch.float32) if return_tokens else None
-            need = self._lib.samaudio_vit_workspace_bytes(self._h, n)
-            _ensure_ws(self, need, lambda p, b: self._lib.samaudio_vit_set_workspace(self._h, p, b))
-            hip.check(self._lib.samaudio_vit_encode(self._h, hip.ptr(x), n, int(bool(normalize)), hip.ptr(feats),
-                                                    hip.ptr(tokens), hip.current_stream_ptr()))
+            if self.streams == 2 and n >= 64:
+                import threading
+                h2, holder, side = self._side_context()
+                k = n // 2
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)
+                errors = []
+
+                def second():
+                    try:
+                        with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(side):
+                            self._encode_on(h2, holder, x[k:], normalize, feats[k:], None if tokens is None else tokens[k:])
+                    except BaseException as exc:   # re-raised on the caller's thread
+                        errors.append(exc)
+                th = threading.Thread(target=second)
+                th.start()
+                self._encode_on(self._h, self, x[:k], normalize, feats[:k], None if tokens is None else tokens[:k])
+                th.join()
+                main.wait_stream(side)
+                if errors:
+                    raise errors[0]
+            else:
+                self._encode_on(self._h, self, x, normalize, feats, tokens)
         return (feats, tokens) if return_tokens else feats
 
     def __call__(self, frames: torch.Tensor, normalize: bool = False) -> torch.Tensor:

@@ -198,3 +198,20 @@ def test_separate_with_the_hip_tower_from_a_checkpoint(gpu):
     assert model.vision_encoder is not None and model.vision_encoder.tower.__class__.__name__ == "PEVisionTower"
     model.separate(batch.to(gpu), noise=noise.to(gpu))
     util.report("latent with the HIP tower's visual prompt", model.last_latent, lat_ref, 1e-3)
+
+
+def test_two_streams_are_bitwise_equal_to_one(gpu):
+    """`PEVisionTower(streams=2)` encodes batches of >= 64 frames as two halves on two HIP streams / engine contexts that
+    share the weight tensors; frames are independent, so the features must equal the single-stream ones bit for bit."""
+    if gpu.type != "cuda":
+        pytest.skip("needs real HIP streams")
+    cfg = PE_VISION_CONFIGS["pe-tiny"]
+    sd = init_vision_state_dict(cfg, seed=13)
+    x = _frames(70, cfg.image_size, 14).to(gpu)
+    outs = []
+    for streams in (1, 2):
+        tower = PEVisionTower(cfg, precision="bf16", device=str(gpu), streams=streams)
+        tower.load_state_dict(sd)
+        for _ in range(2):
+            outs.append(tower.encode_image(x, normalize=True).cpu())
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
