@@ -293,10 +293,11 @@ SYMBOLS = {
 }
 
 
-def traffic_of(kernel: str):
-    """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh -> tools/pmc_traffic.py);
-    they cannot be collected inside a timed run."""
-    for fname in ("r2_traffic.json", "r1_traffic.json"):
+def traffic_of(kernel: str, split: bool = False):
+    """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/r2_final.sh -> tools/pmc_traffic.py); they
+    cannot be collected inside a timed run.  r2_traffic.json: launches not split into whole rounds + tail (what two
+    concurrent row groups run); r2_traffic_split.json: the single-group form."""
+    for fname in (("r2_traffic_split.json",) if split else ()) + ("r2_traffic.json", "r1_traffic.json"):
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
         except (OSError, KeyError, ValueError):
@@ -306,6 +307,9 @@ def traffic_of(kernel: str):
         if hit:
             return round(hit[0]["traffic_bytes_per_launch"]), f"HBM bytes per launch, rocprofv3 PMC passes (profiles/{fname})"
     return None, None
+
+
+SPLIT_MODE = [False]   # set by main(): whether the instrumented step runs launches split into whole rounds + tail
 
 
 def rooflines(stats):
@@ -327,7 +331,7 @@ def rooflines(stats):
         dom = dit_gemm[0]
         ms_all = sum(r["ms"] for r in dit_gemm)
         fl_all = sum(r["_flops"] for r in dit_gemm)
-        traffic, note = traffic_of(dom["kernel"])
+        traffic, note = traffic_of(dom["kernel"], split=SPLIT_MODE[0])
         out["roofline"] = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(dom["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -499,6 +503,7 @@ def main():
     batch, clips, text, tmask = make_batch(my_ids)
     n_streams = model.streams = auto_streams(len(my_ids))
     model.tail_split = n_streams == 1   # pinned, so that the instrumented (single-stream) step launches the timed kernels
+    SPLIT_MODE[0] = n_streams == 1
     log(f"inputs resident ({len(my_ids)} clips on this rank, {n_streams} stream(s)); warm-up")
     elapsed, step, graphed = timed(batch, args.steps, args.warmup, args.scaling)
     value = clips_total * CLIP_SECONDS * args.steps / elapsed
@@ -541,7 +546,7 @@ def main():
                 roof["roofline"]["single_group_tail_split"] = {
                     "what": "the same step solved as one row group with SAMAUDIO_OPT_TAIL_SPLIT on (not the timed configuration)",
                     "kernel": a["kernel"], "achieved": a["achieved"], "frac": a["frac"], "launches_per_step": a["launches_per_step"],
-                    "dit_gemm_all": a["dit_gemm_all"],
+                    "dit_gemm_all": a["dit_gemm_all"], "traffic": traffic_of(a["kernel"], split=True)[0],
                     "tail_kernel": next(({"kernel": k["kernel"], "tflops": k["tflops"], "ms": k["ms"], "launches": k["launches"]}
                                          for k in alt["kernels"] if k["kernel"].endswith("_tail")), None)}
         model.streams = n_streams
