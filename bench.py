@@ -91,6 +91,10 @@ def parse(argv=None):
                     help="BASELINE.json configs[4]: visual prompting - every clip comes with a 250-frame 336x336 uint8 video "
                          "(left half masked out), encoded by the PE-Core-L14-336 tower on the HIP library inside the step "
                          "(random weights); use with --batch 4")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional check of the N-rank path on a box with ONE GPU: every rank uses cuda:0 and the process "
+                         "group runs on gloo (RCCL refuses two ranks on one device); the ranks time-share the GPU, so the "
+                         "value is NOT a scaling number")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU-only: exercise the self-launch + sharding + gather plumbing on gloo (tests/test_bench_spawn_cpu.py)")
     return ap.parse_args(argv)
@@ -377,11 +381,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the hot path has no CPU fallback)"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from sam_audio_amd import SAMAudio, SAMAudioProcessor, preset_config
     from sam_audio_amd.dist import broadcast_state_dict, shard_range
@@ -393,7 +402,7 @@ def main():
         log(f"debug flags {os.environ['SAMAUDIO_DEBUG_FLAGS']}")
 
     # ---- weights: rank 0 creates them, RCCL broadcast over xGMI to the other ranks -----------------------
-    log(f"world {world} (backend {'nccl/RCCL' if world > 1 else 'none'}), preset {args.size}, scaling {args.scaling}, "
+    log(f"world {world} (backend {('gloo, ranks share cuda:0' if args.share_gpu else 'nccl/RCCL') if world > 1 else 'none'}), preset {args.size}, scaling {args.scaling}, "
         f"batch {args.batch}, usable host cores {usable_cores()}")
     sd = init_state_dict(cfg, seed=0, device=dev) if rank == 0 else None
     sd = broadcast_state_dict(sd, src=0, device=dev)
@@ -486,7 +495,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert all(torch.isfinite(w).all() for w in res.target), "non-finite output"
@@ -611,7 +620,8 @@ def main():
                              f"Lt={args.text_len}, midpoint ODE 16 steps = 32 DiT evals, DAC-VAE encode + decode x2"
                              + (", visual prompt: 250 masked video frames per clip through the PE-Core tower" if args.visual
                                 else "")),
-                "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}",
+                "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}" + (" (ranks time-share ONE GPU over gloo: functional check, not a scaling number)"
+                                                                         if args.share_gpu and world > 1 else ""),
                 "streams_per_gpu": n_streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
                 "text_encoder_in_step": "t5-base dims, random init (transformers on PyTorch-ROCm)" if args.t5 else None,
