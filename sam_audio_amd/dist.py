@@ -87,17 +87,22 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], src: int = 0, de
         if not bucket:
             return
         dtype = bucket[0][2]
-        total = sum(int(torch.Size(s).numel()) for _, s, _ in bucket)
+        # every tensor starts at a multiple of 256 bytes inside the bucket: the HIP library borrows these pointers and
+        # requires 16-byte alignment (views at arbitrary element offsets were rejected by samaudio_set_tensor - found by the
+        # 2-rank run on hardware, tools/r2_call17.sh)
+        esz = torch.empty((), dtype=dtype).element_size()
+        pad = max(1, 256 // esz)
+        offs, total = [], 0
+        for _, shape, _ in bucket:
+            offs.append(total)
+            total += (int(torch.Size(shape).numel()) + pad - 1) // pad * pad
+        flat = torch.zeros(total, dtype=dtype, device=device)
         if rank == src:
-            flat = torch.cat([sd[k].reshape(-1).to(device) for k, _, _ in bucket])
-        else:
-            flat = torch.empty(total, dtype=dtype, device=device)
+            for (k, shape, _), off in zip(bucket, offs):
+                flat[off:off + int(torch.Size(shape).numel())] = sd[k].reshape(-1).to(device)
         dist.broadcast(flat, src=src)
-        off = 0
-        for k, shape, _ in bucket:
-            n = int(torch.Size(shape).numel())
-            out[k] = flat[off:off + n].reshape(shape)
-            off += n
+        for (k, shape, _), off in zip(bucket, offs):
+            out[k] = flat[off:off + int(torch.Size(shape).numel())].reshape(shape)
         bucket, bucket_bytes = [], 0
 
     for k, shape, dtype in entries:

@@ -156,6 +156,8 @@ class _CodecEncoder:
     def load(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
             dt = hip.dtype_code(t.dtype)
+            if t.data_ptr() % 16:
+                t = t.clone()
             self._tensors[name] = t
             hip.check(self._lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                     hip.shape_array(t.shape)))
@@ -194,6 +196,8 @@ def _ensure_ws(owner, need: int, setter) -> None:
 def _register(lib_set, handle, store: Dict[str, torch.Tensor], tensors: Dict[str, torch.Tensor]) -> None:
     for name, t in tensors.items():
         dt = hip.dtype_code(t.dtype)
+        if t.data_ptr() % 16:   # a view into a larger buffer: the library needs 16-byte aligned pointers
+            t = t.clone()
         store[name] = t  # keep alive: the library borrows the pointer
         hip.check(lib_set(handle, name.encode(), hip.ptr(t), dt, t.dim(), hip.shape_array(t.shape)))
 

@@ -217,6 +217,8 @@ class SAMAudio:
     def _register(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
             dt = hip.dtype_code(t.dtype)
+            if t.data_ptr() % 16:   # a view into a larger buffer: the library needs 16-byte aligned pointers
+                t = t.clone()
             self._tensors[name] = t  # keep alive: the library borrows the pointer
             hip.check(self._lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                     hip.shape_array(t.shape)))

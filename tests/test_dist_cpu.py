@@ -50,3 +50,30 @@ def test_two_rank_broadcast_and_sharding(tmp_path):
     assert [len(shard_range(5, r, 2)) for r in range(2)] == [3, 2]
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
+def test_broadcast_buckets_keep_every_tensor_aligned():
+    """The HIP library borrows the broadcast tensors' pointers and requires 16-byte alignment (samaudio_set_tensor):
+    tensors are views into flat buckets, so each must start on an aligned offset whatever the sizes before it."""
+    import torch.multiprocessing as mp
+    mp.spawn(_aligned_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _aligned_worker(rank, world, port):
+    import os
+    import torch
+    import torch.distributed as dist
+    from sam_audio_amd.dist import broadcast_state_dict
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(0)
+        sd = {"a": torch.randn(3, generator=g), "b": torch.randn(5, 7, generator=g), "c": torch.randn(1, generator=g),
+              "d": torch.randn(64, 3, generator=g), "i": torch.arange(5), "e": torch.randn(2, generator=g)}
+    out = broadcast_state_dict(sd, src=0, device=torch.device("cpu"))
+    assert all(t.data_ptr() % 16 == 0 for t in out.values()), {k: t.data_ptr() % 16 for k, t in out.items()}
+    want = torch.Generator().manual_seed(0)
+    assert torch.equal(out["a"], torch.randn(3, generator=want)) and torch.equal(out["b"], torch.randn(5, 7, generator=want))
+    assert torch.equal(out["i"], torch.arange(5)) and out["d"].shape == (64, 3)
+    dist.destroy_process_group()
