@@ -228,11 +228,15 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
   if (g_force >= 3) {
     const bool known = g_force == 3 || g_force == 4 || g_force == 5 || g_force == 6 || g_force == 9 ||
                        (g_force >= 12 && g_force < kGemmVariants);  // incl. 25 / 26 / 27
+    if (g_force == 35 && !(g2 && conv7h_ok(p))) return gemm1_variant(p);   // conv7h computes convolutions only
     return g2 && known ? g_force : gemm1_variant(p);
   }
   if (g_force >= 0) return gemm1_variant(p);
   // 64-channel convolutions (first DAC encoder stage: 7 launches per encode, 53 GB of activations at the benchmark
   // shape): one 64-wide tile of the DMA-fed family instead of gemm.hip's first-generation 128x64 tile (flag 14 = old path)
+  // k7 'same' convolutions of the DAC stages with <= 192 channels: halo tile resident in LDS (gemm2.hip conv7h_kernel; same
+  // bits as the implicit GEMM below, which stays the path for launches too small to fill the chip).  Flag 11 = off.
+  if (g2 && !debug_flag(11) && conv7h_ok(p) && (long)((p.M + 255) / 256) * p.nbatch >= 256) return 35;
   // The small-launch fallback must stay in the SAME MFMA family (128x64 BK-32 tile of gemm2.hip, not gemm.hip's 16x16x32
   // kernel): how many waveforms one codec pass holds depends on the workspace the caller happens to have, and a family
   // switch at a row-count threshold made the last clip of a batch differ in the last bits between two identical calls
@@ -280,14 +284,15 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   static const char* names[2][kGemmVariants] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
        "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma",
        "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
        "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
        "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_nostagger",
        "gemm8_bf16_256x256_8phase_noprio", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
-       "gemm2_bf16_128x128_k32_s2", "gemm2_bf16_128x64_k32_s2", "gemm2_bf16_64x128_k32_s3", "gemm2_bf16_128x192_k32_s3"}};
+       "gemm2_bf16_128x128_k32_s2", "gemm2_bf16_128x64_k32_s2", "gemm2_bf16_64x128_k32_s3", "gemm2_bf16_128x192_k32_s3",
+       "conv7h_bf16"}};
   if (v < 0 || v >= kGemmVariants) return "";
   const char* n = names[is_bf16 ? 1 : 0][v];
   return n ? n : "";

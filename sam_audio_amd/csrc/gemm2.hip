@@ -826,6 +826,174 @@ static hipError_t launch3(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---- conv7h: dilated k = 7 convolution with the activation HALO TILE RESIDENT in LDS ---------------------------------
+// The implicit GEMM above re-stages every activation row once per tap (7x the L2 -> LDS traffic) and, with C <= 192
+// output channels, a K-tile is ~0.4 us of MFMA work behind ~2 us of L2 latency (GPU call 13).  Here
+// a workgroup stages the (BM + 6 dil) x C halo tile of its BM output rows ONCE (global_load_lds, row stride padded by 16
+// bytes against bank conflicts - the LDS image of the DMA is lane-linear, so the padding is produced by the per-lane source
+// address), walks the 7 taps by shifting the fragment rows inside LDS, and streams only the weight K-tiles (C x 128 B each)
+// through a ring.  Same MFMA (32x32x16, operands swapped), same fragment <-> k mapping and the same K order as the
+// implicit GEMM: results are bit for bit those of gemm2_kernel (tests/test_gemm2_gpu.py), so the policy may fall back to
+// it for small launches.  8 waves; the whole N = C in one tile.
+template <int C, int BM, int WM_, int WN_, int STAGES, int TAG>
+__global__ __launch_bounds__(512) void conv7h_kernel(const GemmParams p) {
+  constexpr int NW = 8, MAXD = 9;
+  static_assert(WM_ * WN_ == NW, "8 waves");
+  constexpr int WTM = BM / WM_, WTN = C / WN_;
+  constexpr int FM = WTM / 32, FN = WTN / 32;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && C % 16 == 0, "tile shape");
+  constexpr int HS = C * 2 + 16;                 // padded halo row stride in bytes
+  constexpr int CPRH = HS / 16;                  // 16-byte chunks per halo row (the last one is padding)
+  constexpr int HROWS = BM + 6 * MAXD;
+  constexpr int HALO_B = (HROWS * HS + 1023) / 1024 * 1024;
+  constexpr int WR = (C + 63) / 64 * 64;         // weight rows per K-tile as staged (8 waves x 8 rows per instruction)
+  constexpr int RB = 128, TILE_W = WR * RB;      // BK = 64
+  constexpr int BI = WR / 64;                    // weight DMA instructions per wave per K-tile
+  static_assert(HALO_B + STAGES * TILE_W <= 160 * 1024, "LDS budget");
+  static_assert(NW * FN * 4096 <= HALO_B + STAGES * TILE_W, "epilogue staging fits");
+  static_assert((STAGES - 2) * BI <= 63, "vmcnt range");
+  __shared__ __attribute__((aligned(16))) char smem[HALO_B + STAGES * TILE_W];
+  char* const halo = smem;
+  char* const ring = smem + HALO_B;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int dil = (int)(p.tap_stride / C);
+
+  // workgroup -> (batch item, M-tile): contiguous run of tiles per XCD (neighbouring tiles share halo rows in L2)
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int b, tm;
+  {
+    const int total = tiles_m * p.nbatch;
+    const int bid = blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    b = L / tiles_m;
+    tm = L - b * tiles_m;
+  }
+  const int m0 = tm * BM;
+
+  // ---- halo tile: rows m0 .. m0 + BM + 6 dil - 1 of the (already tap-0-shifted) activation window, contiguous in memory ----
+  {
+    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+    const int rows_used = BM + 6 * dil;
+    const int last_row = p.M - 1 + 6 * dil;       // last row of the item's window that exists
+    const int chunks = rows_used * CPRH;
+    for (int c0 = wave * 64; c0 < chunks; c0 += NW * 64) {   // uniform per wave
+      const int g = c0 + lane;
+      int row = g / CPRH;
+      int cc = g - row * CPRH;
+      if (cc >= C / 8) cc = 0;                    // the padding chunk: any valid address
+      int mr = m0 + row;
+      mr = mr < last_row ? mr : last_row;
+      dma16(A + (long)mr * C + cc * 8, halo + c0 * 16);
+    }
+  }
+  // ---- weight ring ------------------------------------------------------------------------------------------
+  const int r8 = lane >> 3;
+  const int wchunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
+  const bf16_t* w_rows[BI];
+  {
+    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      int n = (wave + NW * i) * 8 + r8;
+      n = n < p.N ? n : p.N - 1;
+      w_rows[i] = W + (long)n * p.K + wchunk * 8;
+    }
+  }
+  auto issue = [&](int stage) {
+    char* sB = ring + stage * TILE_W;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (wave + NW * i) * 1024);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) w_rows[i] += 64;
+  };
+
+  f32x16_t acc[FM][FN];
+  {
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
+  }
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+  const int b_base = (wn * WTN + l31) * RB;
+  const char* const a_lane = halo + (wm * WTM + l31) * HS + lh * 16;   // + (i*32 + tap*dil) * HS + c * 2
+
+  const int nslab = p.K / 64;
+  const int k_real = 7 * C;                       // columns beyond are the zero padding of W: skipped
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nslab) issue(s);
+  int st_c = 0, st_i = (STAGES - 1) % STAGES;
+  for (int s = 0; s < nslab; ++s) {
+    if (STAGES > 2 && s + STAGES - 2 < nslab) wait_vmcnt<(STAGES - 2) * BI>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // K-tile s (and, at s = 0, the halo tile) visible; everybody done with K-tile s-1's stage
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + STAGES - 1 < nslab) issue(st_i);
+    const char* sB = ring + st_c * TILE_W;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k = s * 64 + ks * 16;             // the 16 k of this step lie inside one tap (C % 16 == 0)
+      if (k < k_real) {                           // uniform
+        const int tap = k / C, c = k - tap * C;
+        const char* a_k = a_lane + tap * dil * HS + c * 2;
+        const int coff = ((ks * 2 + lh) ^ swz) << 4;
+        bf16x8_t af[FM], wf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(a_k + i * 32 * HS);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(sB + b_base + j * 32 * RB + coff);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = SA_MFMA_32x32x16(wf[j], af[i], acc[i][j]);
+      }
+    }
+    st_c = st_c + 1 == STAGES ? 0 : st_c + 1;
+    st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
+  }
+  __syncthreads();  // every wave is done with the halo tile and the last K-tile (no DMA in flight)
+  gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, wn * WTN, lane, smem + wave * (FN * 4096));
+}
+
+// the launches conv7h covers: k = 7 'same' convolution of C -> C channels as the engine issues it (conv_same(): kc = lda =
+// C, tap_stride = dil * C, W tap-major with K = 7 C rounded up to 64), dilation <= 9, bf16, no per-batch weights
+bool conv7h_ok(const GemmParams& p) {
+  if (!(p.N == 64 || p.N == 96 || p.N == 128 || p.N == 192)) return false;
+  if (p.kc != p.N || p.lda != p.kc || p.w_bstride != 0 || p.swiglu) return false;
+  if (p.tap_stride <= 0 || p.tap_stride % p.kc || p.tap_stride / p.kc > 9) return false;
+  if (p.K != (7 * p.kc + 63) / 64 * 64) return false;
+  return gemm2_ok(p);
+}
+
+template <int C, int BM, int WM_, int WN_, int STAGES>
+static hipError_t launch_c7(const GemmParams& p, hipStream_t st) {
+  const long tiles = (long)((p.M + BM - 1) / BM) * p.nbatch;
+  if (p.tag == 1)
+    hipLaunchKernelGGL((conv7h_kernel<C, BM, WM_, WN_, STAGES, 1>), dim3((unsigned)tiles), dim3(512), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv7h_kernel<C, BM, WM_, WN_, STAGES, 0>), dim3((unsigned)tiles), dim3(512), 0, st, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv7h(const GemmParams& p, hipStream_t st) {
+  switch (p.N) {
+    case 64: return launch_c7<64, 256, 8, 1, 3>(p, st);     // halo 44 KiB + 3 x 8 KiB
+    case 96: return launch_c7<96, 256, 8, 1, 3>(p, st);     // halo 63 KiB + 3 x 16 KiB
+    case 128: return launch_c7<128, 256, 4, 2, 3>(p, st);   // halo 83 KiB + 3 x 16 KiB
+    case 192: return launch_c7<192, 128, 4, 2, 3>(p, st);   // halo 72 KiB + 3 x 24 KiB
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int BM, int BN, int WM_, int WN_, int STAGES, int BK, bool TAGGED = false>
 static hipError_t launch2(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
@@ -891,6 +1059,7 @@ hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
     case 29: return launch2<128, 64, 2, 2, 2, 32>(p, st);   // N <= 64: 24 KiB => six workgroups per CU
     case 30: return launch2<64, 128, 1, 4, 3, 32>(p, st);   // 36 KiB => four workgroups per CU
     case 31: return launch2<128, 192, 2, 2, 3, 32>(p, st);  // N = 192 in one tile, 60 KiB => two workgroups per CU
+    case 32: return launch_conv7h(p, st);  // k7 convolution with the halo tile resident in LDS (conv7h_ok launches only)
     case 25: return launch2<256, 64, 8, 1, 2, 64, true>(p, st);  // N = 64 outputs (first DAC encoder stage) in one 64-wide tile
     case 24: return launch_gemm8s(p, st);  // gemm8.hip: 128x128 tile of the 8-phase kernel's MFMA family
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);

@@ -22,6 +22,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 14: 64-channel convolutions on gemm.hip's 128x64 tile instead of the 256x64 tile of the DMA-fed family (A/B)
 //   flag 13: self-attention with 16 waves (256 query rows) per workgroup when 256-row blocks fit (A/B; measured slower)
 //   flag 12: batch split (blockIdx.z) of cross_attn_fold: 2 / 4 (A/B; measured no gain, default 1)
+//   flag 11: k7 convolutions as implicit GEMMs (no conv7h kernel; A/B)
 //   flag 10: no tail split of 8-phase launches (every 256x256 tile on gemm8_kernel, as before GPU call 7 of round 2)
 //   flag 7: the loader-wave 256x128 kernel (32x32x16 family) for 2048 <= N < 4096 as before GPU call 3 of round 2 (the
 //           8-phase family now covers every N >= 2048: 181.1 vs 173.0 s-audio/s, 200.5 vs 183.2 with two streams)
@@ -32,7 +33,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 35;  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 36;  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
                                    // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family;
                                    // 28 = 256x64 tile of the 32x32x16 family for 64-channel convolutions
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
@@ -43,6 +44,10 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
+// gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
+// LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
+bool conv7h_ok(const GemmParams& p);
+hipError_t launch_conv7h(const GemmParams& p, hipStream_t st);
 // gemm8.hip: one GEMM as two launches - part 0: gemm8 on the first `full` 256x256 tiles (whole rounds of the chip),
 // part 1: the rest as 128x128 quadrants on gemm8s.  gemm_tail_split() = `full` for a launch (0: no split).
 hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st);

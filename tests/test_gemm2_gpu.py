@@ -248,3 +248,36 @@ def test_sixty_four_channel_tiles_are_bitwise_identical(gpu):
     a_ = alpha[None, :, None]
     want = (y + torch.sin(a_ * y) ** 2 / (a_ + 1e-9)).transpose(1, 2)
     util.report("k7 C=64 conv + snake (256x64 tile)", outs[28][0][:, halo:halo + T], want, 4e-2)
+
+
+@pytest.mark.parametrize("C,dil,T,items", [(64, 1, 700, 3), (96, 3, 530, 2), (96, 9, 300, 3), (128, 9, 520, 2), (192, 3, 300, 3),
+                                           (192, 1, 130, 2)])
+def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
+    """conv7h (variant 35: k7 'same' convolution with the activation halo tile resident in LDS, taps walked by shifting
+    fragment rows) against the implicit GEMM of the same MFMA family (variant 4) on identical operands: identical bits -
+    bias + Snake epilogue into a halo-padded buffer, every channel count / dilation the DAC stages use, M not a multiple
+    of the row tile (the last tile's halo rows are clamped), several items; and both against torch's conv1d."""
+    halo = 40
+    x = _mk((items, C, T), 61)
+    xb = torch.zeros(items, T + 2 * halo, C)
+    xb[:, halo:halo + T] = x.transpose(1, 2)
+    Kp = (7 * C + 63) // 64 * 64
+    w = _mk((C, C, 7), 62, 1 / math.sqrt(7 * C))
+    Wm = torch.zeros(C, Kp)
+    Wm[:, : 7 * C] = w.permute(0, 2, 1).reshape(C, 7 * C)   # [Cout][tap][Cin]
+    bias, alpha = _mk((C,), 63, 0.1), (_mk((C,), 64, 0.2) + 1).clamp(0.3, 2)
+    keep = [util.as_act(xb, "bf16", gpu), util.as_act(Wm, "bf16", gpu), bias.to(gpu), alpha.to(gpu)]
+    outs = {}
+    for variant in (35, 4):
+        hip.lib().samaudio_debug_force_gemm_variant(variant)
+        out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+        util.gemm("bf16", keep[0], keep[1], T, C, Kp, nbatch=items, a_off=(halo - 3 * dil) * C, a_bstride=(T + 2 * halo) * C,
+                  lda=C, kc=C, tap_stride=dil * C, bias=keep[2], out_act=out, act_geom=((T + 2 * halo) * C, C, halo * C),
+                  act=hip.ACT_SNAKE, act_alpha=keep[3])
+        outs[variant] = out.cpu()
+    assert torch.equal(outs[35].view(torch.int16), outs[4].view(torch.int16))
+    assert float(outs[35][:, :halo].abs().max()) == 0 and float(outs[35][:, halo + T:].abs().max()) == 0
+    y = F.conv1d(util.rounded(x, "bf16"), util.rounded(w, "bf16"), bias, dilation=dil, padding=3 * dil)
+    a = alpha[None, :, None]
+    want = (y + torch.sin(a * y) ** 2 / (a + 1e-9)).transpose(1, 2)
+    util.report(f"conv7h C={C} dil={dil}", outs[35][:, halo:halo + T], want, 4e-2)

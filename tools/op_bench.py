@@ -101,7 +101,7 @@ xa = torch.randn(items, Tc + 80, Cc, device=dev).to(torch.bfloat16)
 wc = (torch.randn(Cc, 7 * Cc, device=dev) / (7 * Cc) ** 0.5).to(torch.bfloat16)
 oc = torch.empty(items, Tc + 80, Cc, device=dev, dtype=torch.bfloat16)
 bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
-for flag, name in ((1, "codec conv7 C=192 (2 x 128-wide tiles)"), (0, "codec conv7 C=192 (256x192 tile)"), (34, "codec conv7 C=192 (128x192 k32 s3, 2 wg/CU)"), (29, "codec conv7 C=192 (128x128 k32 s3)")):
+for flag, name in ((1, "codec conv7 C=192 (2 x 128-wide tiles)"), (0, "codec conv7 C=192 (256x192 tile)"), (34, "codec conv7 C=192 (128x192 k32 s3, 2 wg/CU)"), (35, "codec conv7 C=192 (conv7h: halo tile resident)")):
     L.samaudio_debug_set_flag(4, 1 if flag == 1 else 0)
     L.samaudio_debug_force_gemm_variant(flag if flag > 1 else -1)
     timeit(name, lambda: util.gemm("bf16", xa, wc, Tc, Cc, 7 * Cc, nbatch=items, a_off=(40 - 9) * Cc, a_bstride=(Tc + 80) * Cc,
@@ -131,7 +131,7 @@ oc = torch.empty(items, Tc + 80, Cc, device=dev, dtype=torch.bfloat16)
 raw = torch.randn(items, Tc + 80, Cc, device=dev)
 w1 = (torch.randn(Cc, 128, device=dev) / Cc ** 0.5).to(torch.bfloat16)   # K padded to 128
 bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
-for v, vname in ((-1, "policy"), (29, "128x128 k32 s3 (3 wg/CU)"), (31, "128x128 k32 s2 (5 wg/CU)"), (33, "64x128 k32 s3 (4 wg/CU)")):
+for v, vname in ((-1, "policy"), (29, "128x128 k32 s3 (3 wg/CU)"), (35, "conv7h: halo tile resident"), (33, "64x128 k32 s3 (4 wg/CU)")):
     L.samaudio_debug_force_gemm_variant(v)
     timeit(f"codec conv7 C=96 [{vname}]", lambda: util.gemm(
         "bf16", xa, wc, Tc, Cc, Kp, nbatch=items, a_off=(40 - 3) * Cc, a_bstride=(Tc + 80) * Cc, lda=Cc, kc=Cc, tap_stride=Cc,
