@@ -84,9 +84,9 @@ def parse(argv=None):
     ap.add_argument("--predict-spans", action="store_true",
                     help="configs[3]: run the PE-A-Frame span predictor first (random weights, stand-in dims)")
     ap.add_argument("--t5", action="store_true",
-                    help="row a3 inside the step: descriptions go through a t5-base-shaped T5EncoderModel (transformers on "
-                         "PyTorch-ROCm, random init, hash tokenizer - no tokenizer files offline) instead of resident text "
-                         "features")
+                    help="row a3 inside the step: descriptions go through a t5-base-shaped T5 encoder stack on the HIP "
+                         "library (weights of a random-init transformers T5EncoderModel, hash tokenizer - no tokenizer files "
+                         "offline) instead of resident text features")
     ap.add_argument("--visual", action="store_true",
                     help="BASELINE.json configs[4]: visual prompting - every clip comes with a 250-frame 336x336 uint8 video "
                          "(left half masked out), encoded by the PE-Core-L14-336 tower on the HIP library inside the step "
@@ -451,7 +451,7 @@ def main():
         torch.manual_seed(11)
         model.text_encoder = T5TextEncoder(cfg.text_encoder, model=transformers.T5EncoderModel(t5cfg), tokenizer=_HashTokenizer(),
                                            device=dev)
-        log("T5 text encoder attached (t5-base dims, random init, hash tokenizer)")
+        log(f"T5 text encoder attached (t5-base dims, random init, hash tokenizer, backend {model.text_encoder.backend})")
 
     vision = None
     if args.visual:
@@ -624,7 +624,7 @@ def main():
                                                                          if args.share_gpu and world > 1 else ""),
                 "streams_per_gpu": n_streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
-                "text_encoder_in_step": "t5-base dims, random init (transformers on PyTorch-ROCm)" if args.t5 else None,
+                "text_encoder_in_step": "t5-base dims, random init, T5 stack on the HIP library (fp32)" if args.t5 else None,
                 "visual_prompt": (f"{cfg.vision_encoder.name} tower, 250 frames x 336x336 per clip, encoded inside the step"
                                   if args.visual else None),
             },

@@ -225,6 +225,35 @@ int samaudio_vit_set_workspace(samaudio_vit* v, void* workspace, size_t bytes);
 int samaudio_vit_encode(samaudio_vit* v, const float* frames, int n, int normalize, float* features, float* tokens_out,
                         samaudio_stream stream);
 
+/* ---- text-prompt encoder ---------------------------------------------------------
+ * T5 encoder stack behind `T5TextEncoder.forward` (reference sam_audio/model/text_encoder.py:19-37:
+ * `transformers.T5EncoderModel("t5-base")(input_ids, attention_mask)["last_hidden_state"]`).  Tokenisation stays with the
+ * caller (the Hugging Face tokenizer, text_encoder.py:21-27); everything from the embedding lookup to the final
+ * T5LayerNorm runs here.  Engine tensor names: sam_audio_amd/t5_encoder.py documents the mapping from the
+ * `shared.* / encoder.*` state_dict keys. */
+typedef struct {
+  int32_t precision;                 /* SAMAUDIO_F32 | SAMAUDIO_BF16 (GEMM operands; the residual stream is f32) */
+  int32_t vocab, d_model, d_kv;      /* 32128, 768, 64 (d_kv <= 128) */
+  int32_t heads, d_ff, layers;       /* 12, 3072, 12; heads * d_kv and d_ff must be multiples of 64 */
+  int32_t max_len;                   /* longest sequence the relative-position table covers (<= 512) */
+  int32_t act;                       /* 6 = ReLU (t5-base), 7 = tanh-form GELU ("gelu_new"); gated variants unsupported */
+  float ln_eps;                      /* 1e-6 */
+} samaudio_t5_config;
+
+typedef struct samaudio_t5 samaudio_t5;
+int samaudio_t5_create(const samaudio_t5_config* cfg, samaudio_t5** out);
+void samaudio_t5_destroy(samaudio_t5* t);
+int samaudio_t5_set_tensor(samaudio_t5* t, const char* name, const void* data, int dtype, int ndim,
+                           const int64_t* shape);
+int samaudio_t5_finalize(samaudio_t5* t);
+size_t samaudio_t5_workspace_bytes(samaudio_t5* t, int rows, int tokens);
+int samaudio_t5_set_workspace(samaudio_t5* t, void* workspace, size_t bytes);
+/* input_ids [rows, tokens] i64 (device), attention_mask [rows, tokens] u8 (1 = token, device) ->
+ * last_hidden_state [rows, tokens, d_model] f32, every position (padding rows included, as transformers returns them).
+ * An id outside [0, vocab) is the caller's error: the lookup clamps it. */
+int samaudio_t5_encode(samaudio_t5* t, const int64_t* input_ids, const unsigned char* attention_mask, int rows, int tokens,
+                       float* last_hidden_state, samaudio_stream stream);
+
 /* ---- measurement ----------------------------------------------------------------------------------- */
 
 /* Live per-kernel timing for bench.py's roofline leg (the reference has no counterpart: it publishes no

@@ -76,6 +76,11 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // nn.GELU() (erf form) and CLIP's x * sigmoid(1.702 x): the vision tower's MLP activations
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// T5's feed-forward activations: ReLU (t5-base) and the tanh-form "gelu_new" (non-gated T5 variants)
+__device__ __forceinline__ float relu_f(float x) { return fmaxf(x, 0.f); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
 __device__ __forceinline__ float snake_f(float x, float a) {
   float s = sinf(a * x);
   return x + s * s / (a + 1e-9f);
@@ -115,7 +120,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- epilogue activation codes --------------------------------------------------------------
-enum : int { ACT_NONE = 0, ACT_SNAKE = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_GELU = 4, ACT_QUICK_GELU = 5 };
+enum : int { ACT_NONE = 0, ACT_SNAKE = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_GELU = 4, ACT_QUICK_GELU = 5, ACT_RELU = 6,
+              ACT_GELU_TANH = 7 };
 
 // ---- generalised (implicit-convolution) GEMM ---------------------------------------------------
 // C[b][m][n] = sum_k A(b, m, k) * W[n][k]

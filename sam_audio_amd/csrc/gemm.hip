@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         else if (p.act == ACT_SILU) a = silu_f(v);
         else if (p.act == ACT_GELU) a = gelu_f(v);
         else if (p.act == ACT_QUICK_GELU) a = quick_gelu_f(v);
+        else if (p.act == ACT_RELU) a = relu_f(v);
+        else if (p.act == ACT_GELU_TANH) a = gelu_tanh_f(v);
         if (p.out_f32)
           p.out_f32[p.f32_off + (long)b * p.f32_bstride + (long)m * p.f32_ld + n] = p.f32_act ? a : v;
         if (p.out_act)

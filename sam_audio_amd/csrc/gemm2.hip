@@ -40,6 +40,8 @@ __device__ __forceinline__ float act_apply(float v, int act, float snake_alpha) 
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_GELU) return gelu_f(v);
   if (act == ACT_QUICK_GELU) return quick_gelu_f(v);
+  if (act == ACT_RELU) return relu_f(v);
+  if (act == ACT_GELU_TANH) return gelu_tanh_f(v);
   if (act == ACT_TANH) return tanhf(v);
   if (act == ACT_SNAKE) {  // x + sin^2(a x) / a; the result feeds a bf16 operand, so the hardware sine suffices
     const float sn = __sinf(snake_alpha * v);

@@ -44,6 +44,8 @@ __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha)
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_GELU) return gelu_f(v);
   if (act == ACT_QUICK_GELU) return quick_gelu_f(v);
+  if (act == ACT_RELU) return relu_f(v);
+  if (act == ACT_GELU_TANH) return gelu_tanh_f(v);
   if (act == ACT_TANH) return tanhf(v);
   if (act == ACT_SNAKE) {
     const float sn = __sinf(snake_alpha * v);

@@ -161,4 +161,10 @@ hipError_t launch_l2_normalize(float* x, int rows, int D, hipStream_t st);
 hipError_t launch_token_mean(const float* x, long x_ld, float* out_f32, void* out_act, bool bf16, int n, int T, int D,
                              hipStream_t st);
 
+// ---- T5 prompt encoder (t5_kernels.hip) ------------------------------------------------------------
+hipError_t launch_t5_embed(const long long* ids, const float* table, float* out, long M, int D, int vocab, hipStream_t st);
+// softmax(q k^T + bias[h][k - q] + key mask) v per (item, head, query row); qkv [B*Lt, 3*H*dkv]; Lt <= 512, dkv <= 128
+hipError_t launch_t5_attention(const void* qkv, const unsigned char* mask, const float* bias, void* out, bool bf16, int B,
+                               int Lt, int H, int dkv, int max_len, hipStream_t st);
+
 }  // namespace sa

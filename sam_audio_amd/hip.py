@@ -44,7 +44,7 @@ def dtype_code(dtype) -> int:
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
 OPT_TAIL_SPLIT = 1
-ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_GELU_TANH = 0, 1, 2, 3, 4, 5, 6, 7
 
 ERR_ARG, ERR_WEIGHT, ERR_WORKSPACE, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5
 
@@ -107,6 +107,13 @@ class VitConfig(C.Structure):
                 ("use_cls_token", C.c_int32), ("use_rope2d", C.c_int32), ("use_ln_pre", C.c_int32),
                 ("use_ln_post", C.c_int32), ("pool_type", C.c_int32), ("pool_heads", C.c_int32), ("act", C.c_int32),
                 ("ln_eps", C.c_float)]
+
+
+class T5Config(C.Structure):
+    """Mirror of `samaudio_t5_config`."""
+    _fields_ = [("precision", C.c_int32), ("vocab", C.c_int32), ("d_model", C.c_int32), ("d_kv", C.c_int32),
+                ("heads", C.c_int32), ("d_ff", C.c_int32), ("layers", C.c_int32), ("max_len", C.c_int32),
+                ("act", C.c_int32), ("ln_eps", C.c_float)]
 
 
 class KernelStat(C.Structure):
@@ -188,6 +195,13 @@ _PROTOS = {
     "samaudio_frame_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "samaudio_frame_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
+    "samaudio_t5_create": (C.c_int, [C.POINTER(T5Config), C.POINTER(C.c_void_p)]),
+    "samaudio_t5_destroy": (None, [C.c_void_p]),
+    "samaudio_t5_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "samaudio_t5_finalize": (C.c_int, [C.c_void_p]),
+    "samaudio_t5_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "samaudio_t5_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "samaudio_t5_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "samaudio_vit_create": (C.c_int, [C.POINTER(VitConfig), C.POINTER(C.c_void_p)]),
     "samaudio_vit_destroy": (None, [C.c_void_p]),
     "samaudio_vit_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),

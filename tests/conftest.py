@@ -46,7 +46,7 @@ def _enable_emu_dryrun():
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")] + (["poison"] if poison else []))
     lib = C.CDLL(emu)
     for name, (res, args) in hip._PROTOS.items():
-        if which == "emu" and name.startswith("samaudio_vit_"):
+        if which == "emu" and name.startswith(("samaudio_vit_", "samaudio_t5_")):
             continue   # the launcher emulation predates the vision tower; the SIMT simulator build carries it
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

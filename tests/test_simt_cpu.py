@@ -79,3 +79,10 @@ def test_round2_policy_tail_split_and_vision_tower_on_the_simulator():
     out = _run(["tests/test_gemm2_gpu.py", "tests/test_vit_gpu.py", "-k",
                 "tail_split or 8phase_family or (test_vit_gpu and not checkpoint)"], 900, SAMAUDIO_SIMT_POLICY="r2")
     assert " passed" in out and "failed" not in out
+
+
+def test_t5_prompt_encoder_on_the_simulator():
+    """The T5 encoder stack (tests/test_t5_gpu.py: ragged masks, > 64 keys per row, 16 / 32 / 128-wide heads, ReLU and
+    gelu_new, error paths, the T5TextEncoder wrapper) against transformers' T5EncoderModel with the real kernel code."""
+    out = _run(["tests/test_t5_gpu.py"], 600)
+    assert " passed" in out and "failed" not in out

@@ -331,8 +331,9 @@ def test_visual_prompt_features_reach_the_ode(gpu):
 
 
 def test_t5_text_encoder_on_the_gpu_feeds_separate(gpu):
-    """Row a3 on the device: descriptions -> `T5TextEncoder` (transformers' T5EncoderModel on PyTorch-ROCm, random init at
-    the model's text width, whitespace-hash tokenizer - t5-base's files cannot be fetched offline) -> `[B, Lt, 768]`
+    """Row a3 on the device: descriptions -> `T5TextEncoder` (the T5 stack on the HIP library, weights of a random-init
+    transformers T5EncoderModel at the model's text width, whitespace-hash tokenizer - t5-base's files cannot be fetched
+    offline; parity of the stack itself: tests/test_t5_gpu.py) -> `[B, Lt, 768]`
     features + bool mask -> the HIP prepare step (reference text_encoder.py:19-37, model.py:256-257).  separate() through
     `model.text_encoder` must equal separate() fed with the same features explicitly (bitwise), and the oracle (1e-3)."""
     import transformers
