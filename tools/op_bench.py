@@ -143,6 +143,22 @@ for v, vname in ((-1, "policy"), (29, "128x128 k32 s3 (3 wg/CU)"), (35, "conv7h:
         act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE, act_alpha=alpha_c), items * Tc * Cc * (2 + 4 + 4 + 2), iters=5)
 L.samaudio_debug_force_gemm_variant(-1)
 
+# conv7h vs the implicit GEMM the policy would pick without it (flag 11), at the other channel counts conv7h covers
+for Cc, Tc in ((64, 480000), (128, 240000)):
+    items = 8
+    xa = torch.randn(items, Tc + 80, Cc, device=dev).to(torch.bfloat16)
+    wc = (torch.randn(Cc, 7 * Cc, device=dev) / (7 * Cc) ** 0.5).to(torch.bfloat16)
+    oc = torch.empty(items, Tc + 80, Cc, device=dev, dtype=torch.bfloat16)
+    bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    for f11, vname in ((0, "policy: conv7h"), (1, "policy without conv7h")):
+        L.samaudio_debug_set_flag(11, f11)
+        timeit(f"codec conv7 C={Cc} dil 3 [{vname}]", lambda: util.gemm(
+            "bf16", xa, wc, Tc, Cc, 7 * Cc, nbatch=items, a_off=(40 - 9) * Cc, a_bstride=(Tc + 80) * Cc, lda=Cc, kc=Cc,
+            tap_stride=3 * Cc, bias=bias_c, out_act=oc, act_geom=((Tc + 80) * Cc, Cc, 40 * Cc), act=hip.ACT_SNAKE,
+            act_alpha=alpha_c), 2 * items * Tc * Cc * 2, iters=5)
+    L.samaudio_debug_set_flag(11, 0)
+items, Tc, Cc = 8, 480000, 96
+
 # the same contraction as a PLAIN GEMM (dense A [M, 704]): separates the implicit-convolution addressing from the
 # narrow-N / short-K regime
 Mp = items * Tc
