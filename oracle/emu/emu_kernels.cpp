@@ -350,9 +350,6 @@ hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv
 // unfolded order (tests set SAMAUDIO_NO_FOLD=1)
 hipError_t launch_cross_attn_probs(const void*, const float*, const void*, long, const unsigned char*, void*, int, int,
                                    int, int, int, int, float, hipStream_t) { return hipErrorNotSupported; }
-hipError_t launch_cross_attn_fold_all(const void* const*, int, const void*, long, void*, long, int, int, int, int, int, hipStream_t) {
-  return hipErrorNotSupported;  // as the per-layer fold: not emulated (SAMAUDIO_NO_FOLD in the dry run)
-}
 hipError_t launch_cross_attn_fold(const void*, const void*, long, void*, int, int, int, int, int, hipStream_t) {
   return hipErrorNotSupported;
 }

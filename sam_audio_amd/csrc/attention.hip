@@ -528,9 +528,9 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
 // j >= Lt), the per-batch weight operand ([N = D][K = KP], K contiguous) of the folded GEMM.
 // One wave = one (head, 16 output channels n): its Wo fragment stays in registers while it walks the batch.
 // MFMA orientation: rows = tokens (A = V), columns = n (B = Wo^T) -> a lane owns 4 consecutive tokens of one n.
-__device__ __forceinline__ void cross_attn_fold_body(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
-                                                     long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt, int LtP,
-                                                     int H, const int zi, const int zn) {
+__global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
+                                                              long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
+                                                              int LtP, int H) {
   const int h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -542,9 +542,9 @@ __device__ __forceinline__ void cross_attn_fold_body(const bf16_t* __restrict__ 
   // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one.  A trip is one
   // load + one store round trip (vmcnt retires in order), so the batch is also split over blockIdx.z: twice the waves,
   // half the dependent trips each (the Wo fragment is re-read from L2 once per split).
-  const int bz = (((B + zn - 1) / zn) + 3) & ~3;
-  const int b_end = (zi + 1) * bz < B ? (zi + 1) * bz : B;
-  for (int b0 = zi * bz; b0 < b_end; b0 += 4) {
+  const int bz = (((B + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3;
+  const int b_end = (int)(blockIdx.z + 1) * bz < B ? (int)(blockIdx.z + 1) * bz : B;
+  for (int b0 = blockIdx.z * bz; b0 < b_end; b0 += 4) {
     uint4 v[4][4];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
@@ -567,27 +567,6 @@ __device__ __forceinline__ void cross_attn_fold_body(const bf16_t* __restrict__ 
         store4<bf16_t>(UT + ((long)(b0 + bb) * D + n) * KP + h * LtP + g * 4, u[0], u[1], u[2], u[3]);
     }
   }
-}
-
-__global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
-                                                              long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
-                                                              int LtP, int H) {
-  cross_attn_fold_body(wo, kv, kv_ld, UT, KP, B, Lt, LtP, H, (int)blockIdx.z, (int)gridDim.z);
-}
-
-// Every layer's fold in ONE launch (blockIdx.z = layer): U of a layer depends only on that layer's Wo and on the text
-// keys / values of the evaluation, which the engine computes for all layers up front (kv row = [layer][k | v]), so
-// nothing orders the folds after their layers.  One layer alone is latency-bound (968 workgroups that each walk the
-// batch in 8 dependent load -> MFMA -> store trips: 48 us for 50 MB); 22 layers side by side turn that into throughput.
-struct FoldLayers {
-  const void* wo[64];
-};
-__global__ __launch_bounds__(256) void cross_attn_fold_all_kernel(const FoldLayers layers, const bf16_t* __restrict__ kv,
-                                                                  long kv_ld, bf16_t* __restrict__ UT, long ut_lstride,
-                                                                  int KP, int B, int Lt, int LtP, int H) {
-  const int l = blockIdx.z;
-  cross_attn_fold_body((const bf16_t*)layers.wo[l], kv + (long)l * 2 * H * 128, kv_ld, UT + (long)l * ut_lstride, KP, B, Lt,
-                       LtP, H, 0, 1);
 }
 
 hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
@@ -651,16 +630,6 @@ __global__ __launch_bounds__(256) void cross_attn_fold2_kernel(const bf16_t* __r
     }
     __syncthreads();
   }
-}
-
-hipError_t launch_cross_attn_fold_all(const void* const* wo_layers, int n_layers, const void* kv, long kv_ld, void* UT,
-                                      long ut_lstride, int KP, int B, int Lt, int LtP, int H, hipStream_t st) {
-  if (n_layers <= 0 || n_layers > 64) return hipErrorInvalidValue;
-  FoldLayers fl;
-  for (int l = 0; l < 64; ++l) fl.wo[l] = l < n_layers ? wo_layers[l] : nullptr;
-  hipLaunchKernelGGL(cross_attn_fold_all_kernel, dim3(H * 128 / 64, H, n_layers), dim3(256), 0, st, fl, (const bf16_t*)kv,
-                     kv_ld, (bf16_t*)UT, ut_lstride, KP, B, Lt, LtP, H);
-  return hipGetLastError();
 }
 
 hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,

@@ -112,7 +112,6 @@ class Engine {
   char* ws_ = nullptr;
   size_t ws_bytes_ = 0;
   int rows_ = 0, frames_ = 0, text_len_ = 0, frames_pad_ = 0;
-  bool fold_all_ = false;           // every layer's U = Wo V from one launch per evaluation (U^T buffer holds n_layers operands)
   int fold_ltp_ = 0, fold_kp_ = 0;  // folded cross-attention: tokens per head slot (8 | 16; 0 = not folded), padded K
   bool has_anchor_ = false;
 

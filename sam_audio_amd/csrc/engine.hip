@@ -258,9 +258,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   // folded cross-attention (bf16, Lt <= 16): probabilities [M, KP] and the per-batch operand U^T [rows][D][KP]
   const long ltp = Lt <= 8 ? 8 : 16, kp = round_up(H * ltp, 64);
   void* probs = (bf16_ && Lt <= 16) ? act(M * kp) : nullptr;
-  // one U^T per layer when every layer is folded by one launch per evaluation (eval_field); n_layers <= 64 there
-  const long ut_layers = cfg_.n_layers >= 1 && cfg_.n_layers <= 64 ? cfg_.n_layers : 1;
-  void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp * ut_layers) : nullptr;
+  void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
@@ -506,9 +504,7 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
     fold_ltp_ = Lt <= 8 ? 8 : 16;
     fold_kp_ = (int)round_up((long)cfg_.n_heads * fold_ltp_, 64);
     SA_HIP(hipMemsetAsync(d_.probs, 0, (size_t)M * fold_kp_ * esz_, st));
-    fold_all_ = !debug_flag(0) && cfg_.n_layers >= 1 && cfg_.n_layers <= 64;
-    // 0 * (K padding of U) must stay 0
-    SA_HIP(hipMemsetAsync(d_.ut, 0, (size_t)rows * D * fold_kp_ * esz_ * (fold_all_ ? cfg_.n_layers : 1), st));
+    SA_HIP(hipMemsetAsync(d_.ut, 0, (size_t)rows * D * fold_kp_ * esz_, st));  // 0 * (K padding of U) must stay 0
   }
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
@@ -616,15 +612,6 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
-  const long ut_lstride = fold_ltp_ && fold_all_ ? (long)rows * D * fold_kp_ : 0;
-  if (fold_ltp_ && fold_all_) {  // U = Wo V of every layer (depends on the layer's Wo and this evaluation's text values only)
-    const void* wo_l[64];
-    for (int l = 0; l < cfg_.n_layers; ++l) wo_l[l] = layers_[l].c_wo;
-    const double L = cfg_.n_layers;
-    SA_TRY(op("cross_attn_fold", L * ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_, 0, st, [&] {
-      return launch_cross_attn_fold_all(wo_l, cfg_.n_layers, d_.kvc, kv_ld, d_.ut, ut_lstride, fold_kp_, rows, Lt, fold_ltp_, H, st);
-    }));
-  }
   for (int l = 0; l < cfg_.n_layers; ++l) {  // DiTBlock.forward, transformer.py:354-391
     const LayerW& w = layers_[l];
     const float* tab = w.mod_table;
@@ -673,11 +660,10 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
         return launch_cross_attn_probs(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.probs, fold_kp_, rows, T, Lt,
                                        fold_ltp_, H, eps, st);
       }));
-      if (!fold_all_)
-        SA_TRY(op("cross_attn_fold", ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_, 0, st, [&] {
-          return launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st);
-        }));
-      GemmParams p = lin(d_.probs, fold_kp_, (const char*)d_.ut + (size_t)l * ut_lstride * esz_, T, D, fold_kp_);
+      SA_TRY(op("cross_attn_fold", ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_, 0, st, [&] {
+        return launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st);
+      }));
+      GemmParams p = lin(d_.probs, fold_kp_, d_.ut, T, D, fold_kp_);
       p.nbatch = rows;
       p.a_bstride = (long)T * fold_kp_;
       p.w_bstride = (long)D * fold_kp_;

@@ -9,7 +9,6 @@ namespace sa {
 hipError_t launch_poison_lds(hipStream_t st);
 
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
-//   flag 0: cross_attn_fold launched once per layer inside the layer loop instead of once per evaluation for all layers (A/B)
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
 //   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
 //   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)
@@ -99,10 +98,6 @@ hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv
 // at column h*LtP + token; UT [B][D][KP] = per-batch weight operand of the GEMM h += P . U
 hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
                                    void* P, int ldp, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st);
-// every layer's fold in one launch: wo_layers[l] = Wo of layer l (l < n_layers <= 64), kv = layer 0 of the [Mt][layer][k | v]
-// rows, UT + l * ut_lstride = layer l's operand (A/B: debug flag 0 = one launch per layer)
-hipError_t launch_cross_attn_fold_all(const void* const* wo_layers, int n_layers, const void* kv, long kv_ld, void* UT,
-                                      long ut_lstride, int KP, int B, int Lt, int LtP, int H, hipStream_t st);
 hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
                                   int H, hipStream_t st);
 // per-(row, layer, head) RMSNorm of the K halves of kv_all [rows, L*2D] (all layers' cross-attention keys at
