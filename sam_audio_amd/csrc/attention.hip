@@ -530,12 +530,23 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
 // MFMA orientation: rows = tokens (A = V), columns = n (B = Wo^T) -> a lane owns 4 consecutive tokens of one n.
 __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
                                                               long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
-                                                              int LtP, int H) {
-  const int h = blockIdx.y;
+                                                              int LtP, int H, int xcd_major) {
+  // Every (batch, n) row of U^T is 2*KP bytes to which each head contributes 2*LtP bytes.  xcd_major: the 1-D grid is dealt
+  // so that the H workgroups of one 64-channel block land on the SAME XCD (workgroup i runs on XCD i % 8) one after the
+  // other: they walk the batch in the same order, so their 16-byte pieces of a row meet in that XCD's L2 and leave as
+  // whole lines.  With heads on blockIdx.y the pieces of a row came from up to 8 different L2s and every one was written
+  // back as a partial line (PMC: 73.6 MB written per launch for 34.6 MB of output, profiles/r2_traffic.json).
+  int h = blockIdx.y, nb = blockIdx.x;
+  if (xcd_major) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    h = slot % H;
+    nb = xcd + 8 * (slot / H);
+    if (nb * 64 >= H * 128) return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int D = H * 128;
-  const int n = (blockIdx.x * 4 + wave) * 16 + r;  // D % 64 == 0
+  const int n = (nb * 4 + wave) * 16 + r;  // D % 64 == 0
   bf16x8_t wf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
@@ -640,8 +651,14 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
     return hipGetLastError();
   }
   const int zs = debug_flag(12) > 0 ? debug_flag(12) : 1;  // flag 12 (A/B): batch split - 48.8 / 50.3 / 53.3 us for 1 / 2 / 4
+  if (!debug_flag(0)) {  // flag 0 (A/B): heads on blockIdx.y as before GPU call 20 of round 2
+    const int nblocks = H * 128 / 64;
+    hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(8 * H * ((nblocks + 7) / 8), 1, zs), dim3(256), 0, st, (const bf16_t*)wo,
+                       (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H, 1);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H, zs), dim3(256), 0, st, (const bf16_t*)wo,
-                     (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
+                     (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H, 0);
   return hipGetLastError();
 }
 

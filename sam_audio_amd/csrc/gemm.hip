@@ -238,7 +238,9 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
   // shape): one 64-wide tile of the DMA-fed family instead of gemm.hip's first-generation 128x64 tile (flag 14 = old path)
   // k7 'same' convolutions of the DAC stages with <= 192 channels: halo tile resident in LDS (gemm2.hip conv7h_kernel; same
   // bits as the implicit GEMM below, which stays the path for launches too small to fill the chip).  Flag 11 = off.
-  if (g2 && !debug_flag(11) && conv7h_ok(p) && (long)((p.M + 255) / 256) * p.nbatch >= 256) return 35;
+  // conv7h where it measured faster than the implicit GEMM of the same family (profiles/r2_call18, r2_call19: C = 64
+  // 485 vs 567 us, C = 96 1149 vs 1307 us; C = 128 874 vs 790 and C = 192 1571 vs 1513 us stay implicit GEMMs)
+  if (g2 && !debug_flag(11) && p.N <= 96 && conv7h_ok(p) && (long)((p.M + 255) / 256) * p.nbatch >= 256) return 35;
   // The small-launch fallback must stay in the SAME MFMA family (128x64 BK-32 tile of gemm2.hip, not gemm.hip's 16x16x32
   // kernel): how many waveforms one codec pass holds depends on the workspace the caller happens to have, and a family
   // switch at a row-count threshold made the last clip of a batch differ in the last bits between two identical calls

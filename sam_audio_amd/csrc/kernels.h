@@ -9,6 +9,8 @@ namespace sa {
 hipError_t launch_poison_lds(hipStream_t st);
 
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
+//   flag 0: cross_attn_fold with heads on blockIdx.y (the pieces of an output row come from different XCDs) instead of the
+//           XCD-major deal of round 2's call 20 (A/B)
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
 //   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
 //   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)

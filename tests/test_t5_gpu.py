@@ -68,7 +68,7 @@ def test_encoder_fp32_matches_transformers(gpu, kw, B, L):
     assert e_hf < 2e-5 and e_or < 2e-5
 
 
-@pytest.mark.parametrize("precision,bound", [("bf16", 3e-2), ("fp16", 4e-3)])
+@pytest.mark.parametrize("precision,bound", [("bf16", 1.4e-2), ("fp16", 1.5e-3)])   # measured 6.7e-3 / 7.1e-4
 def test_small_encoder_16bit_operands(gpu, precision, bound):
     if precision == "fp16" and gpu.type != "cuda":
         pytest.skip("the simulator build carries the bf16-operand library only")
@@ -87,10 +87,10 @@ def test_t5_base_dims_fp32_and_bf16(gpu):
     assert e_hf < 2e-5 and e_or < 2e-5
     e_hf, _, _, _ = _run(T5_BASE, 32, 8, "bf16", gpu)
     print(f"t5-base bf16: vs transformers rel {e_hf:.2e}")
-    assert e_hf < 3e-2
+    assert e_hf < 1.3e-2     # measured 6.35e-3 on MI355X (profiles/r2_call19/gpu_tests_subset.log)
     e_hf, _, _, _ = _run(T5_BASE, 32, 8, "fp16", gpu)
     print(f"t5-base fp16: vs transformers rel {e_hf:.2e}")
-    assert e_hf < 4e-3
+    assert e_hf < 1.6e-3     # measured 7.9e-4
 
 
 def test_all_padding_row_and_argument_errors(gpu):
