@@ -285,6 +285,12 @@ int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capac
 /* C[b] = epilogue(A(b) @ W^T): generalised GEMM / implicit conv, see sam_audio_amd/csrc/common.h GemmParams.
  * `params` points to a HOST copy of sa::GemmParams (size checked against params_bytes). */
 int samaudio_op_gemm(const void* params_host, size_t params_bytes, int precision, samaudio_stream stream);
+/* One DAC residual unit as ONE kernel: the k7 convolution `conv7_params` and the k1 convolution `conv1_params` that reads
+ * its output (two host GemmParams as for samaudio_op_gemm, 16-bit operands only).  The intermediate activation
+ * (conv7_params.out_act == conv1_params.A) is never written; conv1_params.out_act must not be conv7_params.A.  Bitwise
+ * equal to the two samaudio_op_gemm launches; ERR_ARG when the pair is not one the fused kernel covers. */
+int samaudio_op_resunit(const void* conv7_params_host, const void* conv1_params_host, size_t params_bytes,
+                        samaudio_stream stream);
 int samaudio_op_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
                             const float* tvec, int64_t tvec_ld, int shift_off, int scale_off, void* out,
                             int precision, int rows, int dim, int rows_per_batch, float eps, samaudio_stream stream);

@@ -164,6 +164,19 @@ int samaudio_op_gemm(const void* params_host, size_t params_bytes, int precision
   return hip_ret(sa::launch_gemm(p, bf16, (hipStream_t)stream), "gemm");
 }
 
+int samaudio_op_resunit(const void* conv7_params_host, const void* conv1_params_host, size_t params_bytes,
+                        samaudio_stream stream) {
+  if (!conv7_params_host || !conv1_params_host || params_bytes != sizeof(sa::GemmParams))
+    return bad("samaudio_op_resunit: GemmParams size mismatch");
+  sa::GemmParams p, q;
+  std::memcpy(&p, conv7_params_host, sizeof(p));
+  std::memcpy(&q, conv1_params_host, sizeof(q));
+  if (const char* why = sa::gemm_check(p, true)) return bad(why);
+  if (const char* why = sa::gemm_check(q, true)) return bad(why);
+  if (!sa::resunit_ok(p, q)) return bad("samaudio_op_resunit: not a (k7, k1) residual-unit pair the fused kernel covers");
+  return hip_ret(sa::launch_resunit(p, q, (hipStream_t)stream), "resunit");
+}
+
 int samaudio_op_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
                             const float* tvec, int64_t tvec_ld, int shift_off, int scale_off, void* out,
                             int precision, int rows, int dim, int rows_per_batch, float eps, samaudio_stream stream) {

@@ -94,6 +94,7 @@ class Engine {
   // non-GEMM launch, event-bracketed while profiling
   template <class F>
   Status op(const char* name, double alg_bytes, double alg_flops, hipStream_t st, F&& launch);
+  Status res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, double flops7, double flops1, hipStream_t st);
   bool prof_on_ = false;
   std::vector<ProfRec> prof_;
   std::vector<hipEvent_t> ev_pool_;

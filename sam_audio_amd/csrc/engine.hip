@@ -375,6 +375,35 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops) {
   return Status{};
 }
 
+// One DAC residual unit: k7 convolution `p` (Snake'd bf16 intermediate) followed by the k1 convolution `q` on it
+// (+ fp32 residual, Snake'd bf16 copy out).  `cur` = the unit's input activation, `alt` = a second halo-zeroed buffer of
+// the same shape.  Large bf16 launches run as ONE kernel (gemm2.hip resunit_kernel: the intermediate stays in LDS) that
+// writes its activation to `alt` - it must not overwrite rows neighbouring tiles still read - and the buffers swap roles;
+// everything else runs as the two launches with `alt` as the intermediate.  Both forms are bitwise identical.
+Status Engine::res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, double flops7, double flops1, hipStream_t st) {
+  p.out_act = alt;
+  q.A = alt;
+  q.out_act = cur;
+  GemmParams fp = p, fq = q;
+  fq.out_act = alt;
+  fp.tag = fq.tag = prof_cls_[0] == 'c' ? 1 : 0;
+  static const int kMask[4] = {1, 2, 4, 8};
+  const int ci = p.N == 64 ? 0 : p.N == 96 ? 1 : p.N == 128 ? 2 : p.N == 192 ? 3 : -1;
+  const bool fuse = bf16_ && ci >= 0 && !debug_flag(16) && !(debug_flag(17) & kMask[ci]) && resunit_ok(fp, fq) &&
+                    ((long)((p.M + 255) / 256) * p.nbatch >= 256 || debug_flag(18));
+  if (!fuse) {
+    SA_TRY(gemm(p, st, flops7));
+    return gemm(q, st, flops1);
+  }
+  if (const char* why = gemm_check(fp, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
+  if (const char* why = gemm_check(fq, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
+  const double inter = (double)p.M * p.N * p.nbatch * esz_;   // the intermediate: neither written nor read
+  SA_TRY(op("resunit_bf16", gemm_alg_bytes(fp, esz_) + gemm_alg_bytes(fq, esz_) - 2 * inter, flops7 + flops1, st,
+            [&] { return launch_resunit(fp, fq, st); }));
+  std::swap(cur, alt);
+  return Status{};
+}
+
 template <class F>
 Status Engine::op(const char* name, double alg_bytes, double alg_flops, hipStream_t st, F&& launch) {
   if (!prof_on_) {
@@ -824,12 +853,11 @@ Status Engine::codec_encode(const float* wav, int items, int64_t S, float* laten
         GemmParams p = conv_same(sb[i].act, T, C, 7, dil[j], r.w1, r.k1pad, C, n);
         p.bias = r.b1;
         halo_out(p, nullptr, sb[i].tmp, T, C, ACT_SNAKE, r.a2);
-        SA_TRY(gemm(p, st, 2.0 * T * C * 7 * C * n));
-        p = conv_same(sb[i].tmp, T, C, 1, 1, r.w2, r.k2pad, C, n);
-        p.bias = r.b2;
-        p.res = sb[i].raw; p.res_bstride = (T + 2L * HALO) * C; p.res_ld = C; p.res_off = (long)HALO * C;
-        halo_out(p, sb[i].raw, sb[i].act, T, C, ACT_SNAKE, j < 2 ? sw.r[j + 1].a1 : sw.a);
-        SA_TRY(gemm(p, st, 2.0 * T * C * C * n));
+        GemmParams q = conv_same(sb[i].tmp, T, C, 1, 1, r.w2, r.k2pad, C, n);
+        q.bias = r.b2;
+        q.res = sb[i].raw; q.res_bstride = (T + 2L * HALO) * C; q.res_ld = C; q.res_off = (long)HALO * C;
+        halo_out(q, sb[i].raw, sb[i].act, T, C, ACT_SNAKE, j < 2 ? sw.r[j + 1].a1 : sw.a);
+        SA_TRY(res_unit(p, q, sb[i].act, sb[i].tmp, 2.0 * T * C * 7 * C * n, 2.0 * T * C * C * n, st));
       }
       // strided conv k = 2s, stride s, pad s/2: the 2s input rows of one output are contiguous
       const int pad = (s + 1) / 2;
@@ -922,13 +950,12 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
         GemmParams p = conv_same(sb[i + 1].act, Tout, C, 7, dil[j], r.w1, r.k1pad, C, n);
         p.bias = r.b1;
         halo_out(p, nullptr, sb[i + 1].tmp, Tout, C, ACT_SNAKE, r.a2);
-        SA_TRY(gemm(p, st, 2.0 * Tout * C * 7 * C * n));
-        p = conv_same(sb[i + 1].tmp, Tout, C, 1, 1, r.w2, r.k2pad, C, n);
-        p.bias = r.b2;
-        p.res = sb[i + 1].raw; p.res_bstride = (Tout + 2L * HALO) * C; p.res_ld = C; p.res_off = (long)HALO * C;
+        GemmParams q = conv_same(sb[i + 1].tmp, Tout, C, 1, 1, r.w2, r.k2pad, C, n);
+        q.bias = r.b2;
+        q.res = sb[i + 1].raw; q.res_bstride = (Tout + 2L * HALO) * C; q.res_ld = C; q.res_off = (long)HALO * C;
         const float* next_alpha = j < 2 ? sw.r[j + 1].a1 : (i < 3 ? dec_.s[i + 1].a : dec_.out_a);
-        halo_out(p, sb[i + 1].raw, sb[i + 1].act, Tout, C, ACT_SNAKE, next_alpha);
-        SA_TRY(gemm(p, st, 2.0 * Tout * C * C * n));
+        halo_out(q, sb[i + 1].raw, sb[i + 1].act, Tout, C, ACT_SNAKE, next_alpha);
+        SA_TRY(res_unit(p, q, sb[i + 1].act, sb[i + 1].tmp, 2.0 * Tout * C * 7 * C * n, 2.0 * Tout * C * C * n, st));
       }
     }
     {  // conv k7 (C -> 1) + tanh

@@ -966,6 +966,192 @@ __global__ __launch_bounds__(512) void conv7h_kernel(const GemmParams p) {
   gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, wn * WTN, lane, smem + wave * (FN * 4096));
 }
 
+// ------------------------------------------------------------------------------------------------
+// resunit_kernel: one DAC residual unit  x -> x + conv1(snake(conv7_dil(snake(x))))  per launch (reference codec:
+// dacvae ResidualUnit; engine.hip codec_encode / codec_decode issue it as a k7 launch `p` followed by a k1 launch `q`).
+// Phase 1 is conv7h_kernel's K loop (halo tile resident, W7 K-tiles through the ring).  Its epilogue (+bias, Snake, bf16
+// rounding - the arithmetic of gemm_epilogue_lds) leaves the BM x C tile of the intermediate activation in LDS in the halo
+// tile's row layout instead of HBM; phase 2 multiplies it with W1, whose K-tiles follow W7's through the SAME ring (so
+// their DMA latency hides behind phase 1's tail), and the ordinary epilogue applies q (+bias, +fp32 residual, fp32 stream
+// and Snake'd bf16 copy out).  Same MFMA, same K order, same rounding points as the two launches: bitwise identical
+// results (tests/test_gemm2_gpu.py), so a batch may mix fused and unfused launches.  The unit's output activation must
+// NOT alias its input (neighbouring tiles still read input halo rows): the engine ping-pongs two buffers.
+// Saves the intermediate's write + read (4 of every 16 algorithmic bytes per element) and one launch per unit.
+// ------------------------------------------------------------------------------------------------
+template <int C, int BM, int WM_, int WN_, int STAGES, int TAG>
+__global__ __launch_bounds__(512) void resunit_kernel(const GemmParams p, const GemmParams q) {
+  constexpr int NW = 8, MAXD = 9;
+  static_assert(WM_ * WN_ == NW, "8 waves");
+  constexpr int WTM = BM / WM_, WTN = C / WN_;
+  constexpr int FM = WTM / 32, FN = WTN / 32;
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && C % 16 == 0, "tile shape");
+  constexpr int HS = C * 2 + 16;
+  constexpr int CPRH = HS / 16;
+  constexpr int HROWS = BM + 6 * MAXD;
+  constexpr int HALO_B = (HROWS * HS + 1023) / 1024 * 1024;
+  constexpr int WR = (C + 63) / 64 * 64;
+  constexpr int RB = 128, TILE_W = WR * RB;
+  constexpr int BI = WR / 64;
+  static_assert(HALO_B + STAGES * TILE_W <= 160 * 1024, "LDS budget");
+  static_assert(NW * FN * 4096 <= HALO_B + STAGES * TILE_W, "epilogue staging fits");
+  static_assert((STAGES - 2) * BI <= 63, "vmcnt range");
+  __shared__ __attribute__((aligned(16))) char smem[HALO_B + STAGES * TILE_W];
+  __shared__ __attribute__((aligned(16))) float colv[2 * C];   // phase 1's bias | Snake alpha (read between the phases)
+  char* const halo = smem;
+  char* const ring = smem + HALO_B;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_, wn = wave % WN_;
+  const int dil = (int)(p.tap_stride / C);
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int b, tm;
+  {
+    const int total = tiles_m * p.nbatch;
+    const int bid = blockIdx.x;
+    const int qd = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int L = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + idx;
+    b = L / tiles_m;
+    tm = L - b * tiles_m;
+  }
+  const int m0 = tm * BM;
+  if (threadIdx.x < C / 4) {   // published by the K loop's first barrier
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av = bv;
+    if (p.bias) bv = ((const float4*)p.bias)[threadIdx.x];
+    if (p.act == ACT_SNAKE) av = ((const float4*)p.act_alpha)[threadIdx.x];
+    ((float4*)colv)[threadIdx.x] = bv;
+    ((float4*)colv)[C / 4 + threadIdx.x] = av;
+  }
+
+  {  // halo tile of the input activation (as conv7h_kernel)
+    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+    const int rows_used = BM + 6 * dil;
+    const int last_row = p.M - 1 + 6 * dil;
+    const int chunks = rows_used * CPRH;
+    for (int c0 = wave * 64; c0 < chunks; c0 += NW * 64) {
+      const int g = c0 + lane;
+      int row = g / CPRH;
+      int cc = g - row * CPRH;
+      if (cc >= C / 8) cc = 0;
+      int mr = m0 + row;
+      mr = mr < last_row ? mr : last_row;
+      dma16(A + (long)mr * C + cc * 8, halo + c0 * 16);
+    }
+  }
+  // ---- weight ring: the K-tiles of W7 (p.W, row stride p.K) followed by those of W1 (q.W, row stride q.K) ----------
+  const int r8 = lane >> 3;
+  const int wchunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
+  const int nslab1 = p.K / 64, nslab2 = q.K / 64, nslab = nslab1 + nslab2;
+  const bf16_t* w_rows[BI];
+  const bf16_t* w2_rows[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    int n = (wave + NW * i) * 8 + r8;
+    n = n < C ? n : C - 1;
+    w_rows[i] = (const bf16_t*)p.W + (long)n * p.K + wchunk * 8;
+    w2_rows[i] = (const bf16_t*)q.W + (long)n * q.K + wchunk * 8;
+  }
+  int issued = 0;
+  auto issue = [&](int stage) {
+    char* sB = ring + stage * TILE_W;
+    if (issued < nslab1) {  // uniform
+#pragma unroll
+      for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (wave + NW * i) * 1024);
+#pragma unroll
+      for (int i = 0; i < BI; ++i) w_rows[i] += 64;
+    } else {
+#pragma unroll
+      for (int i = 0; i < BI; ++i) dma16(w2_rows[i], sB + (wave + NW * i) * 1024);
+#pragma unroll
+      for (int i = 0; i < BI; ++i) w2_rows[i] += 64;
+    }
+    ++issued;
+  };
+
+  f32x16_t acc[FM][FN];
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int swz = (l31 >> 1) & 7;
+  const int b_base = (wn * WTN + l31) * RB;
+  const char* const a_lane = halo + (wm * WTM + l31) * HS + lh * 16;
+
+  const int k_real = 7 * C;
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nslab) issue(s);
+  int st_c = 0, st_i = (STAGES - 1) % STAGES;
+  for (int s = 0; s < nslab; ++s) {
+    if (s == nslab1) {
+      // ---- between the phases: y = snake(acc + bias) rounded to bf16 -> rows 0 .. BM-1 of the (now free) halo region ----
+      // every wave has finished reading the halo tile once it arrives here (its fragment reads completed before its last
+      // MFMAs issued); a raw barrier, so that W1's first K-tiles stay in flight
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const bool has_bias = p.bias != nullptr, snake_on = p.act == ACT_SNAKE;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n = wn * WTN + j * 32 + 8 * g + 4 * lh;   // 4 consecutive channels of row l31 (gemm_epilogue_lds)
+            const float4 bb = *(const float4*)(colv + n), sa = *(const float4*)(colv + C + n);
+            float v[4] = {acc[i][j][4 * g + 0], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+            if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+            // p.act is ACT_SNAKE or ACT_NONE (resunit_ok): act_apply's Snake expression, without its other branches
+            const float sv[4] = {sa.x, sa.y, sa.z, sa.w};
+            float a[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float sn = __sinf(sv[e] * v[e]);
+              a[e] = snake_on ? v[e] + sn * sn / (sv[e] + 1e-9f) : v[e];
+            }
+            store4<bf16_t>((bf16_t*)(halo + (wm * WTM + i * 32 + l31) * HS) + n, a[0], a[1], a[2], a[3]);
+            acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is in LDS before the barrier below publishes it
+    }
+    if (STAGES > 2 && s + STAGES - 2 < nslab) wait_vmcnt<(STAGES - 2) * BI>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + STAGES - 1 < nslab) issue(st_i);
+    const char* sB = ring + st_c * TILE_W;
+    const bool second = s >= nslab1;               // uniform
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k = (second ? s - nslab1 : s) * 64 + ks * 16;
+      if (k < (second ? C : k_real)) {             // columns beyond are the zero padding of W: skipped
+        const int tap = second ? 0 : k / C, c = k - tap * C;
+        const char* a_k = a_lane + tap * dil * HS + c * 2;
+        const int coff = ((ks * 2 + lh) ^ swz) << 4;
+        bf16x8_t af[FM], wf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(a_k + i * 32 * HS);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(sB + b_base + j * 32 * RB + coff);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = SA_MFMA_32x32x16(wf[j], af[i], acc[i][j]);
+      }
+    }
+    st_c = st_c + 1 == STAGES ? 0 : st_c + 1;
+    st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
+  }
+  __syncthreads();
+  gemm_epilogue_lds<FM, FN>(q, acc, b, m0 + wm * WTM, wn * WTN, lane, smem + wave * (FN * 4096));
+}
+
 // the launches conv7h covers: k = 7 'same' convolution of C -> C channels as the engine issues it (conv_same(): kc = lda =
 // C, tap_stride = dil * C, W tap-major with K = 7 C rounded up to 64), dilation <= 9, bf16, no per-batch weights
 bool conv7h_ok(const GemmParams& p) {
@@ -992,6 +1178,40 @@ hipError_t launch_conv7h(const GemmParams& p, hipStream_t st) {
     case 96: return launch_c7<96, 256, 8, 1, 3>(p, st);     // halo 63 KiB + 3 x 16 KiB
     case 128: return launch_c7<128, 256, 4, 2, 3>(p, st);   // halo 83 KiB + 3 x 16 KiB
     case 192: return launch_c7<192, 128, 4, 2, 3>(p, st);   // halo 72 KiB + 3 x 24 KiB
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// a (k7 launch p, k1 launch q) pair the fused residual-unit kernel covers: p as conv7h_ok, q the k1 convolution of the
+// same rows and channels reading p's output, with a residual stream and an output activation that is not p's input
+bool resunit_ok(const GemmParams& p, const GemmParams& q) {
+  if (!conv7h_ok(p) || !gemm2_ok(q)) return false;
+  if (q.N != p.N || q.M != p.M || q.nbatch != p.nbatch || q.kc != p.N || q.lda != p.N || q.w_bstride != 0) return false;
+  if (q.K != (p.N + 63) / 64 * 64 || q.swiglu || q.gate || q.chan_mod || q.c_ld_rel || q.alpha != 1.f) return false;
+  if (p.gate || p.chan_mod || p.c_ld_rel || p.res || p.out_f32 || p.f32_act || !p.out_act) return false;
+  if (p.act != ACT_SNAKE && p.act != ACT_NONE) return false;
+  // q reads exactly what p writes (the intermediate never reaches memory in the fused form)
+  if (q.A != p.out_act || q.a_off != p.act_off || q.a_bstride != p.act_bstride || p.act_ld != p.N) return false;
+  if (!q.out_act || q.out_act == p.A) return false;
+  return true;
+}
+
+template <int C, int BM, int WM_, int WN_, int STAGES>
+static hipError_t launch_ru(const GemmParams& p, const GemmParams& q, hipStream_t st) {
+  const long tiles = (long)((p.M + BM - 1) / BM) * p.nbatch;
+  if (p.tag == 1)
+    hipLaunchKernelGGL((resunit_kernel<C, BM, WM_, WN_, STAGES, 1>), dim3((unsigned)tiles), dim3(512), 0, st, p, q);
+  else
+    hipLaunchKernelGGL((resunit_kernel<C, BM, WM_, WN_, STAGES, 0>), dim3((unsigned)tiles), dim3(512), 0, st, p, q);
+  return hipGetLastError();
+}
+
+hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st) {
+  switch (p.N) {  // tile shapes of launch_conv7h
+    case 64: return launch_ru<64, 256, 8, 1, 3>(p, q, st);
+    case 96: return launch_ru<96, 256, 8, 1, 3>(p, q, st);
+    case 128: return launch_ru<128, 256, 4, 2, 3>(p, q, st);
+    case 192: return launch_ru<192, 128, 4, 2, 3>(p, q, st);
     default: return hipErrorInvalidValue;
   }
 }

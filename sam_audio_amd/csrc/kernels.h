@@ -11,6 +11,9 @@ hipError_t launch_poison_lds(hipStream_t st);
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
 //   flag 0: cross_attn_fold with heads on blockIdx.y (the pieces of an output row come from different XCDs) instead of the
 //           XCD-major deal of round 2's call 20 (A/B)
+//   flag 16: DAC residual units as two launches (k7 + k1) instead of the fused resunit kernel (A/B)
+//   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
+//   flag 17: bit mask of channel counts the fused residual-unit kernel must NOT take (1: 64, 2: 96, 4: 128, 8: 192; A/B)
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
 //   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
 //   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)
@@ -50,6 +53,9 @@ hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
 bool conv7h_ok(const GemmParams& p);
 hipError_t launch_conv7h(const GemmParams& p, hipStream_t st);
+// one DAC residual unit (k7 launch p + k1 launch q on its output) as ONE kernel, bitwise equal to the two launches
+bool resunit_ok(const GemmParams& p, const GemmParams& q);
+hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st);
 // gemm8.hip: one GEMM as two launches - part 0: gemm8 on the first `full` 256x256 tiles (whole rounds of the chip),
 // part 1: the rest as 128x128 quadrants on gemm8s.  gemm_tail_split() = `full` for a launch (0: no split).
 hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st);

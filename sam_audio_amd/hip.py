@@ -166,6 +166,7 @@ _PROTOS = {
     "samaudio_debug_poison_lds": (C.c_int, [C.c_void_p]),
     "samaudio_profile_end": (C.c_int, [C.c_void_p, C.POINTER(KernelStat), C.c_int, C.POINTER(C.c_int)]),
     "samaudio_op_gemm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "samaudio_op_resunit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "samaudio_op_rmsnorm_mod": (C.c_int, [C.c_void_p] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                              C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "samaudio_op_groupnorm_silu": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),

@@ -281,3 +281,67 @@ def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
     a = alpha[None, :, None]
     want = (y + torch.sin(a * y) ** 2 / (a + 1e-9)).transpose(1, 2)
     util.report(f"conv7h C={C} dil={dil}", outs[35][:, halo:halo + T], want, 4e-2)
+
+
+@pytest.mark.parametrize("C,dil,T,items", [(64, 1, 700, 3), (96, 3, 530, 2), (96, 9, 300, 3), (128, 9, 520, 2), (192, 3, 300, 3),
+                                           (192, 1, 130, 2), (96, 1, 256, 1)])
+def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
+    """resunit (one DAC residual unit per launch: k7 convolution -> Snake -> bf16 intermediate kept in LDS -> k1 convolution
+    + fp32 residual, fp32 stream and Snake'd bf16 copy out) against the two launches the engine otherwise issues, on identical
+    operands: identical bits in both outputs, halo rows of the output activation untouched, the input activation untouched;
+    every channel count / dilation the DAC stages use, M not a multiple of the row tile, several items.  The two-launch
+    form itself is checked against torch (conv1d + Snake + conv1d + residual)."""
+    halo = 40
+    x = _mk((items, C, T), 71)
+    xb = torch.zeros(items, T + 2 * halo, C)
+    xb[:, halo:halo + T] = x.transpose(1, 2)
+    K7, K1 = (7 * C + 63) // 64 * 64, (C + 63) // 64 * 64
+    w7 = _mk((C, C, 7), 72, 1 / math.sqrt(7 * C))
+    W7 = torch.zeros(C, K7)
+    W7[:, : 7 * C] = w7.permute(0, 2, 1).reshape(C, 7 * C)
+    w1 = _mk((C, C), 73, 1 / math.sqrt(C))
+    W1 = torch.zeros(C, K1)
+    W1[:, :C] = w1
+    b7, a7 = _mk((C,), 74, 0.1), (_mk((C,), 75, 0.2) + 1).clamp(0.3, 2)
+    b1, a1 = _mk((C,), 76, 0.1), (_mk((C,), 77, 0.2) + 1).clamp(0.3, 2)
+    raw0 = torch.zeros(items, T + 2 * halo, C)
+    raw0[:, halo:halo + T] = _mk((items, T, C), 78)
+    xin = util.as_act(xb, "bf16", gpu)
+    keep = [xin, util.as_act(W7, "bf16", gpu), util.as_act(W1, "bf16", gpu), b7.to(gpu), a7.to(gpu), b1.to(gpu), a1.to(gpu)]
+    geom = ((T + 2 * halo) * C, C, halo * C)
+
+    def params(mid, raw, out):
+        p7 = util.gemm_params(keep[0], keep[1], T, C, K7, nbatch=items, a_off=(halo - 3 * dil) * C, a_bstride=geom[0], lda=C,
+                              kc=C, tap_stride=dil * C, bias=keep[3], out_act=mid, act_geom=geom, act=hip.ACT_SNAKE,
+                              act_alpha=keep[4])
+        p1 = util.gemm_params(mid, keep[2], T, C, K1, nbatch=items, a_off=halo * C, a_bstride=geom[0], lda=C, kc=C, tap_stride=C,
+                              bias=keep[5], res=raw, res_geom=geom, out_f32=raw, f32_geom=geom, out_act=out, act_geom=geom,
+                              act=hip.ACT_SNAKE, act_alpha=keep[6])
+        return p7, p1
+
+    import ctypes as CT
+    res = {}
+    for fused in (False, True):
+        mid = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+        out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+        raw = raw0.to(gpu)
+        p7, p1 = params(mid, raw, out)
+        if fused:
+            util.resunit(p7, p1)
+            assert float(mid.float().abs().max()) == 0          # the intermediate never reaches memory
+        else:
+            for p in (p7, p1):
+                hip.check(hip.lib().samaudio_op_gemm(CT.byref(p), CT.sizeof(p), hip.BF16, util.stream()))
+        res[fused] = (raw.cpu(), out.cpu())
+    assert torch.equal(xin.cpu().view(torch.int16), util.as_act(xb, "bf16", "cpu").view(torch.int16))
+    assert torch.equal(res[True][0].view(torch.int32), res[False][0].view(torch.int32))
+    assert torch.equal(res[True][1].view(torch.int16), res[False][1].view(torch.int16))
+    assert float(res[True][1][:, :halo].abs().max()) == 0 and float(res[True][1][:, halo + T:].abs().max()) == 0
+    snake = lambda y, a: y + torch.sin(a[None, :, None] * y) ** 2 / (a[None, :, None] + 1e-9)   # noqa: E731
+    y = util.rounded(snake(F.conv1d(util.rounded(x, "bf16"), util.rounded(w7, "bf16"), b7, dilation=dil, padding=3 * dil), a7), "bf16")
+    want_raw = raw0[:, halo:halo + T] + (F.conv1d(y, util.rounded(w1, "bf16")[:, :, None], b1)).transpose(1, 2)
+    util.report(f"resunit C={C} dil={dil} raw", res[True][0][:, halo:halo + T], want_raw, 4e-2)
+    util.report(f"resunit C={C} dil={dil} act", res[True][1][:, halo:halo + T], snake(want_raw.transpose(1, 2), a1).transpose(1, 2), 6e-2)
+    # the output activation must not alias the input (neighbouring tiles read input halo rows): rejected, not raced
+    p7, p1 = params(torch.zeros_like(xin), raw0.to(gpu), xin)
+    assert hip.lib().samaudio_op_resunit(CT.byref(p7), CT.byref(p1), CT.sizeof(p7), util.stream()) == hip.ERR_ARG

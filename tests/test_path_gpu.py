@@ -94,6 +94,37 @@ def test_codec_chunked_equals_unchunked(gpu, monkeypatch):
     assert torch.equal(full, part)
 
 
+def test_codec_fused_residual_units_equal_the_two_launch_form(gpu):
+    """DAC residual units as one kernel each (resunit, debug flag 18 = at any launch size; the activation buffers of a
+    stage swap roles per fused unit) against the two launches per unit (flag 16): identical latents and waveforms, also
+    when the batch is split into chunks."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=6)
+    hop = cfg.audio_codec.hop_length
+    wav = torch.stack([synthetic_clip(i, 3 * hop) for i in range(3)])
+    lat = torch.randn(4, 3, 128, generator=torch.Generator().manual_seed(2))
+    model = _model(cfg, sd, "bf16", gpu)
+    from sam_audio_amd import hip
+    outs = {}
+    try:
+        for name, flags in (("two", {16: 1, 18: 0}), ("fused", {16: 0, 18: 1})):
+            for k, v in flags.items():
+                hip.lib().samaudio_debug_set_flag(k, v)
+            if gpu.type == "cuda":     # the per-kernel records say which form ran (hipEvents: hardware only)
+                model.profile_begin()
+            outs[name] = (model.encode_audio(wav).clone(), model.decode_audio(lat).clone())
+            if gpu.type == "cuda":
+                ran = [r["name"] for r in model.profile_end()]
+                assert any("resunit" in r for r in ran) == (name == "fused"), ran
+    finally:
+        hip.lib().samaudio_debug_set_flag(16, 0)
+        hip.lib().samaudio_debug_set_flag(18, 0)
+    assert torch.equal(outs["two"][0], outs["fused"][0]) and torch.equal(outs["two"][1], outs["fused"][1])
+    with torch.inference_mode():
+        w_ref = O.dac_decode(sd, cfg.audio_codec, lat.transpose(1, 2)).squeeze(1)
+    util.report("codec decode bf16, fused residual units", outs["fused"][1], w_ref, 2e-3)
+
+
 @pytest.mark.parametrize("method", ["midpoint", "euler"])
 def test_separate_matches_oracle_fp32(gpu, method):
     """Whole separate(): ragged clip lengths, ragged text mask, anchors, explicit CPU noise (quirk Q12)."""
