@@ -159,6 +159,32 @@ for Cc, Tc in ((64, 480000), (128, 240000)):
     L.samaudio_debug_set_flag(11, 0)
 items, Tc, Cc = 8, 480000, 96
 
+# one DAC residual unit: the two launches (k7 + k1, tile policy) against the fused resunit kernel
+import ctypes as CT  # noqa: E402
+for Cc, Tc, items in ((64, 480000, 8), (96, 480000, 8), (128, 240000, 8), (192, 240000, 8)):
+    geom = ((Tc + 80) * Cc, Cc, 40 * Cc)
+    K7, K1 = (7 * Cc + 63) // 64 * 64, (Cc + 63) // 64 * 64
+    xa = torch.randn(items, Tc + 80, Cc, device=dev).to(torch.bfloat16)
+    mid = torch.zeros_like(xa)
+    oc = torch.zeros_like(xa)
+    raw = torch.randn(items, Tc + 80, Cc, device=dev)
+    w7 = (torch.randn(Cc, K7, device=dev) / (7 * Cc) ** 0.5).to(torch.bfloat16)
+    w1 = (torch.randn(Cc, K1, device=dev) / Cc ** 0.5).to(torch.bfloat16)
+    bias_c, alpha_c = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    p7 = util.gemm_params(xa, w7, Tc, Cc, K7, nbatch=items, a_off=(40 - 9) * Cc, a_bstride=geom[0], lda=Cc, kc=Cc,
+                          tap_stride=3 * Cc, bias=bias_c, out_act=mid, act_geom=geom, act=hip.ACT_SNAKE, act_alpha=alpha_c)
+    p1 = util.gemm_params(mid, w1, Tc, Cc, K1, nbatch=items, a_off=40 * Cc, a_bstride=geom[0], lda=Cc, kc=Cc, tap_stride=Cc,
+                          bias=bias_c, res=raw, res_geom=geom, out_f32=raw, f32_geom=geom, out_act=oc, act_geom=geom,
+                          act=hip.ACT_SNAKE, act_alpha=alpha_c)
+    unit_bytes = items * Tc * Cc * (2 + 4 + 4 + 2)
+
+    def two():
+        for q in (p7, p1):
+            hip.check(L.samaudio_op_gemm(CT.byref(q), CT.sizeof(q), hip.BF16, st()))
+    timeit(f"residual unit C={Cc} dil 3 [two launches]", two, unit_bytes, iters=5)
+    timeit(f"residual unit C={Cc} dil 3 [fused resunit]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
+items, Tc, Cc = 8, 480000, 96
+
 # the same contraction as a PLAIN GEMM (dense A [M, 704]): separates the implicit-convolution addressing from the
 # narrow-N / short-K regime
 Mp = items * Tc
