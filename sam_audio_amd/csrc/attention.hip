@@ -531,11 +531,12 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
 __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
                                                               long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
                                                               int LtP, int H, int xcd_major) {
-  // Every (batch, n) row of U^T is 2*KP bytes to which each head contributes 2*LtP bytes.  xcd_major: the 1-D grid is dealt
-  // so that the H workgroups of one 64-channel block land on the SAME XCD (workgroup i runs on XCD i % 8) one after the
-  // other: they walk the batch in the same order, so their 16-byte pieces of a row meet in that XCD's L2 and leave as
-  // whole lines.  With heads on blockIdx.y the pieces of a row came from up to 8 different L2s and every one was written
-  // back as a partial line (PMC: 73.6 MB written per launch for 34.6 MB of output, profiles/r2_traffic.json).
+  // Every (batch, n) row of U^T is 2*KP bytes to which each head contributes 2*LtP bytes; with heads on blockIdx.y the
+  // pieces of a row come from up to 8 different L2s and leave as partial lines (PMC: 73.6 MB written per launch for 34.6 MB
+  // of output, profiles/r2_traffic.json).  xcd_major (debug flag 0) deals the 1-D grid so that the H workgroups of one
+  // 64-channel block land on the SAME XCD (workgroup i runs on XCD i % 8) back to back, so that their pieces could merge in
+  // that L2.  Measured SLOWER (57.8 vs 49.5 us, profiles/r2_call20/; the deal is also uneven - 44 blocks over 8 XCDs = 6 | 5
+  // - but that explains 9 % at most): the partial lines are not what bounds this kernel.  Kept as the A/B it was.
   int h = blockIdx.y, nb = blockIdx.x;
   if (xcd_major) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -651,7 +652,7 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
     return hipGetLastError();
   }
   const int zs = debug_flag(12) > 0 ? debug_flag(12) : 1;  // flag 12 (A/B): batch split - 48.8 / 50.3 / 53.3 us for 1 / 2 / 4
-  if (!debug_flag(0)) {  // flag 0 (A/B): heads on blockIdx.y as before GPU call 20 of round 2
+  if (debug_flag(0)) {  // flag 0 (A/B candidate, measured SLOWER on MI355X: 57.8 vs 49.5 us, profiles/r2_call20/): XCD-major deal
     const int nblocks = H * 128 / 64;
     hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(8 * H * ((nblocks + 7) / 8), 1, zs), dim3(256), 0, st, (const bf16_t*)wo,
                        (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H, 1);

@@ -979,9 +979,9 @@ __global__ __launch_bounds__(512) void conv7h_kernel(const GemmParams p) {
 // Saves the intermediate's write + read (4 of every 16 algorithmic bytes per element) and one launch per unit.
 // ------------------------------------------------------------------------------------------------
 template <int C, int BM, int WM_, int WN_, int STAGES, int TAG>
-__global__ __launch_bounds__(512) void resunit_kernel(const GemmParams p, const GemmParams q) {
-  constexpr int NW = 8, MAXD = 9;
-  static_assert(WM_ * WN_ == NW, "8 waves");
+__global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParams p, const GemmParams q) {
+  constexpr int NW = WM_ * WN_, MAXD = 9;      // 8 waves, or 4 (half the rows per workgroup: two workgroups per CU)
+  static_assert(NW == 8 || NW == 4, "4 or 8 waves");
   constexpr int WTM = BM / WM_, WTN = C / WN_;
   constexpr int FM = WTM / 32, FN = WTN / 32;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0 && C % 16 == 0, "tile shape");
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(512) void resunit_kernel(const GemmParams p, const 
   constexpr int HALO_B = (HROWS * HS + 1023) / 1024 * 1024;
   constexpr int WR = (C + 63) / 64 * 64;
   constexpr int RB = 128, TILE_W = WR * RB;
-  constexpr int BI = WR / 64;
+  constexpr int BI = WR / (NW * 8);              // weight DMA instructions per wave per K-tile (8 rows each)
   static_assert(HALO_B + STAGES * TILE_W <= 160 * 1024, "LDS budget");
   static_assert(NW * FN * 4096 <= HALO_B + STAGES * TILE_W, "epilogue staging fits");
   static_assert((STAGES - 2) * BI <= 63, "vmcnt range");
@@ -1200,16 +1200,18 @@ template <int C, int BM, int WM_, int WN_, int STAGES>
 static hipError_t launch_ru(const GemmParams& p, const GemmParams& q, hipStream_t st) {
   const long tiles = (long)((p.M + BM - 1) / BM) * p.nbatch;
   if (p.tag == 1)
-    hipLaunchKernelGGL((resunit_kernel<C, BM, WM_, WN_, STAGES, 1>), dim3((unsigned)tiles), dim3(512), 0, st, p, q);
+    hipLaunchKernelGGL((resunit_kernel<C, BM, WM_, WN_, STAGES, 1>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0, st, p, q);
   else
-    hipLaunchKernelGGL((resunit_kernel<C, BM, WM_, WN_, STAGES, 0>), dim3((unsigned)tiles), dim3(512), 0, st, p, q);
+    hipLaunchKernelGGL((resunit_kernel<C, BM, WM_, WN_, STAGES, 0>), dim3((unsigned)tiles), dim3(WM_ * WN_ * 64), 0, st, p, q);
   return hipGetLastError();
 }
 
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st) {
   switch (p.N) {  // tile shapes of launch_conv7h
     case 64: return launch_ru<64, 256, 8, 1, 3>(p, q, st);
-    case 96: return launch_ru<96, 256, 8, 1, 3>(p, q, st);
+    // 96 channels, flag 20 (A/B): 128-row tiles on 4 waves and a 2-stage ring = 72 KiB, two workgroups per CU, so that one
+    // workgroup's memory-bound phase-2 epilogue overlaps the other's MFMA-bound phase 1
+    case 96: return debug_flag(20) ? launch_ru<96, 128, 4, 1, 2>(p, q, st) : launch_ru<96, 256, 8, 1, 3>(p, q, st);
     case 128: return launch_ru<128, 256, 4, 2, 3>(p, q, st);
     case 192: return launch_ru<192, 128, 4, 2, 3>(p, q, st);
     default: return hipErrorInvalidValue;

@@ -283,9 +283,10 @@ def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
     util.report(f"conv7h C={C} dil={dil}", outs[35][:, halo:halo + T], want, 4e-2)
 
 
-@pytest.mark.parametrize("C,dil,T,items", [(64, 1, 700, 3), (96, 3, 530, 2), (96, 9, 300, 3), (128, 9, 520, 2), (192, 3, 300, 3),
-                                           (192, 1, 130, 2), (96, 1, 256, 1)])
-def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
+@pytest.mark.parametrize("C,dil,T,items,four_waves", [(64, 1, 700, 3, 0), (96, 3, 530, 2, 0), (96, 9, 300, 3, 0), (128, 9, 520, 2, 0),
+                                                      (192, 3, 300, 3, 0), (192, 1, 130, 2, 0), (96, 1, 256, 1, 0),
+                                                      (96, 3, 530, 2, 1), (96, 9, 300, 3, 1), (96, 1, 128, 2, 1)])
+def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items, four_waves):
     """resunit (one DAC residual unit per launch: k7 convolution -> Snake -> bf16 intermediate kept in LDS -> k1 convolution
     + fp32 residual, fp32 stream and Snake'd bf16 copy out) against the two launches the engine otherwise issues, on identical
     operands: identical bits in both outputs, halo rows of the output activation untouched, the input activation untouched;
@@ -321,6 +322,7 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
 
     import ctypes as CT
     res = {}
+    hip.lib().samaudio_debug_set_flag(20, four_waves)   # 96 channels: 128-row tiles on 4 waves (A/B variant of the kernel)
     for fused in (False, True):
         mid = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
         out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
@@ -333,6 +335,7 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
             for p in (p7, p1):
                 hip.check(hip.lib().samaudio_op_gemm(CT.byref(p), CT.sizeof(p), hip.BF16, util.stream()))
         res[fused] = (raw.cpu(), out.cpu())
+    hip.lib().samaudio_debug_set_flag(20, 0)
     assert torch.equal(xin.cpu().view(torch.int16), util.as_act(xb, "bf16", "cpu").view(torch.int16))
     assert torch.equal(res[True][0].view(torch.int32), res[False][0].view(torch.int32))
     assert torch.equal(res[True][1].view(torch.int16), res[False][1].view(torch.int16))

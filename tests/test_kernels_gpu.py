@@ -183,8 +183,8 @@ def debug_flag():
 def test_cross_attn_fold_operand(gpu, debug_flag, Lt, ltp, B, H, candidate):
     """U^T of the folded cross-attention output projection against an fp32 einsum.  candidate = 1: the LDS-staged
     kernel behind debug flag 3 (heads per workgroup = 4: H = 6 and H = 2 exercise the partial last head group, whose
-    missing heads must come out as the zeros the K padding of U holds).  candidate = 2: heads on blockIdx.y (debug flag 0,
-    the mapping before the XCD-major deal; H = 22 -> 44 channel blocks = 5.5 per XCD exercises its ragged last deal)."""
+    missing heads must come out as the zeros the K padding of U holds).  candidate = 2: the XCD-major workgroup deal (debug flag 0,
+    an A/B candidate; H = 22 -> 44 channel blocks = 5.5 per XCD exercises its ragged last deal)."""
     debug_flag(3, 1 if candidate == 1 else 0)
     debug_flag(0, 1 if candidate == 2 else 0)
     D = H * 128

@@ -183,6 +183,10 @@ for Cc, Tc, items in ((64, 480000, 8), (96, 480000, 8), (128, 240000, 8), (192, 
             hip.check(L.samaudio_op_gemm(CT.byref(q), CT.sizeof(q), hip.BF16, st()))
     timeit(f"residual unit C={Cc} dil 3 [two launches]", two, unit_bytes, iters=5)
     timeit(f"residual unit C={Cc} dil 3 [fused resunit]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
+    if Cc == 96:
+        L.samaudio_debug_set_flag(20, 1)
+        timeit(f"residual unit C={Cc} dil 3 [fused, 128-row tiles on 4 waves, 2 wg/CU]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
+        L.samaudio_debug_set_flag(20, 0)
 items, Tc, Cc = 8, 480000, 96
 
 # the same contraction as a PLAIN GEMM (dense A [M, 704]): separates the implicit-convolution addressing from the
