@@ -268,11 +268,12 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
     // invariance.  Codec convolutions with that many output columns ride the same kernels.
     // N >= 1024 since GPU call 5: the vision tower's out_proj / c_proj (N = 1024, M = 144 000) ran at 624 TF/s on the
     // loader-wave kernel, small* (D = 1536) at 264 TF/s on the 128x128 tile of the other family
-    // flag 19 (A/B): the family also takes 256 <= N < 1024 (the DAC stages with 256 - 768 channels, otherwise on the
-    // loader-wave 256x128 kernel); 2 = outputs that are not a multiple of 256 wide (N = 384) on its 128x128 tile
-    if (p.N >= (debug_flag(7) ? 4096 : debug_flag(19) ? 256 : 1024)) {
+    // N >= 256 since GPU call 21: the DAC stages with 256 - 768 channels (38 launches per step) took 44.7 + 13.3 ms on the
+    // loader-wave 256x128 kernel + this family, 47.8 ms on this family alone; outputs that are not a multiple of 256 wide
+    // (N = 384) use its 128x128 tile whatever M (712 / 665 TF/s per symbol vs 554; profiles/r2_call21/).  Flag 19 = before.
+    if (p.N >= (debug_flag(7) ? 4096 : debug_flag(19) ? 1024 : 256)) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
-      if (debug_flag(19) == 2 && p.N % 256) return 27;
+      if (p.N < 1024 && p.N % 256) return 27;
       return t256 >= 128 || debug_flag(6) ? 22 : 27;
     }
     if (p.N == 192 && !debug_flag(4)) return 6;

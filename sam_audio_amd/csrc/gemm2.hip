@@ -1209,9 +1209,10 @@ static hipError_t launch_ru(const GemmParams& p, const GemmParams& q, hipStream_
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st) {
   switch (p.N) {  // tile shapes of launch_conv7h
     case 64: return launch_ru<64, 256, 8, 1, 3>(p, q, st);
-    // 96 channels, flag 20 (A/B): 128-row tiles on 4 waves and a 2-stage ring = 72 KiB, two workgroups per CU, so that one
-    // workgroup's memory-bound phase-2 epilogue overlaps the other's MFMA-bound phase 1
-    case 96: return debug_flag(20) ? launch_ru<96, 128, 4, 1, 2>(p, q, st) : launch_ru<96, 256, 8, 1, 3>(p, q, st);
+    // 96 channels: 128-row tiles on 4 waves and a 2-stage ring = 72 KiB, two workgroups per CU, so that one workgroup's
+    // memory-bound phase-2 epilogue overlaps the other's MFMA-bound phase 1 (2023 vs 2102 us for 8 waveforms, two launches
+    // 2204; profiles/r2_call21/).  Flag 20 = the 8-wave 256-row shape.
+    case 96: return debug_flag(20) ? launch_ru<96, 256, 8, 1, 3>(p, q, st) : launch_ru<96, 128, 4, 1, 2>(p, q, st);
     case 128: return launch_ru<128, 256, 4, 2, 3>(p, q, st);
     case 192: return launch_ru<192, 128, 4, 2, 3>(p, q, st);
     default: return hipErrorInvalidValue;

@@ -10,12 +10,13 @@ hipError_t launch_poison_lds(hipStream_t st);
 
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
 //   flag 0: cross_attn_fold with the XCD-major workgroup deal (A/B candidate of call 20, measured slower: 57.8 vs 49.5 us)
-//   flag 19: 8-phase family for 256 <= N < 1024 too (1), N % 256 != 0 on its 128x128 tile (2) (A/B)
+//   flag 19: 256 <= N < 1024 on the loader-wave 256x128 kernel as before GPU call 21 of round 2 (the 8-phase family now
+//            covers every N >= 256) (A/B)
 //   flag 16: DAC residual units as two launches (k7 + k1) instead of the fused resunit kernel (A/B)
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
 //   flag 17: bit mask TOGGLING the channel counts excluded from the fused residual-unit kernel (1: 64, 2: 96, 4: 128, 8: 192;
 //            excluded by default: 128 and 192) (A/B)
-//   flag 20: fused residual units with 96 channels on 128-row tiles / 4 waves / two workgroups per CU (A/B)
+//   flag 20: fused residual units with 96 channels on 256-row tiles / 8 waves / one workgroup per CU as in call 20 (A/B)
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
 //   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
 //   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)

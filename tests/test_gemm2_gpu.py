@@ -322,7 +322,7 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items, 
 
     import ctypes as CT
     res = {}
-    hip.lib().samaudio_debug_set_flag(20, four_waves)   # 96 channels: 128-row tiles on 4 waves (A/B variant of the kernel)
+    hip.lib().samaudio_debug_set_flag(20, 0 if four_waves else 1)   # 96 channels: 128-row tiles on 4 waves (shipped) | 8 waves
     for fused in (False, True):
         mid = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
         out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)

@@ -185,7 +185,7 @@ for Cc, Tc, items in ((64, 480000, 8), (96, 480000, 8), (128, 240000, 8), (192, 
     timeit(f"residual unit C={Cc} dil 3 [fused resunit]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
     if Cc == 96:
         L.samaudio_debug_set_flag(20, 1)
-        timeit(f"residual unit C={Cc} dil 3 [fused, 128-row tiles on 4 waves, 2 wg/CU]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
+        timeit(f"residual unit C={Cc} dil 3 [fused, 256-row tiles on 8 waves, 1 wg/CU]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
         L.samaudio_debug_set_flag(20, 0)
 items, Tc, Cc = 8, 480000, 96
 
