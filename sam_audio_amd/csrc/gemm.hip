@@ -274,7 +274,7 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
     if (p.N >= (debug_flag(7) ? 4096 : debug_flag(19) ? 1024 : 256)) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
       if (p.N < 1024 && p.N % 256) return 27;
-      return t256 >= (debug_flag(22) > 0 ? debug_flag(22) : 128) || debug_flag(6) ? 22 : 27;   // flag 22 (A/B): the threshold
+      return t256 >= 128 || debug_flag(6) ? 22 : 27;
     }
     if (p.N == 192 && !debug_flag(4)) return 6;
     // Few rows (strong scaling: 4 clips per GPU = 1000 rows): 256-row tiles leave most CUs idle (4 x 22 = 88 tiles at

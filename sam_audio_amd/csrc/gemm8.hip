@@ -390,15 +390,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // 4 waves as 2 (M) x 2 (N), 64 x 64 outputs each; two 32 KiB stages (A tile | W tile) = 64 KiB of LDS and 256 threads, so
 // two workgroups share a CU and one's barriers / epilogue are covered by the other's K loop; a plain double buffer: the
 // DMA of K-tile t+1 is issued before the reads of K-tile t, one counted vmcnt and two barriers per K-tile.
-// S = ring depth.  2: 64 KiB, two workgroups per CU (launches with more workgroups than CUs: the other workgroup covers
-// the DMA latency).  4: 128 KiB, one workgroup per CU with three K-tiles in flight - for launches that cannot give a CU a
-// second workgroup anyway (<= 256 workgroups: M = 1000 rows at N = D is 176), where the double buffer exposed a full
-// L2 round trip per K-tile (1.2 us per K-tile for 0.2 us of MFMA work).  Same arithmetic: bitwise identical results.
-template <int S>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
-  static_assert(S == 2 || S == 4, "ring depth");
-  __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];  // [stage][A tile, W tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -471,19 +465,15 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     return *(const bf16x8_t*)(tile_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
   };
 
-#pragma unroll
-  for (int t = 0; t < S - 1; ++t)
-    if (t < nt) stage(t, t);
+  stage(0, 0);
   for (int t = 0; t < nt; ++t) {
-    const int cb = t & (S - 1);
-    // K-tile t+S-1 goes into the buffer K-tile t-1 was read from (everybody passed that iteration's second barrier)
-    if (t + S - 1 < nt) stage((t + S - 1) & (S - 1), t + S - 1);
-    // 8 loads per K-tile, retired in issue order: K-tile t has landed once at most the later tiles' loads are in flight
-    const int later = nt - 1 - t < S - 1 ? nt - 1 - t : S - 1;
-    if (S == 4 && later == 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (S == 4 && later == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (later >= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int cb = t & 1;
+    if (t + 1 < nt) {
+      stage(cb ^ 1, t + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 loads just issued stay in flight; K-tile t has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     const char* At = smem + cb * (2 * TB);
     const char* Wt = At + TB;
@@ -512,9 +502,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
-  // flag 21 (A/B): the double buffer for every launch, as before GPU call 22 of round 2
-  if (tiles <= 256 && !debug_flag(21)) hipLaunchKernelGGL(gemm8s_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
-  else hipLaunchKernelGGL(gemm8s_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
+  hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
   return hipGetLastError();
 }
 
@@ -535,9 +523,7 @@ hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
   if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
-  else if ((tiles - full) * 4 <= 256 && !debug_flag(21))   // a tail that cannot give a CU two workgroups: deep ring
-    hipLaunchKernelGGL(gemm8s_kernel<4>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
-  else hipLaunchKernelGGL(gemm8s_kernel<2>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
+  else hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
   return hipGetLastError();
 }
 

@@ -189,34 +189,6 @@ def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
     assert torch.equal(a22.view(torch.int16), a27.view(torch.int16))
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 256, 64), (130, 384, 128), (333, 512, 192), (270, 2816, 448)])
-def test_gemm8s_ring_depths_are_bitwise_identical(gpu, M, N, K):
-    """gemm8s picks its LDS ring by launch size (<= 256 workgroups: 4 stages, one workgroup per CU; more: 2 stages, two
-    per CU; debug flag 21 = always 2).  Same arithmetic: identical bits for 1 .. 7 K-tiles (shorter than the ring, equal,
-    longer), against each other and against the 256x256 kernel; gated-residual epilogue, fp32 + bf16 outputs."""
-    A, W = _mk((M, K), 51), _mk((N, K), 52, 1 / math.sqrt(K))
-    tab, gate, res = _mk((N,), 53), _mk((1, N), 54), _mk((M, N), 55)
-    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
-    outs = {}
-    try:
-        for name, variant, flag in (("deep", 27, 0), ("double", 27, 1), ("8phase", 22, 0)):
-            hip.lib().samaudio_debug_force_gemm_variant(variant)
-            hip.lib().samaudio_debug_set_flag(21, flag)
-            out = torch.full((M, N), float("nan"), device=gpu)
-            out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
-            util.gemm("bf16", keep[0], keep[1], M, N, K, gate_tab=keep[2], gate=keep[3], gate_ld=N, rows_per_gate=M,
-                      res=keep[4], res_geom=(0, N, 0), out_f32=out, f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
-            outs[name] = (out.cpu(), out_act.cpu())
-    finally:
-        hip.lib().samaudio_debug_set_flag(21, 0)
-        hip.lib().samaudio_debug_force_gemm_variant(-1)
-    want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
-    util.report(f"gemm8s deep ring {M}x{N}x{K}", outs["deep"][0], want, 5e-4)
-    for other in ("double", "8phase"):
-        assert torch.equal(outs["deep"][0], outs[other][0])
-        assert torch.equal(outs["deep"][1].view(torch.int16), outs[other][1].view(torch.int16))
-
-
 @pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10)])
 def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
     """8-phase launches whose last round of 256x256 tiles is mostly empty run as two kernels (gemm.hip gemm_tail_split:

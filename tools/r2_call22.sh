@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 2, GPU call 22: gemm8s with a 4-stage ring for launches of <= 256 workgroups (flag 21 = the double buffer) - bitwise
+# Round 2, GPU call 22 (NEGATIVE RESULT, the kernel change was reverted - see DESIGN.md 3.4; this script needs commit
+# "gemm8s: 4-stage ring ..." checked out to reproduce): gemm8s with a 4-stage ring for launches of <= 256 workgroups (flag 21 = the double buffer) - bitwise
 # tests on hardware, bench A/B at 4 clips (strong-scaling share), small* 8 clips (configs[1]), one row group with the tail
 # split, the default line; threshold between gemm8s and the 256x256 kernel (flag 22).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
