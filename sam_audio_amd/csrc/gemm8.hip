@@ -29,6 +29,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace sa {
 
 typedef h16x8_t bf16x8_t;  // 8 x 16-bit operand words (bf16, or fp16 with -DSA_OPERAND_FP16: common.h)
@@ -390,9 +392,16 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // 4 waves as 2 (M) x 2 (N), 64 x 64 outputs each; two 32 KiB stages (A tile | W tile) = 64 KiB of LDS and 256 threads, so
 // two workgroups share a CU and one's barriers / epilogue are covered by the other's K loop; a plain double buffer: the
 // DMA of K-tile t+1 is issued before the reads of K-tile t, one counted vmcnt and two barriers per K-tile.
+// PIPE: the form for launches that cannot give a CU a second workgroup (<= 256 workgroups: 176 at M = 1000, N = D).  Alone
+// on its CU the double-buffered loop runs read fragments -> barrier -> MFMA strictly in sequence - one wave per SIMD, nothing
+// to overlap with: ~1 200 cycles per K-tile for 512 cycles of MFMA work.  PIPE keeps a 3-stage ring (96 KiB) and two
+// fragment sets: the LDS reads of K-tile t+1 are issued BEFORE the MFMAs of K-tile t and complete underneath them, one
+// barrier per K-tile.  Same MFMA order per output element: bitwise identical to the plain form and to gemm8_kernel.
+template <bool PIPE>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];  // [stage][A tile, W tile]
+  constexpr int S = PIPE ? 3 : 2;
+  __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -465,6 +474,66 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     return *(const bf16x8_t*)(tile_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
   };
 
+  if constexpr (PIPE) {
+    bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
+    auto read_frags = [&](int buf, auto SET) {
+      const char* At = smem + buf * (2 * TB);
+      const char* Wt = At + TB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          af[SET()][i][ks] = frag(At, wr * 64 + i * 16 + lr, ks);
+          wf[SET()][i][ks] = frag(Wt, wc * 64 + i * 16 + lr, ks);
+        }
+    };
+    // NEXT: K-tile t+1 exists.  A compile-time switch, not a branch: at a control-flow merge the compiler would wait for
+    // EVERY outstanding LDS read before the MFMAs (it cannot keep a per-path count), which serialises read and multiply again.
+    auto step = [&](int t, auto SET, auto NEXT) {   // fragments of K-tile t are set SET (reads issued one step earlier)
+      constexpr int OTHER = 1 - decltype(SET)::value;
+      // K-tile t+2 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
+      if (t + 2 < nt) stage((t + 2) % 3, t + 2);
+      if constexpr (decltype(NEXT)::value) {
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile t+1 has landed (t+2 may be in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of K-tile t are complete
+        __builtin_amdgcn_s_barrier();
+        read_frags((t + 1) % 3, std::integral_constant<int, OTHER>{});      // in flight underneath the MFMAs below
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[i][j] = SA_MFMA_16x16x32(wf[SET()][j][ks], af[SET()][i][ks], acc[i][j]);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    stage(0, 0);
+    if (nt > 1) {
+      stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, I0{});
+    int t = 0;
+    for (; t + 2 < nt; t += 2) {   // both steps have a successor
+      step(t, I0{}, std::true_type{});
+      step(t + 1, I1{}, std::true_type{});
+    }
+    if (nt - t == 2) {
+      step(t, I0{}, std::true_type{});
+      step(t + 1, I1{}, std::false_type{});
+    } else {
+      step(t, I0{}, std::false_type{});
+    }
+    __syncthreads();
+    epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
+    return;
+  }
   stage(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int cb = t & 1;
@@ -502,7 +571,9 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
-  hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
+  // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
+  if (tiles <= 256 && !debug_flag(21)) hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
+  else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
   return hipGetLastError();
 }
 
@@ -523,7 +594,9 @@ hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
   if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
-  else hipLaunchKernelGGL(gemm8s_kernel, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
+  else if ((tiles - full) * 4 <= 256 && !debug_flag(21))   // a tail that cannot give a CU two workgroups
+    hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
+  else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
   return hipGetLastError();
 }
 

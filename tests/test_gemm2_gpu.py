@@ -189,6 +189,35 @@ def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
     assert torch.equal(a22.view(torch.int16), a27.view(torch.int16))
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 256, 64), (130, 384, 128), (333, 512, 192), (270, 2816, 448), (250, 640, 512)])
+def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
+    """gemm8s runs launches of <= 256 workgroups in its pipelined form (3-stage ring, the fragments of K-tile t+1 read
+    underneath the MFMAs of K-tile t; debug flag 21 = the plain double-buffered form).  Same arithmetic: identical bits
+    for 1 .. 8 K-tiles (odd and even counts, shorter than the ring), against the plain form and against the 256x256
+    kernel; gated-residual epilogue, fp32 + bf16 outputs."""
+    A, W = _mk((M, K), 51), _mk((N, K), 52, 1 / math.sqrt(K))
+    tab, gate, res = _mk((N,), 53), _mk((1, N), 54), _mk((M, N), 55)
+    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
+    outs = {}
+    try:
+        for name, variant, flag in (("pipelined", 27, 0), ("plain", 27, 1), ("8phase", 22, 0)):
+            hip.lib().samaudio_debug_force_gemm_variant(variant)
+            hip.lib().samaudio_debug_set_flag(21, flag)
+            out = torch.full((M, N), float("nan"), device=gpu)
+            out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
+            util.gemm("bf16", keep[0], keep[1], M, N, K, gate_tab=keep[2], gate=keep[3], gate_ld=N, rows_per_gate=M,
+                      res=keep[4], res_geom=(0, N, 0), out_f32=out, f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
+            outs[name] = (out.cpu(), out_act.cpu())
+    finally:
+        hip.lib().samaudio_debug_set_flag(21, 0)
+        hip.lib().samaudio_debug_force_gemm_variant(-1)
+    want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
+    util.report(f"gemm8s pipelined {M}x{N}x{K}", outs["pipelined"][0], want, 5e-4)
+    for other in ("plain", "8phase"):
+        assert torch.equal(outs["pipelined"][0], outs[other][0])
+        assert torch.equal(outs["pipelined"][1].view(torch.int16), outs[other][1].view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10)])
 def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
     """8-phase launches whose last round of 256x256 tiles is mostly empty run as two kernels (gemm.hip gemm_tail_split:
