@@ -581,75 +581,6 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
   }
 }
 
-// cross_attn_fold3_kernel (A/B candidate, debug flag 0 = 2): the same product with the V rows of a trip staged ONCE per
-// workgroup in LDS.  In the kernel above every wave loads its (batch, head) rows itself - the four waves of a workgroup and
-// the 44 channel blocks of a head all fetch the same 2 KiB per batch item, 16 cache lines per load instruction: 7.9 M of the
-// launch's 9.9 M L2 requests, ~75 % of what the L2s can take in 49 us.  Here 256 threads fetch the 4 x LtP rows of a trip
-// with one or two 16-byte loads each (next trip's loads in flight underneath this trip's MFMAs), rows j >= Lt zero-filled,
-// 16-byte chunks XOR-swizzled with the row so that the 16 token lanes of a fragment read hit different banks.  Same MFMA
-// operands in the same order: bitwise the kernel above.
-__global__ __launch_bounds__(256) void cross_attn_fold3_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
-                                                               long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
-                                                               int LtP, int H) {
-  __shared__ uint4 vs[2][4 * 16 * 16];   // [buffer][batch item of the trip][token row <= 16][16 chunks of 8 channels]
-  const int h = blockIdx.y, nb = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int D = H * 128;
-  const int n = (nb * 4 + wave) * 16 + r;
-  bf16x8_t wf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
-  const int per_trip = 4 * LtP * 16;       // 16-byte chunks of one trip: 512 (LtP = 8) or 1024 (LtP = 16)
-  const int nld = per_trip >> 8;           // loads per thread: 2 or 4
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  uint4 pre[4];
-  auto fetch = [&](int b0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      pre[q] = zero4;
-      if (q < nld) {
-        const int idx = q * 256 + tid;
-        const int bb = idx / (LtP * 16), rem = idx - bb * (LtP * 16);
-        const int j = rem >> 4, c = rem & 15;
-        const int b = b0 + bb < B ? b0 + bb : B - 1;
-        if (j < Lt) pre[q] = *(const uint4*)(kv + ((long)b * Lt + j) * kv_ld + D + h * 128 + c * 8);
-      }
-    }
-  };
-  auto put = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < nld) {
-        const int idx = q * 256 + tid;
-        const int bb = idx / (LtP * 16), rem = idx - bb * (LtP * 16);
-        const int j = rem >> 4, c = rem & 15;
-        vs[buf][(bb * 16 + j) * 16 + (c ^ j)] = pre[q];
-      }
-  };
-  fetch(0);
-  put(0);
-  __syncthreads();
-  int buf = 0;
-  for (int b0 = 0; b0 < B; b0 += 4) {
-    if (b0 + 4 < B) fetch(b0 + 4);   // in flight underneath the MFMAs below
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        uint4 x = r < LtP ? vs[buf][(bb * 16 + r) * 16 + ((ks * 4 + g) ^ r)] : zero4;
-        u = SA_MFMA_16x16x32(*(const bf16x8_t*)&x, wf[ks], u);
-      }
-      if (b0 + bb < B && g * 4 < LtP)
-        store4<bf16_t>(UT + ((long)(b0 + bb) * D + n) * KP + h * LtP + g * 4, u[0], u[1], u[2], u[3]);
-    }
-    if (b0 + 4 < B) put(buf ^ 1);
-    __syncthreads();   // next trip's rows are in place; everybody is done reading this trip's
-    buf ^= 1;
-  }
-}
-
 hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
                                    void* P, int ldp, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st) {
   hipLaunchKernelGGL(cross_attn_probs_kernel, dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const bf16_t*)q, qw,
@@ -721,11 +652,6 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
     return hipGetLastError();
   }
   const int zs = debug_flag(12) > 0 ? debug_flag(12) : 1;  // flag 12 (A/B): batch split - 48.8 / 50.3 / 53.3 us for 1 / 2 / 4
-  if (debug_flag(0) == 2) {  // flag 0 = 2 (A/B candidate): V rows staged once per workgroup in LDS
-    hipLaunchKernelGGL(cross_attn_fold3_kernel, dim3(H * 128 / 64, H), dim3(256), 0, st, (const bf16_t*)wo, (const bf16_t*)kv,
-                       kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
-    return hipGetLastError();
-  }
   if (debug_flag(0)) {  // flag 0 (A/B candidate, measured SLOWER on MI355X: 57.8 vs 49.5 us, profiles/r2_call20/): XCD-major deal
     const int nblocks = H * 128 / 64;
     hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(8 * H * ((nblocks + 7) / 8), 1, zs), dim3(256), 0, st, (const bf16_t*)wo,

@@ -83,10 +83,6 @@ for flag, name in ((0, "cross_attn_fold"), (1, "cross_attn_fold (LDS-staged rows
     timeit(name, lambda: hip.check(L.samaudio_op_cross_attn_fold(hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt,
                                                                  8, H, st())), B * D * KP * 2 + D * D * 2)
 L.samaudio_debug_set_flag(3, 0)
-L.samaudio_debug_set_flag(0, 2)
-timeit("cross_attn_fold (V rows staged once per workgroup in LDS, candidate)", lambda: hip.check(L.samaudio_op_cross_attn_fold(
-    hip.ptr(wo), hip.ptr(kv), 2 * D, hip.ptr(ut), KP, B, Lt, 8, H, st())), B * D * KP * 2 + D * D * 2)
-L.samaudio_debug_set_flag(0, 0)
 for zs in (1, 2, 4):
     L.samaudio_debug_set_flag(12, zs)
     timeit(f"cross_attn_fold, batch split {zs}", lambda: hip.check(L.samaudio_op_cross_attn_fold(

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 2, GPU call 27: cross_attn_fold with the V rows of a trip staged once per workgroup in LDS (flag 0 = 2) - test on
+# Round 2, GPU call 27 (NEGATIVE RESULT: 57.2 vs 49.2 us; the candidate kernel was removed again - check out commit
+# "cross_attn_fold3 (A/B candidate)" to reproduce): cross_attn_fold with the V rows of a trip staged once per workgroup in LDS (flag 0 = 2) - test on
 # hardware, micro-benchmark, bench A/B.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r2_call27
