@@ -128,6 +128,33 @@ def test_self_attention(gpu, prec, T):
     # bf16: P is rounded to bf16 before P@V (2^-9 relative on weights that sum to 1) and so is the output
     util.report(f"self_attention {prec} T{T}", out, want, 2e-5 if prec == "fp32" else 2e-2)
 
+@pytest.mark.parametrize("B,H,T", [(2, 2, 250), (3, 5, 130), (1, 3, 50), (5, 22, 64)])
+def test_self_attention_xcd_paired_grid_is_bitwise_the_3d_grid(gpu, B, H, T):
+    """debug flag 23: the query blocks of a (batch, head) dealt back to back onto one XCD through a 1-D grid (their K / V^T
+    then come out of that XCD's L2 the second time).  Pure re-indexing of workgroups: identical bits; pair counts that are
+    not a multiple of 8 (ragged last deal) and one / two / three query blocks per pair."""
+    Tp = (T + 63) // 64 * 64
+    D = H * 128
+    q, k, v = _mk((B, H, T, 128), 20) * 1.5, _mk((B, H, T, 128), 21), _mk((B, H, T, 128), 22)
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[B - 1, T - 13:] = False
+    pad = lambda z: torch.nn.functional.pad(z, (0, 0, 0, Tp - T))   # noqa: E731
+    qd, kd = util.as_act(pad(q), "bf16", gpu), util.as_act(pad(k), "bf16", gpu)
+    vtd = util.as_act(pad(v).transpose(2, 3), "bf16", gpu)
+    md = mask.to(gpu).to(torch.uint8)
+    outs = []
+    try:
+        for flag in (0, 1):
+            hip.lib().samaudio_debug_set_flag(23, flag)
+            out = torch.zeros(B * T, D, device=gpu, dtype=torch.bfloat16)
+            hip.check(hip.lib().samaudio_op_self_attention(hip.ptr(qd), hip.ptr(kd), hip.ptr(vtd), hip.ptr(md), hip.ptr(out),
+                                                           util.PREC["bf16"], B, T, Tp, H, util.stream()))
+            outs.append(out.cpu())
+    finally:
+        hip.lib().samaudio_debug_set_flag(23, 0)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
 
 @pytest.mark.parametrize("prec", PRECS)
 def test_cross_attention(gpu, prec):

@@ -57,6 +57,10 @@ for flag, name in ((0, "self_attention (8 waves, 128 query rows)"), (1, "self_at
     timeit(name, lambda: hip.check(L.samaudio_op_self_attention(
         hip.ptr(Q), hip.ptr(K), hip.ptr(Vt), hip.ptr(mask), hip.ptr(out), hip.BF16, B, T, Tp, H, st())), 4 * M * D * 2)
 L.samaudio_debug_set_flag(13, 0)
+L.samaudio_debug_set_flag(23, 1)
+timeit("self_attention (8 waves, query blocks of a (batch, head) on one XCD)", lambda: hip.check(L.samaudio_op_self_attention(
+    hip.ptr(Q), hip.ptr(K), hip.ptr(Vt), hip.ptr(mask), hip.ptr(out), hip.BF16, B, T, Tp, H, st())), 4 * M * D * 2)
+L.samaudio_debug_set_flag(23, 0)
 x = torch.randn(M, D, device=dev)
 w = torch.rand(D, device=dev)
 tab = torch.randn(6, D, device=dev)
