@@ -254,6 +254,36 @@ int samaudio_t5_set_workspace(samaudio_t5* t, void* workspace, size_t bytes);
 int samaudio_t5_encode(samaudio_t5* t, const int64_t* input_ids, const unsigned char* attention_mask, int rows, int tokens,
                        float* last_hidden_state, samaudio_stream stream);
 
+/* ---- Judge / span-predictor text tower -------------------------------------------
+ * ModernBERT encoder behind `SAMAudioJudgeModel._get_text_output` and `PEAudioFrame` (reference sam_audio/model/judge.py:48,
+ * 74-88: `transformers.AutoModel.from_config(ModernBertConfig(...))`, `hidden_states[nth_text_layer]`).  Tokenisation stays
+ * with the caller; everything from the embedding lookup to the requested hidden state runs here.  Engine tensor names:
+ * sam_audio_amd/mbert_encoder.py documents the mapping from the `embeddings.* / layers.* / final_norm.*` state_dict keys. */
+typedef struct {
+  int32_t precision;                  /* SAMAUDIO_F32 | SAMAUDIO_BF16 (GEMM operands; the residual stream is f32) */
+  int32_t vocab, hidden, heads;       /* 50368, 768, 12 (head dim even, <= 128) */
+  int32_t intermediate, layers;       /* 1152 (Wi projects to 2x that: input | gate), 22 */
+  int32_t global_every;               /* 3: layers l % 3 == 0 attend globally, the others within +-window tokens */
+  int32_t window;                     /* 64 = local_attention / 2 */
+  int32_t max_len;                    /* longest sequence the rotary tables cover (<= 512) */
+  float ln_eps;                       /* 1e-5 */
+} samaudio_mbert_config;
+
+typedef struct samaudio_mbert samaudio_mbert;
+int samaudio_mbert_create(const samaudio_mbert_config* cfg, samaudio_mbert** out);
+void samaudio_mbert_destroy(samaudio_mbert* t);
+int samaudio_mbert_set_tensor(samaudio_mbert* t, const char* name, const void* data, int dtype, int ndim,
+                              const int64_t* shape);
+int samaudio_mbert_finalize(samaudio_mbert* t);
+size_t samaudio_mbert_workspace_bytes(samaudio_mbert* t, int rows, int tokens);
+int samaudio_mbert_set_workspace(samaudio_mbert* t, void* workspace, size_t bytes);
+/* input_ids [rows, tokens] i64, attention_mask [rows, tokens] u8 (1 = token) -> hidden [rows, tokens, hidden] f32.
+ * nth_hidden_state: transformers' hidden_states[n] - 0 <= n < layers = the residual stream after n layers (0 = the
+ * normalised embeddings); n == layers or n < 0 = last_hidden_state (after the final LayerNorm; transformers 5.x records the
+ * normalised tensor as the last hidden state, and the reference's default nth_text_layer = 22 = layers selects it). */
+int samaudio_mbert_encode(samaudio_mbert* t, const int64_t* input_ids, const unsigned char* attention_mask, int rows, int tokens,
+                          int nth_hidden_state, float* hidden, samaudio_stream stream);
+
 /* ---- measurement ----------------------------------------------------------------------------------- */
 
 /* Live per-kernel timing for bench.py's roofline leg (the reference has no counterpart: it publishes no

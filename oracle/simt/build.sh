@@ -14,9 +14,9 @@ mkdir -p $OUT
 CXX=/opt/rocm/lib/llvm/bin/clang++
 FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp $POISON -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
 pids=()
-for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 api; do
+for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 mbert api; do
   src=$SRC/$f.hip
-  if [ ! -f $OUT/$f.o ] || [ $src -nt $OUT/$f.o ] || [ stub/hip/hip_runtime.h -nt $OUT/$f.o ] || [ $SRC/common.h -nt $OUT/$f.o ] || [ $SRC/kernels.h -nt $OUT/$f.o ] || [ $SRC/engine.h -nt $OUT/$f.o ] || [ $SRC/peav.h -nt $OUT/$f.o ] || [ $SRC/vit.h -nt $OUT/$f.o ] || [ $SRC/t5.h -nt $OUT/$f.o ]; then
+  if [ ! -f $OUT/$f.o ] || [ $src -nt $OUT/$f.o ] || [ stub/hip/hip_runtime.h -nt $OUT/$f.o ] || [ $SRC/common.h -nt $OUT/$f.o ] || [ $SRC/kernels.h -nt $OUT/$f.o ] || [ $SRC/engine.h -nt $OUT/$f.o ] || [ $SRC/peav.h -nt $OUT/$f.o ] || [ $SRC/vit.h -nt $OUT/$f.o ] || [ $SRC/t5.h -nt $OUT/$f.o ] || [ $SRC/mbert.h -nt $OUT/$f.o ]; then
     EXTRA=""
     if [ $f = gemm2 ]; then
       EXTRA="-O1 -I $SRC"   # the fully unrolled epilogues are slow to optimise on the host
@@ -33,6 +33,6 @@ done
 $CXX $FLAGS -c simt.cpp -o $OUT/simt.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$CXX -shared -fPIC -fopenmp $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/vit_kernels.o $OUT/t5_kernels.o $OUT/engine.o $OUT/peav.o $OUT/vit.o $OUT/t5.o $OUT/api.o $OUT/simt.o -o ../_simt/$LIB.tmp
+$CXX -shared -fPIC -fopenmp $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/vit_kernels.o $OUT/t5_kernels.o $OUT/engine.o $OUT/peav.o $OUT/vit.o $OUT/t5.o $OUT/mbert.o $OUT/api.o $OUT/simt.o -o ../_simt/$LIB.tmp
 mv -f ../_simt/$LIB.tmp ../_simt/$LIB   # atomic: a process that has the old library mapped keeps its inode
 echo "built ../_simt/$LIB"

@@ -5,13 +5,13 @@
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
-SRCS="gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 api"
+SRCS="gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 mbert api"
 build_one() {  # $1 = object dir, $2 = extra flags, $3 = output
   local dir=$1 extra_all=$2 out=$3 pids=() objs=""
   mkdir -p $dir
   for f in $SRCS; do
     objs="$objs $dir/$f.o"
-    if [ ! -f $dir/$f.o ] || [ $f.hip -nt $dir/$f.o ] || [ common.h -nt $dir/$f.o ] || [ kernels.h -nt $dir/$f.o ] || [ engine.h -nt $dir/$f.o ] || [ peav.h -nt $dir/$f.o ] || [ vit.h -nt $dir/$f.o ] || [ t5.h -nt $dir/$f.o ] || [ ../../include/samaudio.h -nt $dir/$f.o ] || [ build.sh -nt $dir/$f.o ]; then
+    if [ ! -f $dir/$f.o ] || [ $f.hip -nt $dir/$f.o ] || [ common.h -nt $dir/$f.o ] || [ kernels.h -nt $dir/$f.o ] || [ engine.h -nt $dir/$f.o ] || [ peav.h -nt $dir/$f.o ] || [ vit.h -nt $dir/$f.o ] || [ t5.h -nt $dir/$f.o ] || [ mbert.h -nt $dir/$f.o ] || [ ../../include/samaudio.h -nt $dir/$f.o ] || [ build.sh -nt $dir/$f.o ]; then
       EXTRA=""
       # gemm2.hip / gemm8.hip: the fully unrolled 4x4-fragment epilogues exceed clang's default pragma-unroll budget; without
       # the full unroll the accumulator array is indexed dynamically and lands in scratch memory.

@@ -178,7 +178,12 @@ hipError_t launch_token_mean(const float* x, long x_ld, float* out_f32, void* ou
 // ---- T5 prompt encoder (t5_kernels.hip) ------------------------------------------------------------
 hipError_t launch_t5_embed(const long long* ids, const float* table, float* out, long M, int D, int vocab, hipStream_t st);
 // softmax(q k^T + bias[h][k - q] + key mask) v per (item, head, query row); qkv [B*Lt, 3*H*dkv]; Lt <= 512, dkv <= 128
+// (bias nullable; scale multiplies q k^T; window > 0: only keys within +-window tokens)
 hipError_t launch_t5_attention(const void* qkv, const unsigned char* mask, const float* bias, void* out, bool bf16, int B,
-                               int Lt, int H, int dkv, int max_len, hipStream_t st);
+                               int Lt, int H, int dkv, int max_len, float scale, int window, hipStream_t st);
+// ModernBERT text tower (mbert.hip): rotate-half RoPE of the q / k segments of q|k|v rows in place; gated GELU
+hipError_t launch_mbert_rope(void* qkv, const float* cs, const float* sn, bool bf16, long M, int Lt, int H, int hd,
+                             hipStream_t st);
+hipError_t launch_geglu(const void* x, void* out, bool bf16, long M, int F, hipStream_t st);
 
 }  // namespace sa

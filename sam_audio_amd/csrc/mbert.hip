@@ -1,0 +1,234 @@
+// ModernBERT text tower: host code that sequences kernels of gemm*.hip / peav_kernels.hip / t5_kernels.hip, and its C entry
+// points (include/samaudio.h "Judge / span-predictor text tower").  "oracle:" = oracle/mbert_oracle.py, the CPU restatement
+// of transformers' ModernBertModel every step below is checked against (itself pinned to that module in tests/).
+#include "mbert.h"
+
+#include <cmath>
+#include <cstring>
+
+struct samaudio_mbert {
+  sa::MBertEncoder* enc;
+};
+
+namespace sa {
+
+#define SA_TRY(expr)                     \
+  do {                                   \
+    Status _s = (expr);                  \
+    if (!_s.ok()) return _s;             \
+  } while (0)
+#define SA_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess)                                                                 \
+      return Status{SAMAUDIO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
+  } while (0)
+
+namespace {
+Status mfail(int code, const std::string& m) { return Status{code, m}; }
+
+GemmParams mlin(const void* A, long lda, const void* W, long M, int N, int K) {
+  GemmParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.lda = lda; p.kc = K; p.tap_stride = 0;
+  p.M = (int)M; p.N = N; p.K = K; p.nbatch = 1; p.alpha = 1.f; p.rows_per_gate = 1;
+  return p;
+}
+Status mgemm(const GemmParams& p, bool bf16, hipStream_t st) {
+  if (const char* why = gemm_check(p, bf16)) return mfail(SAMAUDIO_ERR_ARG, std::string("text tower: ") + why);
+  SA_HIP(launch_gemm(p, bf16, st));
+  return Status{};
+}
+}  // namespace
+
+MBertEncoder::MBertEncoder(const samaudio_mbert_config& c)
+    : cfg_(c), bf16_(c.precision == SAMAUDIO_BF16), esz_(bf16_ ? 2 : 4),
+      at_dtype_(bf16_ ? SAMAUDIO_DT_BF16 : SAMAUDIO_DT_F32), hd_(c.heads > 0 ? c.hidden / c.heads : 0) {}
+
+Status MBertEncoder::set_tensor(const char* name, const void* p, int dtype, int ndim, const int64_t* shape) {
+  ready_ = false;
+  return reg_.set(name, p, dtype, ndim, shape);
+}
+
+Status MBertEncoder::finalize() {
+  const samaudio_mbert_config& c = cfg_;
+  if (c.vocab <= 0 || c.hidden <= 0 || c.heads <= 0 || c.intermediate <= 0 || c.layers < 0 || c.max_len <= 0 ||
+      c.global_every <= 0 || c.window < 0)
+    return mfail(SAMAUDIO_ERR_ARG, "text tower: non-positive dimension");
+  const int kq = bf16_ ? 64 : 32;   // K granule of the GEMM kernels
+  if (c.hidden % kq || c.intermediate % kq || c.hidden % c.heads)
+    return mfail(SAMAUDIO_ERR_ARG, "text tower: hidden and intermediate must be multiples of 64 (fp32 mode: 32), hidden of heads");
+  if (hd_ > 128 || hd_ % 2) return mfail(SAMAUDIO_ERR_ARG, "text tower: head dim must be even and <= 128");
+  if (c.max_len > 512) return mfail(SAMAUDIO_ERR_ARG, "text tower: max_len must be <= 512");
+  const int D = c.hidden, F = c.intermediate;
+  const int F32 = SAMAUDIO_DT_F32, AT = at_dtype_;
+#define NEEDF(field, name, ...) SA_TRY(reg_.need(name, F32, {__VA_ARGS__}, (const void**)&(field)))
+#define NEEDW(field, name, ...) SA_TRY(reg_.need(name, AT, {__VA_ARGS__}, (const void**)&(field)))
+  NEEDF(g_.emb, "emb", c.vocab, D);                  // embeddings.tok_embeddings.weight
+  NEEDF(g_.emb_ln, "emb_ln", D);                     // embeddings.norm.weight
+  NEEDF(g_.final_ln, "final_ln", D);
+  NEEDF(g_.zeros, "zeros", D);                       // the (absent) LayerNorm bias
+  NEEDF(g_.rope_cos, "rope_cos", 2, c.max_len, hd_); // [0] global layers, [1] sliding-window layers
+  NEEDF(g_.rope_sin, "rope_sin", 2, c.max_len, hd_);
+  layers_.assign(c.layers, LayerW{});
+  for (int i = 0; i < c.layers; ++i) {
+    const std::string L = "L" + std::to_string(i) + ".";
+    LayerW& w = layers_[i];
+    w.ln1 = nullptr;
+    if (i > 0) NEEDF(w.ln1, L + "ln1", D);
+    NEEDW(w.wqkv, L + "wqkv", 3 * D, D);
+    NEEDW(w.wo, L + "wo", D, D);
+    NEEDF(w.ln2, L + "ln2", D);
+    NEEDW(w.wi, L + "wi", 2 * F, D);
+    NEEDW(w.wo2, L + "wo2", D, F);
+  }
+#undef NEEDF
+#undef NEEDW
+  ready_ = true;
+  return Status{};
+}
+
+void MBertEncoder::plan(Bump& b, long M, bool assign) {
+  const long D = cfg_.hidden, F = cfg_.intermediate;
+  float* h = (float*)b.take((size_t)M * D * 4);
+  float* e = (float*)b.take((size_t)M * D * 4);
+  void* xn = b.take((size_t)M * D * esz_);
+  void* qkv = b.take((size_t)M * 3 * D * esz_);
+  void* attn = b.take((size_t)M * D * esz_);
+  void* u = b.take((size_t)M * 2 * F * esz_);
+  void* u2 = b.take((size_t)M * F * esz_);
+  if (assign) { w_.h = h; w_.e = e; w_.xn = xn; w_.qkv = qkv; w_.attn = attn; w_.u = u; w_.u2 = u2; }
+}
+
+size_t MBertEncoder::workspace_bytes(int rows, int tokens) {
+  if (rows <= 0 || tokens <= 0) return 0;
+  Bump b;
+  plan(b, (long)rows * tokens, false);
+  return b.used();
+}
+
+Status MBertEncoder::set_workspace(void* p, size_t bytes) {
+  if (!p || (reinterpret_cast<uintptr_t>(p) & 255)) return mfail(SAMAUDIO_ERR_WORKSPACE, "text tower: workspace must be 256-byte aligned");
+  ws_ = (char*)p;
+  ws_bytes_ = bytes;
+  planned_m_ = 0;
+  return Status{};
+}
+
+Status MBertEncoder::encode(const long long* ids, const unsigned char* mask, int rows, int tokens, int nth, float* out,
+                            hipStream_t st) {
+  if (!ready_) return mfail(SAMAUDIO_ERR_STATE, "text tower: weights not finalized");
+  if (!ids || !mask || !out || rows <= 0 || tokens <= 0) return mfail(SAMAUDIO_ERR_ARG, "text tower: bad argument");
+  if (tokens > cfg_.max_len)
+    return mfail(SAMAUDIO_ERR_ARG, "text tower: " + std::to_string(tokens) + " tokens exceed max_len " + std::to_string(cfg_.max_len));
+  if (nth > cfg_.layers) return mfail(SAMAUDIO_ERR_ARG, "text tower: hidden state index beyond the last layer");
+  if (!ws_) return mfail(SAMAUDIO_ERR_WORKSPACE, "text tower: no workspace");
+  const long M = (long)rows * tokens;
+  if (planned_m_ != M) {
+    Bump b(ws_, ws_bytes_);
+    plan(b, M, true);
+    if (!b.fits()) return mfail(SAMAUDIO_ERR_WORKSPACE, "text tower: workspace too small for " + std::to_string(M) + " token rows");
+    planned_m_ = M;
+  }
+  const samaudio_mbert_config& c = cfg_;
+  const int D = c.hidden, F = c.intermediate, H = c.heads;
+  const float eps = c.ln_eps, scale = 1.0f / std::sqrt((float)hd_);
+  // oracle: embeddings = LayerNorm(tok_embeddings[input_ids])
+  SA_HIP(launch_t5_embed(ids, g_.emb, w_.e, M, D, c.vocab, st));
+  SA_HIP(launch_layernorm_rows(w_.e, D, g_.emb_ln, g_.zeros, w_.h, nullptr, bf16_, M, D, eps, st));
+  const int n_layers = nth >= 0 ? nth : c.layers;
+  for (int l = 0; l < n_layers; ++l) {  // oracle: ModernBertEncoderLayer
+    const LayerW& w = layers_[l];
+    const bool global = l % c.global_every == 0;
+    if (w.ln1) SA_HIP(launch_layernorm_rows(w_.h, D, w.ln1, g_.zeros, nullptr, w_.xn, bf16_, M, D, eps, st));
+    else SA_HIP(launch_to_act(w_.h, 0, D, 0, w_.xn, 0, bf16_, 1, M, D, D, 0, st));   // layer 0: attn_norm = Identity
+    {
+      GemmParams p = mlin(w_.xn, D, w.wqkv, M, 3 * D, D);
+      p.out_act = w_.qkv; p.act_ld = 3L * D;
+      SA_TRY(mgemm(p, bf16_, st));
+    }
+    const long roff = (global ? 0L : 1L) * c.max_len * hd_;
+    SA_HIP(launch_mbert_rope(w_.qkv, g_.rope_cos + roff, g_.rope_sin + roff, bf16_, M, tokens, H, hd_, st));
+    SA_HIP(launch_t5_attention(w_.qkv, mask, nullptr, w_.attn, bf16_, rows, tokens, H, hd_, c.max_len, scale,
+                               global ? 0 : c.window, st));
+    {
+      GemmParams p = mlin(w_.attn, D, w.wo, M, D, D);  // h = h + Wo(attn)
+      p.res = w_.h; p.res_ld = D;
+      p.out_f32 = w_.h; p.f32_ld = D;
+      SA_TRY(mgemm(p, bf16_, st));
+    }
+    SA_HIP(launch_layernorm_rows(w_.h, D, w.ln2, g_.zeros, nullptr, w_.xn, bf16_, M, D, eps, st));
+    {
+      GemmParams p = mlin(w_.xn, D, w.wi, M, 2 * F, D);  // input | gate
+      p.out_act = w_.u; p.act_ld = 2L * F;
+      SA_TRY(mgemm(p, bf16_, st));
+      SA_HIP(launch_geglu(w_.u, w_.u2, bf16_, M, F, st));
+      p = mlin(w_.u2, F, w.wo2, M, D, F);  // h = h + Wo(gelu(input) * gate)
+      p.res = w_.h; p.res_ld = D;
+      p.out_f32 = w_.h; p.f32_ld = D;
+      SA_TRY(mgemm(p, bf16_, st));
+    }
+  }
+  if (nth >= 0 && nth < c.layers) SA_HIP(hipMemcpyAsync(out, w_.h, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+  else SA_HIP(launch_layernorm_rows(w_.h, D, g_.final_ln, g_.zeros, out, nullptr, false, M, D, eps, st));
+  return Status{};
+}
+
+}  // namespace sa
+
+namespace {
+int mret(const sa::Status& s) {
+  if (!s.ok()) sa::set_last_error(s.msg);
+  return s.code;
+}
+int mbad(const char* msg) {
+  sa::set_last_error(msg);
+  return SAMAUDIO_ERR_ARG;
+}
+}  // namespace
+
+extern "C" {
+
+int samaudio_mbert_create(const samaudio_mbert_config* cfg, samaudio_mbert** out) {
+  if (!cfg || !out) return mbad("samaudio_mbert_create: null argument");
+  if (cfg->precision != SAMAUDIO_F32 && cfg->precision != SAMAUDIO_BF16) return mbad("samaudio_mbert_create: precision");
+  samaudio_mbert* t = new samaudio_mbert;
+  t->enc = new sa::MBertEncoder(*cfg);
+  *out = t;
+  return SAMAUDIO_OK;
+}
+
+void samaudio_mbert_destroy(samaudio_mbert* t) {
+  if (!t) return;
+  delete t->enc;
+  delete t;
+}
+
+int samaudio_mbert_set_tensor(samaudio_mbert* t, const char* name, const void* data, int dtype, int ndim, const int64_t* shape) {
+  if (!t) return mbad("null text tower");
+  return mret(t->enc->set_tensor(name, data, dtype, ndim, shape));
+}
+
+int samaudio_mbert_finalize(samaudio_mbert* t) {
+  if (!t) return mbad("null text tower");
+  return mret(t->enc->finalize());
+}
+
+size_t samaudio_mbert_workspace_bytes(samaudio_mbert* t, int rows, int tokens) {
+  if (!t) return 0;
+  return t->enc->workspace_bytes(rows, tokens);
+}
+
+int samaudio_mbert_set_workspace(samaudio_mbert* t, void* workspace, size_t bytes) {
+  if (!t) return mbad("null text tower");
+  return mret(t->enc->set_workspace(workspace, bytes));
+}
+
+int samaudio_mbert_encode(samaudio_mbert* t, const int64_t* input_ids, const unsigned char* attention_mask, int rows, int tokens,
+                          int nth_hidden_state, float* hidden, samaudio_stream stream) {
+  if (!t) return mbad("null text tower");
+  return mret(t->enc->encode((const long long*)input_ids, attention_mask, rows, tokens, nth_hidden_state, hidden,
+                             (hipStream_t)stream));
+}
+
+}  // extern "C"

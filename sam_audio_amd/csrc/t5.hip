@@ -136,7 +136,7 @@ Status T5Encoder::encode(const long long* ids, const unsigned char* mask, int ro
       p.out_act = w_.qkv; p.act_ld = 3L * I;
       SA_TRY(tgemm(p, bf16_, st));
     }
-    SA_HIP(launch_t5_attention(w_.qkv, mask, g_.rel_bias, w_.attn, bf16_, rows, tokens, c.heads, c.d_kv, c.max_len, st));
+    SA_HIP(launch_t5_attention(w_.qkv, mask, g_.rel_bias, w_.attn, bf16_, rows, tokens, c.heads, c.d_kv, c.max_len, 1.f, 0, st));
     {
       GemmParams p = tlin(w_.attn, I, w.wo, M, D, I);  // h = h + o(attn)
       p.res = w_.h; p.res_ld = D;

@@ -116,6 +116,13 @@ class T5Config(C.Structure):
                 ("act", C.c_int32), ("ln_eps", C.c_float)]
 
 
+class MBertConfig(C.Structure):
+    """Mirror of `samaudio_mbert_config`."""
+    _fields_ = [("precision", C.c_int32), ("vocab", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32),
+                ("intermediate", C.c_int32), ("layers", C.c_int32), ("global_every", C.c_int32), ("window", C.c_int32),
+                ("max_len", C.c_int32), ("ln_eps", C.c_float)]
+
+
 class KernelStat(C.Structure):
     """Mirror of `samaudio_kernel_stat`."""
     _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("flops", C.c_double), ("bytes", C.c_double),
@@ -196,6 +203,13 @@ _PROTOS = {
     "samaudio_frame_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "samaudio_frame_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                         C.c_void_p]),
+    "samaudio_mbert_create": (C.c_int, [C.POINTER(MBertConfig), C.POINTER(C.c_void_p)]),
+    "samaudio_mbert_destroy": (None, [C.c_void_p]),
+    "samaudio_mbert_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "samaudio_mbert_finalize": (C.c_int, [C.c_void_p]),
+    "samaudio_mbert_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "samaudio_mbert_set_workspace": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "samaudio_mbert_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "samaudio_t5_create": (C.c_int, [C.POINTER(T5Config), C.POINTER(C.c_void_p)]),
     "samaudio_t5_destroy": (None, [C.c_void_p]),
     "samaudio_t5_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),

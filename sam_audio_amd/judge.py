@@ -6,7 +6,8 @@ What runs where
     engine context (`samaudio_finalize(ctx, 2)`).
   * both PE-AV transformers, the Judge's projections / LayerNorm / pooled head, the PE-A-Frame heads and frame logits:
     hand-written HIP behind `samaudio_judge_*` / `samaudio_frame_*` (include/samaudio.h).
-  * the ModernBERT text tower + tokenizer: PyTorch-ROCm through `transformers` (plumbing; a once-per-call cost on a
+  * the ModernBERT text tower: on the HIP library too (sam_audio_amd/mbert_encoder.py, `samaudio_mbert_*`; `text_backend=
+    "torch"` keeps the `transformers` module on PyTorch-ROCm as an explicit option); the tokenizer is Hugging Face's (a once-per-call cost on a
     handful of tokens).
 The reference repeats the mixture once per reranking candidate (ranking/judge.py:31-33).  Every op of the Judge is
 per-row, so `score_candidates` evaluates the mixture branch once per clip: identical results, about half the DAC
@@ -27,6 +28,7 @@ import torch
 
 from . import hip
 from .config import PEAudioFrameConfig, PEAVTransformerConfig, SAMAudioJudgeConfig
+from .judge_util import ensure_ws as _ensure_ws, register as _register
 from .weights import _interleave16, convert_codec
 
 
@@ -181,25 +183,42 @@ class _CodecEncoder:
         return z
 
 
-def _ensure_ws(owner, need: int, setter) -> None:
-    ws = getattr(owner, "_workspace", None)
-    if ws is None or ws.numel() < need + 256:
-        fill = 255 if os.environ.get("SAMAUDIO_POISON") else None  # NaN bytes, see SAMAudio._ensure_workspace
-        ws = (torch.full((need + 256,), fill, dtype=torch.uint8, device=owner.device) if fill is not None
-              else torch.empty(need + 256, dtype=torch.uint8, device=owner.device))
-        owner._workspace = ws
-    base = ws.data_ptr()
-    aligned = (base + 255) // 256 * 256
-    hip.check(setter(C.c_void_p(aligned), ws.numel() - (aligned - base)))
+class _TextTower:
+    """The ModernBERT text tower of a Judge / PE-A-Frame model.  `module` (a `transformers.ModernBertModel`) stays the
+    container of the weights - `state_dict()` / `load_state_dict()` keep their reference semantics - while the forward runs
+    on the HIP library (`backend="hip"`, sam_audio_amd/mbert_encoder.py; fp32: a handful of tokens once per call) once the
+    model sits on a GPU.  `backend="torch"` runs the module itself on PyTorch-ROCm; it is chosen explicitly (constructor
+    argument `text_backend`), never as a silent fallback - an injected non-ModernBERT module must ask for it."""
 
+    default_backend = "hip"   # tests/conftest.py's launcher emulation (no text-tower kernels) switches it to "torch"
 
-def _register(lib_set, handle, store: Dict[str, torch.Tensor], tensors: Dict[str, torch.Tensor]) -> None:
-    for name, t in tensors.items():
-        dt = hip.dtype_code(t.dtype)
-        if t.data_ptr() % 16:   # a view into a larger buffer: the library needs 16-byte aligned pointers
-            t = t.clone()
-        store[name] = t  # keep alive: the library borrows the pointer
-        hip.check(lib_set(handle, name.encode(), hip.ptr(t), dt, t.dim(), hip.shape_array(t.shape)))
+    def __init__(self, module, backend: Optional[str] = None):
+        backend = backend or self.default_backend
+        if backend not in ("hip", "torch"):
+            raise ValueError("text_backend must be 'hip' or 'torch'")
+        self.module, self.backend = module, backend
+        self._hip = None
+        self._device = None
+
+    def place(self, device) -> None:
+        """(re)build the device copy after the weights changed or the model moved"""
+        self._device = torch.device(device)
+        if self.backend == "torch":
+            self.module = self.module.to(self._device).eval()
+            return
+        from .mbert_encoder import ModernBertHIP
+        self._hip = ModernBertHIP.from_module(self.module, self._device, precision="fp32")
+
+    def hidden(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], nth: Optional[int]) -> torch.Tensor:
+        """transformers' `hidden_states[nth]` ([B, Lt, hidden]); nth None = last_hidden_state"""
+        if self.backend == "hip":
+            if self._hip is None:
+                raise hip.SamAudioHipError("text tower: load the model's weights on a ROCm GPU first (no CPU fallback)")
+            return self._hip(input_ids, attention_mask, nth)
+        out = self.module(input_ids=input_ids.to(self._device),
+                          attention_mask=None if attention_mask is None else attention_mask.to(self._device),
+                          output_hidden_states=nth is not None)
+        return out.last_hidden_state if nth is None else out.hidden_states[nth]
 
 
 def _text_tower(text_cfg: Dict[str, Any]):
@@ -214,13 +233,14 @@ class SAMAudioJudgeModel:
     config_cls = SAMAudioJudgeConfig
 
     def __init__(self, config: SAMAudioJudgeConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_model=None):
+                 text_model=None, text_backend: Optional[str] = None):
         config.check_supported()
         hip.check_precision(precision)
         self.config = config
         self.precision = precision
         self.device = torch.device(device) if device is not None else None
         self.text_model = text_model if text_model is not None else _text_tower(config.text_model)  # judge.py:48
+        self._text = _TextTower(self.text_model, text_backend)
         self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
@@ -252,7 +272,6 @@ class SAMAudioJudgeModel:
         if self._tensors and self.device != device:
             raise RuntimeError("move the model before load_state_dict (weights are converted onto the device)")
         self.device = device
-        self.text_model = self.text_model.to(device)
         return self
 
     def cuda(self, index: int = 0):
@@ -304,7 +323,8 @@ class SAMAudioJudgeModel:
         text_sd = {k[len("text_model."):]: v for k, v in state_dict.items() if k.startswith("text_model.")}
         if text_sd:
             self.text_model.load_state_dict(text_sd, strict=False)
-        self.text_model = self.text_model.to(self.device).eval()
+        self._text.place(self.device)
+        self.text_model = self._text.module
         with torch.cuda.device(self.device):
             if not any(k for k in missing if not k.startswith(("audio_codec.", "text_model."))):
                 _register(self._lib.samaudio_judge_set_tensor, self._h, self._tensors,
@@ -320,11 +340,7 @@ class SAMAudioJudgeModel:
     @torch.inference_mode()
     def _get_text_output(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
         """reference judge.py:76-88 -> the n-th hidden state [B, Lt, hidden] (pooler_output = [:, 0])."""
-        nth = self.config.nth_text_layer
-        out = self.text_model(input_ids=input_ids.to(self.device),
-                              attention_mask=None if attention_mask is None else attention_mask.to(self.device),
-                              output_hidden_states=nth is not None)
-        return out.last_hidden_state if nth is None else out.hidden_states[nth]
+        return self._text.hidden(input_ids, attention_mask, self.config.nth_text_layer)
 
     def _score(self, in_lat: torch.Tensor, sep_lat: torch.Tensor, cand: int, pooled: torch.Tensor,
                frame_mask: Optional[torch.Tensor]) -> torch.Tensor:
@@ -445,12 +461,13 @@ class PEAudioFrame:
     `predictor(input_features=[B, T, 128], padding_mask=[B, T], return_spans=True, input_ids=..., attention_mask=...)`."""
 
     def __init__(self, config: PEAudioFrameConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_model=None, hop_length: int = 1920, sample_rate: int = 48_000):
+                 text_model=None, hop_length: int = 1920, sample_rate: int = 48_000, text_backend: Optional[str] = None):
         config.check_supported()
         self.config, self.precision = config, precision
         self.device = torch.device(device) if device is not None else None
         self.hop_length, self.sample_rate = hop_length, sample_rate
         self.text_model = text_model if text_model is not None else _text_tower(config.text_model)
+        self._text = _TextTower(self.text_model, text_backend)
         self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
@@ -477,7 +494,8 @@ class PEAudioFrame:
         text_sd = {k[len("text_model."):]: v for k, v in state_dict.items() if k.startswith("text_model.")}
         if text_sd:
             self.text_model.load_state_dict(text_sd, strict=strict)
-        self.text_model = self.text_model.to(self.device).eval()
+        self._text.place(self.device)
+        self.text_model = self._text.module
         with torch.cuda.device(self.device):
             _register(self._lib.samaudio_frame_set_tensor, self._h, self._tensors,
                       convert_frame(state_dict, self.config, self.act_dtype, self.device))
@@ -509,9 +527,7 @@ class PEAudioFrame:
                  attention_mask: Optional[torch.Tensor] = None,
                  text_pooled: Optional[torch.Tensor] = None) -> PEAudioFrameOutput:
         if text_pooled is None:
-            out = self.text_model(input_ids=input_ids.to(self.device),
-                                  attention_mask=None if attention_mask is None else attention_mask.to(self.device))
-            text_pooled = out.last_hidden_state[:, 0].float()  # hf:847: hidden_states[-1][:, 0]
+            text_pooled = self._text.hidden(input_ids, attention_mask, None)[:, 0].float()  # hf:847: hidden_states[-1][:, 0]
         logits = self.frame_logits(input_features, text_pooled, padding_mask)
         spans = None
         if return_spans:

@@ -46,7 +46,7 @@ def _enable_emu_dryrun():
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")] + (["poison"] if poison else []))
     lib = C.CDLL(emu)
     for name, (res, args) in hip._PROTOS.items():
-        if which == "emu" and name.startswith(("samaudio_vit_", "samaudio_t5_")):
+        if which == "emu" and name.startswith(("samaudio_vit_", "samaudio_t5_", "samaudio_mbert_")):
             continue   # the launcher emulation predates the vision tower; the SIMT simulator build carries it
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -67,6 +67,8 @@ def _enable_emu_dryrun():
     torch.cuda.current_stream = lambda *a, **k: None
     if which == "emu":
         os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection's kernels are not emulated
+        from sam_audio_amd import judge
+        judge._TextTower.default_backend = "torch"   # nor is the ModernBERT text tower (the SIMT simulator build carries it)
     if which == "simt" and os.environ.get("SAMAUDIO_SIMT_POLICY", "r1") == "r1":
         # End-to-end tests on the simulator pick GEMM kernels with the round-1 tile policy (debug flag 5): the round-2
         # kernels (12-wave loader-wave workgroups, the 8-phase kernel's 8 barriers per K-tile) cost the fiber scheduler

@@ -40,7 +40,7 @@ def emu():
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", "emu", "build.sh")])
     lib = C.CDLL(EMU)
     for name, (res, args) in hip._PROTOS.items():
-        if name.startswith(("samaudio_vit_", "samaudio_t5_")):
+        if name.startswith(("samaudio_vit_", "samaudio_t5_", "samaudio_mbert_")):
             continue   # the launcher emulation predates the vision tower (vit.hip); the SIMT simulator build carries it
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

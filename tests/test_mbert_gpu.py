@@ -1,0 +1,111 @@
+"""Parity of the ModernBERT text tower on the HIP library (sam_audio_amd/csrc/mbert.hip; SURVEY.md section 8 rows a17 /
+a18) against `transformers.ModernBertModel` - the reference's own dependency (reference sam_audio/model/judge.py:48,74-88),
+run in fp32 on the CPU - and against oracle/mbert_oracle.py (pinned to the same module, tests/test_mbert_oracle_cpu.py).
+Everything goes through the C ABI (`samaudio_mbert_*`).  Only token positions are compared: transformers leaves the rows
+of padding positions defined but meaningless (the Judge reads position 0).
+
+Tolerances: fp32 mode = exact-fp32 GEMMs + fp32 streaming kernels -> summation-order noise only; bf16 / fp16 operands:
+bounds are 2x the errors measured on MI355X, printed by the tests.
+"""
+import pytest
+import torch
+import transformers
+
+from oracle import mbert_oracle as O
+from sam_audio_amd import hip
+from sam_audio_amd.mbert_encoder import MBertDims, ModernBertHIP
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(hidden_size=64, intermediate_size=96, num_hidden_layers=4, num_attention_heads=2, vocab_size=128, pad_token_id=0,
+             bos_token_id=1, eos_token_id=2, cls_token_id=1, sep_token_id=2, global_attn_every_n_layers=3, local_attention=8,
+             max_position_embeddings=256)
+BASE = dict(hidden_size=768, intermediate_size=1152, num_hidden_layers=22, num_attention_heads=12, vocab_size=50368)
+
+
+def _model(seed, **kw):
+    cfg = transformers.ModernBertConfig(**kw)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(seed)
+    m = transformers.ModernBertModel(cfg).eval()
+    with torch.no_grad():   # default init keeps the norms at 1: make every weight count
+        for n, p in m.named_parameters():
+            if "norm" in n:
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+            else:
+                p.mul_(3.0)
+    return m, cfg
+
+
+def _inputs(cfg, B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(3, cfg.vocab_size, (B, L), generator=g)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    return ids, mask
+
+
+def _rel(got, want, valid):
+    return (got - want)[valid].abs().max().item() / want[valid].abs().max().item()
+
+
+@pytest.mark.parametrize("kw,B,L", [(SMALL, 3, 40), (dict(SMALL, global_attn_every_n_layers=2, num_hidden_layers=3), 2, 9),
+                                    (dict(SMALL, num_attention_heads=1, local_attention=128), 2, 150)])
+def test_tower_fp32_matches_transformers_at_every_hidden_state(gpu, kw, B, L):
+    """ragged masks, sequences longer than the local window and longer than 64 keys, 32- and 64-wide heads, both layer
+    patterns; every `hidden_states[n]` the reference may select with nth_text_layer, and last_hidden_state"""
+    m, cfg = _model(3, **kw)
+    ids, mask = _inputs(cfg, B, L, 4)
+    dims = MBertDims.from_hf(cfg)
+    with torch.inference_mode():
+        ref = m(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+        states, last = O.mbert_hidden_states(m.state_dict(), dims, ids, mask)
+    tower = ModernBertHIP.from_module(m, gpu, precision="fp32")
+    valid = mask.bool()
+    worst = 0.0
+    for n in list(range(cfg.num_hidden_layers + 1)) + [None]:
+        got = tower(ids.to(gpu), mask.to(gpu), n).cpu()
+        want = ref.last_hidden_state if n is None else ref.hidden_states[n]
+        worst = max(worst, _rel(got, want, valid), _rel(got, last if n is None else states[n], valid))
+    print(f"mbert fp32 B={B} L={L}: worst hidden state vs transformers / oracle rel {worst:.2e}")
+    assert worst < 2e-5
+    no_mask = tower(ids.to(gpu), None).cpu()
+    with torch.inference_mode():
+        want = m(input_ids=ids).last_hidden_state
+    assert _rel(no_mask, want, torch.ones_like(valid)) < 2e-5
+
+
+def test_modernbert_base_dims_fp32_and_16bit(gpu):
+    """ModernBERT-base (22 layers, 768 wide, 12 heads, GeGLU 1152), random init: 8 prompts x 12 tokens"""
+    if gpu.type != "cuda":
+        pytest.skip("ModernBERT-base dims: too slow on the simulator (the small configurations cover the kernels there)")
+    m, cfg = _model(5, **BASE)
+    ids, mask = _inputs(cfg, 8, 12, 6)
+    with torch.inference_mode():
+        want = m(input_ids=ids, attention_mask=mask).last_hidden_state
+    valid = mask.bool()
+    for precision, bound in (("fp32", 2e-5), ("bf16", None), ("fp16", None)):
+        tower = ModernBertHIP.from_module(m, gpu, precision=precision)
+        err = _rel(tower(ids.to(gpu), mask.to(gpu)).cpu(), want, valid)
+        print(f"mbert-base {precision}: last_hidden_state vs transformers rel {err:.2e}")
+        assert err < (bound if bound is not None else 5e-2)
+
+
+def test_argument_errors(gpu):
+    m, cfg = _model(7, **SMALL)
+    tower = ModernBertHIP(MBertDims.from_hf(cfg, max_len=16), precision="fp32", device=str(gpu))
+    ids, mask = _inputs(cfg, 2, 6, 8)
+    with pytest.raises(hip.SamAudioHipError, match="no weights"):
+        tower(ids.to(gpu), mask.to(gpu))
+    sd = m.state_dict()
+    with pytest.raises(RuntimeError, match="Missing keys"):
+        tower.load_state_dict({k: v for k, v in sd.items() if "layers.1.mlp.Wo" not in k})
+    tower.load_state_dict({"text_model." + k: v for k, v in sd.items()})
+    with pytest.raises(IndexError):
+        tower(torch.full((1, 2), cfg.vocab_size).to(gpu), None)
+    with pytest.raises(IndexError):
+        tower(ids.to(gpu), mask.to(gpu), cfg.num_hidden_layers + 1)
+    with pytest.raises(ValueError, match="max_len"):
+        tower(torch.zeros(1, 17, dtype=torch.long).to(gpu), None)
+    assert tower(torch.zeros(0, 4, dtype=torch.long).to(gpu), None).shape == (0, 4, 64)

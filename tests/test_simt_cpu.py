@@ -86,3 +86,11 @@ def test_t5_prompt_encoder_on_the_simulator():
     gelu_new, error paths, the T5TextEncoder wrapper) against transformers' T5EncoderModel with the real kernel code."""
     out = _run(["tests/test_t5_gpu.py"], 600)
     assert " passed" in out and "failed" not in out
+
+
+def test_modernbert_text_tower_on_the_simulator():
+    """The Judge's / PE-A-Frame's ModernBERT text tower (tests/test_mbert_gpu.py: every hidden state, ragged masks, sequences
+    longer than the local window, both layer patterns, error paths) against transformers' ModernBertModel with the real
+    kernel code."""
+    out = _run(["tests/test_mbert_gpu.py"], 600)
+    assert " passed" in out and "failed" not in out
