@@ -85,11 +85,11 @@ def test_modernbert_base_dims_fp32_and_16bit(gpu):
     with torch.inference_mode():
         want = m(input_ids=ids, attention_mask=mask).last_hidden_state
     valid = mask.bool()
-    for precision, bound in (("fp32", 2e-5), ("bf16", None), ("fp16", None)):
+    for precision, bound in (("fp32", 2e-5), ("bf16", 2.9e-2), ("fp16", 3.6e-3)):   # measured 2.7e-6 / 1.46e-2 / 1.77e-3 on MI355X
         tower = ModernBertHIP.from_module(m, gpu, precision=precision)
         err = _rel(tower(ids.to(gpu), mask.to(gpu)).cpu(), want, valid)
         print(f"mbert-base {precision}: last_hidden_state vs transformers rel {err:.2e}")
-        assert err < (bound if bound is not None else 5e-2)
+        assert err < bound
 
 
 def test_argument_errors(gpu):
