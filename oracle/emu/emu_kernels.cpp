@@ -143,6 +143,38 @@ static void rmsnorm_mod_t(const float* x, const float* w, const float* shift_tab
     }
   }
 }
+hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec, long tvec_ld, int nt, float* gs, int D,
+                             hipStream_t) {
+  for (int n = 0; n < n_norms; ++n)
+    for (int tt = 0; tt < nt; ++tt) {
+      const float* trow = tvec + (long)tt * tvec_ld;
+      float* g = gs + (((long)n * nt + tt) * 2) * D;
+      float* s = g + D;
+      for (int i = 0; i < D; ++i) {
+        const float sc = t.scale_tab[n][i] + trow[t.scale_off[n] + i];
+        g[i] = t.w[n][i] * (1.f + sc);
+        s[i] = t.shift_tab[n][i] + trow[t.shift_off[n] + i];
+      }
+    }
+  return hipSuccess;
+}
+hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
+                             float eps, hipStream_t) {
+  for (int row = 0; row < M; ++row) {
+    const float* xr = x + (long)row * D;
+    double ss = 0;
+    for (int i = 0; i < D; ++i) ss += (double)xr[i] * xr[i];
+    const float inv = 1.f / std::sqrt((float)(ss / D) + eps);
+    const float* g = gs + (long)(row / rows_per_b) * gs_ld;
+    const float* s = g + D;
+    for (int i = 0; i < D; ++i) {
+      const float o = xr[i] * inv * g[i] + s[i];
+      if (bf16) HE<bf16_t>::st((bf16_t*)out + (long)row * D + i, o);
+      else ((float*)out)[(long)row * D + i] = o;
+    }
+  }
+  return hipSuccess;
+}
 hipError_t launch_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
                               const float* tvec, long tvec_ld, int shift_off, int scale_off, void* out, bool bf16,
                               int M, int D, int rows_per_b, float eps, hipStream_t) {

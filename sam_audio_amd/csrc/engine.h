@@ -147,7 +147,7 @@ class Engine {
 
   // DiT workspace (assigned by plan_dit)
   struct {
-    float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *tsin, *vtmp, *times;
+    float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
         *feats, *text, *video, *anch, *probs, *ut;
     unsigned char *pad_mask, *text_mask;

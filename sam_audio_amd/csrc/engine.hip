@@ -247,6 +247,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   float* ymid = f32(M * C2); float* aligned = f32(M * D); float* cond = f32(M * D); float* h = f32(M * D);
   float* hp1 = f32(M * D); float* text_proj = f32(Mt * D); float* t_emb = f32(nt * D); float* t0 = f32(nt * 6 * D);
   float* tsin = f32(nt * D); float* vtmp = f32(M * D); float* times = f32(4096);
+  float* modgs = f32(2L * cfg_.n_layers * nt * 2 * D);   // pre-combined RMSNorm + modulate operands of an evaluation
   void* ybf = act(M * C2); void* xn = act(M * D); void* qkv = act(M * 3 * D);
   void* Q = act((long)rows * H * Tp * 128); void* K = act((long)rows * H * Tp * 128);
   void* Vt = act((long)rows * H * 128 * Tp);
@@ -264,7 +265,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
   if (assign) {
     d.ymid = ymid; d.aligned = aligned; d.cond = cond; d.h = h; d.hp1 = hp1; d.text_proj = text_proj; d.t_emb = t_emb;
-    d.t0 = t0; d.tsin = tsin; d.vtmp = vtmp; d.times = times; d.ybf = ybf; d.xn = xn; d.qkv = qkv; d.Q = Q; d.K = K;
+    d.t0 = t0; d.modgs = modgs; d.tsin = tsin; d.vtmp = vtmp; d.times = times; d.ybf = ybf; d.xn = xn; d.qkv = qkv; d.Q = Q; d.K = K;
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
     d.video = video; d.anch = anch; d.probs = probs; d.ut = ut; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
@@ -621,6 +622,28 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     out_f32(p, d_.t0, 6L * D);
     SA_TRY(gemm(p, st));
   }
+  // RMSNorm + modulate operands of this evaluation, pre-combined for every layer's two norms (kernels.hip mod_tables)
+  const bool mod_gs = !debug_flag(24) && 2 * cfg_.n_layers <= kMaxModNorms && cfg_.n_layers > 0 && D <= 256 * 12;
+  const long gs_ld = nt == 1 ? 0 : 2L * D;
+  if (mod_gs) {
+    ModTables mt;
+    for (int l = 0; l < cfg_.n_layers; ++l)
+      for (int k = 0; k < 2; ++k) {
+        const int n = 2 * l + k;
+        mt.w[n] = k ? layers_[l].ffn_norm : layers_[l].attn_norm;
+        mt.shift_tab[n] = layers_[l].mod_table + (k ? 3 : 0) * D;
+        mt.scale_tab[n] = layers_[l].mod_table + (k ? 4 : 1) * D;
+        mt.shift_off[n] = (k ? 3 : 0) * D;
+        mt.scale_off[n] = (k ? 4 : 1) * D;
+      }
+    for (int n = 2 * cfg_.n_layers; n < kMaxModNorms; ++n) {
+      mt.w[n] = mt.shift_tab[n] = mt.scale_tab[n] = nullptr;
+      mt.shift_off[n] = mt.scale_off[n] = 0;
+    }
+    SA_TRY(op("mod_tables", 2.0 * cfg_.n_layers * (5.0 + 2.0 * nt) * D * 4, 0, st, [&] {
+      return launch_mod_tables(mt, 2 * cfg_.n_layers, d_.t0, t6, nt, d_.modgs, D, st);
+    }));
+  }
   // memory = memory_proj(text) + sincos(t); y = y_embedder(memory)  (model.py:170-172, transformer.py:495)
   SA_HIP(launch_add_rowvec(d_.text_proj, d_.tsin, t1, d_.mem, bf16_, (int)Mt, D, Lt, st));
   {
@@ -649,6 +672,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     const float* tab = w.mod_table;
     // self-attention branch
     SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
+      if (mod_gs)
+        return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st);
       return launch_rmsnorm_mod(d_.h, w.attn_norm, tab + 0 * D, tab + 1 * D, d_.t0, t6, 0 * D, 1 * D, d_.xn, bf16_, (int)M, D,
                                 T, eps, st);
     }));
@@ -715,6 +740,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     trace("  h after cross", d_.h, (size_t)M * D, false, st);
     // feed-forward branch
     SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
+      if (mod_gs)
+        return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l + 1) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st);
       return launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_, (int)M, D,
                                 T, eps, st);
     }));

@@ -16,6 +16,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
 //   flag 17: bit mask TOGGLING the channel counts excluded from the fused residual-unit kernel (1: 64, 2: 96, 4: 128, 8: 192;
 //            excluded by default: 128 and 192) (A/B)
+//   flag 24: RMSNorm + modulate loads its five operand vectors per row instead of the two pre-combined per evaluation (A/B)
 //   flag 23: self-attention as a 1-D grid with the query blocks of a (batch, head) back to back on one XCD (A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined 3-stage form
 //            since GPU call 25 of round 2) (A/B)
@@ -87,6 +88,19 @@ hipError_t launch_groupnorm_silu(const float* x, const float* w, const float* b,
                                  bool bf16, int B, int T, int C, int halo, float eps, hipStream_t st);
 
 // q/k: per-head RMSNorm (shared weight) + RoPE (adjacent pairs) -> Q,K [B,H,Tp,128]; v -> Vt [B,H,128,Tp]
+// RMSNorm + modulate with pre-combined operands (kernels.hip): one launch per evaluation folds (w, shift / scale tables, the
+// evaluation's shift / scale vectors) of up to kMaxModNorms norms into [norm][time value][g | s][D]
+constexpr int kMaxModNorms = 96;
+struct ModTables {
+  const float* w[kMaxModNorms];
+  const float* shift_tab[kMaxModNorms];
+  const float* scale_tab[kMaxModNorms];
+  int shift_off[kMaxModNorms], scale_off[kMaxModNorms];   // offsets of the norm's shift / scale inside a time vector
+};
+hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec, long tvec_ld, int nt, float* gs, int D,
+                             hipStream_t st);
+hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
+                             float eps, hipStream_t st);
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st);

@@ -98,6 +98,79 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_reg_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RMSNorm + modulate with the per-evaluation operands pre-combined.  rmsnorm_mod above loads five column vectors per row
+// (w, the layer's shift / scale tables, the evaluation's shift / scale vectors: 55 KB from L2 for 11 KB of row) and that
+// costs 27 % of the kernel (34.2 vs 25.1 us without them at M = 8000, D = 2816, profiles/r2_call32/).  All five depend only
+// on (layer, norm, time value), so one small launch per evaluation folds them into two vectors per norm,
+//   g = w * (1 + (scale_tab + t_scale)),  s = shift_tab + t_shift,
+// and the row kernel computes x * inv * g + s.  (Reassociates the reference's (x * inv * w) * (1 + scale) + shift:
+// fp32 rounding differs in the last bit.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mod_tables_kernel(const ModTables t, const float* __restrict__ tvec, long tvec_ld,
+                                                         float* __restrict__ gs, int D, int nt) {
+  const int n = blockIdx.y, tt = blockIdx.z;   // norm index, time value
+  const float* trow = tvec + (long)tt * tvec_ld;
+  float* g = gs + (((long)n * nt + tt) * 2) * D;
+  float* s = g + D;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < D; i += gridDim.x * 256) {
+    const float sc = t.scale_tab[n][i] + trow[t.scale_off[n] + i];
+    g[i] = t.w[n][i] * (1.f + sc);
+    s[i] = t.shift_tab[n][i] + trow[t.shift_off[n] + i];
+  }
+}
+
+hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec, long tvec_ld, int nt, float* gs, int D,
+                             hipStream_t st) {
+  if (n_norms <= 0 || n_norms > kMaxModNorms) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mod_tables_kernel, dim3((D + 255) / 256, n_norms, nt), dim3(256), 0, st, t, tvec, tvec_ld, gs, D, nt);
+  return hipGetLastError();
+}
+
+template <typename TO, int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_gs_reg_kernel(const float* __restrict__ x, const float* __restrict__ gs,
+                                                             long gs_ld, TO* __restrict__ out, int M, int D, int rows_per_b,
+                                                             float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + (long)row * D);
+  const int n4 = D >> 2;
+  float4 v[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss / (float)D + eps);
+  const float4* g = (const float4*)(gs + (long)(row / rows_per_b) * gs_ld);
+  const float4* s = g + n4;
+  TO* orow = out + (long)row * D;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i >= n4) continue;
+    const float4 gg = g[i], sv = s[i];
+    store4<TO>(orow + 4 * i, v[k].x * inv * gg.x + sv.x, v[k].y * inv * gg.y + sv.y, v[k].z * inv * gg.z + sv.z,
+               v[k].w * inv * gg.w + sv.w);
+  }
+}
+
+// gs = [g | s] of this norm for time value 0, gs_ld = floats between the time values (0: one time value for every row)
+hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
+                             float eps, hipStream_t st) {
+  if (D > 256 * 12 || D % 4) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+  if (bf16)
+    hipLaunchKernelGGL((rmsnorm_gs_reg_kernel<bf16_t, 12>), grid, block, 0, st, x, gs, gs_ld, (bf16_t*)out, M, D, rows_per_b, eps);
+  else
+    hipLaunchKernelGGL((rmsnorm_gs_reg_kernel<float, 12>), grid, block, 0, st, x, gs, gs_ld, (float*)out, M, D, rows_per_b, eps);
+  return hipGetLastError();
+}
+
 hipError_t launch_rmsnorm_mod(const float* x, const float* w, const float* shift_tab, const float* scale_tab,
                               const float* tvec, long tvec_ld, int shift_off, int scale_off, void* out, bool bf16,
                               int M, int D, int rows_per_b, float eps, hipStream_t st) {

@@ -72,6 +72,9 @@ for flag, name in ((1, "rmsnorm_mod (two-pass, round 1)"), (0, "rmsnorm_mod (row
         hip.ptr(x), hip.ptr(w), C.c_void_p(tab[0].data_ptr()), C.c_void_p(tab[1].data_ptr()), hip.ptr(t0), 0, 0, D,
         hip.ptr(xn), hip.BF16, M, D, T, 1e-5, st())), M * D * 6)
 L.samaudio_debug_set_flag(2, 0)
+# probe: the same kernel without the modulation operands (4 of its 5 table vectors are not loaded): what do they cost?
+timeit("rmsnorm without modulation (probe)", lambda: hip.check(L.samaudio_op_rmsnorm_mod(
+    hip.ptr(x), hip.ptr(w), None, None, None, 0, 0, 0, hip.ptr(xn), hip.BF16, M, D, T, 1e-5, st())), M * D * 6)
 q = torch.randn(M, D, device=dev).to(torch.bfloat16)
 kv = torch.randn(B * Lt, 2 * D, device=dev).to(torch.bfloat16)
 tmask = torch.ones(B, Lt, dtype=torch.uint8, device=dev)
