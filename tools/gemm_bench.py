@@ -137,12 +137,14 @@ def main():
         return
     if args.raster:
         VARIANTS.clear()
-        VARIANTS.update({4: "256x128 s2", 9: "pp 256x256"})
+        VARIANTS.update({22: "8-phase 256x256"})
         for gm in (8, 2, 4, 16, 32, 8):
             RASTER[0] = gm
             run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
             run_case("c_wq", M, D, D, "plain", dev, args.iters)
+            run_case("wo/c_wo (gate+res)", M, D, D, "gated", dev, args.iters)
             run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
+            run_case("w2 (gate+res)", M, D, Fh, "gated", dev, args.iters)
         return
     if args.ablate:
         run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
