@@ -397,19 +397,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // to overlap with: ~1 200 cycles per K-tile for 512 cycles of MFMA work.  PIPE keeps a 3-stage ring (96 KiB) and two
 // fragment sets: the LDS reads of K-tile t+1 are issued BEFORE the MFMAs of K-tile t and complete underneath them, one
 // barrier per K-tile.  Same MFMA order per output element: bitwise identical to the plain form and to gemm8_kernel.
-// WM = wave rows: 2 -> 128 x 128 tile on 4 waves (above); 4 -> 256 x 128 on 8 waves (PIPE only, 144 KiB): per K-tile a
-// workgroup then pulls 48 KiB through 6 DMA pieces per wave for twice the MFMA work, and the weight panel is re-read once
-// per 256 rows instead of once per 128 - for launches with few rows, where 128 x 128 workgroups are bound by their DMA
-// issue and by the L2, not by MFMA.  Each wave still owns 64 x 64 outputs with the same fragment <-> k mapping: same bits.
-template <bool PIPE, int WM>
-__global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, const int skip256) {
-  constexpr int BM = 64 * WM, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of a 128-row operand tile (128 B per row)
-  constexpr int TBA = BM * 128, STG = TBA + TB;                   // A tile, one stage (A tile | W tile)
+template <bool PIPE>
+__global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
+  constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 3 : 2;
-  constexpr int NQW = 8 / WM;                                     // W rows per wave = 128 / (2 WM) = 8 NQW
-  constexpr int NDMA = 4 + NQW;                                   // DMA instructions per wave per K-tile
-  static_assert(WM == 2 || (WM == 4 && PIPE), "the 256 x 128 tile exists in the pipelined form only");
-  __shared__ __attribute__((aligned(16))) char smem[S * STG];     // [stage][A tile, W tile]
+  __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -421,7 +413,7 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
   // launch covers the remaining ones as 4 quadrants each - consecutive workgroups of an XCD's run share a 256-tile's
   // operand panels.  Same arithmetic either way, so the split is invisible in the results.
   int b, tm, tn, m0, n0;
-  if (WM == 2 && skip256 >= 0) {
+  if (skip256 >= 0) {
     const int total256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
     const int pos = xcd_run_pos((total256 - skip256) * 4);
     tile_of(p, 256, 256, skip256 + (pos >> 2), b, tm, tn);
@@ -436,10 +428,9 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
 
   // staging: wave w moves rows 32w .. 32w+31 of both tiles as 4 + 4 wave instructions of 8 rows (1 KiB each):
   // lane -> row 32w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
-  // (WM = 4: 32 A rows but only 16 W rows per wave, 4 + 2 instructions)
   const int r8 = lane >> 3;
   const bf16_t* a_row[4];
-  const bf16_t* w_row[NQW];
+  const bf16_t* w_row[4];
   int a_in[4];
   long a_tap[4];
   {
@@ -452,27 +443,21 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
       a_row[q] = A + (long)m * p.lda;
+      int n = n0 + row;
+      n = n < p.N ? n : p.N - 1;
+      w_row[q] = W + (long)n * p.K + chunk * 8;
       a_in[q] = chunk * 8;
       a_tap[q] = 0;
       while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
     }
-#pragma unroll
-    for (int q = 0; q < NQW; ++q) {
-      const int row = wave * (8 * NQW) + q * 8 + r8;
-      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-      int n = n0 + row;
-      n = n < p.N ? n : p.N - 1;
-      w_row[q] = W + (long)n * p.K + chunk * 8;
-    }
   }
   const int nt = p.K / BK;
   auto stage = [&](int buf, int kt) {  // K-tile kt (the a_in / a_tap state points at it) -> stage buf
-    char* dst = smem + buf * STG + wave * 4096;
+    char* dst = smem + buf * (2 * TB) + wave * 4096;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dma16_8(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
-    char* dstw = smem + buf * STG + TBA + wave * (1024 * NQW);
 #pragma unroll
-    for (int q = 0; q < NQW; ++q) dma16_8(w_row[q] + (long)kt * BK, dstw + q * 1024);
+    for (int q = 0; q < 4; ++q) dma16_8(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       a_in[q] += BK;
@@ -492,8 +477,8 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
   if constexpr (PIPE) {
     bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
     auto read_frags = [&](int buf, auto SET) {
-      const char* At = smem + buf * STG;
-      const char* Wt = At + TBA;
+      const char* At = smem + buf * (2 * TB);
+      const char* Wt = At + TB;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -504,17 +489,12 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
     };
     // NEXT: K-tile t+1 exists.  A compile-time switch, not a branch: at a control-flow merge the compiler would wait for
     // EVERY outstanding LDS read before the MFMAs (it cannot keep a per-path count), which serialises read and multiply again.
-    // at most ONE K-tile's DMA instructions (NDMA per wave) still in flight; literal counts (the simulator build reads them)
-    auto wait_one_tile = [&] {
-      if constexpr (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    };
     auto step = [&](int t, auto SET, auto NEXT) {   // fragments of K-tile t are set SET (reads issued one step earlier)
       constexpr int OTHER = 1 - decltype(SET)::value;
       // K-tile t+2 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
       if (t + 2 < nt) stage((t + 2) % 3, t + 2);
       if constexpr (decltype(NEXT)::value) {
-        if (t + 2 < nt) wait_one_tile();       // K-tile t+1 has landed (t+2 may be in flight)
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile t+1 has landed (t+2 may be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();
@@ -533,7 +513,7 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
     stage(0, 0);
     if (nt > 1) {
       stage(1, 1);
-      wait_one_tile();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -564,8 +544,8 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    const char* At = smem + cb * STG;
-    const char* Wt = At + TBA;
+    const char* At = smem + cb * (2 * TB);
+    const char* Wt = At + TB;
     bf16x8_t af[4][2], wf[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -592,15 +572,8 @@ __global__ __launch_bounds__(128 * WM) void gemm8s_kernel(const GemmParams p, co
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
-  // flag 25 (A/B): no 256 x 128 tile.  It takes the launches of the pipelined form whose rows fill at least one 256-row tile
-  if (tiles <= 256 && !debug_flag(21) && !debug_flag(25) && p.M > 128) {
-    const long t2 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.nbatch;
-    hipLaunchKernelGGL((gemm8s_kernel<true, 4>), dim3((unsigned)t2), dim3(512), 0, st, p, -1);
-  } else if (tiles <= 256 && !debug_flag(21)) {
-    hipLaunchKernelGGL((gemm8s_kernel<true, 2>), dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
-  } else {
-    hipLaunchKernelGGL((gemm8s_kernel<false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
-  }
+  if (tiles <= 256 && !debug_flag(21)) hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
+  else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
   return hipGetLastError();
 }
 
@@ -622,8 +595,8 @@ hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
   if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
   else if ((tiles - full) * 4 <= 256 && !debug_flag(21))   // a tail that cannot give a CU two workgroups
-    hipLaunchKernelGGL((gemm8s_kernel<true, 2>), dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
-  else hipLaunchKernelGGL((gemm8s_kernel<false, 2>), dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
+    hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
+  else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
   return hipGetLastError();
 }
 

@@ -16,7 +16,6 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
 //   flag 17: bit mask TOGGLING the channel counts excluded from the fused residual-unit kernel (1: 64, 2: 96, 4: 128, 8: 192;
 //            excluded by default: 128 and 192) (A/B)
-//   flag 25: no 256x128 tile of gemm8s for few-row launches (A/B)
 //   flag 24: RMSNorm + modulate loads its five operand vectors per row instead of the two pre-combined per evaluation (A/B)
 //   flag 23: self-attention as a 1-D grid with the query blocks of a (batch, head) back to back on one XCD (A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined 3-stage form

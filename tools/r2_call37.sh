@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 2, GPU call 37: 256x128 pipelined tile of gemm8s for few-row launches (flag 25 = 128x128 only): the whole -m gpu
+# Round 2, GPU call 37 (NEGATIVE RESULT, the kernel form was removed again - check out commit "gemm8s: 256x128 pipelined
+# tile" to reproduce): 256x128 pipelined tile of gemm8s for few-row launches (flag 25 = 128x128 only): the whole -m gpu
 # suite on it, GEMM micro-benchmarks at M = 1000, bench A/B at 4 clips and on small* 8 clips, default line as the control.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r2_call37
