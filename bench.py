@@ -31,8 +31,8 @@ The JSON line also carries
   roofline_hbm   - the DAC-VAE convolutions (their own kernel symbols) and the streaming kernels of the DiT against
                    max(flops / MFMA peak, algorithmic bytes / HBM peak);
   cpu_baseline   - the CPU oracle (oracle/samaudio_oracle.py, a torch fp32 restatement of the reference algorithm)
-                   timed on this box's host cores on a bounded sample (rank 0, N=1 only);
-  parity_check   - the same sample (2 clips, fixed noise, ONE midpoint step) run through the HIP path in the benchmarked
+                   timed on this box's host cores on a bounded sample (2 clips, the whole path; rank 0, N=1 only);
+  parity_check   - the same sample (2 clips, fixed noise, the full 16-step solve) run through the HIP path in the benchmarked
                    precision and compared with the oracle's result: encode latent, ODE latent and waveform max-abs error.
 """
 from __future__ import annotations
@@ -75,9 +75,6 @@ def parse(argv=None):
                          "clips on the rank, else 1; with 2, one group's GEMM "
                          "tile tails - 352 tiles of 256x256 on 256 CUs at N = D - and epilogues are filled by the other's "
                          "workgroups; bitwise equal to 1 stream; 200.5 vs 181.1 s-audio/s, profiles/r2_call3/)")
-    ap.add_argument("--graph", type=int, default=0,
-                    help="replay the ODE solve from a captured hipGraph: 1 on, 0 off (default: kernels at >= 4 clips per "
-                         "GPU average > 40 us, the host launch path is not the limiter - profiles/r2_bench_batch4_*.log)")
     ap.add_argument("--candidates", type=int, default=1,
                     help="> 1: BASELINE.json configs[3] - reranking_candidates per clip, scored by the HIP Judge "
                          "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
@@ -172,9 +169,9 @@ def selftest_spawn(args) -> None:
 
 
 def oracle_sample(cfg, sd_cpu, clips, text, tmask, noise, threads):
-    """The oracle on the host cores, bounded: R clips of 10 s; DAC encode, ONE of the 16 midpoint steps (2 of the
-    32 DiT evaluations) and DAC decode are each timed once; ODE time is scaled x16.  Returns (cpu_baseline dict, the
-    oracle's tensors for parity_check)."""
+    """The oracle on the host cores, bounded to R clips of 10 s but otherwise the WHOLE path: DAC encode, the full 16-step
+    midpoint solve (32 DiT evaluations) and DAC decode of target + residual, each timed once.  Returns (cpu_baseline
+    dict, the oracle's tensors for parity_check)."""
     import torch
     from oracle import samaudio_oracle as O
     torch.set_num_threads(threads)
@@ -196,48 +193,59 @@ def oracle_sample(cfg, sd_cpu, clips, text, tmask, noise, threads):
                                       anchor_ids=ids, anchor_alignment=align, pad_mask=pad)
 
         t0 = time.perf_counter()
-        lat = O.ode_fixed_grid(field, noise, method="midpoint", step_size=1.0)  # one step = 2 evaluations
-        t_step = time.perf_counter() - t0
-        log(f"cpu baseline: one midpoint step {t_step:.2f} s")
+        lat = O.ode_fixed_grid(field, noise, method="midpoint", step_size=2 / 32)  # reference model.py:22: 16 steps
+        t_ode = time.perf_counter() - t0
+        log(f"cpu baseline: 16 midpoint steps (32 DiT evaluations) {t_ode:.2f} s")
         gen = lat.transpose(1, 2).reshape(2 * R, lat.shape[2] // 2, T)
         t0 = time.perf_counter()
         wav = O.dac_decode(sd_cpu, codec, gen)
         t_dec = time.perf_counter() - t0
         log(f"cpu baseline: DAC decode x{2 * R} {t_dec:.2f} s")
-    per_clip = (t_enc + 16 * t_step + t_dec) / R
+    per_clip = (t_enc + t_ode + t_dec) / R
     base = {
         "value": CLIP_SECONDS / per_clip, "unit": "s-audio/s", "cores": threads, "kind": "port",
         "sample": (f"{R} clips x 10 s, same dims, fp32 torch oracle (restatement of the reference, pinned to its own "
-                   f"classes; the reference package itself cannot be imported on the GPU box), one run: DAC encode "
-                   f"{t_enc:.2f} s + 1 of 16 midpoint steps (2 of 32 DiT evals) {t_step:.2f} s (scaled x16) + DAC decode "
+                   f"classes; the reference package itself cannot be imported on the GPU box), the whole path once: DAC "
+                   f"encode {t_enc:.2f} s + 16 midpoint steps = 32 DiT evaluations {t_ode:.2f} s + DAC decode "
                    f"x{2 * R} {t_dec:.2f} s => {per_clip:.1f} s per clip"),
     }
     return base, {"z": z, "lat": lat, "wav": wav.reshape(R, 2, -1)}
 
 
 def parity_check(model, sub, noise, ref, R, dev, precision):
-    """The oracle's sample (`sub`: the same R clips as a device batch) through the HIP path in the benchmarked precision."""
+    """The oracle's sample (`sub`: the same R clips as a device batch) through the HIP path in the benchmarked precision:
+    the full default solve (16 midpoint steps) exactly as the timed steps run it."""
     import torch
     with torch.inference_mode():
         z = model.encode_audio(sub.audios)
-        model.separate(sub, noise=noise.to(dev), ode_opt={"method": "midpoint", "options": {"step_size": 1.0}})
+        res = model.separate(sub, noise=noise.to(dev))
         lat = model.last_latent
-        half = lat.size(2) // 2
-        gen = lat.reshape(R, lat.size(1), 2, half).permute(0, 2, 1, 3).reshape(2 * R, lat.size(1), half).contiguous()
-        wav = model.decode_audio(gen).view(R, 2, -1)
+        wav = torch.stack([torch.stack(res.target), torch.stack(res.residual)], 1)
         torch.cuda.synchronize()
 
     def err(a, b):
         return float((a.float().cpu() - b).abs().max())
 
+    e_lat, e_wav = err(lat, ref["lat"]), err(wav, ref["wav"])
     return {
-        "precision": precision, "rows": R,
-        "what": "DAC encode -> ONE midpoint step (2 DiT evaluations, step_size 1.0) on fixed CPU noise -> DAC decode of "
-                "target+residual; HIP path vs the fp32 CPU oracle, max-abs",
+        "precision": precision, "f32_classes": [c for c in hip_classes() if model.f32_classes & hip_cls(c)], "rows": R,
+        "what": "DAC encode -> the full 16-step midpoint solve (32 DiT evaluations) on fixed CPU noise -> DAC decode of "
+                "target+residual, i.e. separate() as timed; HIP path vs the fp32 CPU oracle, max-abs",
+        "tolerance": 1e-3, "within_tolerance": bool(e_lat <= 1e-3 and e_wav <= 1e-3),
         "encode_latent_err": err(z, ref["z"]), "encode_latent_ref_max": float(ref["z"].abs().max()),
-        "ode_latent_err": err(lat, ref["lat"]), "ode_latent_ref_max": float(ref["lat"].abs().max()),
-        "waveform_err": err(wav, ref["wav"]), "waveform_ref_max": float(ref["wav"].abs().max()),
+        "ode_latent_err": e_lat, "ode_latent_ref_max": float(ref["lat"].abs().max()),
+        "waveform_err": e_wav, "waveform_ref_max": float(ref["wav"].abs().max()),
     }
+
+
+def hip_classes():
+    from sam_audio_amd import hip
+    return hip.CLASSES
+
+
+def hip_cls(name):
+    from sam_audio_amd import hip
+    return hip.CLS[name]
 
 
 PROMPTS = ["a dog barking", "man speaking", "rain on a tin roof", "acoustic guitar strumming chords", "car engine idling",
@@ -477,7 +485,6 @@ def main():
         torch.cuda.synchronize()
 
     def timed(batch, steps, warmup, label):
-        model.use_graph = args.graph == 1
 
         def step():
             # noise=None: drawn on device inside, like the reference (model.py:274-275)
@@ -499,7 +506,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert all(torch.isfinite(w).all() for w in res.target), "non-finite output"
-        return elapsed, step, model.use_graph
+        return elapsed, step
 
     # ---- the timed run ------------------------------------------------------------------------------------
     if args.scaling == "weak":
@@ -514,7 +521,7 @@ def main():
     model.tail_split = n_streams == 1   # pinned, so that the instrumented (single-stream) step launches the timed kernels
     SPLIT_MODE[0] = n_streams == 1
     log(f"inputs resident ({len(my_ids)} clips on this rank, {n_streams} stream(s)); warm-up")
-    elapsed, step, graphed = timed(batch, args.steps, args.warmup, args.scaling)
+    elapsed, step = timed(batch, args.steps, args.warmup, args.scaling)
     value = clips_total * CLIP_SECONDS * args.steps / elapsed
     log(f"timed {args.steps} steps in {elapsed:.3f} s -> {value:.2f} s-audio/s")
 
@@ -525,20 +532,18 @@ def main():
         s_batch = make_batch(s_ids)[0]
         s_steps = max(2, min(args.steps, 5))
         model.streams = auto_streams(len(s_ids))
-        s_elapsed, _, s_graphed = timed(s_batch, s_steps, 1, "strong")
+        s_elapsed, _ = timed(s_batch, s_steps, 1, "strong")
         strong = {"scaling": "strong", "global_batch": args.batch, "clips_per_gpu": len(s_ids), "steps": s_steps,
-                  "ms_per_step": round(1e3 * s_elapsed / s_steps, 2), "hip_graph": bool(s_graphed),
+                  "ms_per_step": round(1e3 * s_elapsed / s_steps, 2),
                   "streams_per_gpu": model.streams,
                   "value": round(args.batch * CLIP_SECONDS * s_steps / s_elapsed, 3), "unit": "s-audio/s"}
         log(f"strong: {s_steps} steps in {s_elapsed:.3f} s -> {strong['value']:.2f} s-audio/s")
-        model.use_graph = graphed
         model.streams = n_streams
 
     # ---- rooflines: one extra, instrumented step (HIP events on the launch stream) ----------------------------
     roof = {"roofline": None, "roofline_hbm": None, "kernels": None}
     if rank == 0 and not args.no_roofline:
         model.streams = 1  # events bracket single launches: keep the GPU to one stream while they are recorded
-        model.use_graph = False  # events cannot be recorded inside a captured graph
         model.profile_begin()
         step()
         roof = rooflines(model.profile_end())
@@ -599,7 +604,6 @@ def main():
         noise = torch.randn(R, n_samples // cfg.audio_codec.hop_length, tcfg.out_channels, generator=g)
         cpu, ref = oracle_sample(cfg, sd_cpu, torch.stack(clips[:R]), text[:R], tmask[:R], noise, threads)
         if want_verify:
-            model.use_graph = False
             sub = proc(descriptions=["sound"] * R, audios=clips[:R], text_features=text[:R], text_mask=tmask[:R]).to(dev)
             parity = parity_check(model, sub, noise, ref, R, dev, args.precision)
             log(f"parity_check: {parity}")
@@ -622,7 +626,7 @@ def main():
                                 else "")),
                 "clips_per_gpu": len(my_ids), "global_batch": clips_total, "parallelism": f"clip-sharded x{world}" + (" (ranks time-share ONE GPU over gloo: functional check, not a scaling number)"
                                                                          if args.share_gpu and world > 1 else ""),
-                "streams_per_gpu": n_streams, "hip_graph": bool(graphed), "reranking_candidates": args.candidates,
+                "streams_per_gpu": n_streams, "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
                 "text_encoder_in_step": "t5-base dims, random init, T5 stack on the HIP library (fp32)" if args.t5 else None,
                 "visual_prompt": (f"{cfg.vision_encoder.name} tower, 250 frames x 336x336 per clip, encoded inside the step"

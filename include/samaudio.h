@@ -87,6 +87,34 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   two kernels (whole rounds + a 128x128-tile tail).  Set to 0 for contexts that share the GPU with another context's
  *   stream (SAMAudio(streams=2)): there the other stream's workgroups fill the idle CUs and the extra launches cost 2 %. */
 #define SAMAUDIO_OPT_TAIL_SPLIT 1
+/* Precision of single GEMM classes (the reference computes everything in fp32: README.md:48, no autocast anywhere).
+ *   SAMAUDIO_OPT_F32_CLASSES (16-bit contexts; value = mask of SAMAUDIO_CLS_* bits, default 0): the named classes run on
+ *   exact-fp32 operands (v_mfma_f32_16x16x4f32) inside an otherwise 16-bit context.  Needs the class's weights registered
+ *   a second time in fp32 under "<name>.f32" (samaudio_set_tensor); only the classes in SAMAUDIO_CLS_F32_CAPABLE - the
+ *   ones whose fp32 cost is < 1 % of a step - are accepted.
+ *   SAMAUDIO_OPT_QUANT_CLASSES / SAMAUDIO_OPT_QUANT_FORMAT (fp32 contexts; measurement aid for the error budget of
+ *   DESIGN.md section 4): the GEMMs of the named classes round BOTH operands to the 16-bit format (1 = bfloat16,
+ *   2 = IEEE fp16) before multiplying, everything else stays exact - the numerical effect of running only that class on
+ *   16-bit operands. */
+#define SAMAUDIO_OPT_F32_CLASSES 2
+#define SAMAUDIO_OPT_QUANT_CLASSES 3
+#define SAMAUDIO_OPT_QUANT_FORMAT 4
+#define SAMAUDIO_CLS_TIME (1 << 0)   /* t_embedder MLP + t_block (transformer.py:236-257,462-467): 1 row per time value */
+#define SAMAUDIO_CLS_OUT (1 << 1)    /* DiT output projection D -> 256 (transformer.py:519): feeds the ODE state */
+#define SAMAUDIO_CLS_IN (1 << 2)     /* proj, noisy-audio columns (model.py:116-125): reads the ODE state */
+#define SAMAUDIO_CLS_PREP (1 << 3)   /* hoisted conditioning: proj feature columns, video conv1x1, anchors, memory_proj */
+#define SAMAUDIO_CLS_YEMB (1 << 4)   /* y_embedder (transformer.py:260-288) */
+#define SAMAUDIO_CLS_CKV (1 << 5)    /* cross-attention K | V projections of all layers */
+#define SAMAUDIO_CLS_PATCH (1 << 6)  /* patcher k3 convolutions (patcher.py:48-67) */
+#define SAMAUDIO_CLS_QKV (1 << 7)
+#define SAMAUDIO_CLS_WO (1 << 8)
+#define SAMAUDIO_CLS_CWQ (1 << 9)
+#define SAMAUDIO_CLS_CWO (1 << 10)
+#define SAMAUDIO_CLS_W13 (1 << 11)
+#define SAMAUDIO_CLS_W2 (1 << 12)
+#define SAMAUDIO_CLS_CODEC (1 << 13) /* every DAC-VAE convolution */
+#define SAMAUDIO_CLS_COUNT 14
+#define SAMAUDIO_CLS_F32_CAPABLE (SAMAUDIO_CLS_TIME | SAMAUDIO_CLS_OUT | SAMAUDIO_CLS_IN | SAMAUDIO_CLS_PREP | SAMAUDIO_CLS_YEMB)
 int samaudio_set_option(samaudio_ctx* ctx, int option, int value);
 
 /* ---- hot path ------------------------------------------------------------------------------------ */

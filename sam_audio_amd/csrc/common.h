@@ -162,7 +162,8 @@ struct GemmParams {
   long w_bstride;          // per-batch offset of W in elements (0: one weight matrix for every batch)
   int raster_gm;           // gemm2/gemm3 tile raster: M-tiles per group (0 = default 8)
   int flags;               // launch switches: bit 0 (set by launch_gemm2) accumulator-layout epilogue; bit 1 (set by the
-                           // caller) never split the launch into whole rounds + tail (gemm.hip gemm_tail_split)
+                           // caller) never split the launch into whole rounds + tail (gemm.hip gemm_tail_split);
+                           // bits 2-3 / 4-5 (fp32 kernel only): round the A / W operand to bf16 (1) or fp16 (2) first
   int tag;                 // 1: DAC-VAE launch - same code under its own kernel symbol (rocprofv3 / roofline attribution)
 };
 

@@ -83,8 +83,12 @@ class Engine {
                     hipStream_t st);
   Status plan_dit(Bump& b, int rows, int frames, int text_len, bool assign);
   size_t codec_bytes(int items, int64_t samples) const;
-  // alg_flops < 0: 2*M*N*K*nbatch (exact unless K carries zero padding, then the caller passes the true count)
-  Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0);
+  // alg_flops < 0: 2*M*N*K*nbatch (exact unless K carries zero padding, then the caller passes the true count).
+  // cls: SAMAUDIO_CLS_* bit of the launch (0: codec launches are classed by prof_cls_); f32: exact-fp32 operands inside a
+  // 16-bit context (SAMAUDIO_OPT_F32_CLASSES - the caller hands fp32 A / W / out_act pointers)
+  Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0, int cls = 0, bool f32 = false);
+  bool f32c(int cls) const { return bf16_ && (f32_classes_ & cls) != 0; }
+  const void* opt(const std::string& name, std::vector<int64_t> shape) const;  // optional fp32 tensor, null if absent / mis-shaped
   struct ProfRec {
     std::string key;
     double flops, bytes;
@@ -106,6 +110,8 @@ class Engine {
   samaudio_config cfg_;
   bool bf16_;
   bool tail_split_ = true;  // SAMAUDIO_OPT_TAIL_SPLIT
+  int f32_classes_ = 0;     // SAMAUDIO_OPT_F32_CLASSES (16-bit contexts)
+  int quant_classes_ = 0, quant_fmt_ = 0;  // SAMAUDIO_OPT_QUANT_CLASSES / _FORMAT (fp32 contexts)
   size_t esz_;  // bytes per activation / GEMM-operand element
   int at_dtype_;
   std::map<std::string, TensorRef> tensors_;
@@ -128,6 +134,9 @@ class Engine {
     const void *w_out, *pw1, *pw2, *y_w13, *y_w2, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w,
         *c_wkv_all;
   } g_;
+  struct {  // optional fp32 copies ("<name>.f32") of the weights of the SAMAUDIO_CLS_F32_CAPABLE classes
+    const float *w_out, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w, *y_w13, *y_w2;
+  } g32_;
   struct ResUnitW {
     const float *a1, *b1, *a2, *b2;
     const void *w1, *w2;
@@ -150,6 +159,7 @@ class Engine {
     float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
         *feats, *text, *video, *anch, *probs, *ut;
+    float *temb32, *tu32, *tsilu32, *xn32, *prep32, *mem32, *yu32, *yemb32;  // fp32 operands of the f32 classes (16-bit contexts)
     unsigned char *pad_mask, *text_mask;
     double* gn_part;
   } d_;

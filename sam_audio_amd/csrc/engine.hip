@@ -63,6 +63,7 @@ Engine::Engine(const samaudio_config& c) : cfg_(c) {
   esz_ = bf16_ ? 2 : 4;
   at_dtype_ = bf16_ ? SAMAUDIO_DT_BF16 : SAMAUDIO_DT_F32;
   std::memset(&g_, 0, sizeof(g_));
+  std::memset(&g32_, 0, sizeof(g32_));
   std::memset(&enc_, 0, sizeof(enc_));
   std::memset(&dec_, 0, sizeof(dec_));
   std::memset(&d_, 0, sizeof(d_));
@@ -101,6 +102,11 @@ Status Engine::need(const std::string& name, int dtype, std::vector<int64_t> sha
   }
   *out = t->p;
   return Status{};
+}
+
+const void* Engine::opt(const std::string& name, std::vector<int64_t> shape) const {
+  const TensorRef* t = find(name);
+  return t && t->dtype == SAMAUDIO_DT_F32 && t->shape == shape ? t->p : nullptr;
 }
 
 static int kpad(int k, bool bf16) { return (int)round_up(k, bf16 ? 64 : 32); }
@@ -168,6 +174,21 @@ Status Engine::finalize(int what) {
     // the y-embedder, so one GEMM per evaluation serves the 22 layers (reference transformer.py:382-388, :102-114)
     NEEDW(g_.c_wkv_all, "c_wkv_all", (int64_t)L * 2 * D, D);
     NEEDF(g_.c_k_norm_all, "c_k_norm_all", L, 128);
+    if (bf16_) {  // fp32 copies for SAMAUDIO_OPT_F32_CLASSES: optional, checked when a class is switched on / used
+#define OPTF(field, name, ...) g32_.field = (const float*)opt(name ".f32", {__VA_ARGS__})
+      OPTF(w_out, "w_out", C2, D);
+      OPTF(t_w13, "t_w13", 2 * D, cfg_.freq_dim);
+      OPTF(t_w2, "t_w2", D, D);
+      OPTF(tb_w, "tb_w", 6 * D, D);
+      OPTF(proj_wy, "proj_wy", D, C2);
+      OPTF(proj_wf, "proj_wf", D, C2);
+      OPTF(mem_w, "mem_w", D, cfg_.text_dim);
+      OPTF(vid_w, "vid_w", D, cfg_.video_dim);
+      OPTF(anc_w, "anc_w", D, cfg_.anchor_dim);
+      OPTF(y_w13, "y_w13", 2 * D, D);
+      OPTF(y_w2, "y_w2", D, D);
+#undef OPTF
+    }
     dit_ready_ = true;
   } else {
     const int CD = cfg_.codec_dim, CL = cfg_.codec_latent;
@@ -256,6 +277,14 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   void* kvc = act(Mt * 2 * D * cfg_.n_layers); void* temb = act(nt * cfg_.freq_dim); void* tu = act(nt * D); void* tsilu = act(nt * D);
   void* feats = act(M * C2); void* text = act(Mt * cfg_.text_dim); void* video = act(M * cfg_.video_dim);
   void* anch = act(M * cfg_.anchor_dim);
+  // fp32 operands of the classes SAMAUDIO_OPT_F32_CLASSES may switch to exact fp32 (16-bit contexts only)
+  float *temb32 = nullptr, *tu32 = nullptr, *tsilu32 = nullptr, *xn32 = nullptr, *prep32 = nullptr, *mem32 = nullptr,
+        *yu32 = nullptr, *yemb32 = nullptr;
+  if (bf16_) {
+    temb32 = f32(nt * cfg_.freq_dim); tu32 = f32(nt * D); tsilu32 = f32(nt * D); xn32 = f32(M * D);
+    prep32 = f32(M * (cfg_.video_dim > cfg_.anchor_dim ? cfg_.video_dim : cfg_.anchor_dim));
+    mem32 = f32(Mt * D); yu32 = f32(Mt * D); yemb32 = f32(Mt * D);
+  }
   // folded cross-attention (bf16, Lt <= 16): probabilities [M, KP] and the per-batch operand U^T [rows][D][KP]
   const long ltp = Lt <= 8 ? 8 : 16, kp = round_up(H * ltp, 64);
   void* probs = (bf16_ && Lt <= 16) ? act(M * kp) : nullptr;
@@ -268,7 +297,8 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
     d.t0 = t0; d.modgs = modgs; d.tsin = tsin; d.vtmp = vtmp; d.times = times; d.ybf = ybf; d.xn = xn; d.qkv = qkv; d.Q = Q; d.K = K;
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
-    d.video = video; d.anch = anch; d.probs = probs; d.ut = ut; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
+    d.video = video; d.anch = anch; d.temb32 = temb32; d.tu32 = tu32; d.tsilu32 = tsilu32; d.xn32 = xn32; d.prep32 = prep32;
+    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
   }
   return Status{};
 }
@@ -342,13 +372,36 @@ Status Engine::set_option(int option, int value) {
     tail_split_ = value != 0;
     return Status{};
   }
+  if (option == SAMAUDIO_OPT_F32_CLASSES) {
+    if (value && !bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_F32_CLASSES applies to 16-bit contexts (an fp32 context is exact already)");
+    if (value & ~SAMAUDIO_CLS_F32_CAPABLE)
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_F32_CLASSES: only the classes of SAMAUDIO_CLS_F32_CAPABLE can run in fp32");
+    f32_classes_ = value;
+    return Status{};
+  }
+  if (option == SAMAUDIO_OPT_QUANT_CLASSES || option == SAMAUDIO_OPT_QUANT_FORMAT) {
+    if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_QUANT_*: operand-rounding emulation needs an fp32 context");
+    if (option == SAMAUDIO_OPT_QUANT_FORMAT && (value < 0 || value > 2))
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_QUANT_FORMAT: 0 (off), 1 (bfloat16) or 2 (fp16)");
+    (option == SAMAUDIO_OPT_QUANT_CLASSES ? quant_classes_ : quant_fmt_) = value;
+    return Status{};
+  }
   return fail(SAMAUDIO_ERR_ARG, "samaudio_set_option: unknown option " + std::to_string(option));
 }
 
-Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops) {
+Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, bool f32) {
   GemmParams p = p_in;
   p.tag = prof_cls_[0] == 'c' ? 1 : 0;  // codec launches run under their own kernel symbols
   p.flags = tail_split_ ? 0 : 2;        // bit 1: no tail split (gemm.hip gemm_tail_split)
+  if (p.tag) cls = SAMAUDIO_CLS_CODEC;
+  if (f32) {  // a class of SAMAUDIO_OPT_F32_CLASSES: exact-fp32 kernel inside a 16-bit context
+    if (!p.W) return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_F32_CLASSES: the class's \"<name>.f32\" weight copy is not registered");
+    if (const char* why = gemm_check(p, false)) return fail(SAMAUDIO_ERR_ARG, why);
+    const double flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
+    return op(gemm_variant_name(gemm_variant(p, false), false), gemm_alg_bytes(p, 4), flops, st,
+              [&] { return launch_gemm(p, false, st); });
+  }
+  if (!bf16_ && quant_fmt_ && (quant_classes_ & cls)) p.flags |= (quant_fmt_ << 2) | (quant_fmt_ << 4);
   if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
   if (!prof_on_) {
     SA_HIP(launch_gemm(p, bf16_, st));
@@ -512,22 +565,28 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   // patcher conv input: halo rows stay zero for the whole solve
   SA_HIP(hipMemsetAsync(d_.gnbuf, 0, (size_t)rows * (T + 2) * D * esz_, st));
 
+  // SAMAUDIO_CLS_PREP in exact fp32 (16-bit contexts): the caller's fp32 tensors are the operands themselves
+  const bool pf = f32c(SAMAUDIO_CLS_PREP);
+  const int PREP = SAMAUDIO_CLS_PREP;
   // cond = proj_b + audio_features @ Wf^T                           (model.py:116-125, columns 512..767)
-  SA_HIP(launch_to_act(feats, 0, C2, 0, d_.feats, 0, bf16_, 1, M, C2, C2, 0, st));
+  if (!pf) SA_HIP(launch_to_act(feats, 0, C2, 0, d_.feats, 0, bf16_, 1, M, C2, C2, 0, st));
   {
-    GemmParams p = lin(d_.feats, C2, g_.proj_wf, M, D, C2);
+    GemmParams p = pf ? lin(feats, C2, g32_.proj_wf, M, D, C2) : lin(d_.feats, C2, g_.proj_wf, M, D, C2);
     p.bias = g_.proj_b;
     out_f32(p, d_.cond, D);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, PREP, pf));
   }
   // cond += tanh(g_v) * LayerNorm(conv1x1(video))                   (align.py:41-50; zeros if no video: Q8)
-  if (video) SA_HIP(launch_to_act(video, 0, cfg_.video_dim, 0, d_.video, 0, bf16_, 1, M, cfg_.video_dim, cfg_.video_dim, 0, st));
+  const void* vid_op = d_.video;
+  if (pf && video) vid_op = video;
+  else if (pf) { vid_op = d_.prep32; SA_HIP(hipMemsetAsync(d_.prep32, 0, (size_t)M * cfg_.video_dim * 4, st)); }
+  else if (video) SA_HIP(launch_to_act(video, 0, cfg_.video_dim, 0, d_.video, 0, bf16_, 1, M, cfg_.video_dim, cfg_.video_dim, 0, st));
   else SA_HIP(hipMemsetAsync(d_.video, 0, (size_t)M * cfg_.video_dim * esz_, st));
   {
-    GemmParams p = lin(d_.video, cfg_.video_dim, g_.vid_w, M, D, cfg_.video_dim);
+    GemmParams p = lin(vid_op, cfg_.video_dim, pf ? (const void*)g32_.vid_w : g_.vid_w, M, D, cfg_.video_dim);
     p.bias = g_.vid_b;
     out_f32(p, d_.vtmp, D);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, PREP, pf));
     SA_HIP(launch_layernorm_accum(d_.vtmp, g_.vid_ln_w, g_.vid_ln_b, g_.vid_gate, d_.cond, (int)M, D, 1e-5f, st));
   }
   // cond += tanh(g_a) * proj(Emb[ids.gather(alignment)])            (model.py:54-65; tanh folded into anc_w)
@@ -541,20 +600,23 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   }
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
-    SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment, d_.anch,
-                                bf16_, rows, T, cfg_.anchor_dim, cfg_.anchor_vocab, st));
-    GemmParams p = lin(d_.anch, cfg_.anchor_dim, g_.anc_w, M, D, cfg_.anchor_dim);
+    SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment,
+                                pf ? (void*)d_.prep32 : d_.anch, pf ? false : bf16_, rows, T, cfg_.anchor_dim,
+                                cfg_.anchor_vocab, st));
+    GemmParams p = pf ? lin(d_.prep32, cfg_.anchor_dim, g32_.anc_w, M, D, cfg_.anchor_dim)
+                      : lin(d_.anch, cfg_.anchor_dim, g_.anc_w, M, D, cfg_.anchor_dim);
     with_res(p, d_.cond, D);
     out_f32(p, d_.cond, D);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, PREP, pf));
   }
   // text_proj = memory_proj(text)                                   (model.py:171)
   if (text) {
-    SA_HIP(launch_to_act(text, 0, cfg_.text_dim, 0, d_.text, 0, bf16_, 1, Mt, cfg_.text_dim, cfg_.text_dim, 0, st));
-    GemmParams p = lin(d_.text, cfg_.text_dim, g_.mem_w, Mt, D, cfg_.text_dim);
+    if (!pf) SA_HIP(launch_to_act(text, 0, cfg_.text_dim, 0, d_.text, 0, bf16_, 1, Mt, cfg_.text_dim, cfg_.text_dim, 0, st));
+    GemmParams p = pf ? lin(text, cfg_.text_dim, g32_.mem_w, Mt, D, cfg_.text_dim)
+                      : lin(d_.text, cfg_.text_dim, g_.mem_w, Mt, D, cfg_.text_dim);
     p.bias = g_.mem_b;
     out_f32(p, d_.text_proj, D);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, PREP, pf));
   } else {
     SA_HIP(hipMemsetAsync(d_.text_proj, 0, (size_t)Mt * D * 4, st));
   }
@@ -578,12 +640,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   const double MD = (double)M * D;
 
   // aligned = noisy @ Wy^T + cond                                   (model.py:116-125, columns 0..255)
-  SA_HIP(launch_to_act(noisy, 0, C2, 0, d_.ybf, 0, bf16_, 1, M, C2, C2, 0, st));
   {
-    GemmParams p = lin(d_.ybf, C2, g_.proj_wy, M, D, C2);
+    const bool f = f32c(SAMAUDIO_CLS_IN);   // exact fp32: the ODE state itself is the operand
+    if (!f) SA_HIP(launch_to_act(noisy, 0, C2, 0, d_.ybf, 0, bf16_, 1, M, C2, C2, 0, st));
+    GemmParams p = f ? lin(noisy, C2, g32_.proj_wy, M, D, C2) : lin(d_.ybf, C2, g_.proj_wy, M, D, C2);
     with_res(p, d_.cond, D);
     out_f32(p, d_.aligned, D);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_IN, f));
   }
   // patcher: (GroupNorm(1) -> SiLU -> conv k3) x 2 + skip           (patcher.py:138-141)
   auto patch_conv = [&](const void* W, const float* bias, const float* skip, float* dst) -> Status {
@@ -593,7 +656,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     if (skip) { with_res(p, skip, D); p.res_bstride = (long)T * D; }
     out_f32(p, dst, D);
     p.f32_bstride = (long)T * D;
-    return gemm(p, st);
+    return gemm(p, st, -1.0, SAMAUDIO_CLS_PATCH);
   };
   trace("cond", d_.cond, (size_t)M * D, false, st);
   trace("aligned", d_.aligned, (size_t)M * D, false, st);
@@ -607,20 +670,25 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   SA_TRY(patch_conv(g_.pw2, g_.pb2, d_.aligned, d_.h));
 
   // timestep embeddings                                             (transformer.py:490-493, model.py:170)
-  SA_HIP(launch_time_features(time, nt, g_.t_freqs, cfg_.freq_dim, g_.mem_inv_freq, D, d_.temb, d_.tsin, bf16_, st));
   {
-    GemmParams p = lin(d_.temb, cfg_.freq_dim, g_.t_w13, nt, 2 * D, cfg_.freq_dim);
+    // one row per time value: in exact fp32 these three GEMMs cost nothing, and their rounding would reach the shift /
+    // scale / gate of every row of every layer coherently
+    const bool f = f32c(SAMAUDIO_CLS_TIME);
+    const int TIME = SAMAUDIO_CLS_TIME;
+    void *temb = f ? (void*)d_.temb32 : d_.temb, *tu = f ? (void*)d_.tu32 : d_.tu, *tsilu = f ? (void*)d_.tsilu32 : d_.tsilu;
+    SA_HIP(launch_time_features(time, nt, g_.t_freqs, cfg_.freq_dim, g_.mem_inv_freq, D, temb, d_.tsin, f ? false : bf16_, st));
+    GemmParams p = lin(temb, cfg_.freq_dim, f ? (const void*)g32_.t_w13 : g_.t_w13, nt, 2 * D, cfg_.freq_dim);
     p.swiglu = 1;
-    out_act(p, d_.tu, D);
-    SA_TRY(gemm(p, st));
-    p = lin(d_.tu, D, g_.t_w2, nt, D, D);
+    out_act(p, tu, D);
+    SA_TRY(gemm(p, st, -1.0, TIME, f));
+    p = lin(tu, D, f ? (const void*)g32_.t_w2 : g_.t_w2, nt, D, D);
     out_f32(p, d_.t_emb, D);
-    out_act(p, d_.tsilu, D, ACT_SILU);
-    SA_TRY(gemm(p, st));
-    p = lin(d_.tsilu, D, g_.tb_w, nt, 6 * D, D);
+    out_act(p, tsilu, D, ACT_SILU);
+    SA_TRY(gemm(p, st, -1.0, TIME, f));
+    p = lin(tsilu, D, f ? (const void*)g32_.tb_w : g_.tb_w, nt, 6 * D, D);
     p.bias = g_.tb_b;
     out_f32(p, d_.t0, 6L * D);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, TIME, f));
   }
   // RMSNorm + modulate operands of this evaluation, pre-combined for every layer's two norms (kernels.hip mod_tables)
   const bool mod_gs = !debug_flag(24) && 2 * cfg_.n_layers <= kMaxModNorms && cfg_.n_layers > 0 && D <= 256 * 12;
@@ -645,15 +713,24 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     }));
   }
   // memory = memory_proj(text) + sincos(t); y = y_embedder(memory)  (model.py:170-172, transformer.py:495)
-  SA_HIP(launch_add_rowvec(d_.text_proj, d_.tsin, t1, d_.mem, bf16_, (int)Mt, D, Lt, st));
   {
-    GemmParams p = lin(d_.mem, D, g_.y_w13, Mt, 2 * D, D);
+    const bool f = f32c(SAMAUDIO_CLS_YEMB);
+    const int YEMB = SAMAUDIO_CLS_YEMB;
+    void *mem = f ? (void*)d_.mem32 : d_.mem, *yu = f ? (void*)d_.yu32 : d_.yu;
+    SA_HIP(launch_add_rowvec(d_.text_proj, d_.tsin, t1, mem, f ? false : bf16_, (int)Mt, D, Lt, st));
+    GemmParams p = lin(mem, D, f ? (const void*)g32_.y_w13 : g_.y_w13, Mt, 2 * D, D);
     p.swiglu = 1;
-    out_act(p, d_.yu, D);
-    SA_TRY(gemm(p, st));
-    p = lin(d_.yu, D, g_.y_w2, Mt, D, D);
-    out_act(p, d_.yemb, D);
-    SA_TRY(gemm(p, st));
+    out_act(p, yu, D);
+    SA_TRY(gemm(p, st, -1.0, YEMB, f));
+    p = lin(yu, D, f ? (const void*)g32_.y_w2 : g_.y_w2, Mt, D, D);
+    if (f) {  // the K | V projections read the 16-bit copy
+      out_f32(p, d_.yemb32, D);
+      SA_TRY(gemm(p, st, -1.0, YEMB, true));
+      SA_HIP(launch_to_act(d_.yemb32, 0, D, 0, d_.yemb, 0, true, 1, Mt, D, D, 0, st));
+    } else {
+      out_act(p, d_.yemb, D);
+      SA_TRY(gemm(p, st, -1.0, YEMB));
+    }
   }
 
   trace("patcher out h", d_.h, (size_t)M * D, false, st);
@@ -663,7 +740,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   if (cfg_.n_layers > 0) {  // cross-attention keys / values of every layer (k-normed), [Mt, L*2D]
     GemmParams p = lin(d_.yemb, D, g_.c_wkv_all, Mt, (int)kv_ld, D);
     out_act(p, d_.kvc, kv_ld);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CKV));
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
@@ -680,7 +757,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     {
       GemmParams p = lin(d_.xn, D, w.wqkv, M, 3 * D, D);
       out_act(p, d_.qkv, 3L * D);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_QKV));
     }
     SA_TRY(op("qkv_prep", 2 * 3 * MD * esz_, 0, st, [&] {
       return launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp, H,
@@ -701,14 +778,14 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
       out_act(p, d_.hbf, D);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
     }
     trace("  h after wo", d_.h, (size_t)M * D, false, st);
     // cross-attention branch: h = h + CA(h, y)   (no norm, no gate: quirk Q4)
     {
       GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
       out_act(p, d_.qc, D);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWQ));
     }
     const void* kv_l = (const char*)d_.kvc + (size_t)l * 2 * D * esz_;
     if (fold_ltp_) {
@@ -728,13 +805,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.res_bstride = (long)T * D;
       out_f32(p, d_.h, D);
       p.f32_bstride = (long)T * D;
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
       SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     }
     trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
     trace("  h after cross", d_.h, (size_t)M * D, false, st);
@@ -749,24 +826,26 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       GemmParams p = lin(d_.xn, D, w.w13, M, 2 * F, D);
       p.swiglu = 1;
       out_act(p, d_.u, F);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
       p = lin(d_.u, F, w.w2, M, D, F);  // out = h + gate_mlp * ff
       p.gate_tab = tab + 5 * D; p.gate = d_.t0 + 5 * D; p.gate_ld = t6; p.rows_per_gate = T;
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
-      SA_TRY(gemm(p, st));
+      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W2));
     }
   }
   trace("h after layers", d_.h, (size_t)M * D, false, st);
   // final modulated norm + output projection                         (transformer.py:507-519)
-  SA_HIP(launch_rmsnorm_mod(d_.h, g_.final_norm, g_.final_table, g_.final_table + D, d_.t_emb, t1, 0, 0, d_.xn, bf16_,
-                            (int)M, D, T, eps, st));
   {
-    GemmParams p = lin(d_.xn, D, g_.w_out, M, C2, D);
+    const bool f = f32c(SAMAUDIO_CLS_OUT);   // exact fp32: the result is the ODE's vector field itself
+    void* xn = f ? (void*)d_.xn32 : d_.xn;
+    SA_HIP(launch_rmsnorm_mod(d_.h, g_.final_norm, g_.final_table, g_.final_table + D, d_.t_emb, t1, 0, 0, xn,
+                              f ? false : bf16_, (int)M, D, T, eps, st));
+    GemmParams p = lin(xn, D, f ? (const void*)g32_.w_out : g_.w_out, M, C2, D);
     p.alpha = alpha;
     if (res) with_res(p, res, C2);
     out_f32(p, out, C2);
-    SA_TRY(gemm(p, st));
+    SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_OUT, f));
   }
   return Status{};
 }

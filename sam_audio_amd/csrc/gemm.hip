@@ -44,6 +44,23 @@ template <> struct Mma<float> {
   }
 };
 
+// fp32 kernel only (GemmParams.flags bits 2-3: A operand, 4-5: W operand): round an operand to a 16-bit format before the
+// multiply - 1 = bfloat16, 2 = IEEE fp16, both round-to-nearest-even as the 16-bit kernels' stores do.  Products of two
+// such values are exact in fp32, so the launch computes what the 16-bit MFMA would, operand class by operand class
+// (SAMAUDIO_OPT_QUANT_CLASSES: the error budget of DESIGN.md section 4).
+__device__ __forceinline__ float quant16(float x, int fmt) {
+  if (fmt == 1) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+  }
+  if (fmt == 2) return (float)(_Float16)x;
+  return x;
+}
+__device__ __forceinline__ f32x4_t quant16x4(f32x4_t v, int fmt) {
+  return f32x4_t{quant16(v[0], fmt), quant16(v[1], fmt), quant16(v[2], fmt), quant16(v[3], fmt)};
+}
+
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
   // lane i's 16 bytes land at lds_wave_base + 16*i  (wave-uniform base, lane-linear destination)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -127,6 +144,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   const int nslab = p.K / BK;
   const int lr = lane & 15, lg = lane >> 4;
+  const int qa = (p.flags >> 2) & 3, qw = (p.flags >> 4) & 3;  // operand rounding (fp32 kernel only, see quant16)
   issue(0);
   for (int s = 0; s < nslab; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -147,6 +165,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       for (int j = 0; j < FN; ++j) {
         const int row = wn * WTN + j * 16 + lr;
         bfr[j] = *(const typename Mma<T>::frag_t*)(sB + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+      }
+      if constexpr (sizeof(T) == 4) {
+        if (qa) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) af[i] = quant16x4(af[i], qa);
+        }
+        if (qw) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) bfr[j] = quant16x4(bfr[j], qw);
+        }
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)

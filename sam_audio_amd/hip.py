@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -39,11 +40,36 @@ def act_dtype(precision: str):
     return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
 
 
-def dtype_code(dtype) -> int:
+def dtype_code(dtype, operands: Optional[str] = None) -> int:
+    """C-ABI dtype code of a torch dtype.  `operands` ("bf16" | "fp16"): the build of the library the tensor is handed to -
+    a 16-bit tensor in the other build's format would be reinterpreted silently, so it is refused here."""
     import torch
+    if operands is not None and dtype in (torch.bfloat16, torch.float16):
+        want = torch.float16 if operands == "fp16" else torch.bfloat16
+        if dtype != want:
+            raise TypeError(f"{dtype} tensor handed to the {operands}-operand build of libsamaudio_hip")
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
-OPT_TAIL_SPLIT = 1
+OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT = 1, 2, 3, 4
+# GEMM classes of the DiT / codec (samaudio.h SAMAUDIO_CLS_*), in bit order
+CLASSES = ("time", "out", "in", "prep", "yemb", "ckv", "patch", "qkv", "wo", "cwq", "cwo", "w13", "w2", "codec")
+CLS = {name: 1 << i for i, name in enumerate(CLASSES)}
+CLS_F32_CAPABLE = CLS["time"] | CLS["out"] | CLS["in"] | CLS["prep"] | CLS["yemb"]
+QUANT_FORMATS = {"bf16": 1, "fp16": 2}
+
+
+def class_mask(classes) -> int:
+    """'time,out' | ['time', 'out'] | int -> bit mask of SAMAUDIO_CLS_* ("all" = every class)."""
+    if isinstance(classes, int):
+        return classes
+    if isinstance(classes, str):
+        classes = [c for c in classes.split(",") if c]
+    mask = 0
+    for c in classes:
+        mask |= (1 << len(CLASSES)) - 1 if c == "all" else CLS[c]
+    return mask
+
+
 ACT_NONE, ACT_SNAKE, ACT_TANH, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_GELU_TANH = 0, 1, 2, 3, 4, 5, 6, 7
 
 ERR_ARG, ERR_WEIGHT, ERR_WORKSPACE, ERR_HIP, ERR_STATE = -1, -2, -3, -4, -5
@@ -131,7 +157,10 @@ class KernelStat(C.Structure):
 
 _lib = None     # the default (bf16-operand) library; tests/conftest.py swaps it for its CPU dry-run builds
 _libs = {}      # operand format -> loaded library
-_last = None    # library of the most recent call: check() reads samaudio_last_error() from the one that reported
+# library of this THREAD's most recent call: check() reads samaudio_last_error() (itself a thread-local string of the
+# library) from the one that reported.  Per thread, because the concurrent row groups and the two-stream vision tower call
+# into the bf16 and fp16 builds from several threads at once.
+_tls = threading.local()
 
 
 class _Handle:
@@ -144,8 +173,7 @@ class _Handle:
         fn = getattr(self._cdll, name)
 
         def call(*args, _fn=fn, _self=self):
-            global _last
-            _last = _self
+            _tls.last = _self
             return _fn(*args)
         object.__setattr__(self, name, call)
         return call
@@ -264,7 +292,7 @@ def check(code: int) -> None:
     (SURVEY.md §8b 'Errors')."""
     if code == 0:
         return
-    src = _last if _last is not None else lib()
+    src = getattr(_tls, "last", None) or lib()
     msg = src.samaudio_last_error().decode()
     if code == ERR_ARG:
         raise AssertionError(msg)

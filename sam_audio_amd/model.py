@@ -58,10 +58,11 @@ class _Lane:
         self._ctx = C.c_void_p()
         hip.check(self.lib.samaudio_create(C.byref(model._hc), C.byref(self._ctx)))
         for name, t in model._tensors.items():
-            dt = hip.dtype_code(t.dtype)
+            dt = hip.dtype_code(t.dtype, hip.operands_for(model.precision))
             hip.check(self.lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                    hip.shape_array(t.shape)))
         hip.check(self.lib.samaudio_finalize(self._ctx, 0))
+        model._set_precision_options(self._ctx)
         if model._has_codec:   # the lane also decodes its own row group (SAMAudio._solve_concurrent)
             hip.check(self.lib.samaudio_finalize(self._ctx, 1))
         self._workspace: Optional[torch.Tensor] = None
@@ -78,11 +79,18 @@ class SAMAudio:
     config_cls = SAMAudioConfig
 
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_encoder: Optional[Callable] = None, streams: int = 1):
+                 text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto"):
+        """`f32_classes` (16-bit precisions): the GEMM classes that run on exact-fp32 operands inside the 16-bit engine
+        (hip.CLASSES names or a mask; "auto" = every class whose fp32 cost is < 1 % of a step: the one-row time /
+        modulation GEMMs, the input and output projections that touch the ODE state, the hoisted conditioning and the
+        y-embedder - DESIGN.md section 4)."""
         cfg.check_supported()
         hip.check_precision(precision)
         self.cfg = cfg
         self.precision = precision
+        self.f32_classes = 0 if precision == "fp32" else (
+            hip.CLS_F32_CAPABLE if f32_classes == "auto" else hip.class_mask(f32_classes))
+        self.quant_classes, self.quant_format = 0, 0   # fp32 engines: operand-rounding emulation (error budget)
         self.device = torch.device(device) if device is not None else None
         self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])
         # rerankers (reference model.py:94-95): any callable with the reference's Ranker.forward keywords that returns
@@ -105,7 +113,6 @@ class SAMAudio:
             # measured on MI355X: 2 groups +3 %, 3-4 groups no further gain
             raise ValueError("streams must be 1 or 2 (set SAMAUDIO_ALLOW_STREAMS=1 to experiment with more)")
         self.streams = int(streams)           # row groups solved concurrently on separate HIP streams
-        self.use_graph = False                # replay the ODE solve from a captured hipGraph (small per-GPU batches)
         # GEMM launches split into whole rounds + a small-tile tail (samaudio.h SAMAUDIO_OPT_TAIL_SPLIT): None = automatic,
         # on when the batch is solved as one row group, off when two groups share the GPU (their kernels fill each other's
         # tails: +2 % without the split, profiles/r2_call7/); True / False pin it (bench.py keeps the instrumented step on
@@ -123,6 +130,7 @@ class SAMAudio:
             dec_rates=(C.c_int32 * 4)(*c.decoder_rates))
         self._hc = hc
         hip.check(self._lib.samaudio_create(C.byref(hc), C.byref(self._ctx)))
+        self._set_precision_options(self._ctx)
 
     def __del__(self):
         ctx = getattr(self, "_ctx", None)
@@ -214,9 +222,31 @@ class SAMAudio:
         pe = PE_VISION_CONFIGS.get(self.cfg.vision_encoder.name)
         return pe is not None and all(("model.visual." + k) in vis for k in expected_keys(pe))
 
+    def _set_precision_options(self, ctx) -> None:
+        if self.precision != "fp32":
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_F32_CLASSES, self.f32_classes))
+        else:
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_CLASSES, self.quant_classes))
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_FORMAT, self.quant_format))
+
+    def set_f32_classes(self, classes) -> None:
+        """Switch the exact-fp32 GEMM classes of a 16-bit model (see __init__); takes effect from the next call."""
+        self.f32_classes = hip.class_mask(classes)
+        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+            self._set_precision_options(ctx)
+
+    def set_quantised_classes(self, classes, fmt: str = "bf16") -> None:
+        """fp32 models only - measurement aid: the GEMMs of `classes` round both operands to `fmt` ("bf16" | "fp16")
+        before multiplying, everything else stays exact (samaudio.h SAMAUDIO_OPT_QUANT_CLASSES)."""
+        if self.precision != "fp32":
+            raise ValueError("operand-rounding emulation needs precision='fp32'")
+        self.quant_classes, self.quant_format = hip.class_mask(classes), hip.QUANT_FORMATS[fmt]
+        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+            self._set_precision_options(ctx)
+
     def _register(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
-            dt = hip.dtype_code(t.dtype)
+            dt = hip.dtype_code(t.dtype, hip.operands_for(self.precision))
             if t.data_ptr() % 16:   # a view into a larger buffer: the library needs 16-byte aligned pointers
                 t = t.clone()
             self._tensors[name] = t  # keep alive: the library borrows the pointer

@@ -92,6 +92,13 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
     def op(x):  # GEMM operand
         return x.detach().to(device=device, dtype=torch.float32).to(act_dtype).contiguous()
 
+    def op_f32(name, x):
+        """GEMM operand of a class that may run in exact fp32 inside a 16-bit engine (samaudio.h SAMAUDIO_OPT_F32_CLASSES):
+        the 16-bit copy under `name`, the fp32 one under `name + ".f32"` (0.5 GB at large* dims for all eleven)."""
+        out[name] = op(x)
+        if act_dtype != torch.float32:
+            out[name + ".f32"] = f32(x)
+
     def W(key):
         return sd[key].detach().to(device=device, dtype=torch.float32)
 
@@ -116,7 +123,7 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
     out["c_k_norm_all"] = f32(torch.stack([sd[f"{P}layers.{i}.cross_attention.k_norm.weight"] for i in range(t.n_layers)]))
     out["final_table"] = f32(sd[P + "final_layer_scale_shift_table"])
     out["final_norm"] = f32(sd[P + "norm.weight"])
-    out["w_out"] = op(W(P + "output.weight"))
+    op_f32("w_out", W(P + "output.weight"))
     for n, blk in ((1, "block1"), (2, "block2")):
         B = f"{P}x_embedder.block.{blk}."
         out[f"patch{n}.gn_w"] = f32(sd[B + "groupnorm.weight"])
@@ -125,26 +132,26 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
         out[f"patch{n}.b"] = f32(sd[B + "project.bias"])
     for pre, name in (("y", "y_embedder"), ("t", "t_embedder")):
         Q = f"{P}{name}.projection."
-        out[f"{pre}_w13"] = op(_interleave16(W(Q + "w1.weight"), W(Q + "w3.weight")))
-        out[f"{pre}_w2"] = op(W(Q + "w2.weight"))
-    out["tb_w"] = op(W(P + "t_block.weight"))
+        op_f32(f"{pre}_w13", _interleave16(W(Q + "w1.weight"), W(Q + "w3.weight")))
+        op_f32(f"{pre}_w2", W(Q + "w2.weight"))
+    op_f32("tb_w", W(P + "t_block.weight"))
     out["tb_b"] = f32(sd[P + "t_block.bias"])
 
     c2 = t.out_channels
     proj = W("proj.weight")
     assert proj.shape[1] == 3 * c2, "proj expects [noisy | zeros | features]"
-    out["proj_wy"] = op(proj[:, :c2])
-    out["proj_wf"] = op(proj[:, 2 * c2:])
+    op_f32("proj_wy", proj[:, :c2])
+    op_f32("proj_wf", proj[:, 2 * c2:])
     out["proj_b"] = f32(sd["proj.bias"])
-    out["mem_w"] = op(W("memory_proj.weight"))
+    op_f32("mem_w", W("memory_proj.weight"))
     out["mem_b"] = f32(sd["memory_proj.bias"])
-    out["vid_w"] = op(W("align_masked_video.conv.weight").squeeze(-1))
+    op_f32("vid_w", W("align_masked_video.conv.weight").squeeze(-1))
     out["vid_b"] = f32(sd["align_masked_video.conv.bias"])
     out["vid_ln_w"] = f32(sd["align_masked_video.layer_norm.weight"])
     out["vid_ln_b"] = f32(sd["align_masked_video.layer_norm.bias"])
     out["vid_gate"] = f32(sd["align_masked_video.gate"].reshape(1))
     out["anc_emb"] = f32(sd["embed_anchors.embed.weight"])
-    out["anc_w"] = op(torch.tanh(W("embed_anchors.gate")).reshape(1, 1) * W("embed_anchors.proj.weight"))
+    op_f32("anc_w", torch.tanh(W("embed_anchors.gate")).reshape(1, 1) * W("embed_anchors.proj.weight"))
 
     # fp32 tables, computed with the reference's op sequence on the CPU
     hd = t.head_dim
