@@ -18,10 +18,11 @@ offline, so the dims are the labelled stand-in `large*` (D=2816, H=22, L=22, F=7
 weights are seeded random, text features are synthetic T5-shaped tensors (no tokenizer offline).
 Rank 0 creates the weights and broadcasts them over RCCL/xGMI before the timed region; the steady state has no collective.
 
-Scaling.  `--scaling weak` (default, the line's `value`): every rank processes its own batch of --batch clips.
-`--scaling strong`: ONE global batch of --batch clips is split contiguously over the ranks (32 -> 8 x 4, SURVEY.md section
-8e).  With N > 1 the weak run also times the strong configuration and reports it under "strong_scaling", so one driver
-invocation per N yields both curves.
+Scaling.  BASELINE configs[2] is ONE batch of 32 clips sharded over the GPUs ("batch=32x10 s clips ... 1->8 MI355X
+batch-sharded"; north_star: >= 7.5x at 8 vs 1 GPU on that batch), so with N > 1 the line's `value` is `--scaling strong`: the
+global batch of --batch clips is split contiguously over the ranks (32 -> 8 x 4).  `--scaling weak`:
+every rank processes its own batch of --batch clips.  With N > 1 the run also times the other mode and reports it under
+"other_scaling", so one driver invocation per N yields both curves.  At N = 1 the two coincide.
 
 The JSON line also carries
   roofline       - bf16 MFMA roofline of the dominant DiT GEMM kernel symbol: algorithmic flops of its launches / their
@@ -60,14 +61,20 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", default="large*", help="dims preset (sam_audio_amd.config.SIZE_PRESETS)")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (weak) / global batch (strong)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--no-strong", action="store_true", help="N > 1, weak: skip the extra strong-scaling measurement")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="default: strong for N > 1 (BASELINE configs[2] is ONE batch of 32 clips split over the GPUs: the "
+                         "north_star's 8-vs-1 figure), weak for N = 1 (the same thing there)")
+    ap.add_argument("--no-other-scaling", "--no-strong", dest="no_other", action="store_true",
+                    help="N > 1: skip the extra measurement of the other scaling mode")
     ap.add_argument("--text-len", type=int, default=8)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="bf16 (default) | fp16 = the same kernels on IEEE fp16 operands (libsamaudio_hip_f16.so) | fp32 parity mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip parity_check (it shares the oracle run with cpu_baseline)")
+    ap.add_argument("--no-parity-mode", action="store_true",
+                    help="bf16 runs also time the SAME step in the parity mode (--precision fp16: IEEE fp16 operands, the mode "
+                         "that meets the 1e-3 bound on the full solve) and report it under \"parity_mode\"; this skips it")
     ap.add_argument("--verify", action="store_true", help="run parity_check even with --no-cpu-baseline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--streams", type=int, default=0,
@@ -378,6 +385,8 @@ def rooflines(stats):
 
 def main():
     args = parse()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     maybe_self_launch(args)
     if args.selftest_spawn:
         return selftest_spawn(args)
@@ -422,6 +431,9 @@ def main():
 
     model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=max(args.streams, 2))
     model.load_state_dict(sd, strict=False)
+    want_parity_mode = (args.precision == "bf16" and not args.no_parity_mode and not args.visual and args.candidates == 1
+                        and not args.predict_spans and not args.t5)
+    sd_keep = sd if want_parity_mode else None   # the parity-mode model is built from the same weights after the timed run
     del sd
     torch.cuda.empty_cache()
     log("weights loaded")
@@ -525,20 +537,23 @@ def main():
     value = clips_total * CLIP_SECONDS * args.steps / elapsed
     log(f"timed {args.steps} steps in {elapsed:.3f} s -> {value:.2f} s-audio/s")
 
-    # ---- N > 1, weak: the strong-scaling configuration of BASELINE configs[2] in the same invocation -----------
+    # ---- N > 1: the other scaling mode in the same invocation (strong is the line's value, weak the side key, or v.v.) ----
     strong = None
-    if world > 1 and args.scaling == "weak" and not args.no_strong and args.batch >= world:
-        s_ids = list(shard_range(args.batch, rank, world))
-        s_batch = make_batch(s_ids)[0]
-        s_steps = max(2, min(args.steps, 5))
-        model.streams = auto_streams(len(s_ids))
-        s_elapsed, _ = timed(s_batch, s_steps, 1, "strong")
-        strong = {"scaling": "strong", "global_batch": args.batch, "clips_per_gpu": len(s_ids), "steps": s_steps,
-                  "ms_per_step": round(1e3 * s_elapsed / s_steps, 2),
-                  "streams_per_gpu": model.streams,
-                  "value": round(args.batch * CLIP_SECONDS * s_steps / s_elapsed, 3), "unit": "s-audio/s"}
-        log(f"strong: {s_steps} steps in {s_elapsed:.3f} s -> {strong['value']:.2f} s-audio/s")
+    if world > 1 and not args.no_other and args.batch >= world:
+        other = "weak" if args.scaling == "strong" else "strong"
+        o_ids = (list(range(rank * args.batch, (rank + 1) * args.batch)) if other == "weak"
+                 else list(shard_range(args.batch, rank, world)))
+        o_total = world * args.batch if other == "weak" else args.batch
+        o_batch = make_batch(o_ids)[0]
+        o_steps = max(2, min(args.steps, 5))
+        model.streams = auto_streams(len(o_ids))
+        o_elapsed, _ = timed(o_batch, o_steps, 1, other)
+        strong = {"scaling": other, "global_batch": o_total, "clips_per_gpu": len(o_ids), "steps": o_steps,
+                  "ms_per_step": round(1e3 * o_elapsed / o_steps, 2), "streams_per_gpu": model.streams,
+                  "value": round(o_total * CLIP_SECONDS * o_steps / o_elapsed, 3), "unit": "s-audio/s"}
+        log(f"{other}: {o_steps} steps in {o_elapsed:.3f} s -> {strong['value']:.2f} s-audio/s")
         model.streams = n_streams
+        del o_batch
 
     # ---- rooflines: one extra, instrumented step (HIP events on the launch stream) ----------------------------
     roof = {"roofline": None, "roofline_hbm": None, "kernels": None}
@@ -596,6 +611,37 @@ def main():
                           "(all GEMMs + attention) / HIP-event time on the current stream"}
         log(f"vision tower: {vision['ms']} ms per 250 frames, {vision['achieved']} TFLOP/s")
 
+    # ---- the parity mode, side by side: the same steps on IEEE fp16 operands --------------------------------------------
+    pmodel = pmode = None
+    if want_parity_mode:
+        pmodel = SAMAudio(cfg, precision="fp16", device=str(dev), streams=max(args.streams, 2))
+        pmodel.load_state_dict(sd_keep, strict=False)
+        del sd_keep
+        torch.cuda.empty_cache()
+        pmodel.streams, pmodel.tail_split = n_streams, model.tail_split
+        p_steps = max(2, min(args.steps, 10))
+
+        def pstep():
+            return pmodel.separate(batch)
+
+        pstep()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(p_steps):
+            pstep()
+        fence()
+        p_elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            p_elapsed = float(t.item())
+        pmode = {"precision": "fp16", "what": "the same workload and streams with IEEE fp16 GEMM operands (libsamaudio_hip_f16.so: "
+                 "same kernels, same MFMA rate) - the mode whose full-solve latent and waveform stay inside the 1e-3 bound "
+                 "(tests/test_large_gpu.py::test_full_solve_and_decode asserts it)",
+                 "value": round(clips_total * CLIP_SECONDS * p_steps / p_elapsed, 3), "unit": "s-audio/s", "steps": p_steps,
+                 "ms_per_step": round(1e3 * p_elapsed / p_steps, 2), "parity_check": None}
+        log(f"parity mode (fp16): {p_steps} steps in {p_elapsed:.3f} s -> {pmode['value']:.2f} s-audio/s")
+
     cpu = parity = None
     if want_cpu or want_verify:
         R = min(2, len(my_ids))
@@ -607,6 +653,9 @@ def main():
             sub = proc(descriptions=["sound"] * R, audios=clips[:R], text_features=text[:R], text_mask=tmask[:R]).to(dev)
             parity = parity_check(model, sub, noise, ref, R, dev, args.precision)
             log(f"parity_check: {parity}")
+            if pmodel is not None and rank == 0:
+                pmode["parity_check"] = parity_check(pmodel, sub, noise, ref, R, dev, "fp16")
+                log(f"parity_check (parity mode): {pmode['parity_check']}")
         if not want_cpu:
             cpu = None
 
@@ -634,7 +683,7 @@ def main():
             },
             "vision_tower": vision,
             "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,
-            "parity_check": parity, "strong_scaling": strong, "kernels": roof.get("kernels"),
+            "parity_check": parity, "parity_mode": pmode, "other_scaling": strong, "kernels": roof.get("kernels"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

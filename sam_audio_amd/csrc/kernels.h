@@ -16,6 +16,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
 //   flag 17: bit mask TOGGLING the channel counts excluded from the fused residual-unit kernel (1: 64, 2: 96, 4: 128, 8: 192;
 //            excluded by default: 128 and 192) (A/B)
+//   flag 26: never the 256x192 tile of the 8-phase kernel (A/B: the policy before GPU call 2 of round 3)
 //   flag 24: RMSNorm + modulate loads its five operand vectors per row instead of the two pre-combined per evaluation (A/B)
 //   flag 23: self-attention as a 1-D grid with the query blocks of a (batch, head) back to back on one XCD (A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined 3-stage form
@@ -45,7 +46,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 36;  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 37;  // 36 = gemm8n, the 256x192 tile of the 8-phase kernel (bitwise identical to 22 / 27);  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
                                    // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family;
                                    // 28 = 256x64 tile of the 32x32x16 family for 64-channel convolutions
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
@@ -56,6 +57,8 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
+// gemm8.hip: 256x192 tile of the 8-phase kernel (bitwise identical results; not for SwiGLU launches); needs gemm2_ok(p)
+hipError_t launch_gemm8n(const GemmParams& p, hipStream_t st);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
 // LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
 bool conv7h_ok(const GemmParams& p);

@@ -55,6 +55,11 @@ OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT = 1, 2, 3, 
 CLASSES = ("time", "out", "in", "prep", "yemb", "ckv", "patch", "qkv", "wo", "cwq", "cwo", "w13", "w2", "codec")
 CLS = {name: 1 << i for i, name in enumerate(CLASSES)}
 CLS_F32_CAPABLE = CLS["time"] | CLS["out"] | CLS["in"] | CLS["prep"] | CLS["yemb"]
+# what precision="bf16" / "fp16" models switch on by default: the classes that touch the ODE state or the hoisted
+# conditioning.  Measured on the full solve at large* (profiles/r3_call1/error_budget.log, bf16 / fp16 operands, max-abs on
+# |latent| <= 5.2): out 4.3e-3 / 6.0e-4, in 2.5e-3 / 3.5e-4, prep 2.6e-3 / 3.0e-4 against yemb 9.7e-4 / 1.3e-4 and
+# time 4.6e-4 / 5.9e-5 - the last two cost 1 ms per evaluation in fp32 and buy nothing measurable; they stay selectable.
+CLS_F32_DEFAULT = CLS["out"] | CLS["in"] | CLS["prep"]
 QUANT_FORMATS = {"bf16": 1, "fp16": 2}
 
 

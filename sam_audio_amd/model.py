@@ -81,15 +81,15 @@ class SAMAudio:
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
                  text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto"):
         """`f32_classes` (16-bit precisions): the GEMM classes that run on exact-fp32 operands inside the 16-bit engine
-        (hip.CLASSES names or a mask; "auto" = every class whose fp32 cost is < 1 % of a step: the one-row time /
-        modulation GEMMs, the input and output projections that touch the ODE state, the hoisted conditioning and the
-        y-embedder - DESIGN.md section 4)."""
+        (hip.CLASSES names or a mask; "auto" = hip.CLS_F32_DEFAULT: the input and output projections that touch the ODE
+        state and the hoisted conditioning, which carry most of a 16-bit mode's error for < 1 % of a step; "time" and
+        "yemb" can be added - DESIGN.md section 4)."""
         cfg.check_supported()
         hip.check_precision(precision)
         self.cfg = cfg
         self.precision = precision
         self.f32_classes = 0 if precision == "fp32" else (
-            hip.CLS_F32_CAPABLE if f32_classes == "auto" else hip.class_mask(f32_classes))
+            hip.CLS_F32_DEFAULT if f32_classes == "auto" else hip.class_mask(f32_classes))
         self.quant_classes, self.quant_format = 0, 0   # fp32 engines: operand-rounding emulation (error budget)
         self.device = torch.device(device) if device is not None else None
         self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])

@@ -60,8 +60,8 @@ def test_f32_classes_run_and_do_not_hurt(gpu, case):
         assert torch.isfinite(lat).all()
         assert not torch.equal(lat, base), f"f32 class '{cls}' left the result bit-identical: path not taken"
         print(f"bf16, f32 class {cls:5s}: max-abs err {(lat - case['want']).abs().max().item():.3e} (none: {e_none:.3e})")
-    m, lat = _solve(case, gpu, "bf16")   # default = auto = every capable class
-    assert m.f32_classes == hip.CLS_F32_CAPABLE
+    m, lat = _solve(case, gpu, "bf16")   # default = auto = out + in + prep
+    assert m.f32_classes == hip.CLS_F32_DEFAULT
     e_auto = (lat - case["want"]).abs().max().item()
     print(f"bf16 4-step latent: f32_classes none {e_none:.3e} -> auto {e_auto:.3e}")
     assert e_auto <= 1.1 * e_none and e_auto < 2e-2

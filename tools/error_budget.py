@@ -96,7 +96,7 @@ def main():
     torch.cuda.empty_cache()
     for fmt in args.formats.split(","):
         for label, classes in (("f32_classes = none", 0), ("f32_classes = auto", "auto"),
-                               ("f32_classes = time only", "time"), ("f32_classes = time+out+in", "time,out,in")):
+                               ("f32_classes = all five", "time,out,in,prep,yemb"), ("f32_classes = out+in", "out,in")):
             m = SAMAudio(cfg, precision=fmt, device=str(dev), f32_classes=classes)
             m.load_state_dict(sd, strict=False)
             run(m)   # warm-up (workspace allocation)

@@ -20,6 +20,7 @@ from sam_audio_amd.config import preset_config  # noqa: E402
 from tests import util  # noqa: E402
 
 RASTER = [0]
+BLAS = [False]
 VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256"}
 # force-only kernels (gemm2.hip "gemm5" family: 4 loader waves + 8 compute waves; and the BK-32 two-workgroup tile)
 EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 256x256 h4", 17: "ld 256x128 s3",
@@ -92,6 +93,17 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
         us = e0.elapsed_time(e1) * 1e3 / iters
         line += f" | {vname}: {us:8.1f} us {flops / us / 1e6:7.1f} TF {'ok' if ok else 'WRONG'} ({', '.join(errs)})"
     hip.lib().samaudio_debug_force_gemm_variant(-1)
+    if BLAS[0]:   # yardstick: hipBLASLt through torch.matmul on the same operands (plain product, 16-bit output, no epilogue)
+        for _ in range(2):
+            torch.matmul(A, W.t())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            torch.matmul(A, W.t())
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        line += f" | hipBLASLt (plain): {us:8.1f} us {flops / us / 1e6:7.1f} TF"
     print(line, flush=True)
 
 
@@ -105,6 +117,8 @@ def main():
     ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size on the shipped variants")
     ap.add_argument("--experimental", action="store_true", help="shipped policy kernels vs the force-only experimental ones")
     ap.add_argument("--family", action="store_true", help="only the kernels the round-2 tile policy picks from")
+    ap.add_argument("--r3", action="store_true",
+                    help="round 3: the 8-phase family incl. its 256x192 tile, at 32 / 16 / 4 clips, hipBLASLt beside it")
     ap.add_argument("--vit", action="store_true", help="the PE-Core-L14-336 tower's GEMM shapes (250 frames x 577 tokens)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -128,6 +142,20 @@ def main():
         return
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
+    if args.r3:
+        VARIANTS.clear()
+        VARIANTS.update({-1: "auto policy", 22: "8-phase 256x256", 36: "8-phase 256x192", 27: "gemm8s 128x128"})
+        BLAS[0] = True
+        run_case("square 4096", 4096, 4096, 4096, "plain", dev, args.iters)
+        for clips in (32, 16, 4):
+            Mr = clips * 250
+            run_case("qkv", Mr, 3 * D, D, "plain", dev, args.iters)
+            run_case("wo/c_wo (gate+res)", Mr, D, D, "gated", dev, args.iters)
+            run_case("c_wq", Mr, D, D, "plain", dev, args.iters)
+            run_case("w13 swiglu", Mr, 2 * Fh, D, "swiglu", dev, args.iters)
+            run_case("w2 (gate+res)", Mr, D, Fh, "gated", dev, args.iters)
+            run_case("patcher conv-as-gemm shape", Mr, D, 3 * D, "plain", dev, args.iters)
+        return
     M = args.batch * 250
     # small correctness shapes first: ragged M, N tails, several K
     run_case("edge small", 300, 640, 192, "plain", dev, 2)
