@@ -547,35 +547,41 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
 }
 
 // cross_attn_fold_kernel: U^T[b][n][h*LtP + j] = sum_d Wo[n][h*128 + d] * V[b][j][h*128 + d]   (bf16, zero for
-// j >= Lt), the per-batch weight operand ([N = D][K = KP], K contiguous) of the folded GEMM.
-// One wave = one (head, 16 output channels n): its Wo fragment stays in registers while it walks the batch.
-// MFMA orientation: rows = tokens (A = V), columns = n (B = Wo^T) -> a lane owns 4 consecutive tokens of one n.
-__global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
+// j >= Lt and for the K padding), the per-batch weight operand ([N = D][K = KP], K contiguous) of the folded GEMM.
+//
+// Round 3 form.  What bounded the round-2 kernel (one wave = one head x 16 output channels, 8-byte stores straight from
+// the accumulator layout: 49 us per launch at the benchmark shape, 0.9 TB/s) was not latency, partial lines or request
+// rate taken one at a time but the SUM of its memory traffic: every (batch, head) slice of V - 2 KB -
+// was fetched by each of the D/16 = 176 waves that needed it (PMC: 7.9 M of the launch's 9.9 M L2 requests), and every
+// 16-byte piece of the output left as its own partial line (73.6 MB written for 34.6 MB of output).  Here
+//   * a wave keeps the Wo fragments of 64 output channels of its head in registers (4 n-fragments x 4 k-steps), so a V
+//     slice is fetched by D/64 = 44 waves: a quarter of the requests;
+//   * the 8 waves of a workgroup take 8 CONSECUTIVE heads of the same 64 channels and 4 batch items per trip, stage
+//     [item][channel][8 heads x LtP tokens] in LDS and the workgroup writes every (item, channel) row as ONE contiguous,
+//     aligned run of 8 LtP elements = 128 B (LtP = 8) or 256 B (LtP = 16): whole cache lines only.
+// grid (D/64, ceil(KP / (8 LtP)), batch splits).  Heads >= H of the last group write the zeros the K padding of U holds.
+// MFMA orientation: rows = tokens (A = V), columns = n (B = Wo^T) -> a lane owns 4 consecutive tokens of one n; the sum
+// over d runs through the same four MFMAs in the same order as before: bitwise the round-2 result.
+__global__ __launch_bounds__(512) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
                                                               long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
-                                                              int LtP, int H, int xcd_major) {
-  // Every (batch, n) row of U^T is 2*KP bytes to which each head contributes 2*LtP bytes; with heads on blockIdx.y the
-  // pieces of a row come from up to 8 different L2s and leave as partial lines (PMC: 73.6 MB written per launch for 34.6 MB
-  // of output, profiles/r2_traffic.json).  xcd_major (debug flag 0) deals the 1-D grid so that the H workgroups of one
-  // 64-channel block land on the SAME XCD (workgroup i runs on XCD i % 8) back to back, so that their pieces could merge in
-  // that L2.  Measured SLOWER (57.8 vs 49.5 us, profiles/r2_call20/; the deal is also uneven - 44 blocks over 8 XCDs = 6 | 5
-  // - but that explains 9 % at most): the partial lines are not what bounds this kernel.  Kept as the A/B it was.
-  int h = blockIdx.y, nb = blockIdx.x;
-  if (xcd_major) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    h = slot % H;
-    nb = xcd + 8 * (slot / H);
-    if (nb * 64 >= H * 128) return;
-  }
+                                                              int LtP, int H) {
+  __shared__ __attribute__((aligned(16))) unsigned short stage[4 * 64 * 8 * 16];  // [item][n][head][token <= 16]: 64 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int D = H * 128;
-  const int n = (nb * 4 + wave) * 16 + r;  // D % 64 == 0
-  bf16x8_t wf[4];
+  const int h = blockIdx.y * 8 + wave;
+  const bool head_ok = h < H;
+  const int hc = head_ok ? h : H - 1;
+  const int n0 = blockIdx.x * 64;
+  bf16x8_t wf[4][4];  // [n-fragment][k-step]
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)n * D + h * 128 + ks * 32 + g * 8);
-  // four batch items per trip: 16 independent 16-byte loads in flight before the first MFMA needs one.  A trip is one
-  // load + one store round trip (vmcnt retires in order), so the batch is also split over blockIdx.z: twice the waves,
-  // half the dependent trips each (the Wo fragment is re-read from L2 once per split).
+  for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      wf[s4][ks] = *(const bf16x8_t*)(wo + (long)(n0 + s4 * 16 + r) * D + hc * 128 + ks * 32 + g * 8);
+  const int run = 8 * LtP;                        // elements of one (item, channel) run: this workgroup's heads
+  const int k0 = blockIdx.y * run;                // first column of the run inside a U^T row
+  const int segs = run / 8;                       // 16-byte segments per run
   const int bz = (((B + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3;
   const int b_end = (int)(blockIdx.z + 1) * bz < B ? (int)(blockIdx.z + 1) * bz : B;
   for (int b0 = blockIdx.z * bz; b0 < b_end; b0 += 4) {
@@ -583,23 +589,34 @@ __global__ __launch_bounds__(256) void cross_attn_fold_kernel(const bf16_t* __re
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
       const int b = b0 + bb < B ? b0 + bb : B - 1;
-      const bf16_t* vrow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + D + h * 128 + g * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) v[bb][ks] = *(const uint4*)(vrow + ks * 32);
-    }
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const bf16_t* vrow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + D + hc * 128 + g * 8;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        uint4 x = v[bb][ks];
-        if (r >= Lt) x = make_uint4(0u, 0u, 0u, 0u);
-        u = SA_MFMA_16x16x32(*(const bf16x8_t*)&x, wf[ks], u);
+        v[bb][ks] = *(const uint4*)(vrow + ks * 32);
+        // rows of tokens that do not exist / heads beyond H must be exact zeros (never "multiplied away": 0 x NaN)
+        if (r >= Lt || !head_ok) v[bb][ks] = make_uint4(0u, 0u, 0u, 0u);
       }
-      // lane: tokens g*4 .. g*4+3 of column n
-      if (b0 + bb < B && g * 4 < LtP)
-        store4<bf16_t>(UT + ((long)(b0 + bb) * D + n) * KP + h * LtP + g * 4, u[0], u[1], u[2], u[3]);
     }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) u = SA_MFMA_16x16x32(*(const bf16x8_t*)&v[bb][ks], wf[s4][ks], u);
+        if (g * 4 < LtP) {  // lane: tokens g*4 .. g*4+3 of channel s4*16 + r
+          ushort4 o;
+          o.x = f2bf(u[0]); o.y = f2bf(u[1]); o.z = f2bf(u[2]); o.w = f2bf(u[3]);
+          *(ushort4*)(stage + ((bb * 64 + s4 * 16 + r) * 8 + wave) * LtP + g * 4) = o;
+        }
+      }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * 64 * segs; idx += 512) {
+      const int seg = idx % segs, n = (idx / segs) & 63, bb = idx / (segs * 64);
+      if (b0 + bb < B && k0 + seg * 8 < KP)
+        *(uint4*)(UT + ((long)(b0 + bb) * D + n0 + n) * KP + k0 + seg * 8) = *(const uint4*)(stage + (bb * 64 + n) * run + seg * 8);
+    }
+    __syncthreads();
   }
 }
 
@@ -610,78 +627,16 @@ hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* k
   return hipGetLastError();
 }
 
-// Candidate replacement (debug flag 3, never on by default - not yet timed).  The kernel above writes 8 bytes per
-// (batch, n) with a stride of KP*2 bytes between lanes: every store opens its own 64-byte segment.  Here the 4 waves of a
-// workgroup take 4 CONSECUTIVE heads for the same 16 output channels, stage their results in LDS as
-// [batch item][n][4 heads x LtP tokens] and the workgroup writes each (batch, n) row as one contiguous 8*LtP-byte run.
-// grid (D/16, ceil(H/4)); heads >= H contribute the zeros the K padding of U must hold.
-__global__ __launch_bounds__(256) void cross_attn_fold2_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
-                                                               long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
-                                                               int LtP, int H) {
-  __shared__ __attribute__((aligned(16))) unsigned short stage[4 * 16 * 4 * 16];  // [bb][n][head][token <= 16]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  const int D = H * 128;
-  const int h = blockIdx.y * 4 + wave;
-  const bool head_ok = h < H;
-  const int hc = head_ok ? h : H - 1;
-  const int n0 = blockIdx.x * 16;
-  bf16x8_t wf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) wf[ks] = *(const bf16x8_t*)(wo + (long)(n0 + r) * D + hc * 128 + ks * 32 + g * 8);
-  const int row_el = 4 * LtP;              // elements per (batch, n) row of the staging tile / contiguous global run
-  const int segs = row_el / 8;             // 16-byte segments per row: 4 (LtP = 8) or 8 (LtP = 16)
-  for (int b0 = 0; b0 < B; b0 += 4) {
-    uint4 v[4][4];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      const int b = b0 + bb < B ? b0 + bb : B - 1;
-      const bf16_t* vrow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + D + hc * 128 + g * 8;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) v[bb][ks] = *(const uint4*)(vrow + ks * 32);
-    }
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        uint4 x = v[bb][ks];
-        if (r >= Lt || !head_ok) x = make_uint4(0u, 0u, 0u, 0u);
-        u = SA_MFMA_16x16x32(*(const bf16x8_t*)&x, wf[ks], u);
-      }
-      // lane: tokens g*4 .. g*4+3 of column n = r
-      if (g * 4 < LtP) {
-        unsigned short* d = stage + ((bb * 16 + r) * 4 + wave) * LtP + g * 4;
-        d[0] = f2bf(u[0]); d[1] = f2bf(u[1]); d[2] = f2bf(u[2]); d[3] = f2bf(u[3]);
-      }
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 4 * 16 * segs; idx += 256) {
-      const int seg = idx % segs, n = (idx / segs) & 15, bb = idx / (segs * 16);
-      if (b0 + bb < B)
-        *(uint4*)(UT + ((long)(b0 + bb) * D + n0 + n) * KP + (long)blockIdx.y * row_el + seg * 8) =
-            *(const uint4*)(stage + (bb * 16 + n) * row_el + seg * 8);
-    }
-    __syncthreads();
-  }
-}
-
 hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
                                   int H, hipStream_t st) {
-  if (debug_flag(3) && ((H + 3) / 4) * 4 * LtP <= KP) {  // A/B candidate, see cross_attn_fold2_kernel
-    hipLaunchKernelGGL(cross_attn_fold2_kernel, dim3(H * 128 / 16, (H + 3) / 4), dim3(256), 0, st, (const bf16_t*)wo,
-                       (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
-    return hipGetLastError();
-  }
-  const int zs = debug_flag(12) > 0 ? debug_flag(12) : 1;  // flag 12 (A/B): batch split - 48.8 / 50.3 / 53.3 us for 1 / 2 / 4
-  if (debug_flag(0)) {  // flag 0 (A/B candidate, measured SLOWER on MI355X: 57.8 vs 49.5 us, profiles/r2_call20/): XCD-major deal
-    const int nblocks = H * 128 / 64;
-    hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(8 * H * ((nblocks + 7) / 8), 1, zs), dim3(256), 0, st, (const bf16_t*)wo,
-                       (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H, 1);
-    return hipGetLastError();
-  }
-  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, H, zs), dim3(256), 0, st, (const bf16_t*)wo,
-                     (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H, 0);
+  if ((H * 128) % 64 || (LtP != 8 && LtP != 16) || KP % 8 || KP < H * LtP) return hipErrorInvalidValue;
+  const int groups = (KP + 8 * LtP - 1) / (8 * LtP);   // 8-head groups covering the padded row
+  // batch splits: enough workgroups for two per CU, at least 4 items each (a trip handles 4)
+  int zs = (512 + (H * 128 / 64) * groups - 1) / ((H * 128 / 64) * groups);
+  const int zmax = (B + 3) / 4;
+  zs = zs < 1 ? 1 : zs > zmax ? zmax : zs;
+  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, groups, zs), dim3(512), 0, st, (const bf16_t*)wo,
+                     (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
   return hipGetLastError();
 }
 

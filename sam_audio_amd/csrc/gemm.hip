@@ -307,16 +307,12 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
     if (p.N >= (debug_flag(7) ? 4096 : debug_flag(19) ? 1024 : 256)) {
       const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
       if (p.N < 1024 && p.N % 256) return 27;
-      if (!(t256 >= 128 || debug_flag(6))) return 27;
-      // 256x256 or 256x192 tiles (gemm8.hip, identical bits): whichever needs less time for its rounds of 256 workgroups.
-      // A 256x192 tile is 3/4 of the work at a somewhat lower rate (fewer MFMAs per fragment read and per staged byte).
-      // N = D = 2816, 8000 rows: 352 tiles = 2 rounds vs 480 tiles = 2 rounds of 0.8 -> 1.6; 4000 rows: 1.0 vs 0.8.
-      if (!p.swiglu && !debug_flag(26)) {
-        const long t192 = (long)((p.M + 255) / 256) * ((p.N + 191) / 192) * p.nbatch;
-        const double c256 = (double)((t256 + 255) / 256), c192 = (double)((t192 + 255) / 256) * 0.8;
-        if (c192 < 0.95 * c256) return 36;
-      }
-      return 22;
+      // (round 3, GPU call 2: the same kernel on a 256x192 tile - 480 instead of 352 tiles at N = D, bitwise identical - was
+      // 8 - 13 % faster per launch on the N = D shapes and 5 % SLOWER end to end: 199.5 vs 210.2 s-audio/s with two row
+      // groups, 191.2 vs 193.1 with one.  A 256x192 tile delivers 20 % fewer flops per CU-second than a 256x256 one, and
+      // the CUs a 352-tile launch leaves idle are not idle in the timed configuration - the other row group's HBM-bound
+      // kernels run on them.  Removed; profiles/r3_call2/)
+      return t256 >= 128 || debug_flag(6) ? 22 : 27;
     }
     if (p.N == 192 && !debug_flag(4)) return 6;
     // Few rows (strong scaling: 4 clips per GPU = 1000 rows): 256-row tiles leave most CUs idle (4 x 22 = 88 tiles at
@@ -334,15 +330,15 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   static const char* names[2][kGemmVariants] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
+      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
       {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
        "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma",
        "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
        "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
-       "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_nostagger",
-       "gemm8_bf16_256x256_8phase_noprio", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
+       "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_r2loop",
+       "gemm8_bf16_256x256_8phase_plainspec", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
        "gemm2_bf16_128x128_k32_s2", "gemm2_bf16_128x64_k32_s2", "gemm2_bf16_64x128_k32_s3", "gemm2_bf16_128x192_k32_s3",
-       "conv7h_bf16", "gemm8n_bf16_256x192_8phase"}};
+       "conv7h_bf16"}};
   if (v < 0 || v >= kGemmVariants) return "";
   const char* n = names[is_bf16 ? 1 : 0][v];
   return n ? n : "";

@@ -1287,7 +1287,6 @@ hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
     case 32: return launch_conv7h(p, st);  // k7 convolution with the halo tile resident in LDS (conv7h_ok launches only)
     case 25: return launch2<256, 64, 8, 1, 2, 64, true>(p, st);  // N = 64 outputs (first DAC encoder stage) in one 64-wide tile
     case 24: return launch_gemm8s(p, st);  // gemm8.hip: 128x128 tile of the 8-phase kernel's MFMA family
-    case 33: return p.swiglu ? launch_gemm8(p, 0, st) : launch_gemm8n(p, st);  // gemm8.hip: 256x192 tile of the 8-phase kernel
     case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
     case 3: return launch2<256, 192, 4, 2, 2, 64, true>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
     case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);

@@ -64,10 +64,8 @@ __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha)
 // chunks XOR-swizzled with the row): after it a lane owns 4 consecutive columns and the 16 lanes of a row group cover
 // 256 contiguous bytes, so residual / gate loads and fp32 / bf16 stores move whole cache lines per row
 // (MI355X_MICROARCH.md "store-ISSUE-bound" epilogues, cdna_hip_programming.md T21).
-// NJ: 16-column fragments the wave owns (4 = 64 columns; 3 = 48 columns: the 256 x 192 tile - its staged rows keep the
-// 64-column pitch and the lanes of the 4 missing chunks sit out the read phase; SwiGLU pairs fragments, so NJ is even there).
-template <int NH, int NJ = 4>
-__device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH * 4][NJ], char* const stg, const int b,
+template <int NH>
+__device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH * 4][4], char* const stg, const int b,
                                           const int m_wave0, const int n_wave0, const int lane) {
   const int lr = lane & 15, lg = lane >> 4;
   const long bM = (long)b * p.M;
@@ -94,11 +92,11 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
     for (int i = 0; i < 4; ++i) {
       const int row = i * 16 + lr;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const f32x4_t a = acc[half * 4 + i][j];
         if (p.swiglu) {  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
-          if ((j & 1) || NJ % 2) continue;
-          const f32x4_t g = acc[half * 4 + i][(j | 1) < NJ ? (j | 1) : j];
+          if (j & 1) continue;
+          const f32x4_t g = acc[half * 4 + i][j | 1];
           const int chunk = (j >> 1) * 4 + lg;
           *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) =
               make_float4(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1], silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
@@ -146,7 +144,7 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
       if (has_res) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
       const float a0 = act_apply8(v[0], p.act, sa.x), a1 = act_apply8(v[1], p.act, sa.y),
                   a2 = act_apply8(v[2], p.act, sa.z), a3 = act_apply8(v[3], p.act, sa.w);
-      bool ok = m_ok && n < n_out && (NJ == 4 || csub < NJ * 4);
+      bool ok = m_ok && n < n_out;
       if (p.c_ld_rel) {
         const long erel = (long)m * p.c_ld_rel + n;
         ok = ok && erel >= p.c_lo && erel < p.c_hi;
@@ -212,19 +210,16 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 
 // STAGGER: the two wave groups run one barrier apart (off: all 8 waves read together, then multiply together);
 // PRIO: s_setprio 1 around each MFMA cluster.  Both on = the guide's template; the others are A/B builds.
-// NJ = 4: the 256 x 256 tile described above.  NJ = 3: 256 x 192 - a wave owns 128 x 48 = acc[8][3], the weight tile of a
-// K-tile is 192 rows (24 KiB, staged as 2 + 1 wave-instructions in P3 / P4), Bs0 = the wave's first two column fragments,
-// Bs1 = its third (P2 / P3 issue 8 MFMAs instead of 16).  Same MFMA, same fragment <-> k mapping, same K order: an output
-// element is accumulated bit for bit as by the 256 x 256 tile, so the policy may pick the tile by (M, N) freely.  What it
-// is for: N = D = 2816 is 11 x 256 but 14.7 x 192 - 352 tiles of 256 x 256 need 2 rounds of the 256 CUs for 1.375 rounds
-// of work (69 %), 480 tiles of 256 x 192 need 2 rounds for 1.875 (94 %); a 4000-row group 176 -> 240 tiles in one round.
-template <bool STAGGER, bool PRIO, int NJ>
+// CONV: A's k axis is split into taps (implicit convolutions: kc < K); plain GEMMs compile the per-K-tile tap walk - a
+// per-lane loop under an exec mask, twice per K-tile - out of the K loop.
+// SPLITDMA: the second of a phase's two staging instructions is issued from INSIDE the wave's own MFMA cluster (after its
+// 4th MFMA) instead of from the read section before it.  A global_load_lds costs its wave 100 - 185 issue cycles inside a
+// section that also carries ds_reads (MI355X_MICROARCH.md), ~60 among bare MFMAs: with both in the read section that
+// section outlasts the other group's 256-cycle MFMA cluster it is meant to hide behind, and the matrix pipe idles.
+template <bool STAGGER, bool PRIO, bool CONV, bool SPLITDMA>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
-  constexpr int BM = 256, BN = 64 * NJ, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile (128 rows x 128 B)
-  constexpr int BT = BN * 128;                                    // bytes of the weight tile of one K-tile
-  constexpr int KB = 2 * HT + BT;                                 // one K-tile buffer: HA0, HA1, weight rows 0 .. BN-1
-  // the epilogue stages 16 KiB per wave whatever NJ
-  __shared__ __attribute__((aligned(16))) char smem[2 * KB > 8 * 16384 ? 2 * KB : 8 * 16384];
+  constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -244,8 +239,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   // lane -> row 16w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
   const int r8 = lane >> 3;
   const bf16_t* a_row[2][2];  // [half][q] activation row pointers (row clamped to M-1), without the k offset
-  const bf16_t* w_row[2][2];  // NJ = 4: [half][q] weight row pointers incl. the lane's chunk; NJ = 3: [0][q] = rows 64q + 8 wave
-                              // + r8 (q = 0, 1), [1][0] = rows 128 + 8 wave + r8
+  const bf16_t* w_row[2][2];  // [half][q] weight row pointers incl. the lane's chunk
   int chunk[2];
   {
     const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
@@ -259,24 +253,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
         int m = m0 + h * 128 + row;
         m = m < p.M ? m : p.M - 1;
         a_row[h][q] = A + (long)m * p.lda;
-        if constexpr (NJ == 4) {
-          int n = n0 + h * 128 + row;
-          n = n < p.N ? n : p.N - 1;
-          w_row[h][q] = W + (long)n * p.K + chunk[q] * 8;
-        }
-      }
-    }
-    if constexpr (NJ != 4) {
-      // 8-row pieces 8 wave + 64 q (q = 0 .. 2): the swizzle term (row >> 1) & 7 of a row 64 q + 8 wave + r8 is that of
-      // row 8 wave + r8
-      const int wchunk = (lane & 7) ^ (((wave * 8 + r8) >> 1) & 7);
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        int n = n0 + q * 64 + wave * 8 + r8;
+        int n = n0 + h * 128 + row;
         n = n < p.N ? n : p.N - 1;
-        w_row[q >> 1][q & 1] = W + (long)n * p.K + wchunk * 8;
+        w_row[h][q] = W + (long)n * p.K + chunk[q] * 8;
       }
-      w_row[1][1] = nullptr;
     }
   }
   // position of the lane's chunk in the (tap, offset) structure of A's k axis, per q, for the K-tile being staged.
@@ -287,77 +267,78 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   for (int q = 0; q < 2; ++q) {
     a_in[q] = chunk[q] * 8;
     a_tap[q] = 0;
-    while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+    if constexpr (CONV)
+      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
   }
   const int nt = p.K / BK;
-  auto stage_a = [&](int h, int buf) {  // HA_h of the K-tile the a_in / a_tap state points at
-    char* dst = smem + buf * KB + h * HT + wave * 2048;
+  // q0 .. q1: which of the two wave-instructions of the half-tile
+  auto stage_a = [&](int h, int buf, int q0 = 0, int q1 = 1) {  // HA_h of the K-tile the a_in / a_tap state points at
+    char* dst = smem + buf * (4 * HT) + h * HT + wave * 2048;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
+    for (int q = 0; q < 2; ++q)
+      if (q >= q0 && q <= q1) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
   };
   auto advance_a = [&]() {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       a_in[q] += BK;
-      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+      if constexpr (CONV)
+        while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
     }
   };
-  auto stage_w = [&](int h, int buf, int kt) {  // HB_h of K-tile kt (NJ = 3: h = 0 -> weight rows 0 .. 127, h = 1 -> 128 .. 191)
-    if constexpr (NJ == 4) {
-      char* dst = smem + buf * KB + (2 + h) * HT + wave * 2048;
+  auto stage_w = [&](int h, int buf, int kt, int q0 = 0, int q1 = 1) {  // HB_h of K-tile kt
+    char* dst = smem + buf * (4 * HT) + (2 + h) * HT + wave * 2048;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
-    } else {
-      char* dst = smem + buf * KB + 2 * HT + wave * 1024;
-      if (h == 0) {
-        dma16_8(w_row[0][0] + (long)kt * BK, dst);
-        dma16_8(w_row[0][1] + (long)kt * BK, dst + 64 * 128);
-      } else {
-        dma16_8(w_row[1][0] + (long)kt * BK, dst + 128 * 128);
-      }
-    }
+    for (int q = 0; q < 2; ++q)
+      if (q >= q0 && q <= q1) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
   };
-  constexpr int W_LOADS = NJ == 4 ? 4 : 3;  // wave-instructions per weight tile: what stays in flight across a K-tile
 
   // ---- fragments --------------------------------------------------------------------------------------------
-  f32x4_t acc[8][NJ];
+  f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   bf16x8_t af[4][2];      // activation fragments of the current 64-row half: [m-fragment][k-step]
-  bf16x8_t wf[2][2][2];   // weight fragments: [Bs0 | Bs1][n-fragment][k-step]  (NJ = 3: Bs1 is one fragment)
+  bf16x8_t wf[2][2][2];   // weight fragments: [32-column half][n-fragment][k-step]
 
   auto frag = [&](const char* half_base, int row, int ks) -> bf16x8_t {
     return *(const bf16x8_t*)(half_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
   };
   auto read_a = [&](int buf, int sub) {  // rows 64*sub .. +63 of the wave's half-tile HA_wr
-    const char* base = smem + buf * KB + wr * HT;
+    const char* base = smem + buf * (4 * HT) + wr * HT;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[i][ks] = frag(base, sub * 64 + i * 16 + lr, ks);
   };
   // weight rows (output columns) 64*(wc&1) + 32*SUB .. +31 of HB_(wc>>1); SUB compile-time (static register index)
-  // (the weight tile is one run of BN rows: row wc * 16 NJ + 32 SUB + 16 j of it - for NJ = 4 that is row
-  //  (wc & 1) * 64 + ... of half-tile HB_(wc >> 1))
 #define SA_GEMM8_READ_W(BUF, SUB)                                                                                 \
   do {                                                                                                            \
-    const char* base_ = smem + (BUF) * KB + 2 * HT;                                                               \
-    _Pragma("unroll") for (int j = 0; j < ((SUB) == 1 && NJ == 3 ? 1 : 2); ++j)                                   \
+    const char* base_ = smem + (BUF) * (4 * HT) + (2 + (wc >> 1)) * HT;                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
-        wf[SUB][j][ks] = frag(base_, wc * (16 * NJ) + (SUB) * 32 + j * 16 + lr, ks);                              \
+        wf[SUB][j][ks] = frag(base_, (wc & 1) * 64 + (SUB) * 32 + j * 16 + lr, ks);                               \
   } while (0)
   // one C quadrant x K = 64: 16 MFMAs.  ASUB / WSUB are compile-time so that acc[][] is indexed statically and stays in
   // registers (a run-time quadrant index sends the whole accumulator to scratch).
-#define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
+  // HOOK: statement issued after the cluster's 4th MFMA (SPLITDMA: the phase's second staging instruction; else empty)
+#define SA_GEMM8_MMA(ASUB, WSUB, HOOK)                                                                            \
   do {                                                                                                            \
     if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-      _Pragma("unroll") for (int j = 0; j < ((WSUB) == 1 && NJ == 3 ? 1 : 2); ++j)                                \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
           acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = SA_MFMA_16x16x32(                          \
               wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                          \
+        if (ks == 0 && j == 0) {                                                                                  \
+          if constexpr (SPLITDMA) {                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            HOOK;                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+          }                                                                                                       \
+        }                                                                                                         \
+      }                                                                                                           \
     if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 
@@ -370,8 +351,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   if (nt > 1) {
     stage_w(0, 1, 1);
     stage_w(1, 1, 1);
-    if constexpr (W_LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -385,36 +365,40 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
     SA_GEMM8_READ_W(cb, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(cb, 0);
-    if (s1) stage_a(0, nb);
+    if (s1) stage_a(0, nb, 0, SPLITDMA ? 0 : 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SA_GEMM8_MMA(0, 0);
+    SA_GEMM8_MMA(0, 0, if (s1) stage_a(0, nb, 1, 1));
     __builtin_amdgcn_s_barrier();
     // P2
     SA_GEMM8_READ_W(cb, 1);
-    if (s1) { stage_a(1, nb); advance_a(); }
+    if (s1) {
+      stage_a(1, nb, 0, SPLITDMA ? 0 : 1);
+      if (!SPLITDMA) advance_a();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // HB(t) is restaged in the next phase: its reads end here
     __builtin_amdgcn_s_barrier();
-    SA_GEMM8_MMA(0, 1);
+    SA_GEMM8_MMA(0, 1, if (s1) { stage_a(1, nb, 1, 1); advance_a(); });
     __builtin_amdgcn_s_barrier();
     // P3
     read_a(cb, 1);
-    if (s2) stage_w(0, cb, t + 2);
+    if (s2) stage_w(0, cb, t + 2, 0, SPLITDMA ? 0 : 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SA_GEMM8_MMA(1, 1);
+    SA_GEMM8_MMA(1, 1, if (s2) stage_w(0, cb, t + 2, 1, 1));
     __builtin_amdgcn_s_barrier();
     // P4
     if (s2) {
-      stage_w(1, cb, t + 2);
-      // HB0 / HB1 of t+2 stay in flight; K-tile t+1 has landed
-      if constexpr (W_LOADS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      stage_w(1, cb, t + 2, 0, SPLITDMA ? 0 : 1);
+      // HB0 / HB1 of t+2 stay in flight; K-tile t+1 has landed.  SPLITDMA: the 3 youngest are HB0.q0, HB0.q1, HB1.q0 of
+      // t+2 (HB1.q1 follows inside the MFMA cluster below); every piece of K-tile t+1 is older than those
+      if constexpr (SPLITDMA) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    SA_GEMM8_MMA(1, 0);
+    SA_GEMM8_MMA(1, 0, if (s2) stage_w(1, cb, t + 2, 1, 1));
     __builtin_amdgcn_s_barrier();
   }
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
@@ -423,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 
   // ---- epilogue (contract of GemmParams, common.h): shared with gemm8s_kernel below ----------------------------
   __syncthreads();
-  epilogue8<2, NJ>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * (16 * NJ), lane);
+  epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 // gemm8s: the SAME arithmetic as gemm8_kernel on a 128 x 128 tile - 16x16x32 MFMA with swapped operands, identical
@@ -622,17 +606,12 @@ hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const dim3 grid((unsigned)tiles), block(512);
-  if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<false, true, 4>), grid, block, 0, st, p, 0);        // no stagger
-  else if (mode == 2) hipLaunchKernelGGL((gemm8_kernel<true, false, 4>), grid, block, 0, st, p, 0);   // no setprio
-  else hipLaunchKernelGGL((gemm8_kernel<true, true, 4>), grid, block, 0, st, p, 0);
-  return hipGetLastError();
-}
-
-// the 256 x 192 tile of the same kernel (bitwise identical results); not for SwiGLU launches (fragment pairs)
-hipError_t launch_gemm8n(const GemmParams& p, hipStream_t st) {
-  if (p.swiglu) return hipErrorInvalidValue;
-  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 191) / 192) * p.nbatch;
-  hipLaunchKernelGGL((gemm8_kernel<true, true, 3>), dim3((unsigned)tiles), dim3(512), 0, st, p, 0);
+  // A/B builds (tools/gemm_bench.py): mode 1 = the round-2 kernel (tap walk always compiled in, both staging instructions in
+  // the read section); mode 2 = CONV specialisation only; mode 0 = shipped
+  if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<true, true, true, false>), grid, block, 0, st, p, 0);
+  else if (mode == 2 && p.kc >= p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, false, false>), grid, block, 0, st, p, 0);
+  else if (p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true, true>), grid, block, 0, st, p, 0);
+  else hipLaunchKernelGGL((gemm8_kernel<true, true, false, true>), grid, block, 0, st, p, 0);
   return hipGetLastError();
 }
 
@@ -643,7 +622,8 @@ hipError_t launch_gemm8n(const GemmParams& p, hipStream_t st) {
 hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
-  if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true, 4>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  if (part == 0 && p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  else if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true, false, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
   else if ((tiles - full) * 4 <= 256 && !debug_flag(21))   // a tail that cannot give a CU two workgroups
     hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
   else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);

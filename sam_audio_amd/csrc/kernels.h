@@ -9,14 +9,12 @@ namespace sa {
 hipError_t launch_poison_lds(hipStream_t st);
 
 // tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
-//   flag 0: cross_attn_fold with the XCD-major workgroup deal (A/B candidate of call 20, measured slower: 57.8 vs 49.5 us)
 //   flag 19: 256 <= N < 1024 on the loader-wave 256x128 kernel as before GPU call 21 of round 2 (the 8-phase family now
 //            covers every N >= 256) (A/B)
 //   flag 16: DAC residual units as two launches (k7 + k1) instead of the fused resunit kernel (A/B)
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
 //   flag 17: bit mask TOGGLING the channel counts excluded from the fused residual-unit kernel (1: 64, 2: 96, 4: 128, 8: 192;
 //            excluded by default: 128 and 192) (A/B)
-//   flag 26: never the 256x192 tile of the 8-phase kernel (A/B: the policy before GPU call 2 of round 3)
 //   flag 24: RMSNorm + modulate loads its five operand vectors per row instead of the two pre-combined per evaluation (A/B)
 //   flag 23: self-attention as a 1-D grid with the query blocks of a (batch, head) back to back on one XCD (A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined 3-stage form
@@ -24,7 +22,6 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 20: fused residual units with 96 channels on 256-row tiles / 8 waves / one workgroup per CU as in call 20 (A/B)
 //   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
 //   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
-//   flag 3: cross_attn_fold stages through LDS and writes contiguous (batch, n) rows (timed in round 2: slower, 54.9 vs 49.1 us)
 //   flag 4: N = 192 GEMMs use two 128-wide tiles instead of the 256x192 tile
 //   flag 5: round-1 GEMM tile policy (256x128 2-stage ring, 256x256 ping-pong for N >= 12288)
 //   flag 6: M-blind tile policy (no 128- / 64-row tiles for launches with few rows)
@@ -34,7 +31,6 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 15: DAC stages with 96 - 192 channels on the 256-row tiles of call 12 instead of the BK-32 multi-workgroup tiles (A/B)
 //   flag 14: 64-channel convolutions on gemm.hip's 128x64 tile instead of the 256x64 tile of the DMA-fed family (A/B)
 //   flag 13: self-attention with 16 waves (256 query rows) per workgroup when 256-row blocks fit (A/B; measured slower)
-//   flag 12: batch split (blockIdx.z) of cross_attn_fold: 2 / 4 (A/B; measured no gain, default 1)
 //   flag 11: k7 convolutions as implicit GEMMs (no conv7h kernel; A/B)
 //   flag 10: no tail split of 8-phase launches (every 256x256 tile on gemm8_kernel, as before GPU call 7 of round 2)
 //   flag 7: the loader-wave 256x128 kernel (32x32x16 family) for 2048 <= N < 4096 as before GPU call 3 of round 2 (the
@@ -46,7 +42,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 37;  // 36 = gemm8n, the 256x192 tile of the 8-phase kernel (bitwise identical to 22 / 27);  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 36;  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
                                    // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family;
                                    // 28 = 256x64 tile of the 32x32x16 family for 64-channel convolutions
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
@@ -57,8 +53,6 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
-// gemm8.hip: 256x192 tile of the 8-phase kernel (bitwise identical results; not for SwiGLU launches); needs gemm2_ok(p)
-hipError_t launch_gemm8n(const GemmParams& p, hipStream_t st);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
 // LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
 bool conv7h_ok(const GemmParams& p);

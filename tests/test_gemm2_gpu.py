@@ -170,7 +170,7 @@ def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
     tab, gate, res = _mk((n_out,), 33), _mk((B, n_out), 34), _mk((M, n_out), 35)
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
     outs = {}
-    for variant in (22, 27) + (() if swiglu else (36,)):   # 36 = the 256x192 tile (no SwiGLU form: fragment pairs)
+    for variant in (22, 27):
         hip.lib().samaudio_debug_force_gemm_variant(variant)
         out_act = torch.zeros(M, n_out, device=gpu, dtype=torch.bfloat16)
         if swiglu:
@@ -187,50 +187,6 @@ def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
     assert torch.isfinite(o22.float()).all()
     assert torch.equal(o22.view(torch.int16) if swiglu else o22, o27.view(torch.int16) if swiglu else o27)
     assert torch.equal(a22.view(torch.int16), a27.view(torch.int16))
-    if 36 in outs:
-        assert torch.equal(o22, outs[36][0]) and torch.equal(a22.view(torch.int16), outs[36][1].view(torch.int16))
-
-
-@pytest.mark.parametrize("M,N,K,T,taps", [(300, 192, 64, 0, 1), (520, 200, 128, 0, 1), (257, 580, 192, 0, 1),
-                                          (90, 384, 384, 90, 3), (700, 2816, 320, 0, 1)])
-def test_256x192_tile_of_the_8phase_kernel(gpu, M, N, K, T, taps):
-    """gemm8n (variant 36; round 3): the 8-phase kernel on a 256 x 192 tile - 128 x 48 per wave, a 192-row weight tile
-    staged as 2 + 1 wave-instructions, 3 weight loads in flight across a K-tile instead of 4.  1 .. 6 K-tiles, ragged M and
-    N (N not a multiple of 192, of 16, of the lane's 4 columns ... 580 = 3 x 192 + 4), batched 3-tap implicit convolution with
-    bias + SiLU (the patcher's form), against fp32 matmul on the rounded operands and bitwise against the 256x256 tile."""
-    B = 3 if taps > 1 else 1
-    g = torch.Generator().manual_seed(61)
-    if taps > 1:     # [B][T + 2][C] halo-padded rows, kc = C, tap_stride = C, K = 3 C
-        C = K // taps
-        X = torch.randn(B, T + 2, C, generator=g)
-        X[:, 0] = 0
-        X[:, -1] = 0
-        A = X
-        cols = torch.cat([X[:, j:j + T] for j in range(taps)], dim=2).reshape(B * T, K)
-        kw = dict(nbatch=B, a_bstride=(T + 2) * C, lda=C, kc=C, tap_stride=C)
-        rows, Mk = B * T, T
-    else:
-        A = torch.randn(M, K, generator=g)
-        cols, kw, rows, Mk = A, {}, M, M
-    W = torch.randn(N, K, generator=g) / math.sqrt(K)
-    bias, res = torch.randn(N, generator=g), torch.randn(rows, N, generator=g)
-    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), bias.to(gpu), res.to(gpu)]
-    outs = {}
-    try:
-        for variant in (36, 22):
-            hip.lib().samaudio_debug_force_gemm_variant(variant)
-            out = torch.full((rows, N), float("nan"), device=gpu)
-            out_act = torch.zeros(rows, N, device=gpu, dtype=torch.bfloat16)
-            util.gemm("bf16", keep[0], keep[1], Mk, N, K, bias=keep[2], alpha=0.5, res=keep[3], res_geom=(Mk * N, N, 0),
-                      out_f32=out, f32_geom=(Mk * N, N, 0), out_act=out_act, act_geom=(Mk * N, N, 0), act=hip.ACT_SILU, **kw)
-            outs[variant] = (out.cpu(), out_act.cpu())
-    finally:
-        hip.lib().samaudio_debug_force_gemm_variant(-1)
-    want = (util.rounded(cols, "bf16") @ util.rounded(W, "bf16").T + bias) * 0.5 + res
-    util.report(f"gemm8n {rows}x{N}x{K}", outs[36][0], want, 5e-4)
-    util.report(f"gemm8n act {rows}x{N}x{K}", outs[36][1], torch.nn.functional.silu(want), 4e-2)
-    assert torch.equal(outs[36][0], outs[22][0])
-    assert torch.equal(outs[36][1].view(torch.int16), outs[22][1].view(torch.int16))
 
 
 @pytest.mark.parametrize("M,N,K", [(200, 256, 64), (130, 384, 128), (333, 512, 192), (270, 2816, 448), (250, 640, 512)])

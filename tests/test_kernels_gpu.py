@@ -205,21 +205,18 @@ def debug_flag():
         hip.lib().samaudio_debug_set_flag(flag, 0)
 
 
-@pytest.mark.parametrize("candidate", [0, 1, 2])
-@pytest.mark.parametrize("Lt,ltp,B,H", [(3, 8, 3, 4), (8, 8, 3, 4), (11, 16, 3, 4), (8, 8, 6, 6), (16, 16, 5, 2), (8, 8, 5, 22)])
-def test_cross_attn_fold_operand(gpu, debug_flag, Lt, ltp, B, H, candidate):
-    """U^T of the folded cross-attention output projection against an fp32 einsum.  candidate = 1: the LDS-staged
-    kernel behind debug flag 3 (heads per workgroup = 4: H = 6 and H = 2 exercise the partial last head group, whose
-    missing heads must come out as the zeros the K padding of U holds).  candidate = 2: the XCD-major workgroup deal (debug flag 0,
-    an A/B candidate; H = 22 -> 44 channel blocks = 5.5 per XCD exercises its ragged last deal)."""
-    debug_flag(3, 1 if candidate == 1 else 0)
-    debug_flag(0, 1 if candidate == 2 else 0)
+@pytest.mark.parametrize("Lt,ltp,B,H", [(3, 8, 3, 4), (8, 8, 3, 4), (11, 16, 3, 4), (8, 8, 6, 6), (16, 16, 5, 2), (8, 8, 5, 22),
+                                        (8, 8, 33, 10), (13, 16, 9, 22)])
+def test_cross_attn_fold_operand(gpu, Lt, ltp, B, H):
+    """U^T of the folded cross-attention output projection against an fp32 einsum.  A workgroup writes the runs of 8
+    consecutive heads: H = 4 / 6 / 2 / 10 / 22 exercise partial last head groups (whose missing heads must come out as the
+    zeros the K padding of U holds, so the buffer starts as NaN wherever a run covers it) and runs clipped at KP; B = 33 /
+    9 the batch split over blockIdx.z with a ragged last trip."""
     D = H * 128
     kp = (H * ltp + 63) // 64 * 64
     wo = _mk((D, D), 30, 1 / math.sqrt(D)).to(torch.bfloat16)
     kv = _mk((B * Lt, 2 * D), 31).to(torch.bfloat16)
-    ut = torch.full((B, D, kp), float("nan"), device=gpu, dtype=torch.bfloat16) if candidate == 1 and (H + 3) // 4 * 4 * ltp == kp \
-        else torch.zeros(B, D, kp, device=gpu, dtype=torch.bfloat16)   # the candidate rewrites the whole padded row
+    ut = torch.full((B, D, kp), float("nan"), device=gpu, dtype=torch.bfloat16)   # the kernel writes the whole padded row
     hip.check(hip.lib().samaudio_op_cross_attn_fold(P(wo.to(gpu)), P(kv.to(gpu)), 2 * D, hip.ptr(ut), kp, B, Lt, ltp, H,
                                                     util.stream()))
     v = kv.float()[:, D:].reshape(B, Lt, H, 128)
