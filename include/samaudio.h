@@ -306,9 +306,13 @@ int samaudio_mbert_finalize(samaudio_mbert* t);
 size_t samaudio_mbert_workspace_bytes(samaudio_mbert* t, int rows, int tokens);
 int samaudio_mbert_set_workspace(samaudio_mbert* t, void* workspace, size_t bytes);
 /* input_ids [rows, tokens] i64, attention_mask [rows, tokens] u8 (1 = token) -> hidden [rows, tokens, hidden] f32.
- * nth_hidden_state: transformers' hidden_states[n] - 0 <= n < layers = the residual stream after n layers (0 = the
- * normalised embeddings); n == layers or n < 0 = last_hidden_state (after the final LayerNorm; transformers 5.x records the
- * normalised tensor as the last hidden state, and the reference's default nth_text_layer = 22 = layers selects it). */
+ * nth_hidden_state: 0 <= n <= layers = the residual stream after n layers (0 = the normalised embeddings), NEVER passed
+ * through final_norm; n < 0 = last_hidden_state (after the final LayerNorm).  The two transformers generations disagree
+ * about hidden_states[layers] - 4.48 .. 4.5x (what the reference pins, pyproject.toml: transformers>=4.54, and what the
+ * released Judge was trained with) append the last layer's output BEFORE final_norm, 5.x records the normalised tensor -
+ * and the reference's default nth_text_layer = 22 = layers selects exactly that entry (judge.py:74-88).  The ABI is
+ * explicit: n == layers is the pre-norm tensor; a caller that wants 5.x semantics passes -1 (the host classes do this
+ * under SAMAudioJudgeConfig.last_text_layer_prenorm = False). */
 int samaudio_mbert_encode(samaudio_mbert* t, const int64_t* input_ids, const unsigned char* attention_mask, int rows, int tokens,
                           int nth_hidden_state, float* hidden, samaudio_stream stream);
 

@@ -48,8 +48,13 @@ def _rot(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
     return x * cos + torch.cat((-x[..., half:], x[..., :half]), dim=-1) * sin
 
 
-def mbert_hidden_states(sd: Dict[str, Tensor], cfg: Any, input_ids: Tensor, attention_mask: Tensor) -> Tuple[List[Tensor], Tensor]:
-    """-> (hidden_states[0 .. num_hidden_layers], last_hidden_state); cfg: any object with the fields hidden_size,
+def mbert_hidden_states(sd: Dict[str, Tensor], cfg: Any, input_ids: Tensor, attention_mask: Tensor,
+                        last_prenorm: bool = False) -> Tuple[List[Tensor], Tensor]:
+    """-> (hidden_states[0 .. num_hidden_layers], last_hidden_state).  `last_prenorm`: what hidden_states[num_hidden_layers]
+    is - False = transformers 5.x (the normalised tensor, what the installed module returns and the default pin of
+    tests/test_mbert_oracle_cpu.py), True = transformers 4.48 - 4.5x (the last layer's output before final_norm: the
+    reference's pinned generation, pinned here against the INPUT of the installed module's final_norm).
+    cfg: any object with the fields hidden_size,
     num_attention_heads, num_hidden_layers, global_attn_every_n_layers, local_attention, norm_eps, global_rope_theta,
     local_rope_theta (transformers 5 keeps the last four inside `layer_types` / `rope_parameters`)."""
     global_theta, local_theta = cfg.global_rope_theta, cfg.local_rope_theta
@@ -79,5 +84,6 @@ def mbert_hidden_states(sd: Dict[str, Tensor], cfg: Any, input_ids: Tensor, atte
         h = h + (F.gelu(a) * g) @ sd[p + "mlp.Wo.weight"].t()
         states.append(h)
     last = ln(h, sd["final_norm.weight"])
-    states[-1] = last
+    if not last_prenorm:   # transformers 5.x: hidden_states[layers] is the normalised tensor (= last_hidden_state);
+        states[-1] = last  # 4.48 - 4.5x append the last layer's output before final_norm (states[-1] as it stands)
     return states, last

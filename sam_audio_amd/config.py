@@ -293,7 +293,14 @@ class SAMAudioJudgeConfig:
     runs on PyTorch-ROCm through transformers)."""
 
     def __init__(self, audio_codec=None, transformer=None, text_model: Optional[Dict[str, Any]] = None,
-                 finetune_transformer=None, nth_text_layer: Optional[int] = 22, bottleneck_dim: int = 256):
+                 finetune_transformer=None, nth_text_layer: Optional[int] = 22, bottleneck_dim: int = 256,
+                 last_text_layer_prenorm: bool = True):
+        """`last_text_layer_prenorm` (no reference counterpart): what `hidden_states[nth_text_layer]` means when
+        nth_text_layer == num_hidden_layers (the reference's default, 22 on a 22-layer tower, judge.py:74-88).  transformers
+        4.48 - 4.5x - the generation the reference pins and the released Judge checkpoint was trained with - append the last
+        layer's output BEFORE `final_norm`; transformers 5.x record the normalised tensor there.  True (default) = the 4.x
+        meaning whatever transformers version is installed; False = the 5.x meaning (= last_hidden_state)."""
+        self.last_text_layer_prenorm = bool(last_text_layer_prenorm)
         self.audio_codec = _build(DACVAEConfig, audio_codec)
         self.transformer = _build(PEAVTransformerConfig, transformer)
         self.text_model = dict(text_model or {})

@@ -336,7 +336,7 @@ const char* gemm_variant_name(int v, bool is_bf16) {
        "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
        "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
        "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_r2loop",
-       "gemm8_bf16_256x256_8phase_plainspec", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
+       "", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
        "gemm2_bf16_128x128_k32_s2", "gemm2_bf16_128x64_k32_s2", "gemm2_bf16_64x128_k32_s3", "gemm2_bf16_128x192_k32_s3",
        "conv7h_bf16"}};
   if (v < 0 || v >= kGemmVariants) return "";

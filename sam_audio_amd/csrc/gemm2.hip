@@ -1273,8 +1273,7 @@ hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
     case 17: return launch5<256, 128, 4, 2, 3, 64, true, true, true>(p, st);  // 16 + persistent tile walk
     case 18: return launch5<256, 256, 2, 4, 2, 64, false, true>(p, st); // 12 + persistent tile walk
     case 19: return launch_gemm8(p, 0, st);  // gemm8.hip: the guide's 8-phase K loop, 16x16x32 MFMA
-    case 20: return launch_gemm8(p, 1, st);  // ... A/B: wave groups not staggered
-    case 21: return launch_gemm8(p, 2, st);  // ... A/B: no s_setprio around the MFMA clusters
+    case 20: return launch_gemm8(p, 1, st);  // ... A/B: the round-2 build (tap walk compiled in for plain GEMMs too)
     case 22: return launch2<128, 128, 2, 2, 2, 64>(p, st);  // small M: 4 waves, 64 KiB => two workgroups per CU
     case 23: return launch2<64, 128, 1, 4, 3, 64>(p, st);   // smaller M: 4 waves, 72 KiB => two workgroups per CU
     // experimental (GPU call 14): more K-tiles in flight per CU for narrow-N / short-K convolutions - BK 32, 4 waves

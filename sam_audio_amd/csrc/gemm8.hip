@@ -212,11 +212,11 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 // PRIO: s_setprio 1 around each MFMA cluster.  Both on = the guide's template; the others are A/B builds.
 // CONV: A's k axis is split into taps (implicit convolutions: kc < K); plain GEMMs compile the per-K-tile tap walk - a
 // per-lane loop under an exec mask, twice per K-tile - out of the K loop.
-// SPLITDMA: the second of a phase's two staging instructions is issued from INSIDE the wave's own MFMA cluster (after its
-// 4th MFMA) instead of from the read section before it.  A global_load_lds costs its wave 100 - 185 issue cycles inside a
-// section that also carries ds_reads (MI355X_MICROARCH.md), ~60 among bare MFMAs: with both in the read section that
-// section outlasts the other group's 256-cycle MFMA cluster it is meant to hide behind, and the matrix pipe idles.
-template <bool STAGGER, bool PRIO, bool CONV, bool SPLITDMA>
+// (Round 3, GPU call 3: issuing the second staging instruction of every phase from inside the wave's own MFMA cluster -
+// to shorten the read sections, which carry 2 global_load_lds at 100 - 185 issue cycles each - measured 4 - 7 % SLOWER on
+// every DiT shape than this loop (profiles/r3_call3/gemm_bench_r3.log); removed.  Compiling the tap walk out of plain
+// GEMMs measured 3 - 5 % faster and is what CONV = false is.)
+template <bool STAGGER, bool PRIO, bool CONV>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
@@ -271,12 +271,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
       while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
   }
   const int nt = p.K / BK;
-  // q0 .. q1: which of the two wave-instructions of the half-tile
-  auto stage_a = [&](int h, int buf, int q0 = 0, int q1 = 1) {  // HA_h of the K-tile the a_in / a_tap state points at
+  auto stage_a = [&](int h, int buf) {  // HA_h of the K-tile the a_in / a_tap state points at
     char* dst = smem + buf * (4 * HT) + h * HT + wave * 2048;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (q >= q0 && q <= q1) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
+    for (int q = 0; q < 2; ++q) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
   };
   auto advance_a = [&]() {
 #pragma unroll
@@ -286,11 +284,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
         while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
     }
   };
-  auto stage_w = [&](int h, int buf, int kt, int q0 = 0, int q1 = 1) {  // HB_h of K-tile kt
+  auto stage_w = [&](int h, int buf, int kt) {  // HB_h of K-tile kt
     char* dst = smem + buf * (4 * HT) + (2 + h) * HT + wave * 2048;
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (q >= q0 && q <= q1) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
+    for (int q = 0; q < 2; ++q) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
   };
 
   // ---- fragments --------------------------------------------------------------------------------------------
@@ -322,23 +319,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   } while (0)
   // one C quadrant x K = 64: 16 MFMAs.  ASUB / WSUB are compile-time so that acc[][] is indexed statically and stays in
   // registers (a run-time quadrant index sends the whole accumulator to scratch).
-  // HOOK: statement issued after the cluster's 4th MFMA (SPLITDMA: the phase's second staging instruction; else empty)
-#define SA_GEMM8_MMA(ASUB, WSUB, HOOK)                                                                            \
+#define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
   do {                                                                                                            \
     if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                             \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
           acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = SA_MFMA_16x16x32(                          \
               wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                          \
-        if (ks == 0 && j == 0) {                                                                                  \
-          if constexpr (SPLITDMA) {                                                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            HOOK;                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-          }                                                                                                       \
-        }                                                                                                         \
-      }                                                                                                           \
     if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 
@@ -365,40 +353,34 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
     SA_GEMM8_READ_W(cb, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_a(cb, 0);
-    if (s1) stage_a(0, nb, 0, SPLITDMA ? 0 : 1);
+    if (s1) stage_a(0, nb);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SA_GEMM8_MMA(0, 0, if (s1) stage_a(0, nb, 1, 1));
+    SA_GEMM8_MMA(0, 0);
     __builtin_amdgcn_s_barrier();
     // P2
     SA_GEMM8_READ_W(cb, 1);
-    if (s1) {
-      stage_a(1, nb, 0, SPLITDMA ? 0 : 1);
-      if (!SPLITDMA) advance_a();
-    }
+    if (s1) { stage_a(1, nb); advance_a(); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // HB(t) is restaged in the next phase: its reads end here
     __builtin_amdgcn_s_barrier();
-    SA_GEMM8_MMA(0, 1, if (s1) { stage_a(1, nb, 1, 1); advance_a(); });
+    SA_GEMM8_MMA(0, 1);
     __builtin_amdgcn_s_barrier();
     // P3
     read_a(cb, 1);
-    if (s2) stage_w(0, cb, t + 2, 0, SPLITDMA ? 0 : 1);
+    if (s2) stage_w(0, cb, t + 2);
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SA_GEMM8_MMA(1, 1, if (s2) stage_w(0, cb, t + 2, 1, 1));
+    SA_GEMM8_MMA(1, 1);
     __builtin_amdgcn_s_barrier();
     // P4
     if (s2) {
-      stage_w(1, cb, t + 2, 0, SPLITDMA ? 0 : 1);
-      // HB0 / HB1 of t+2 stay in flight; K-tile t+1 has landed.  SPLITDMA: the 3 youngest are HB0.q0, HB0.q1, HB1.q0 of
-      // t+2 (HB1.q1 follows inside the MFMA cluster below); every piece of K-tile t+1 is older than those
-      if constexpr (SPLITDMA) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      stage_w(1, cb, t + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // HB0 / HB1 of t+2 stay in flight; K-tile t+1 has landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    SA_GEMM8_MMA(1, 0, if (s2) stage_w(1, cb, t + 2, 1, 1));
+    SA_GEMM8_MMA(1, 0);
     __builtin_amdgcn_s_barrier();
   }
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
@@ -423,7 +405,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // to overlap with: ~1 200 cycles per K-tile for 512 cycles of MFMA work.  PIPE keeps a 3-stage ring (96 KiB) and two
 // fragment sets: the LDS reads of K-tile t+1 are issued BEFORE the MFMAs of K-tile t and complete underneath them, one
 // barrier per K-tile.  Same MFMA order per output element: bitwise identical to the plain form and to gemm8_kernel.
-template <bool PIPE>
+// CONV as in gemm8_kernel: plain GEMMs (kc == K) compile the tap walk out of the staging step.
+template <bool PIPE, bool CONV>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 3 : 2;
@@ -474,7 +457,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       w_row[q] = W + (long)n * p.K + chunk * 8;
       a_in[q] = chunk * 8;
       a_tap[q] = 0;
-      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+      if constexpr (CONV)
+        while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
     }
   }
   const int nt = p.K / BK;
@@ -487,7 +471,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       a_in[q] += BK;
-      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+      if constexpr (CONV)
+        while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
     }
   };
 
@@ -598,20 +583,21 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
-  if (tiles <= 256 && !debug_flag(21)) hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
-  else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, st, p, -1);
+  const bool pipe = tiles <= 256 && !debug_flag(21), conv = p.kc < p.K;
+  const dim3 grid((unsigned)tiles), block(256);
+  if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, -1);
+  else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, -1);
+  else if (conv) hipLaunchKernelGGL((gemm8s_kernel<false, true>), grid, block, 0, st, p, -1);
+  else hipLaunchKernelGGL((gemm8s_kernel<false, false>), grid, block, 0, st, p, -1);
   return hipGetLastError();
 }
 
 hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const dim3 grid((unsigned)tiles), block(512);
-  // A/B builds (tools/gemm_bench.py): mode 1 = the round-2 kernel (tap walk always compiled in, both staging instructions in
-  // the read section); mode 2 = CONV specialisation only; mode 0 = shipped
-  if (mode == 1) hipLaunchKernelGGL((gemm8_kernel<true, true, true, false>), grid, block, 0, st, p, 0);
-  else if (mode == 2 && p.kc >= p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, false, false>), grid, block, 0, st, p, 0);
-  else if (p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true, true>), grid, block, 0, st, p, 0);
-  else hipLaunchKernelGGL((gemm8_kernel<true, true, false, true>), grid, block, 0, st, p, 0);
+  // mode 1 (A/B, tools/gemm_bench.py): the tap walk compiled in whatever the launch (the round-2 kernel)
+  if (mode == 1 || p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true>), grid, block, 0, st, p, 0);
+  else hipLaunchKernelGGL((gemm8_kernel<true, true, false>), grid, block, 0, st, p, 0);
   return hipGetLastError();
 }
 
@@ -622,11 +608,17 @@ hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
 hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
-  if (part == 0 && p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
-  else if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true, false, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
-  else if ((tiles - full) * 4 <= 256 && !debug_flag(21))   // a tail that cannot give a CU two workgroups
-    hipLaunchKernelGGL(gemm8s_kernel<true>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
-  else hipLaunchKernelGGL(gemm8s_kernel<false>, dim3((unsigned)((tiles - full) * 4)), dim3(256), 0, st, p, full);
+  if (part == 0 && p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  else if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true, false>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  else {
+    const bool pipe = (tiles - full) * 4 <= 256 && !debug_flag(21);   // a tail that cannot give a CU two workgroups
+    const bool conv = p.kc < p.K;
+    const dim3 grid((unsigned)((tiles - full) * 4)), block(256);
+    if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, full);
+    else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, full);
+    else if (conv) hipLaunchKernelGGL((gemm8s_kernel<false, true>), grid, block, 0, st, p, full);
+    else hipLaunchKernelGGL((gemm8s_kernel<false, false>), grid, block, 0, st, p, full);
+  }
   return hipGetLastError();
 }
 

@@ -169,7 +169,9 @@ Status MBertEncoder::encode(const long long* ids, const unsigned char* mask, int
       SA_TRY(mgemm(p, bf16_, st));
     }
   }
-  if (nth >= 0 && nth < c.layers) SA_HIP(hipMemcpyAsync(out, w_.h, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+  // nth in [0, layers]: the residual stream after nth layers, never normalised (nth == layers: what transformers 4.48 - 4.5x
+  // records as hidden_states[layers]); nth < 0: last_hidden_state = final_norm of it (= transformers 5.x's hidden_states[layers])
+  if (nth >= 0) SA_HIP(hipMemcpyAsync(out, w_.h, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
   else SA_HIP(launch_layernorm_rows(w_.h, D, g_.final_ln, g_.zeros, out, nullptr, false, M, D, eps, st));
   return Status{};
 }

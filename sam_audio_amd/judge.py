@@ -209,16 +209,31 @@ class _TextTower:
         from .mbert_encoder import ModernBertHIP
         self._hip = ModernBertHIP.from_module(self.module, self._device, precision="fp32")
 
-    def hidden(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], nth: Optional[int]) -> torch.Tensor:
-        """transformers' `hidden_states[nth]` ([B, Lt, hidden]); nth None = last_hidden_state"""
+    def hidden(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor], nth: Optional[int],
+               last_prenorm: bool = True) -> torch.Tensor:
+        """transformers' `hidden_states[nth]` ([B, Lt, hidden]); nth None = last_hidden_state.  nth == num_hidden_layers is
+        version-dependent in transformers (SAMAudioJudgeConfig.last_text_layer_prenorm): `last_prenorm` True = the 4.x
+        meaning (output of the last layer, before final_norm), False = the 5.x meaning (last_hidden_state) - independent of
+        the transformers version that happens to be installed, on both backends."""
         if self.backend == "hip":
             if self._hip is None:
                 raise hip.SamAudioHipError("text tower: load the model's weights on a ROCm GPU first (no CPU fallback)")
-            return self._hip(input_ids, attention_mask, nth)
-        out = self.module(input_ids=input_ids.to(self._device),
-                          attention_mask=None if attention_mask is None else attention_mask.to(self._device),
-                          output_hidden_states=nth is not None)
-        return out.last_hidden_state if nth is None else out.hidden_states[nth]
+            return self._hip(input_ids, attention_mask, nth, last_prenorm=last_prenorm)
+        layers = self.module.config.num_hidden_layers
+        grabbed = []
+        hook = None
+        if nth == layers and last_prenorm:   # the input of final_norm IS the 4.x hidden_states[layers]
+            hook = self.module.final_norm.register_forward_pre_hook(lambda mod, args: grabbed.append(args[0]))
+        try:
+            out = self.module(input_ids=input_ids.to(self._device),
+                              attention_mask=None if attention_mask is None else attention_mask.to(self._device),
+                              output_hidden_states=nth is not None and nth != layers)
+        finally:
+            if hook is not None:
+                hook.remove()
+        if nth is None or (nth == layers and not last_prenorm):
+            return out.last_hidden_state
+        return grabbed[0] if nth == layers else out.hidden_states[nth]
 
 
 def _text_tower(text_cfg: Dict[str, Any]):
@@ -340,7 +355,8 @@ class SAMAudioJudgeModel:
     @torch.inference_mode()
     def _get_text_output(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor]) -> torch.Tensor:
         """reference judge.py:76-88 -> the n-th hidden state [B, Lt, hidden] (pooler_output = [:, 0])."""
-        return self._text.hidden(input_ids, attention_mask, self.config.nth_text_layer)
+        return self._text.hidden(input_ids, attention_mask, self.config.nth_text_layer,
+                                 last_prenorm=self.config.last_text_layer_prenorm)
 
     def _score(self, in_lat: torch.Tensor, sep_lat: torch.Tensor, cand: int, pooled: torch.Tensor,
                frame_mask: Optional[torch.Tensor]) -> torch.Tensor:

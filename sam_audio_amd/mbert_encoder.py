@@ -168,7 +168,10 @@ class ModernBertHIP:
 
     @torch.inference_mode()
     def encode(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-               nth: Optional[int] = None) -> torch.Tensor:
+               nth: Optional[int] = None, last_prenorm: bool = True) -> torch.Tensor:
+        """nth None = last_hidden_state; 0 <= nth < layers = `hidden_states[nth]`; nth == layers = `hidden_states[layers]` as
+        transformers 4.48 - 4.5x define it (the last layer's output BEFORE final_norm; `last_prenorm=True`, the default) or as
+        transformers 5.x define it (= last_hidden_state; `last_prenorm=False`)."""
         if not self._loaded:
             raise hip.SamAudioHipError("ModernBertHIP: no weights loaded")
         assert input_ids.dim() == 2, "input_ids must be [B, Lt]"
@@ -190,7 +193,8 @@ class ModernBertHIP:
             need = self._lib.samaudio_mbert_workspace_bytes(self._h, rows, tokens)
             ensure_ws(self, need, lambda p, b: self._lib.samaudio_mbert_set_workspace(self._h, p, b))
             hip.check(self._lib.samaudio_mbert_encode(self._h, hip.ptr(ids), hip.ptr(mask), rows, tokens,
-                                                      -1 if nth is None else int(nth), hip.ptr(out), hip.current_stream_ptr()))
+                                                      -1 if nth is None or (nth == self.dims.num_hidden_layers and not last_prenorm)
+                                                      else int(nth), hip.ptr(out), hip.current_stream_ptr()))
         return out
 
     __call__ = encode

@@ -276,3 +276,33 @@ def test_attach_rankers_skips_what_cannot_be_built_offline():
     m.text_ranker = marker
     m.attach_rankers()
     assert m.text_ranker is marker          # an attached ranker is never replaced
+
+
+def test_last_text_hidden_state_semantics_do_not_depend_on_the_installed_transformers():
+    """hidden_states[num_hidden_layers] is the last layer's output BEFORE final_norm in transformers
+    4.48 - 4.5x (what the reference pins and the Judge was trained with) and the normalised tensor in 5.x; the reference's
+    default nth_text_layer = 22 selects exactly that entry.  `last_text_layer_prenorm` (default True = 4.x) decides, on the
+    torch backend too (the HIP backend: tests/test_mbert_gpu.py)."""
+    from sam_audio_amd.judge import _TextTower
+    tm = G.make_text_model(SAMAudioJudgeConfig(text_model=G.TINY_TEXT), seed=5) if hasattr(G, "make_text_model") else None
+    if tm is None:
+        import transformers
+        torch.manual_seed(5)
+        tm = transformers.ModernBertModel(transformers.ModernBertConfig(**G.TINY_TEXT)).eval()
+    L = tm.config.num_hidden_layers
+    tower = _TextTower(tm, backend="torch")
+    tower.place("cpu")
+    ids = torch.randint(3, 128, (2, 7), generator=torch.Generator().manual_seed(1))
+    mask = torch.ones(2, 7, dtype=torch.long)
+    grabbed = []
+    hook = tm.final_norm.register_forward_pre_hook(lambda mod, args: grabbed.append(args[0]))
+    with torch.inference_mode():
+        ref = tm(input_ids=ids, attention_mask=mask, output_hidden_states=True)
+    hook.remove()
+    with torch.inference_mode():
+        pre = tower.hidden(ids, mask, L)                        # default: 4.x meaning
+        post = tower.hidden(ids, mask, L, last_prenorm=False)   # 5.x meaning
+        mid = tower.hidden(ids, mask, L - 1)
+    assert torch.equal(pre, grabbed[0]) and torch.equal(post, ref.last_hidden_state)
+    assert torch.equal(mid, ref.hidden_states[L - 1]) and not torch.allclose(pre, post)
+    assert SAMAudioJudgeConfig().last_text_layer_prenorm is True

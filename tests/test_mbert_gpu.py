@@ -65,9 +65,19 @@ def test_tower_fp32_matches_transformers_at_every_hidden_state(gpu, kw, B, L):
     valid = mask.bool()
     worst = 0.0
     for n in list(range(cfg.num_hidden_layers + 1)) + [None]:
-        got = tower(ids.to(gpu), mask.to(gpu), n).cpu()
+        # last_prenorm=False: hidden_states[layers] as the installed transformers (5.x) records it
+        got = tower(ids.to(gpu), mask.to(gpu), n, last_prenorm=False).cpu()
         want = ref.last_hidden_state if n is None else ref.hidden_states[n]
         worst = max(worst, _rel(got, want, valid), _rel(got, last if n is None else states[n], valid))
+    # the default: hidden_states[layers] as transformers 4.48 - 4.5x record it = the input of final_norm
+    grabbed = []
+    hook = m.final_norm.register_forward_pre_hook(lambda mod, args: grabbed.append(args[0]))
+    with torch.inference_mode():
+        m(input_ids=ids, attention_mask=mask)
+    hook.remove()
+    pre = tower(ids.to(gpu), mask.to(gpu), cfg.num_hidden_layers).cpu()
+    worst = max(worst, _rel(pre, grabbed[0], valid))
+    assert _rel(pre, ref.last_hidden_state, valid) > 1e-2   # and it is NOT the normalised tensor
     print(f"mbert fp32 B={B} L={L}: worst hidden state vs transformers / oracle rel {worst:.2e}")
     assert worst < 2e-5
     no_mask = tower(ids.to(gpu), None).cpu()

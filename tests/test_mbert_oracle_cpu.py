@@ -54,6 +54,17 @@ def test_oracle_matches_transformers_modernbert(kw, B, L):
     err = (last - ref.last_hidden_state)[valid].abs().max().item() / ref.last_hidden_state[valid].abs().max().item()
     print(f"mbert oracle vs transformers: last_hidden_state rel {err:.2e}")
     assert err < 5e-6
+    # the other generation's hidden_states[layers] (transformers 4.48 - 4.5x: before final_norm) = what goes INTO the
+    # installed module's final_norm, whatever that module then records as its last hidden state
+    grabbed = []
+    hook = m.final_norm.register_forward_pre_hook(lambda mod, args: grabbed.append(args[0]))
+    with torch.inference_mode():
+        m(input_ids=ids, attention_mask=mask)
+        pre, last4 = O.mbert_hidden_states(m.state_dict(), dims, ids, mask, last_prenorm=True)
+    hook.remove()
+    err = (pre[-1] - grabbed[0])[valid].abs().max().item() / grabbed[0][valid].abs().max().item()
+    assert err < 5e-6 and torch.equal(last4, last)
+    assert not torch.allclose(pre[-1], states[-1]) and all(torch.equal(a, b) for a, b in zip(pre[:-1], states[:-1]))
 
 
 def test_host_relayout_keys_and_rope_tables():

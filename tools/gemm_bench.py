@@ -144,8 +144,7 @@ def main():
     D, Fh = t.dim, t.ffn_hidden
     if args.r3:
         VARIANTS.clear()
-        VARIANTS.update({-1: "auto policy", 22: "8-phase 256x256 (shipped: plain spec + split DMA)", 23: "8-phase round-2 loop",
-                         24: "8-phase plain spec only", 27: "gemm8s 128x128"})
+        VARIANTS.update({-1: "auto policy", 22: "8-phase 256x256", 23: "8-phase, round-2 build", 27: "gemm8s 128x128"})
         BLAS[0] = True
         run_case("square 4096", 4096, 4096, 4096, "plain", dev, args.iters)
         for clips in (32, 16, 4):
