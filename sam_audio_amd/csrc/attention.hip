@@ -29,27 +29,17 @@ template <int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt,
                                                                  const unsigned char* __restrict__ key_mask,
-                                                                 bf16_t* __restrict__ out, int T, int Tp, int H, int nq,
-                                                                 int npairs) {
+                                                                 bf16_t* __restrict__ out, int T, int Tp, int H) {
   constexpr int CH = HD / 8;       // 16-byte chunks per K row
   constexpr int KS = HD / 32;      // k-steps of the S = Q K^T contraction
   constexpr int NF = HD / 16;      // output fragments (16 head channels each)
   __shared__ __attribute__((aligned(16))) char Ks[64 * HD * 2];   // [key][HD d] bf16, chunk ^= key & (CH - 1)
   __shared__ __attribute__((aligned(16))) char Vs[HD * 128];      // [d][64 keys] bf16, chunk ^= (d >> 1) & 7
   __shared__ __attribute__((aligned(16))) char Ps[NW * 16 * 128];  // per wave [16 q][64 keys] bf16
-  // nq > 0: 1-D grid dealt so that the nq query blocks of one (batch, head) run back to back on the SAME XCD (workgroup i
-  // runs on XCD i % 8): each of them streams the pair's whole K and V^T, and with (query block, head, batch) as a 3-D grid
-  // consecutive query blocks land on different XCDs, so every block fetched them through its own L2 (PMC: 225 MB fetched
-  // per launch for 135 MB of Q + K + V^T at T = 250, profiles/r2_traffic.json).
-  int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  if (nq > 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int pair = xcd + 8 * (slot / nq);
-    if (pair >= npairs) return;
-    qb = slot % nq;
-    h = pair % H;
-    b = pair / H;
-  }
+  // (Round 2, call 28: a 1-D grid dealing the query blocks of a (batch, head) onto one XCD, so that the second block finds
+  // K / V^T in that L2 - PMC: 225 MB fetched per launch for 135 MB of operands - was bitwise identical, 65.2 vs 66.8 us in
+  // isolation and nothing end to end; a 16-wave / 256-query-row workgroup measured slower, 72.8 vs 66.4 us.  Both removed.)
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int q0 = qb * (16 * NW);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
@@ -251,29 +241,12 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
 template <int HD>
 static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                           void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
-  // flag 13 (A/B, off): HD = 128 and whole 256-row blocks with 16 waves per workgroup, so that K / V^T of a (batch, head)
-  // are staged once instead of once per 128 query rows - measured SLOWER (72.8 vs 66.4 us, profiles/r2_call12/)
-  if constexpr (HD == 128) {
-    if (bf16 && Tp % 256 == 0 && debug_flag(13)) {
-      hipLaunchKernelGGL((self_attn_bf16_kernel<16, HD>), dim3(Tp / 256, H, B), dim3(1024), 0, st, (const bf16_t*)Q,
-                         (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H, 0, 0);
-      return hipGetLastError();
-    }
-  }
-  // flag 23 (A/B): 1-D grid with the query blocks of a (batch, head) on one XCD (see the kernel)
-  const int pairs = H * B;
-  const bool xcd_pairs = debug_flag(23) != 0;
-  if (bf16 && Tp % 128 == 0) {
-    const int nq = Tp / 128;
-    const dim3 grid = xcd_pairs ? dim3(8 * nq * ((pairs + 7) / 8)) : dim3(nq, H, B);
-    hipLaunchKernelGGL((self_attn_bf16_kernel<8, HD>), grid, dim3(512), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H, xcd_pairs ? nq : 0, pairs);
-  } else if (bf16) {
-    const int nq = Tp / 64;
-    const dim3 grid = xcd_pairs ? dim3(8 * nq * ((pairs + 7) / 8)) : dim3(nq, H, B);
-    hipLaunchKernelGGL((self_attn_bf16_kernel<4, HD>), grid, dim3(256), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
-                       (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H, xcd_pairs ? nq : 0, pairs);
-  }
+  if (bf16 && Tp % 128 == 0)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<8, HD>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else if (bf16)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<4, HD>), dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
   else
     hipLaunchKernelGGL(self_attn_f32_kernel<HD>, dim3((T + 31) / 32, H, B), dim3(256), 0, st, (const float*)Q,
                        (const float*)K, (const float*)Vt, key_mask, (float*)out, T, Tp, H);

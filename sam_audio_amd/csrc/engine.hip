@@ -444,8 +444,8 @@ Status Engine::res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, doub
   static const int kMask[4] = {1, 2, 4, 8};
   const int ci = p.N == 64 ? 0 : p.N == 96 ? 1 : p.N == 128 ? 2 : p.N == 192 ? 3 : -1;
   // fused where it measured faster than the two launches (profiles/r2_call20/op_bench.log, 8 waveforms: C = 64 844 vs
-  // 1028 us, C = 96 2127 vs 2236; C = 128 1419 vs 1395 and C = 192 2825 vs 2772 stay two launches); flag 17 toggles bits
-  const int excluded = (4 | 8) ^ debug_flag(17);
+  // 1028 us, C = 96 2127 vs 2236; C = 128 1419 vs 1395 and C = 192 2825 vs 2772 stay two launches)
+  const int excluded = 4 | 8;
   const bool fuse = bf16_ && ci >= 0 && !debug_flag(16) && !(excluded & kMask[ci]) && resunit_ok(fp, fq) &&
                     ((long)((p.M + 255) / 256) * p.nbatch >= 256 || debug_flag(18));
   if (!fuse) {
@@ -691,7 +691,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_TRY(gemm(p, st, -1.0, TIME, f));
   }
   // RMSNorm + modulate operands of this evaluation, pre-combined for every layer's two norms (kernels.hip mod_tables)
-  const bool mod_gs = !debug_flag(24) && 2 * cfg_.n_layers <= kMaxModNorms && cfg_.n_layers > 0 && D <= 256 * 12;
+  const bool mod_gs = 2 * cfg_.n_layers <= kMaxModNorms && cfg_.n_layers > 0 && D <= 256 * 12;
   const long gs_ld = nt == 1 ? 0 : 2L * D;
   if (mod_gs) {
     ModTables mt;

@@ -255,93 +255,72 @@ static int gemm1_variant(const GemmParams& p) {
   if (t128 < 192) return 2 * t128 < 192 ? 2 : 1;
   return 0;
 }
-// Which kernel launch_gemm runs: 0..2 = gemm.hip tiles, 3 + v = gemm2.hip variant v (bf16 only).  The choice
-// depends on (N, K, epilogue) only - never on M or the batch count - so that sharding the batch cannot change
-// the accumulation order of any output element.
+// Which kernel launch_gemm runs: 0..2 = gemm.hip tiles, 3 + v = gemm2.hip / gemm8.hip variant v (16-bit operands only).  The
+// choice depends on (N, K, epilogue) and - only INSIDE one accumulation-order family - on the number of rows, so that
+// sharding the batch cannot change the accumulation order of any output element:
+//   16x16x32 family: 22 = gemm8 (256x256, 8-phase K loop), 27 = gemm8s (128x128) - every N >= 256;
+//   32x32x16 family: 25 / 26 (128x128, 64x128 BK 64), 28 (256x64), 29 / 32 / 33 / 34 (BK 32 multi-workgroup tiles),
+//                    35 = conv7h - the DAC-VAE stages with 64 .. 192 channels.
+// How each entry was chosen (one-box A/B per step, round 2): DESIGN.md sections 3.1 and 3.4, profiles/r2_call*/.
 int gemm_variant(const GemmParams& p, bool is_bf16) {
   const bool g2 = is_bf16 && gemm2_ok(p);
   if (g_force >= 3) {
-    const bool known = g_force == 3 || g_force == 4 || g_force == 5 || g_force == 6 || g_force == 9 ||
-                       (g_force >= 12 && g_force < kGemmVariants);  // incl. 25 / 26 / 27
+    const bool known = g_force == 22 || (g_force >= 25 && g_force <= 29) || (g_force >= 32 && g_force < kGemmVariants);
     if (g_force == 35 && !(g2 && conv7h_ok(p))) return gemm1_variant(p);   // conv7h computes convolutions only
     return g2 && known ? g_force : gemm1_variant(p);
   }
-  if (g_force >= 0) return gemm1_variant(p);
-  // 64-channel convolutions (first DAC encoder stage: 7 launches per encode, 53 GB of activations at the benchmark
-  // shape): one 64-wide tile of the DMA-fed family instead of gemm.hip's first-generation 128x64 tile (flag 14 = old path)
-  // k7 'same' convolutions of the DAC stages with <= 192 channels: halo tile resident in LDS (gemm2.hip conv7h_kernel; same
-  // bits as the implicit GEMM below, which stays the path for launches too small to fill the chip).  Flag 11 = off.
-  // conv7h where it measured faster than the implicit GEMM of the same family (profiles/r2_call18, r2_call19: C = 64
-  // 485 vs 567 us, C = 96 1149 vs 1307 us; C = 128 874 vs 790 and C = 192 1571 vs 1513 us stay implicit GEMMs)
-  if (g2 && !debug_flag(11) && p.N <= 96 && conv7h_ok(p) && (long)((p.M + 255) / 256) * p.nbatch >= 256) return 35;
-  // The small-launch fallback must stay in the SAME MFMA family (128x64 BK-32 tile of gemm2.hip, not gemm.hip's 16x16x32
-  // kernel): how many waveforms one codec pass holds depends on the workspace the caller happens to have, and a family
-  // switch at a row-count threshold made the last clip of a batch differ in the last bits between two identical calls
-  // (caught by tests/test_path_gpu.py::test_concurrent_streams_are_bitwise_equal_to_one_stream, GPU call 14).
-  if (g2 && p.N >= 64 && p.N < 96 && p.K >= 64 && !debug_flag(14))
-    return (long)((p.M + 255) / 256) * p.nbatch >= 256 ? 28 : 32;
-  // Narrow outputs with very many rows (the DAC stages with 96 / 128 / 192 channels at T = 240 000 .. 480 000): a K-tile
-  // of such a tile is ~0.4 us of MFMA work behind ~2 us of L2 latency, so what pays is MORE TILES IN FLIGHT per CU, not a
-  // deeper ring in one workgroup: BK 32, 36 - 60 KiB per workgroup, 2 - 4 workgroups per CU (op_bench on MI355X,
-  // profiles/r2_call13/: k7 C=96 1429 -> 1207 us, k1+residual C=96 1255 -> 1065, k1 C=192 1442 -> 1277, k7 C=192 1587 ->
-  // 1509 for 8 waveforms).  Same MFMA shape and K order as the rest of the family.  Flag 15 = previous choice.
-  if (g2 && !debug_flag(15) && p.N >= 96 && p.N <= 192 && p.K >= 64 && (long)((p.M + 127) / 128) * p.nbatch >= 1024) {
+  if (g_force >= 0 || !g2) return gemm1_variant(p);
+  const long rows256 = (long)((p.M + 255) / 256) * p.nbatch, rows128 = (long)((p.M + 127) / 128) * p.nbatch;
+  // k7 'same' convolutions of the DAC stages with <= 96 channels: halo tile resident in LDS (C = 64 485 vs 567 us, C = 96
+  // 1149 vs 1307 us for the implicit GEMM; C = 128 / 192 measured slower and stay implicit GEMMs).  Flag 11 = off (tests).
+  if (!debug_flag(11) && p.N <= 96 && conv7h_ok(p) && rows256 >= 256) return 35;
+  // 64-channel outputs (first DAC encoder stage): one 64-wide tile of the DMA-fed family.  The small-launch fallback stays
+  // in the SAME MFMA family: how many waveforms one codec pass holds depends on the caller's workspace, and a family
+  // switch at a row-count threshold made two identical calls differ in the last bits (round 2, GPU call 14).
+  if (p.N >= 64 && p.N < 96 && p.K >= 64) return rows256 >= 256 ? 28 : 32;
+  // 96 - 192 channels with very many rows: a K-tile of such a tile is ~0.4 us of MFMA work behind ~2 us of L2 latency, so
+  // what pays is MORE TILES IN FLIGHT per CU: BK 32, 36 - 60 KiB per workgroup, 2 - 4 workgroups per CU.
+  if (p.N >= 96 && p.N <= 192 && p.K >= 64 && rows128 >= 1024) {
     if (p.N <= 128) return p.K <= 256 ? 33 : 29;   // 64x128 k32 s3 (k1) | 128x128 k32 s3 (k7)
-    if (p.N == 192) return p.K <= 256 ? 29 : 34;   // 128x128 k32 s3 (k1) | 128x192 k32 s3 (k7)
+    return p.K <= 256 ? 29 : 34;                   // 128x128 k32 s3 (k1) | 128x192 k32 s3 (k7)
   }
-  if (g2 && p.N >= 96 && p.K >= 128) {
-    // round-1 policy (A/B switch, flag 5): 256x256 ping-pong for the widest outputs, 256x128 2-stage ring elsewhere
-    if (debug_flag(5)) return p.N >= 12288 ? 9 : (p.N == 192 && !debug_flag(4) ? 6 : 4);
-    // round 2, measured on MI355X (profiles/r2_gemm_variants.log, profiles/r2_call3/, M = 8000): the 8-phase 256x256
-    // kernel (16x16x32 MFMA) for every DiT-class output width - w13 1128 vs 957 TF/s for the best other kernel, qkv 960
-    // vs 855, w2 860 vs 814, c_wq 839 vs 821, wo 615 vs 615 -; with its LDS-staged epilogue it no longer loses at N = D
-    // (352 tiles on 256 CUs) and a second stream fills its tile tails (200.5 vs 183.2 s-audio/s for the previous policy).
-    // Few rows: the 128x128 tile of the SAME family (gemm8s, bitwise identical results, two workgroups per CU) once the
-    // 256x256 tiling would leave most CUs without a tile - so the choice may depend on M without breaking batch-sharding
-    // invariance.  Codec convolutions with that many output columns ride the same kernels.
-    // N >= 1024 since GPU call 5: the vision tower's out_proj / c_proj (N = 1024, M = 144 000) ran at 624 TF/s on the
-    // loader-wave kernel, small* (D = 1536) at 264 TF/s on the 128x128 tile of the other family
-    // N >= 256 since GPU call 21: the DAC stages with 256 - 768 channels (38 launches per step) took 44.7 + 13.3 ms on the
-    // loader-wave 256x128 kernel + this family, 47.8 ms on this family alone; outputs that are not a multiple of 256 wide
-    // (N = 384) use its 128x128 tile whatever M (712 / 665 TF/s per symbol vs 554; profiles/r2_call21/).  Flag 19 = before.
-    if (p.N >= (debug_flag(7) ? 4096 : debug_flag(19) ? 1024 : 256)) {
-      const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
+  if (p.N >= 96 && p.K >= 128) {
+    if (p.N >= 256) {
+      // The 8-phase family: gemm8 when the 256x256 tiling yields >= 128 tiles, else its 128x128 tile (few rows: 4 clips per
+      // GPU, the Judge's small batches; N = 384 whatever M).  (Round 3, GPU call 2: the same kernel on a 256x192 tile - 480
+      // instead of 352 tiles at N = D - was 8 - 13 % faster per launch on the N = D shapes and 5 % SLOWER end to end: a
+      // 256x192 tile delivers 20 % fewer flops per CU-second, and the CUs a 352-tile launch leaves idle are not idle in the
+      // timed configuration - the other row group's HBM-bound kernels run on them.  profiles/r3_call2/.)
+      const long t256 = rows256 * ((p.N + 255) / 256);
       if (p.N < 1024 && p.N % 256) return 27;
-      // (round 3, GPU call 2: the same kernel on a 256x192 tile - 480 instead of 352 tiles at N = D, bitwise identical - was
-      // 8 - 13 % faster per launch on the N = D shapes and 5 % SLOWER end to end: 199.5 vs 210.2 s-audio/s with two row
-      // groups, 191.2 vs 193.1 with one.  A 256x192 tile delivers 20 % fewer flops per CU-second than a 256x256 one, and
-      // the CUs a 352-tile launch leaves idle are not idle in the timed configuration - the other row group's HBM-bound
-      // kernels run on them.  Removed; profiles/r3_call2/)
-      return t256 >= 128 || debug_flag(6) ? 22 : 27;
+      return t256 >= 128 ? 22 : 27;
     }
-    if (p.N == 192 && !debug_flag(4)) return 6;
-    // Few rows (strong scaling: 4 clips per GPU = 1000 rows): 256-row tiles leave most CUs idle (4 x 22 = 88 tiles at
-    // N = D).  Smaller M-tiles of the SAME kernel family keep every element's accumulation order (32x32x16 MFMA, K walked
-    // slab by slab), so the choice may depend on M without breaking bitwise batch-sharding invariance.
-    if (!debug_flag(6)) {
-      const long tn = (p.N + 127) / 128;
-      if ((long)((p.M + 255) / 256) * tn * p.nbatch >= 192) return debug_flag(9) ? 19 : 20;
-      if ((long)((p.M + 127) / 128) * tn * p.nbatch >= 192) return 25;
-      return 26;
-    }
-    return debug_flag(9) ? 19 : 20;
+    // 96 <= N < 256 with few rows: 128- / 64-row tiles of the 32x32x16 family
+    return rows128 * ((p.N + 127) / 128) >= 192 ? 25 : 26;
   }
   return gemm1_variant(p);
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
-  static const char* names[2][kGemmVariants] = {
-      {"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", "", ""},
-      {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32", "gemm2_bf16_256x128_s3", "gemm2_bf16_256x128_s2",
-       "gemm2_bf16_256x256_s2", "gemm2_bf16_256x192_s2", "", "", "gemm3_bf16_256x256_pp2", "", "", "abl_nodma", "abl_nomfma",
-       "abl_noread", "gemm5_bf16_256x256_ld_s2", "gemm5_bf16_256x256_ld_h4", "gemm5_bf16_256x128_ld_s3",
-       "gemm2_bf16_256x128_k32_s3", "gemm5_bf16_256x128_ld_s3_pf",
-       "gemm5_bf16_256x128_ld_s3_pf_persist", "gemm5_bf16_256x256_ld_s2_persist", "gemm8_bf16_256x256_8phase", "gemm8_bf16_256x256_8phase_r2loop",
-       "", "gemm2_bf16_128x128_s2", "gemm2_bf16_64x128_s3", "gemm8s_bf16_128x128", "gemm2_bf16_256x64_s2", "gemm2_bf16_128x128_k32_s3", "gemm2_bf16_128x128_k32_s4",
-       "gemm2_bf16_128x128_k32_s2", "gemm2_bf16_128x64_k32_s2", "gemm2_bf16_64x128_k32_s3", "gemm2_bf16_128x192_k32_s3",
-       "conv7h_bf16"}};
   if (v < 0 || v >= kGemmVariants) return "";
-  const char* n = names[is_bf16 ? 1 : 0][v];
-  return n ? n : "";
+  if (v < 3) {
+    static const char* base[2][3] = {{"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32"},
+                                     {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32"}};
+    return base[is_bf16 ? 1 : 0][v];
+  }
+  if (!is_bf16) return "";
+  switch (v) {
+    case 22: return "gemm8_bf16_256x256_8phase";
+    case 25: return "gemm2_bf16_128x128_s2";
+    case 26: return "gemm2_bf16_64x128_s3";
+    case 27: return "gemm8s_bf16_128x128";
+    case 28: return "gemm2_bf16_256x64_s2";
+    case 29: return "gemm2_bf16_128x128_k32_s3";
+    case 32: return "gemm2_bf16_128x64_k32_s2";
+    case 33: return "gemm2_bf16_64x128_k32_s3";
+    case 34: return "gemm2_bf16_128x192_k32_s3";
+    case 35: return "conv7h_bf16";
+    default: return "";
+  }
 }
 
 template <typename T>
@@ -357,7 +336,7 @@ static hipError_t launch_t(const GemmParams& p, int variant, hipStream_t st) {
 // returns the number of tiles the main launch keeps, 0 = one launch.  Only when the policy (not a forced variant) chose
 // the kernel; the tail must be worth a launch (>= 16 tiles) and the last round must be at most 3/4 full.
 int gemm_tail_split(const GemmParams& p, bool is_bf16) {
-  if (g_force >= 0 || debug_flag(10) || (p.flags & 2) || gemm_variant(p, is_bf16) != 22) return 0;
+  if (g_force >= 0 || (p.flags & 2) || gemm_variant(p, is_bf16) != 22) return 0;
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const long full = tiles / 256 * 256, rem = tiles - full;
   // ... and only for launches of a few rounds: with many rounds the idle part of the last one is a small share of the

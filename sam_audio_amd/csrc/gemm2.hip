@@ -52,93 +52,6 @@ __device__ __forceinline__ float act_apply(float v, int act, float snake_alpha) 
 
 }  // namespace
 
-// ---- epilogue shared by the gemm2 / gemm3 kernels -----------------------------------------------------------
-// swapped operands: D[n][m]; a lane holds m = m_first + i*32 + l31 and, per 32x32 fragment j, the columns
-// n = n_first + j*32 + 8*g + 4*lh + (0..3) for register group g = reg>>2.  Per fragment all loads (bias / gate /
-// residual, float4 each) are issued first, then the arithmetic, then 16-byte fp32 / 8-byte bf16 stores.
-// U = register groups per round trip (2: 32 registers of loads in flight; 1 for kernels with a 168-register budget).
-template <int FM, int FN, int U = 2>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[FM][FN], int b, int m_first,
-                                              int n_first, int l31, int lh) {
-  const long bM = (long)b * p.M;
-  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
-             has_res = p.res != nullptr, has_snake = p.act == ACT_SNAKE;
-  const int NG = p.swiglu ? 2 : 4;       // swiglu: groups 0,1 = w1 rows of the 32-row block, groups 2,3 = matching w3 rows
-  const int n_out = p.swiglu ? p.N >> 1 : p.N;
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = m_first + i * 32 + l31;
-    const bool m_ok = m < p.M;
-    const int mc = m_ok ? m : p.M - 1;
-    const float* grow = has_gate ? p.gate + ((bM + mc) / p.rows_per_gate) * p.gate_ld : nullptr;
-    const float* rrow = has_res ? p.res + p.res_off + (long)b * p.res_bstride + (long)mc * p.res_ld : nullptr;
-    float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)mc * p.f32_ld : nullptr;
-    bf16_t* arow = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)mc * p.act_ld : nullptr;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int nf = n_first + j * 32;  // first GEMM column of this 32-wide fragment
-      const int nb = (p.swiglu ? nf >> 1 : nf) + 4 * lh;
-      // U register groups (4 output columns per lane each) per round trip: 16*U registers of loads in flight
-#pragma unroll
-      for (int gp = 0; gp < 4; gp += U) {
-        if (gp >= NG) continue;
-        int ncol[U];
-        float4 bb[U], gg[U], tt[U], rr[U], sa[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int n = nb + 8 * (gp + u);
-          ncol[u] = n;
-          const int nc = n + 4 <= n_out ? n : n_out - 4;  // clamped address for the loads of masked columns
-          const int ch = p.chan_mod ? nc % p.chan_mod : nc;  // channel of a (phase, channel) column: transposed conv
-          if (has_bias) bb[u] = *(const float4*)(p.bias + ch);
-          if (has_snake) sa[u] = *(const float4*)(p.act_alpha + ch);
-          if (has_gate) gg[u] = *(const float4*)(grow + nc);
-          if (has_tab) tt[u] = *(const float4*)(p.gate_tab + nc);
-          if (has_res) rr[u] = *(const float4*)(rrow + nc);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int g = gp + u;
-          float v[4];
-          if (p.swiglu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(acc[i][j][4 * g + e]) * acc[i][j][4 * ((g + 2) & 3) + e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-          }
-          if (has_bias) { v[0] += bb[u].x; v[1] += bb[u].y; v[2] += bb[u].z; v[3] += bb[u].w; }
-          if (has_gate) {
-            float4 q = gg[u];
-            if (has_tab) { q.x += tt[u].x; q.y += tt[u].y; q.z += tt[u].z; q.w += tt[u].w; }
-            v[0] *= q.x; v[1] *= q.y; v[2] *= q.z; v[3] *= q.w;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-          if (has_res) { v[0] += rr[u].x; v[1] += rr[u].y; v[2] += rr[u].z; v[3] += rr[u].w; }
-          float a[4];
-          a[0] = act_apply(v[0], p.act, has_snake ? sa[u].x : 0.f);
-          a[1] = act_apply(v[1], p.act, has_snake ? sa[u].y : 0.f);
-          a[2] = act_apply(v[2], p.act, has_snake ? sa[u].z : 0.f);
-          a[3] = act_apply(v[3], p.act, has_snake ? sa[u].w : 0.f);
-          bool ok = m_ok && ncol[u] < n_out;
-          if (p.c_ld_rel) {  // transposed conv: keep only the (row, phase) pairs that fall inside the output
-            const long erel = (long)m * p.c_ld_rel + ncol[u];
-            ok = ok && erel >= p.c_lo && erel < p.c_hi;
-          }
-          if (ok) {
-            if (frow) {
-              if (p.f32_act) *(float4*)(frow + ncol[u]) = make_float4(a[0], a[1], a[2], a[3]);
-              else *(float4*)(frow + ncol[u]) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            if (arow) store4<bf16_t>(arow + ncol[u], a[0], a[1], a[2], a[3]);
-          }
-        }
-      }
-    }
-  }
-}
-
 // ---- LDS-staged variant of the same epilogue ----------------------------------------------------------------------
 // In the accumulator layout above one store instruction covers 32 different rows for 32 contiguous bytes each: 32 cache
 // lines per instruction, for the fp32 residual read, the fp32 write and the bf16 write alike - the three residual GEMMs
@@ -374,458 +287,9 @@ __global__ __launch_bounds__(WM_* WN_ * 64, (WM_ * WN_ == 4 && BM * BN >= 256 * 
     st_i = st_i + 1 == STAGES ? 0 : st_i + 1;
   }
 
-  if (p.flags & 1) {  // A/B: the round-1 epilogue straight from the accumulator layout
-    gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
-  } else {
-    static_assert(NW * FN * 4096 <= STAGES * STAGE, "epilogue staging fits the ring");
-    __syncthreads();  // every wave is done with the last slab (no DMA is in flight any more)
-    gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (FN * 4096));
-  }
-}
-
-// ---- gemm3: role-split ("ping-pong") main loop ---------------------------------------------------------------
-// PMC on gemm2 (profiles/r1_pmc_gemm): MFMA busy 42 %, no LDS bank conflicts, L2 hit 81 %, waves parked 40 % of
-// their cycles in s_waitcnt / s_barrier - all 8 waves read LDS together and then fight for the matrix pipe together.
-// Here the two waves that share a SIMD (wave w and w+4: groups 0 and 1) run ONE PHASE APART: while group 0 issues
-// the MFMAs of a half-slab from registers (s_setprio 1, nothing else in the stream), group 1 fetches its next
-// fragments from LDS (+ issues the next slab's DMA), then they swap.  Every phase boundary is one s_barrier for all
-// 8 waves; group 1 simply idles through the first phase.  Fragments of a phase live in registers (KSP k-steps:
-// KSP*(FM+FN) ds_read_b128 per wave), two LDS stages, BK = 64.
-//   global phase p, group g: local step q = p - g;  q even -> R(h = q/2): ds_reads of half-slab h (+ DMA of slab
-//   s+1 when h is the first half of slab s);  q odd -> M(h): MFMAs of half-slab h.
-//   Slab s is read during global phases [2*HPS*s, 2*HPS*(s+1)) only, so the DMA of slab s+1 (same stage as slab
-//   s-1) may start at phase 2*HPS*s and must have landed before phase 2*HPS*(s+1): every wave drains its own
-//   vmcnt before the barrier that ends phase 2*HPS*(s+1)-1.
-// ABL (tuning only, wrong results): 1 = no DMA after the prologue, 2 = no MFMA, 3 = no LDS fragment reads.
-template <int BM, int BN, int WM_, int WN_, int KSP, int NS, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm3_kernel(const GemmParams p) {
-  constexpr int NW = 8;
-  static_assert(WM_ * WN_ == NW && (WM_ == 2 || WN_ == 2), "8 waves; the 2-wide axis is the group axis");
-  constexpr int WTM = BM / WM_, WTN = BN / WN_;
-  constexpr int FM = WTM / 32, FN = WTN / 32;
-  constexpr int BK = 64, RB = 128, CH = 8, KS = 4;
-  constexpr int HPS = KS / KSP;  // phases pairs ("half-slabs") per slab
-  static_assert(KSP == 2 || KSP == 4, "KSP");
-  constexpr int AI = BM / (8 * NW), BI = BN / (8 * NW);
-  constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
-  constexpr int G = AI + BI;
-  static_assert(BM % 64 == 0 && BN % 64 == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile");
-  static_assert((NS == 2 || NS == 3) && NS * STAGE <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;  // waves w and w+4 share a SIMD
-  const int wm = WM_ == 2 ? grp : (wave & 3), wn = WM_ == 2 ? (wave & 3) : grp;
-
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int per_batch = tiles_m * tiles_n;
-  int b, tm, tn;
-  {
-    const int total = per_batch * p.nbatch;
-    const int bid = blockIdx.x;
-    const int q = total >> 3, r = total & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    b = L / per_batch;
-    const int l2 = L - b * per_batch;
-    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
-    const int per_group = GM * tiles_n;
-    const int gi = l2 / per_group;
-    const int first_m = gi * GM;
-    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
-    const int in_grp = l2 - gi * per_group;
-    tm = first_m + in_grp % gsz;
-    tn = in_grp / gsz;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // DMA bookkeeping kept to a handful of registers (the accumulators and the phase's fragments own the file):
-  // piece i of this wave covers tile row (wave + 8*i)*8 + r8; its source address is rebuilt at issue time from
-  // the clamped global row and the running k offset.
-  const int r8 = lane >> 3;
-  const int chunk = (lane & 7) ^ ((4 * (wave & 1) + (r8 >> 1)) & 7);
-  const bf16_t* const Abase = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
-  const bf16_t* const Wbase = (const bf16_t*)p.W + (long)b * p.w_bstride;
-  const int row0 = wave * 8 + r8;
-  int a_in = chunk * CH;
-  long a_tap = 0;
-  while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
-  int w_k = chunk * CH;
-
-  auto issue = [&](int stage) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + TILE_A;
-    const long a_k = a_tap + a_in;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      int m = m0 + row0 + 64 * i;
-      m = m < p.M ? m : p.M - 1;
-      dma16(Abase + (long)m * p.lda + a_k, sA + (wave + NW * i) * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      int n = n0 + row0 + 64 * i;
-      n = n < p.N ? n : p.N - 1;
-      dma16(Wbase + (long)n * p.K + w_k, sB + (wave + NW * i) * 1024);
-    }
-    a_in += BK;
-    while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
-    w_k += BK;
-  };
-
-  f32x16_t acc[FM][FN];
-  {
-    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
-  }
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int swz = (l31 >> 1) & 7;
-  const int a_base = (wm * WTM + l31) * RB, b_base = TILE_A + (wn * WTN + l31) * RB;
-
-  const int nslab = p.K / BK;
-  bf16x8_t af[KSP][FM], wf[KSP][FN];
-
-  auto phase_barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // prologue: NS-1 slabs in flight, slab 0 landed
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nslab) issue(s);
-  if (NS == 3 && nslab > 1) wait_vmcnt<G>();
-  else wait_vmcnt<0>();
-  phase_barrier();
-  // Both groups run the same straight-line program  R(h) | M(h) | R(h+1) | M(h+1) ...  with one barrier per
-  // phase; group 1 executes one extra barrier first (so it runs one phase behind) and group 0 one extra at the end.
-  // Slab s+NS-1 is DMA'd into the stage slab s-1 occupied (last read in global phase 2*HPS*s-1) from phase
-  // 2*HPS*s on; slab s+1 must have landed before phase 2*HPS*(s+1): each wave drains its own share (all but the
-  // G pieces of slab s+2 when NS = 3) before the barrier that ends phase 2*HPS*(s+1)-1.
-  auto drain = [&](int s) {
-    if (NS == 3 && s + 2 < nslab) wait_vmcnt<G>();
-    else wait_vmcnt<0>();
-  };
-  if (grp == 1) phase_barrier();
-  int st_c = 0, st_i = NS - 1;
-  for (int s = 0; s < nslab; ++s) {
-    const char* st = smem + st_c * STAGE;
-#pragma unroll
-    for (int hh = 0; hh < HPS; ++hh) {
-      // ---- R: fragments of this half-slab -> registers (+ DMA of a later slab behind the first half)
-      if (ABL != 1 && hh == 0 && s + NS - 1 < nslab) issue(st_i);
-      if (ABL != 3 || s == 0) {
-#pragma unroll
-        for (int kk = 0; kk < KSP; ++kk) {
-          const int coff = ((((hh * KSP + kk) << 1) + lh) ^ swz) << 4;
-#pragma unroll
-          for (int i = 0; i < FM; ++i) af[kk][i] = *(const bf16x8_t*)(st + a_base + i * 32 * RB + coff);
-#pragma unroll
-          for (int j = 0; j < FN; ++j) wf[kk][j] = *(const bf16x8_t*)(st + b_base + j * 32 * RB + coff);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the stage may be overwritten
-      if (hh == HPS - 1 && grp == 1) drain(s);             // group 1: this is global phase 2*HPS*(s+1)-1
-      phase_barrier();
-      // ---- M: matrix pipe only
-      __builtin_amdgcn_s_setprio(1);
-      if (ABL == 2 && s > 0) {  // keep the fragments alive without touching the matrix pipe
-#pragma unroll
-        for (int kk = 0; kk < KSP; ++kk) {
-#pragma unroll
-          for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[kk][i]));
-#pragma unroll
-          for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(wf[kk][j]));
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < KSP; ++kk)
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = SA_MFMA_32x32x16(wf[kk][j], af[kk][i], acc[i][j]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (hh == HPS - 1 && grp == 0) drain(s);             // group 0: this is global phase 2*HPS*(s+1)-1
-      phase_barrier();
-    }
-    st_c = st_c + 1 == NS ? 0 : st_c + 1;
-    st_i = st_i + 1 == NS ? 0 : st_i + 1;
-  }
-  if (grp == 0) phase_barrier();
-
-  if (p.flags & 1) {
-    gemm_epilogue<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, l31, lh);
-  } else {
-    static_assert(NW * FN * 4096 <= NS * STAGE, "epilogue staging fits the stages");
-    phase_barrier();  // both groups are past their last fragment reads
-    gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (FN * 4096));
-  }
-}
-
-// ---- gemm5: dedicated loader waves (EXPERIMENTAL - reachable only through samaudio_debug_force_gemm_variant) ----
-// The ablation runs on gemm3 (profiles/r1_gemm_ablation.log) are close to ADDITIVE: MFMA-only ~380 us, DMA ~285 us,
-// fragment reads ~180 us against 791 us for the full kernel - i.e. in the 8-wave kernels, where every wave issues its
-// share of the slab's global_load_lds pieces between its MFMAs, the three hardly overlap (a piece costs the issuing
-// wave 100-190 cycles in a phase that also carries ds_reads, MI355X_MICROARCH.md "LDS-DMA piece issue cost").
-// Here the roles are split by WAVE instead of by phase: 8 compute waves (2 per SIMD) never touch VMEM inside the K
-// loop, and 4 loader waves (1 per SIMD, a handful of live registers) issue every DMA piece and own the vmcnt waits.
-// One s_barrier per slab couples them (g = running slab count of this workgroup):
-//   loader :  [vmcnt: slab g landed]  B_g  [issue slab g+NS-1 into the stage slab g-1 occupied] ...
-//   compute:                          B_g  [fragment reads + MFMAs of slab g] ...
-// B_g tells the compute waves that slab g is visible and tells the loaders that every compute wave is done with
-// slab g-1 (its MFMAs were issued, so its fragment reads have returned).  12 waves = 3 per SIMD => <= 168 registers.
-// Same LDS image, swizzle, raster, epilogue and accumulation order as gemm2_kernel.
-//   PF      : the compute waves fetch the fragments of k-step ks+1 into a second register set before issuing the
-//             MFMAs of k-step ks (only the first k-step after each barrier waits for LDS).
-//   PERSIST : one workgroup per CU walks its XCD's run of tiles (slot, slot + W/8, ...); the slab count g simply runs
-//             on across tiles, so the loaders fill the ring with the next tile's first NS-1 slabs while the compute
-//             waves are still in the epilogue (no prologue bubble, no workgroup relaunch per tile).
-struct TileRaster {
-  int tiles_m, tiles_n, per_batch, total;
-  __device__ __forceinline__ void init(const GemmParams& p, int BM, int BN) {
-    tiles_n = (p.N + BN - 1) / BN;
-    tiles_m = (p.M + BM - 1) / BM;
-    per_batch = tiles_m * tiles_n;
-    total = per_batch * p.nbatch;
-  }
-  // tiles owned by XCD x: the contiguous run [first(x), first(x) + count(x))
-  __device__ __forceinline__ int count(int xcd) const { return (total >> 3) + (xcd < (total & 7) ? 1 : 0); }
-  __device__ __forceinline__ int first(int xcd) const {
-    const int q = total >> 3, r = total & 7;
-    return xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  }
-  // L-th tile in XCD-contiguous order -> (batch, m-tile, n-tile), walked in groups of GM m-tiles x all n-tiles
-  __device__ __forceinline__ void locate(const GemmParams& p, int L, int& b, int& tm, int& tn) const {
-    b = L / per_batch;
-    const int l2 = L - b * per_batch;
-    const int GM = p.raster_gm > 0 ? p.raster_gm : 8;
-    const int per_group = GM * tiles_n;
-    const int gi = l2 / per_group;
-    const int first_m = gi * GM;
-    const int gsz = tiles_m - first_m < GM ? tiles_m - first_m : GM;
-    const int in_grp = l2 - gi * per_group;
-    tm = first_m + in_grp % gsz;
-    tn = in_grp / gsz;
-  }
-};
-
-template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false, int TAG = 0>
-__global__ __launch_bounds__(768) void gemm5_kernel(const GemmParams p) {
-  constexpr int NC = 8, NL = 4;  // compute / loader waves
-  static_assert(WM_ * WN_ == NC, "8 compute waves");
-  constexpr int WTM = BM / WM_, WTN = BN / WN_;
-  constexpr int FM = WTM / 32, FN = WTN / 32;
-  constexpr int RB = BK * 2, CPR = RB / 16, RPI = 1024 / RB, KS = BK / 16, CH = 8;
-  constexpr int PA = BM / RPI, PB = BN / RPI;              // wave-wide DMA pieces per slab (A rows, W rows)
-  static_assert(BK == 64 || BK == 32, "BK");
-  static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
-  constexpr int AI = PA / NL, BI = PB / NL, G = AI + BI;   // pieces per loader wave per slab
-  constexpr int TILE_A = BM * RB, TILE_B = BN * RB, STAGE = TILE_A + TILE_B;
-  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS budget");
-  static_assert((NS - 2) * G <= 63, "vmcnt range");
-  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  TileRaster ras;
-  ras.init(p, BM, BN);
-  // this workgroup's tiles: L = base + idx0 + k*stride, k = 0 .. ntile-1
-  const int xcd = blockIdx.x & 7;
-  const int base = ras.first(xcd);
-  const int idx0 = blockIdx.x >> 3;
-  const int stride = PERSIST ? (int)(gridDim.x >> 3) : 1;
-  const int cnt = ras.count(xcd);
-  const int ntile = PERSIST ? (idx0 < cnt ? (cnt - idx0 + stride - 1) / stride : 0) : 1;
-  if (ntile == 0) return;  // whole workgroup
-  const int nslab = p.K / BK;
-  const int total_slabs = ntile * nslab;
-
-  if (wave >= NC) {
-    // ================================ loader wave ================================
-    // piece j = lw + NL*i fills tile rows RPI*j .. RPI*j+RPI-1; lane -> (row RPI*j + lane/CPR, slot lane%CPR);
-    // slot s of row r holds source chunk s ^ swz(r)  (NL is even, so (j & 1) == (lw & 1): same form as gemm2_kernel)
-    const int lw = wave - NC;
-    const int r8 = lane / CPR;
-    const int chunk = BK == 64 ? (lane & 7) ^ ((4 * (lw & 1) + (r8 >> 1)) & 7) : (lane & 3) ^ ((r8 >> 2) & 3);
-    const bf16_t* a_rows[AI];
-    const bf16_t* w_rows[BI];
-    int a_in = 0;
-    long a_tap = 0;
-    int tile_k = 0, slab_in_tile = 0;  // issue cursor
-    auto open_tile = [&]() {
-      int b, tm, tn;
-      ras.locate(p, base + idx0 + tile_k * stride, b, tm, tn);
-      const int m0 = tm * BM, n0 = tn * BN;
-      const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        int m = m0 + (lw + NL * i) * RPI + r8;
-        m = m < p.M ? m : p.M - 1;
-        a_rows[i] = A + (long)m * p.lda;
-      }
-      const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
-#pragma unroll
-      for (int i = 0; i < BI; ++i) {
-        int n = n0 + (lw + NL * i) * RPI + r8;
-        n = n < p.N ? n : p.N - 1;
-        w_rows[i] = W + (long)n * p.K + chunk * CH;
-      }
-      a_in = chunk * CH;
-      a_tap = 0;
-      while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
-    };
-    auto issue = [&](int stage) {  // next slab of the issue cursor -> stage
-      if (slab_in_tile == 0) open_tile();
-      char* sA = smem + stage * STAGE;
-      char* sB = sA + TILE_A;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) dma16(a_rows[i] + a_tap + a_in, sA + (lw + NL * i) * 1024);
-#pragma unroll
-      for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (lw + NL * i) * 1024);
-      a_in += BK;
-      while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
-#pragma unroll
-      for (int i = 0; i < BI; ++i) w_rows[i] += BK;
-      if (++slab_in_tile == nslab) { slab_in_tile = 0; ++tile_k; }
-    };
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-      if (s < total_slabs) issue(s);
-    int st_i = (NS - 1) % NS;
-    for (int g = 0; g < total_slabs; ++g) {
-      // slab g has landed once at most the NS-2 younger slabs' pieces of this wave are still outstanding
-      if (NS > 2 && g + NS - 2 < total_slabs) wait_vmcnt<(NS - 2) * G>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // B_g
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + NS - 1 < total_slabs) issue(st_i);
-      st_i = st_i + 1 == NS ? 0 : st_i + 1;
-    }
-    if (!PERSIST) {  // B_end: tells the compute waves that every one of them is done with the ring (LDS-staged epilogue)
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-    }
-    return;
-  }
-
-  // ================================ compute wave ================================
-  const int wm = wave / WN_, wn = wave % WN_;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int swz = BK == 64 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
-  const int a_base = (wm * WTM + l31) * RB, b_base = TILE_A + (wn * WTN + l31) * RB;
-  int st_c = 0;
-  for (int tk = 0; tk < ntile; ++tk) {
-    f32x16_t acc[FM][FN];
-    {
-      const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = zero16;
-    }
-    for (int s = 0; s < nslab; ++s) {
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // B_g: slab g visible; this wave's reads of slab g-1 returned long ago
-      __builtin_amdgcn_sched_barrier(0);
-      const char* st = smem + st_c * STAGE;
-      if (PF) {
-        bf16x8_t af[2][FM], wf[2][FN];
-        auto fetch = [&](int ks, int buf) {
-          const int coff = ((ks * 2 + lh) ^ swz) << 4;
-#pragma unroll
-          for (int i = 0; i < FM; ++i) af[buf][i] = *(const bf16x8_t*)(st + a_base + i * 32 * RB + coff);
-#pragma unroll
-          for (int j = 0; j < FN; ++j) wf[buf][j] = *(const bf16x8_t*)(st + b_base + j * 32 * RB + coff);
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if (ks + 1 < KS) fetch(ks + 1, (ks + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = SA_MFMA_32x32x16(wf[ks & 1][j], af[ks & 1][i], acc[i][j]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int coff = ((ks * 2 + lh) ^ swz) << 4;
-          bf16x8_t af[FM], wf[FN];
-#pragma unroll
-          for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(st + a_base + i * 32 * RB + coff);
-#pragma unroll
-          for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8_t*)(st + b_base + j * 32 * RB + coff);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-              acc[i][j] = SA_MFMA_32x32x16(wf[j], af[i], acc[i][j]);
-        }
-      }
-      st_c = st_c + 1 == NS ? 0 : st_c + 1;
-    }
-    int b, tm, tn;
-    ras.locate(p, base + idx0 + tk * stride, b, tm, tn);
-    if (PERSIST) {  // the loaders are already filling the ring with the next tile: no LDS to stage through
-      gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
-    } else {
-      static_assert(PERSIST || NC * FN * 4096 <= NS * STAGE, "epilogue staging fits the ring");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();  // B_end (all 12 waves)
-      __builtin_amdgcn_sched_barrier(0);
-      if (p.flags & 1)
-        gemm_epilogue<FM, FN, (FM * FN > 4 ? 1 : 2)>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, l31, lh);
-      else
-        gemm_epilogue_lds<FM, FN>(p, acc, b, tm * BM + wm * WTM, tn * BN + wn * WTN, lane, smem + wave * (FN * 4096));
-    }
-  }
-}
-
-static int persistent_grid(long tiles) {  // one workgroup per CU, a multiple of the 8 XCDs
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        n < 8)
-      n = 256;
-    cus = n & ~7;
-  }
-  const long want = (tiles + 7) & ~7L;
-  return (int)(want < cus ? want : cus);
-}
-
-template <int BM, int BN, int WM_, int WN_, int NS, int BK, bool PF = false, bool PERSIST = false, bool TAGGED = false>
-static hipError_t launch5(const GemmParams& p, hipStream_t st) {
-  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
-  const unsigned grid = PERSIST ? (unsigned)persistent_grid(tiles) : (unsigned)tiles;
-  if (TAGGED && p.tag == 1)
-    hipLaunchKernelGGL((gemm5_kernel<BM, BN, WM_, WN_, NS, BK, PF, PERSIST, TAGGED ? 1 : 0>), dim3(grid), dim3(768), 0, st, p);
-  else
-    hipLaunchKernelGGL((gemm5_kernel<BM, BN, WM_, WN_, NS, BK, PF, PERSIST, 0>), dim3(grid), dim3(768), 0, st, p);
-  return hipGetLastError();
-}
-
-template <int BM, int BN, int WM_, int WN_, int KSP, int NS, int ABL = 0>
-static hipError_t launch3(const GemmParams& p, hipStream_t st) {
-  const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
-  hipLaunchKernelGGL((gemm3_kernel<BM, BN, WM_, WN_, KSP, NS, ABL>), dim3((unsigned)tiles), dim3(512), 0, st, p);
-  return hipGetLastError();
+  static_assert(NW * FN * 4096 <= STAGES * STAGE, "epilogue staging fits the ring");
+  __syncthreads();  // every wave is done with the last slab (no DMA is in flight any more)
+  gemm_epilogue_lds<FM, FN>(p, acc, b, m0 + wm * WTM, n0 + wn * WTN, lane, smem + wave * (FN * 4096));
 }
 
 // ---- conv7h: dilated k = 7 convolution with the activation HALO TILE RESIDENT in LDS ---------------------------------
@@ -1212,7 +676,7 @@ hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t 
     // 96 channels: 128-row tiles on 4 waves and a 2-stage ring = 72 KiB, two workgroups per CU, so that one workgroup's
     // memory-bound phase-2 epilogue overlaps the other's MFMA-bound phase 1 (2023 vs 2102 us for 8 waveforms, two launches
     // 2204; profiles/r2_call21/).  Flag 20 = the 8-wave 256-row shape.
-    case 96: return debug_flag(20) ? launch_ru<96, 256, 8, 1, 3>(p, q, st) : launch_ru<96, 128, 4, 1, 2>(p, q, st);
+    case 96: return launch_ru<96, 128, 4, 1, 2>(p, q, st);   // 72 KiB: two workgroups per CU (2 023 vs 2 127 us on 256 rows / 8 waves)
     case 128: return launch_ru<128, 256, 4, 2, 3>(p, q, st);
     case 192: return launch_ru<192, 128, 4, 2, 3>(p, q, st);
     default: return hipErrorInvalidValue;
@@ -1255,42 +719,21 @@ bool gemm2_ok(const GemmParams& p) {
 // 256x128 role-split with 3 stages (7, 8), 256x256 with one 512-register wave per SIMD (12), hand-pipelined asm
 // fragment reads (13, 14) - all within +-3 % of the kept kernels or slower.  Ablation builds (9-11: no DMA / no MFMA /
 // no LDS reads; wrong results, timing only) compile with -DSAMAUDIO_GEMM_ABLATIONS.
-hipError_t launch_gemm2(const GemmParams& p_in, int variant, hipStream_t st) {
-  GemmParams p = p_in;
-  p.flags = debug_flag(8) ? 1 : 0;  // bit 0: epilogue straight from the accumulator layout (round-1 path, A/B)
+// variant = gemm_variant()'s number - 3 (gemm.hip): only the tiles the policy selects are built
+hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
   switch (variant) {
-#ifdef SAMAUDIO_GEMM_ABLATIONS
-    case 11: return launch3<256, 256, 2, 4, 2, 2, 3>(p, st);
-    case 10: return launch3<256, 256, 2, 4, 2, 2, 2>(p, st);
-    case 9: return launch3<256, 256, 2, 4, 2, 2, 1>(p, st);
-#endif
-    // experimental, never chosen by gemm_variant() (see "gemm5" above and DESIGN.md section 3.1):
-    case 12: return launch5<256, 256, 2, 4, 2, 64>(p, st);  // loader waves, 2 x 64 KiB stages
-    case 13: return launch5<256, 256, 2, 4, 4, 32>(p, st);  // loader waves, 4 x 32 KiB half-slab stages
-    case 14: return launch5<256, 128, 4, 2, 3, 64>(p, st);  // loader waves, 3 x 48 KiB stages
-    case 15: return launch2<256, 128, 4, 2, 3, 32>(p, st);  // 8 waves, BK 32, 72 KiB => two workgroups per CU
-    case 16: return launch5<256, 128, 4, 2, 3, 64, true>(p, st);  // 14 + register-prefetched fragments
-    case 17: return launch5<256, 128, 4, 2, 3, 64, true, true, true>(p, st);  // 16 + persistent tile walk
-    case 18: return launch5<256, 256, 2, 4, 2, 64, false, true>(p, st); // 12 + persistent tile walk
-    case 19: return launch_gemm8(p, 0, st);  // gemm8.hip: the guide's 8-phase K loop, 16x16x32 MFMA
-    case 20: return launch_gemm8(p, 1, st);  // ... A/B: the round-2 build (tap walk compiled in for plain GEMMs too)
-    case 22: return launch2<128, 128, 2, 2, 2, 64>(p, st);  // small M: 4 waves, 64 KiB => two workgroups per CU
-    case 23: return launch2<64, 128, 1, 4, 3, 64>(p, st);   // smaller M: 4 waves, 72 KiB => two workgroups per CU
-    // experimental (GPU call 14): more K-tiles in flight per CU for narrow-N / short-K convolutions - BK 32, 4 waves
-    case 26: return launch2<128, 128, 2, 2, 3, 32>(p, st);  // 48 KiB => three workgroups per CU, 3 stages each
-    case 27: return launch2<128, 128, 2, 2, 4, 32>(p, st);  // 64 KiB => two workgroups per CU, 4 stages each
-    case 28: return launch2<128, 128, 2, 2, 2, 32>(p, st);  // 32 KiB => five workgroups per CU
+    case 19: return launch_gemm8(p, st);   // gemm8.hip: 256x256 tile, the guide's 8-phase K loop, 16x16x32 MFMA
+    case 24: return launch_gemm8s(p, st);  // gemm8.hip: 128x128 tile of the same arithmetic (few rows; split tails)
+    // 32x32x16 family (DAC-VAE stages with 64 - 192 channels): M-aware tiles, bitwise equal among themselves
+    case 22: return launch2<128, 128, 2, 2, 2, 64>(p, st);  // few rows: 4 waves, 64 KiB => two workgroups per CU
+    case 23: return launch2<64, 128, 1, 4, 3, 64>(p, st);   // fewer rows: 4 waves, 72 KiB => two workgroups per CU
+    case 25: return launch2<256, 64, 8, 1, 2, 64, true>(p, st);  // N = 64 outputs (first DAC encoder stage) in one 64-wide tile
+    case 26: return launch2<128, 128, 2, 2, 3, 32>(p, st);  // BK 32: 48 KiB => three workgroups per CU, 3 stages each
     case 29: return launch2<128, 64, 2, 2, 2, 32>(p, st);   // N <= 64: 24 KiB => six workgroups per CU
     case 30: return launch2<64, 128, 1, 4, 3, 32>(p, st);   // 36 KiB => four workgroups per CU
     case 31: return launch2<128, 192, 2, 2, 3, 32>(p, st);  // N = 192 in one tile, 60 KiB => two workgroups per CU
     case 32: return launch_conv7h(p, st);  // k7 convolution with the halo tile resident in LDS (conv7h_ok launches only)
-    case 25: return launch2<256, 64, 8, 1, 2, 64, true>(p, st);  // N = 64 outputs (first DAC encoder stage) in one 64-wide tile
-    case 24: return launch_gemm8s(p, st);  // gemm8.hip: 128x128 tile of the 8-phase kernel's MFMA family
-    case 6: return launch3<256, 256, 2, 4, 2, 2>(p, st);
-    case 3: return launch2<256, 192, 4, 2, 2, 64, true>(p, st);  // N = 192 outputs (DAC stage with 192 channels) in one tile
-    case 2: return launch2<256, 256, 2, 4, 2, 64>(p, st);
-    case 0: return launch2<256, 128, 4, 2, 3, 64>(p, st);
-    default: return launch2<256, 128, 4, 2, 2, 64, true>(p, st);
+    default: return hipErrorInvalidValue;
   }
 }
 

@@ -5,8 +5,7 @@
 //
 // Shipped since round 2 for every GEMM with N >= 1024 (gemm.hip gemm_variant): measured on MI355X at 1 349 TF/s on 8192^3
 // and 860 - 1 134 TF/s on the DiT's shapes (the round-1 ablation, profiles/r1_gemm_ablation.log,
-// had shown the LDS side of the earlier kernels - not their wave schedules - as the limiter).  A/B builds of the template
-// (no wave-group stagger, no s_setprio) stay force-able as variants 23 / 24.  Epilogue = the full GemmParams contract,
+// had shown the LDS side of the earlier kernels - not their wave schedules - as the limiter).  Epilogue = the full GemmParams contract,
 // operands swapped (W fragment as the MFMA's A operand) so that a lane owns 4 consecutive output columns of one row.
 // gemm8s_kernel below is the same arithmetic on a 128 x 128 tile (few rows; the tail of a split launch).
 //
@@ -208,16 +207,17 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 
 }  // namespace
 
-// STAGGER: the two wave groups run one barrier apart (off: all 8 waves read together, then multiply together);
-// PRIO: s_setprio 1 around each MFMA cluster.  Both on = the guide's template; the others are A/B builds.
+// The two wave groups run one barrier apart and every MFMA cluster runs under s_setprio 1 (round-2 A/B builds of the
+// template on one box: without the stagger -11 %, without the priority -9 %; profiles/r2_call3/).
 // CONV: A's k axis is split into taps (implicit convolutions: kc < K); plain GEMMs compile the per-K-tile tap walk - a
 // per-lane loop under an exec mask, twice per K-tile - out of the K loop.
 // (Round 3, GPU call 3: issuing the second staging instruction of every phase from inside the wave's own MFMA cluster -
 // to shorten the read sections, which carry 2 global_load_lds at 100 - 185 issue cycles each - measured 4 - 7 % SLOWER on
 // every DiT shape than this loop (profiles/r3_call3/gemm_bench_r3.log); removed.  Compiling the tap walk out of plain
 // GEMMs measured 3 - 5 % faster and is what CONV = false is.)
-template <bool STAGGER, bool PRIO, bool CONV>
+template <bool CONV>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
+  constexpr bool STAGGER = true, PRIO = true;
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
 
@@ -592,12 +592,11 @@ hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
+hipError_t launch_gemm8(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const dim3 grid((unsigned)tiles), block(512);
-  // mode 1 (A/B, tools/gemm_bench.py): the tap walk compiled in whatever the launch (the round-2 kernel)
-  if (mode == 1 || p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true>), grid, block, 0, st, p, 0);
-  else hipLaunchKernelGGL((gemm8_kernel<true, true, false>), grid, block, 0, st, p, 0);
+  if (p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, 0);
+  else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, 0);
   return hipGetLastError();
 }
 
@@ -608,8 +607,8 @@ hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st) {
 hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st) {
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
-  if (part == 0 && p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true, true, true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
-  else if (part == 0) hipLaunchKernelGGL((gemm8_kernel<true, true, false>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  if (part == 0 && p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  else if (part == 0) hipLaunchKernelGGL((gemm8_kernel<false>), dim3((unsigned)full), dim3(512), 0, st, p, full);
   else {
     const bool pipe = (tiles - full) * 4 <= 256 && !debug_flag(21);   // a tail that cannot give a CU two workgroups
     const bool conv = p.kc < p.K;

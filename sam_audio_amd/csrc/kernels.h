@@ -8,33 +8,12 @@ namespace sa {
 // test aid: fill the LDS of every CU with NaN bit patterns (LDS persists between kernels)
 hipError_t launch_poison_lds(hipStream_t st);
 
-// tuning switches for A/B timing of kernel generations (tools/op_bench.py); 0 = shipped path.
-//   flag 19: 256 <= N < 1024 on the loader-wave 256x128 kernel as before GPU call 21 of round 2 (the 8-phase family now
-//            covers every N >= 256) (A/B)
-//   flag 16: DAC residual units as two launches (k7 + k1) instead of the fused resunit kernel (A/B)
+// test / tuning switches (samaudio_debug_set_flag); 0 = shipped path.  Round 3 removed the A/B generations that had lost
+// their measurements (the logs are under profiles/, the code in the git history); what is left are hooks the tests use:
+//   flag 11: k7 convolutions as implicit GEMMs (no conv7h kernel) - the bitwise-equality tests of conv7h
+//   flag 16: DAC residual units as two launches (k7 + k1) instead of the fused resunit kernel - its bitwise-equality tests
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
-//   flag 17: bit mask TOGGLING the channel counts excluded from the fused residual-unit kernel (1: 64, 2: 96, 4: 128, 8: 192;
-//            excluded by default: 128 and 192) (A/B)
-//   flag 24: RMSNorm + modulate loads its five operand vectors per row instead of the two pre-combined per evaluation (A/B)
-//   flag 23: self-attention as a 1-D grid with the query blocks of a (batch, head) back to back on one XCD (A/B)
-//   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined 3-stage form
-//            since GPU call 25 of round 2) (A/B)
-//   flag 20: fused residual units with 96 channels on 256-row tiles / 8 waves / one workgroup per CU as in call 20 (A/B)
-//   flag 1: bf16 qkv_prep uses the first-generation (2-byte access) kernel
-//   flag 2: rmsnorm_mod falls back to the two-pass kernel (the register-resident row is the shipped path since round 2)
-//   flag 4: N = 192 GEMMs use two 128-wide tiles instead of the 256x192 tile
-//   flag 5: round-1 GEMM tile policy (256x128 2-stage ring, 256x256 ping-pong for N >= 12288)
-//   flag 6: M-blind tile policy (no 128- / 64-row tiles for launches with few rows)
-//   flag 8: GEMM epilogues straight from the accumulator layout (round 1) instead of the LDS-staged coalesced form
-//   flag 9: loader-wave 256x128 kernel WITHOUT the persistent tile walk (its ring is free after the K loop, so it can use
-//           the LDS-staged epilogue; the persistent walk keeps the accumulator-layout epilogue)
-//   flag 15: DAC stages with 96 - 192 channels on the 256-row tiles of call 12 instead of the BK-32 multi-workgroup tiles (A/B)
-//   flag 14: 64-channel convolutions on gemm.hip's 128x64 tile instead of the 256x64 tile of the DMA-fed family (A/B)
-//   flag 13: self-attention with 16 waves (256 query rows) per workgroup when 256-row blocks fit (A/B; measured slower)
-//   flag 11: k7 convolutions as implicit GEMMs (no conv7h kernel; A/B)
-//   flag 10: no tail split of 8-phase launches (every 256x256 tile on gemm8_kernel, as before GPU call 7 of round 2)
-//   flag 7: the loader-wave 256x128 kernel (32x32x16 family) for 2048 <= N < 4096 as before GPU call 3 of round 2 (the
-//           8-phase family now covers every N >= 2048: 181.1 vs 173.0 s-audio/s, 200.5 vs 183.2 with two streams)
+//   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined form)
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);
 
@@ -48,9 +27,8 @@ constexpr int kGemmVariants = 36;  // 35 = conv7h (k7 convolution, halo tile res
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
 bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
-// gemm8.hip: experimental 256x256 8-phase kernel (force-only variants 22..24 = gemm2 variants 19..21: template, no
-// stagger, no setprio); needs gemm2_ok(p)
-hipError_t launch_gemm8(const GemmParams& p, int mode, hipStream_t st);
+// gemm8.hip: 256x256 8-phase kernel (variant 22); needs gemm2_ok(p)
+hipError_t launch_gemm8(const GemmParams& p, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in

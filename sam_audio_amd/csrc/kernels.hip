@@ -176,8 +176,9 @@ hipError_t launch_rmsnorm_mod(const float* x, const float* w, const float* shift
                               int M, int D, int rows_per_b, float eps, hipStream_t st) {
   dim3 grid((M + 3) / 4), block(256);
   // the row stays in registers between the statistics pass and the output pass (one read of x; bit-identical to the
-  // two-pass kernel): 34.3 vs 37.6 us at M = 8000, D = 2816 on MI355X (profiles/r2_op_bench_first.log); flag 2 = old path
-  if (!debug_flag(2) && D <= 256 * 12) {
+  // two-pass kernel): 34.3 vs 37.6 us at M = 8000, D = 2816 on MI355X (profiles/r2_op_bench_first.log); wider rows take
+  // the two-pass kernel below
+  if (D <= 256 * 12) {
     if (bf16)
       hipLaunchKernelGGL((rmsnorm_mod_reg_kernel<bf16_t, 12>), grid, block, 0, st, x, w, shift_tab, scale_tab, tvec, tvec_ld,
                          shift_off, scale_off, (bf16_t*)out, M, D, rows_per_b, eps);
@@ -458,10 +459,7 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st) {
   dim3 grid(Tp / 64, H, B), block(256);
-  if (bf16 && debug_flag(1))
-    hipLaunchKernelGGL(qkv_prep_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin,
-                       (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
-  else if (bf16)
+  if (bf16)
     hipLaunchKernelGGL(qkv_prep_bf16_kernel, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin,
                        (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
   else

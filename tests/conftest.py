@@ -69,14 +69,6 @@ def _enable_emu_dryrun():
         os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection's kernels are not emulated
         from sam_audio_amd import judge
         judge._TextTower.default_backend = "torch"   # nor is the ModernBERT text tower (the SIMT simulator build carries it)
-    if which == "simt" and os.environ.get("SAMAUDIO_SIMT_POLICY", "r1") == "r1":
-        # End-to-end tests on the simulator pick GEMM kernels with the round-1 tile policy (debug flag 5): the round-2
-        # kernels (12-wave loader-wave workgroups, the 8-phase kernel's 8 barriers per K-tile) cost the fiber scheduler
-        # several times more per simulated launch and the codec issues hundreds of launches.  The shipped kernels
-        # themselves are covered on the simulator by tests/test_gemm2_gpu.py (variants 20 and 22, all epilogues and conv
-        # forms); both policies stay inside one accumulation-order family per (N, K).  SAMAUDIO_SIMT_POLICY=r2 runs the
-        # shipped policy end to end (by hand, slow).
-        lib.samaudio_debug_set_flag(5, 1)
 
 
 if EMU_DRYRUN:

@@ -32,7 +32,7 @@ def _restore_variant():
     hip.lib("fp16").samaudio_debug_force_gemm_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 4, 20, 22, 25, 26, 27])
+@pytest.mark.parametrize("variant", [-1, 1, 22, 25, 26, 27])
 def test_gemm_kernels_on_fp16_operands(gpu, variant):
     """fp16 x fp16 products are exact in fp32 and the accumulation is fp32: fp32 outputs agree with a CPU fp32 matmul
     on the same fp16-rounded operands to summation-order noise; fp16 outputs add half an fp16 ulp (2^-11 relative)."""

@@ -1,5 +1,6 @@
-"""Parity of the 256-row-tile bf16 GEMM kernels (sam_audio_amd/csrc/gemm2.hip: gemm2 ring kernels and the
-gemm3 role-split kernels) through the C ABI, every tile variant forced in turn.
+"""Parity of the 16-bit GEMM kernels of sam_audio_amd/csrc/gemm2.hip (32x32x16-MFMA ring tiles, conv7h, fused residual
+units) and gemm8.hip (16x16x32-MFMA 8-phase 256x256 kernel and its 128x128 tile) through the C ABI, every tile variant the
+policy can select forced in turn.
 
 Checker: plain PyTorch fp32 on the CPU on the same bf16-rounded operands.  Tolerances: products of bf16 values are
 exact in fp32 and the accumulation is fp32, so fp32 outputs agree to summation-order noise (<= 5e-4 at K <= 1344
@@ -16,14 +17,9 @@ from sam_audio_amd import hip
 from tests import util
 
 pytestmark = pytest.mark.gpu
-# 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 6 = 256x192 2-stage ring,
-# 9 = 256x256 role-split.  15..22 = experimental kernels (loader-wave "gemm5" family, BK-32 two-workgroup tile,
-# 22..24 = gemm8.hip: the guide's 8-phase K loop and its no-stagger / no-setprio A/B builds) that
-# no policy selects; they join the sweep only with SAMAUDIO_TEST_EXPERIMENTAL=1 (run them under `timeout`).
-# Round 2 ships 20 (loader-wave 256x128, persistent tile walk) and 22 (8-phase 256x256): they are always in the sweep.
-SHIPPED_R2 = [20, 22, 25, 26, 27, 28, 29, 32, 33, 34]   # + the 128x128 / 64x128 tiles the M-aware policy picks for few rows (27 = gemm8s)
-EXPERIMENTAL = [v for v in list(range(15, 25)) + [29, 30, 31, 32, 33, 34] if v not in SHIPPED_R2] if os.environ.get("SAMAUDIO_TEST_EXPERIMENTAL") == "1" else []
-VARIANTS = [3, 4, 5, 6, 9] + SHIPPED_R2 + EXPERIMENTAL
+# gemm.hip gemm_variant numbering: 22 = gemm8 (8-phase 256x256), 27 = gemm8s (its 128x128 tile); 32x32x16 family: 25 / 26 =
+# 128x128 / 64x128 (BK 64), 28 = 256x64, 29 / 32 / 33 / 34 = BK-32 multi-workgroup tiles; 35 = conv7h (its own tests).
+VARIANTS = [22, 25, 26, 27, 28, 29, 32, 33, 34]
 
 
 def _mk(shape, seed, scale=1.0):
@@ -91,7 +87,7 @@ def test_gate_residual_dual_output_and_swiglu(gpu, variant):
     util.report(f"swiglu v{variant}", u, want_u, 3.2e-2)
 
 
-@pytest.mark.parametrize("variant", [3, 4, 9] + SHIPPED_R2 + EXPERIMENTAL)
+@pytest.mark.parametrize("variant", VARIANTS)
 def test_conv_forms(gpu, variant):
     """The codec's implicit-convolution forms on the 256-row kernels: dilated k7 conv with snake epilogue into a
     halo-padded buffer, and a stride-4 transposed conv (phase-major columns, chan_mod bias, output window mask)."""
@@ -148,7 +144,7 @@ def test_row_tile_variants_are_bitwise_identical(gpu):
     tab, gate, res = _mk((N,), 23), _mk((B, N), 24), _mk((M, N), 25)
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
     outs = {}
-    for variant in (4, 3, 5, 9, 20, 25, 26, 28, 29, 32, 33, 34):
+    for variant in (25, 26, 28, 29, 32, 33, 34):
         hip.lib().samaudio_debug_force_gemm_variant(variant)
         out = torch.full((M, N), float("nan"), device=gpu)
         out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
@@ -156,7 +152,7 @@ def test_row_tile_variants_are_bitwise_identical(gpu):
                   res_geom=(0, N, 0), out_f32=out, f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
         outs[variant] = (out.cpu(), out_act.cpu())
     for variant, (o, a) in outs.items():
-        assert torch.equal(o, outs[4][0]) and torch.equal(a.view(torch.int16), outs[4][1].view(torch.int16)), variant
+        assert torch.equal(o, outs[25][0]) and torch.equal(a.view(torch.int16), outs[25][1].view(torch.int16)), variant
 
 
 @pytest.mark.parametrize("M,N,K,swiglu", [(270, 384, 448, 0), (700, 2816, 256, 0), (333, 512, 320, 1)])
@@ -224,8 +220,6 @@ def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
     whole rounds on gemm8, the rest as 128x128 quadrants on gemm8s).  272 / 280 tiles here -> 256 + 16 / 24; ragged M and N
     put quadrants partly and wholly outside the problem.  The automatic (split) result must equal the forced single-kernel
     one bit for bit - gated residual epilogue, fp32 + bf16 outputs, per-batch strides."""
-    if os.environ.get("SAMAUDIO_EMU_DRYRUN") == "simt" and os.environ.get("SAMAUDIO_SIMT_POLICY", "r1") == "r1":
-        pytest.skip("the simulator's default policy is the round-1 one (tests/conftest.py); run with SAMAUDIO_SIMT_POLICY=r2")
     A, W = _mk((nbatch, M, K), 41), _mk((N, K), 42, 1 / math.sqrt(K))
     tab, gate, res = _mk((N,), 43), _mk((nbatch, N), 44), _mk((nbatch, M, N), 45)
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
@@ -283,7 +277,7 @@ def test_sixty_four_channel_tiles_are_bitwise_identical(gpu):
                                            (192, 1, 130, 2)])
 def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
     """conv7h (variant 35: k7 'same' convolution with the activation halo tile resident in LDS, taps walked by shifting
-    fragment rows) against the implicit GEMM of the same MFMA family (variant 4) on identical operands: identical bits -
+    fragment rows) against the implicit GEMM of the same MFMA family (variant 25) on identical operands: identical bits -
     bias + Snake epilogue into a halo-padded buffer, every channel count / dilation the DAC stages use, M not a multiple
     of the row tile (the last tile's halo rows are clamped), several items; and both against torch's conv1d."""
     halo = 40
@@ -297,14 +291,14 @@ def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
     bias, alpha = _mk((C,), 63, 0.1), (_mk((C,), 64, 0.2) + 1).clamp(0.3, 2)
     keep = [util.as_act(xb, "bf16", gpu), util.as_act(Wm, "bf16", gpu), bias.to(gpu), alpha.to(gpu)]
     outs = {}
-    for variant in (35, 4):
+    for variant in (35, 25):
         hip.lib().samaudio_debug_force_gemm_variant(variant)
         out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
         util.gemm("bf16", keep[0], keep[1], T, C, Kp, nbatch=items, a_off=(halo - 3 * dil) * C, a_bstride=(T + 2 * halo) * C,
                   lda=C, kc=C, tap_stride=dil * C, bias=keep[2], out_act=out, act_geom=((T + 2 * halo) * C, C, halo * C),
                   act=hip.ACT_SNAKE, act_alpha=keep[3])
         outs[variant] = out.cpu()
-    assert torch.equal(outs[35].view(torch.int16), outs[4].view(torch.int16))
+    assert torch.equal(outs[35].view(torch.int16), outs[25].view(torch.int16))
     assert float(outs[35][:, :halo].abs().max()) == 0 and float(outs[35][:, halo + T:].abs().max()) == 0
     y = F.conv1d(util.rounded(x, "bf16"), util.rounded(w, "bf16"), bias, dilation=dil, padding=3 * dil)
     a = alpha[None, :, None]
@@ -312,10 +306,9 @@ def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
     util.report(f"conv7h C={C} dil={dil}", outs[35][:, halo:halo + T], want, 4e-2)
 
 
-@pytest.mark.parametrize("C,dil,T,items,four_waves", [(64, 1, 700, 3, 0), (96, 3, 530, 2, 0), (96, 9, 300, 3, 0), (128, 9, 520, 2, 0),
-                                                      (192, 3, 300, 3, 0), (192, 1, 130, 2, 0), (96, 1, 256, 1, 0),
-                                                      (96, 3, 530, 2, 1), (96, 9, 300, 3, 1), (96, 1, 128, 2, 1)])
-def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items, four_waves):
+@pytest.mark.parametrize("C,dil,T,items", [(64, 1, 700, 3), (96, 3, 530, 2), (96, 9, 300, 3), (128, 9, 520, 2), (192, 3, 300, 3),
+                                           (192, 1, 130, 2), (96, 1, 256, 1), (96, 1, 128, 2)])
+def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
     """resunit (one DAC residual unit per launch: k7 convolution -> Snake -> bf16 intermediate kept in LDS -> k1 convolution
     + fp32 residual, fp32 stream and Snake'd bf16 copy out) against the two launches the engine otherwise issues, on identical
     operands: identical bits in both outputs, halo rows of the output activation untouched, the input activation untouched;
@@ -351,7 +344,6 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items, 
 
     import ctypes as CT
     res = {}
-    hip.lib().samaudio_debug_set_flag(20, 0 if four_waves else 1)   # 96 channels: 128-row tiles on 4 waves (shipped) | 8 waves
     for fused in (False, True):
         mid = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
         out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
@@ -364,7 +356,6 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items, 
             for p in (p7, p1):
                 hip.check(hip.lib().samaudio_op_gemm(CT.byref(p), CT.sizeof(p), hip.BF16, util.stream()))
         res[fused] = (raw.cpu(), out.cpu())
-    hip.lib().samaudio_debug_set_flag(20, 0)
     assert torch.equal(xin.cpu().view(torch.int16), util.as_act(xb, "bf16", "cpu").view(torch.int16))
     assert torch.equal(res[True][0].view(torch.int32), res[False][0].view(torch.int32))
     assert torch.equal(res[True][1].view(torch.int16), res[False][1].view(torch.int16))

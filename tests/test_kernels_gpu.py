@@ -37,10 +37,9 @@ def _mk(shape, seed, scale=1.0):
 
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("shared_time", [False, True])
-@pytest.mark.parametrize("D,candidate", [(512, 0), (512, 1), (2816, 1)])
-def test_rmsnorm_modulate(gpu, debug_flag, prec, shared_time, D, candidate):
-    """candidate = 1: the register-resident kernel behind debug flag 2 (D = 2816: 11 of its 12 float4 slots per lane)."""
-    debug_flag(2, candidate)
+@pytest.mark.parametrize("D", [512, 2816, 3328])
+def test_rmsnorm_modulate(gpu, prec, shared_time, D):
+    """D <= 3072: the register-resident kernel (D = 2816: 11 of its 12 float4 slots per lane); D = 3328: the two-pass kernel."""
     B, T = 3, 37
     x, w = _mk((B * T, D), 1), _mk((D,), 2, 0.1) + 1
     tab = _mk((6, D), 3, 0.2)
@@ -128,34 +127,6 @@ def test_self_attention(gpu, prec, T):
     # bf16: P is rounded to bf16 before P@V (2^-9 relative on weights that sum to 1) and so is the output
     util.report(f"self_attention {prec} T{T}", out, want, 2e-5 if prec == "fp32" else 2e-2)
 
-@pytest.mark.parametrize("B,H,T", [(2, 2, 250), (3, 5, 130), (1, 3, 50), (5, 22, 64)])
-def test_self_attention_xcd_paired_grid_is_bitwise_the_3d_grid(gpu, B, H, T):
-    """debug flag 23: the query blocks of a (batch, head) dealt back to back onto one XCD through a 1-D grid (their K / V^T
-    then come out of that XCD's L2 the second time).  Pure re-indexing of workgroups: identical bits; pair counts that are
-    not a multiple of 8 (ragged last deal) and one / two / three query blocks per pair."""
-    Tp = (T + 63) // 64 * 64
-    D = H * 128
-    q, k, v = _mk((B, H, T, 128), 20) * 1.5, _mk((B, H, T, 128), 21), _mk((B, H, T, 128), 22)
-    mask = torch.ones(B, T, dtype=torch.bool)
-    mask[B - 1, T - 13:] = False
-    pad = lambda z: torch.nn.functional.pad(z, (0, 0, 0, Tp - T))   # noqa: E731
-    qd, kd = util.as_act(pad(q), "bf16", gpu), util.as_act(pad(k), "bf16", gpu)
-    vtd = util.as_act(pad(v).transpose(2, 3), "bf16", gpu)
-    md = mask.to(gpu).to(torch.uint8)
-    outs = []
-    try:
-        for flag in (0, 1):
-            hip.lib().samaudio_debug_set_flag(23, flag)
-            out = torch.zeros(B * T, D, device=gpu, dtype=torch.bfloat16)
-            hip.check(hip.lib().samaudio_op_self_attention(hip.ptr(qd), hip.ptr(kd), hip.ptr(vtd), hip.ptr(md), hip.ptr(out),
-                                                           util.PREC["bf16"], B, T, Tp, H, util.stream()))
-            outs.append(out.cpu())
-    finally:
-        hip.lib().samaudio_debug_set_flag(23, 0)
-    assert torch.isfinite(outs[0].float()).all()
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
-
-
 @pytest.mark.parametrize("prec", PRECS)
 def test_cross_attention(gpu, prec):
     B, T, Lt, H = 2, 40, 6, 2
@@ -189,20 +160,6 @@ def test_layernorm_accum(gpu):
                                                     P(gate.to(gpu)), hip.ptr(acc_d), M, D, 1e-5, util.stream()))
     want = acc + torch.tanh(gate) * torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
     util.report("layernorm_accum", acc_d, want, 1e-5)
-
-
-@pytest.fixture
-def debug_flag():
-    """Switch an A/B kernel generation on for one test (samaudio_debug_set_flag) and back off afterwards."""
-    touched = []
-
-    def set_flag(flag, value):
-        hip.lib().samaudio_debug_set_flag(flag, value)
-        touched.append(flag)
-
-    yield set_flag
-    for flag in touched:
-        hip.lib().samaudio_debug_set_flag(flag, 0)
 
 
 @pytest.mark.parametrize("Lt,ltp,B,H", [(3, 8, 3, 4), (8, 8, 3, 4), (11, 16, 3, 4), (8, 8, 6, 6), (16, 16, 5, 2), (8, 8, 5, 22),

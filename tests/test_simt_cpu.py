@@ -5,8 +5,8 @@ This is what stands in for hardware in the CPU suite: the kernels' FUNCTION (ind
 masks, epilogues) is exercised through the same C ABI and the same test bodies that run on MI355X.  The simulator
 itself is calibrated by the GPU-verified kernels: all of tests/test_kernels_gpu.py, test_gemm_gpu.py and
 test_gemm2_gpu.py pass on it.  It models no timing and no asynchrony - races and performance stay with the GPU runs.
-The full sweep (incl. experimental GEMM variants and the codec-heavy end-to-end tests, ~80 min) is run by hand:
-    SAMAUDIO_EMU_DRYRUN=simt SAMAUDIO_TEST_EXPERIMENTAL=1 python -m pytest tests -m gpu -q
+The full sweep (incl. the codec-heavy end-to-end tests, ~80 min) is run by hand:
+    SAMAUDIO_EMU_DRYRUN=simt python -m pytest tests -m gpu -q
 """
 import os
 import subprocess
@@ -51,8 +51,8 @@ def test_pipelined_gemm_kernels_with_dma_landing_as_late_as_the_isa_allows():
     """SAMAUDIO_SIMT_DMA=late: a global_load_lds lands only when the issuing wave's s_waitcnt vmcnt(N) / __syncthreads
     retires it, so a kernel whose counted waits let a wave read a slab too early reads stale LDS here.  (Mutation check
     done by hand: loosening gemm2.hip's counts by 8 fails all 43 tests of this file in this mode and none in the
-    default one.)  Covers the ring, role-split and - with SAMAUDIO_TEST_EXPERIMENTAL=1 - the loader-wave kernels."""
-    env_extra = {"SAMAUDIO_SIMT_DMA": "late", "SAMAUDIO_TEST_EXPERIMENTAL": "1"}
+    default one.)  Covers the ring tiles, conv7h / the fused residual units and the 8-phase kernels."""
+    env_extra = {"SAMAUDIO_SIMT_DMA": "late"}
     old = {k: os.environ.get(k) for k in env_extra}
     os.environ.update(env_extra)
     try:
@@ -77,7 +77,7 @@ def test_round2_policy_tail_split_and_vision_tower_on_the_simulator():
     quadrant tail must be bitwise invisible, and the PE-Core vision tower (tests/test_vit_gpu.py: every structural switch,
     fp32 and bf16, uint8 video -> resize -> tower) must match its oracle with the real kernel code."""
     out = _run(["tests/test_gemm2_gpu.py", "tests/test_vit_gpu.py", "-k",
-                "tail_split or 8phase_family or (test_vit_gpu and not checkpoint)"], 900, SAMAUDIO_SIMT_POLICY="r2")
+                "tail_split or 8phase_family or (test_vit_gpu and not checkpoint)"], 900)
     assert " passed" in out and "failed" not in out
 
 

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
-"""GEMM variant sweep on the real DiT shapes (run on the GPU box): correctness of every kernel variant against a
-torch fp32 matmul on the same bf16-rounded operands, then timing (HIP events on the launch stream, random data).
+"""GEMM sweep on the real DiT shapes (run on the GPU box): correctness of the policy's kernels against a torch fp32 matmul
+on the same bf16-rounded operands, then timing (HIP events on the launch stream, random data), with hipBLASLt
+(`torch.matmul`, plain product) on the same operands beside it.
 
-    python tools/gemm_bench.py [--dims large*|default|small*] [--batch 32] [--iters 10]
+    python tools/gemm_bench.py [--dims large*|default|small*] [--clips 32 16 4] [--iters 10]
 """
 import argparse
 import math
@@ -21,15 +22,8 @@ from tests import util  # noqa: E402
 
 RASTER = [0]
 BLAS = [False]
-VARIANTS = {0: "v1 128x128", 3: "256x128 s3", 4: "256x128 s2", 5: "256x256 s2", 9: "pp 256x256"}
-# force-only kernels (gemm2.hip "gemm5" family: 4 loader waves + 8 compute waves; and the BK-32 two-workgroup tile)
-EXPERIMENTAL = {4: "256x128 s2", 9: "pp 256x256", 15: "ld 256x256 s2", 16: "ld 256x256 h4", 17: "ld 256x128 s3",
-                18: "k32 256x128 2wg", 19: "ld 256x128 s3 pf", 20: "ld 256x128 pf persist", 21: "ld 256x256 persist", 22: "8-phase 256x256", 23: "8-phase no stagger", 24: "8-phase no setprio"}
-
-
-# round 2, after GPU call 3: the kernels the tile policy can pick for a DiT-class GEMM, for A/B at several row counts
-FAMILY = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128", 20: "ld 256x128 pf persist", 25: "128x128 s2 (32x32x16)",
-          26: "64x128 s3 (32x32x16)"}
+# the kernels the tile policy picks from for a DiT-class GEMM (gemm.hip gemm_variant numbering)
+VARIANTS = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128"}
 
 
 def interleave16(w1, w3):
@@ -110,30 +104,16 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dims", default="large*")
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--clips", type=int, nargs="+", default=[32, 16, 4], help="rows = clips x 250 frames")
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--ablate", action="store_true", help="time the gemm3 256x256 ablation builds (results are wrong)")
-    ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size on the shipped variants")
-    ap.add_argument("--experimental", action="store_true", help="shipped policy kernels vs the force-only experimental ones")
-    ap.add_argument("--family", action="store_true", help="only the kernels the round-2 tile policy picks from")
-    ap.add_argument("--r3", action="store_true",
-                    help="round 3: the 8-phase family incl. its 256x192 tile, at 32 / 16 / 4 clips, hipBLASLt beside it")
+    ap.add_argument("--quick", action="store_true", help="only the small correctness shapes")
+    ap.add_argument("--no-blas", action="store_true", help="skip the hipBLASLt (torch.matmul) column")
+    ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size of the 8-phase kernel")
     ap.add_argument("--vit", action="store_true", help="the PE-Core-L14-336 tower's GEMM shapes (250 frames x 577 tokens)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    if args.ablate:
-        VARIANTS.clear()
-        VARIANTS.update({9: "pp 256x256", 12: "no DMA", 13: "no MFMA", 14: "no LDS reads"})  # needs -DSAMAUDIO_GEMM_ABLATIONS
-    if args.experimental:
-        VARIANTS.clear()
-        VARIANTS.update(EXPERIMENTAL)
-    if args.family:
-        VARIANTS.clear()
-        VARIANTS.update(FAMILY)
+    BLAS[0] = not args.no_blas
     if args.vit:
-        VARIANTS.clear()
-        VARIANTS.update({-1: "auto policy", 22: "8-phase 256x256", 27: "gemm8s 128x128", 20: "ld 256x128 pf persist"})
         Mv = 250 * 577
         run_case("vit qkv (bias)", Mv, 3072, 1024, "plain", dev, 5)
         run_case("vit out_proj (bias+res)", Mv, 1024, 1024, "gated", dev, 5)
@@ -142,52 +122,25 @@ def main():
         return
     t = preset_config(args.dims).transformer
     D, Fh = t.dim, t.ffn_hidden
-    if args.r3:
-        VARIANTS.clear()
-        VARIANTS.update({-1: "auto policy", 22: "8-phase 256x256", 23: "8-phase, round-2 build", 27: "gemm8s 128x128"})
-        BLAS[0] = True
-        run_case("square 4096", 4096, 4096, 4096, "plain", dev, args.iters)
-        for clips in (32, 16, 4):
-            Mr = clips * 250
-            run_case("qkv", Mr, 3 * D, D, "plain", dev, args.iters)
-            run_case("wo/c_wo (gate+res)", Mr, D, D, "gated", dev, args.iters)
-            run_case("c_wq", Mr, D, D, "plain", dev, args.iters)
-            run_case("w13 swiglu", Mr, 2 * Fh, D, "swiglu", dev, args.iters)
-            run_case("w2 (gate+res)", Mr, D, Fh, "gated", dev, args.iters)
-            run_case("patcher conv-as-gemm shape", Mr, D, 3 * D, "plain", dev, args.iters)
-        return
-    M = args.batch * 250
     # small correctness shapes first: ragged M, N tails, several K
     run_case("edge small", 300, 640, 192, "plain", dev, 2)
     run_case("edge gated", 517, 1152, 320, "gated", dev, 2, T=47)
     run_case("edge swiglu", 333, 1280, 256, "swiglu", dev, 2)
     if args.quick:
         return
-    if args.raster:
-        VARIANTS.clear()
-        VARIANTS.update({22: "8-phase 256x256"})
-        for gm in (8, 2, 4, 16, 32, 8):
-            RASTER[0] = gm
+    # the guide's reference shape (cdna_hip_programming.md section 5: 8-phase template ~1320-1340 TF at 4096^3 on random
+    # operands): calibrates this box / this kernel against that ladder
+    run_case("square 4096", 4096, 4096, 4096, "plain", dev, args.iters)
+    for gm in ((8, 2, 4, 16, 32) if args.raster else (0,)):
+        RASTER[0] = gm
+        for clips in args.clips:
+            M = clips * 250
             run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
-            run_case("c_wq", M, D, D, "plain", dev, args.iters)
             run_case("wo/c_wo (gate+res)", M, D, D, "gated", dev, args.iters)
+            run_case("c_wq", M, D, D, "plain", dev, args.iters)
             run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
             run_case("w2 (gate+res)", M, D, Fh, "gated", dev, args.iters)
-        return
-    if args.ablate:
-        run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
-        run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
-        return
-    if args.experimental:  # the guide's reference shapes (cdna_hip_programming.md section 5: 8-phase template ~1320-1340 TF
-        # at 4096^3 and ~1470 TF at 8192^3 on random operands) - calibrates this box / these kernels against that ladder
-        run_case("square 4096", 4096, 4096, 4096, "plain", dev, args.iters)
-        run_case("square 8192", 8192, 8192, 8192, "plain", dev, max(2, args.iters // 3))
-    run_case("qkv", M, 3 * D, D, "plain", dev, args.iters)
-    run_case("wo/c_wo (gate+res)", M, D, D, "gated", dev, args.iters)
-    run_case("c_wq", M, D, D, "plain", dev, args.iters)
-    run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
-    run_case("w2 (gate+res)", M, D, Fh, "gated", dev, args.iters)
-    run_case("c_wkv (text rows)", args.batch * 8, 2 * D, D, "plain", dev, args.iters)
+            run_case("patcher conv-as-gemm shape", M, D, 3 * D, "plain", dev, args.iters)
 
 
 if __name__ == "__main__":
