@@ -82,6 +82,10 @@ def parse(argv=None):
                          "clips on the rank, else 1; with 2, one group's GEMM "
                          "tile tails - 352 tiles of 256x256 on 256 CUs at N = D - and epilogues are filled by the other's "
                          "workgroups; bitwise equal to 1 stream; 200.5 vs 181.1 s-audio/s, profiles/r2_call3/)")
+    ap.add_argument("--serial-groups", action="store_true",
+                    help="measurement aid: the row groups of --streams 2 run one after the other on one stream (the launches "
+                         "of the timed configuration without their overlap) - the command whose rocprofv3 --kernel-trace "
+                         "--stats summary the roofline's per-launch durations must agree with")
     ap.add_argument("--candidates", type=int, default=1,
                     help="> 1: BASELINE.json configs[3] - reranking_candidates per clip, scored by the HIP Judge "
                          "(pe-av-large stand-in dims, random weights); the default bench line stays configs[2]")
@@ -305,10 +309,9 @@ def build_span_predictor(cfg, precision, dev):
 
 # rocprofv3 kernel symbols of the profile names (profiles/r2_traffic.json is keyed by symbol)
 SYMBOLS = {
-    "gemm8_bf16_256x256_8phase": "sa::gemm8_kernel<true, true",
-    "gemm5_bf16_256x128_ld_s3_pf_persist": "sa::gemm5_kernel<256, 128, 4, 2, 3, 64, true, true, 0>",
-    "gemm2_bf16_256x128_s2": "sa::gemm2_kernel<256, 128, 4, 2, 2, 64, 0>",
-    "gemm3_bf16_256x256_pp2": "sa::gemm3_kernel<256, 256, 2, 4, 2, 2, 0>",
+    "gemm8_bf16_256x256_8phase": "sa::gemm8_kernel<false>",        # plain GEMMs: every Linear of the DiT
+    "gemm8_bf16_256x256_8phase_conv": "sa::gemm8_kernel<true>",    # implicit convolutions (patcher, wide codec stages)
+    "gemm8s_bf16_128x128": "sa::gemm8s_kernel<",
 }
 
 
@@ -316,7 +319,7 @@ def traffic_of(kernel: str, split: bool = False):
     """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/r2_final.sh -> tools/pmc_traffic.py); they
     cannot be collected inside a timed run.  r2_traffic.json: launches not split into whole rounds + tail (what two
     concurrent row groups run); r2_traffic_split.json: the single-group form."""
-    for fname in (("r2_traffic_split.json",) if split else ()) + ("r2_traffic.json", "r1_traffic.json"):
+    for fname in ("r3_traffic.json",) + (("r2_traffic_split.json",) if split else ()) + ("r2_traffic.json", "r1_traffic.json"):
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
         except (OSError, KeyError, ValueError):
@@ -329,6 +332,17 @@ def traffic_of(kernel: str, split: bool = False):
 
 
 SPLIT_MODE = [False]   # set by main(): whether the instrumented step runs launches split into whole rounds + tail
+
+
+def reference_flops(cfg, clips, text_len):
+    """Algorithmic FLOPs of one separate() over `clips` 10 s clips as the REFERENCE executes it:
+    per evaluation L x (2T D^2 x 6 + 4 T^2 D + 6 T D F + cross K,V and scores) + patcher 12 T D^2 + the 768/1024/128/256-wide
+    projections, x 32 evaluations; DAC-VAE encode 0.487 TF + decode 2 x 1.096 TF per clip (default codec dims)."""
+    t = cfg.transformer
+    D, F, L, T, Lt = t.dim, t.ffn_hidden, t.n_layers, 250, text_len
+    layer = 2 * T * D * D * 6 + 4 * T * T * D + 6 * T * D * F + 2 * Lt * D * D * 2 + 4 * T * Lt * D
+    per_eval = L * layer + 12 * T * D * D + 2 * T * D * (768 + 1024 + 128 + 256) + 2 * Lt * D * 768 + 6 * Lt * D * D
+    return clips * (32.0 * per_eval + 0.487e12 + 2 * 1.096e12)
 
 
 def rooflines(stats):
@@ -530,6 +544,7 @@ def main():
         assert my_ids, f"strong scaling: rank {rank} got no clip (global batch {args.batch} < {world} ranks)"
     batch, clips, text, tmask = make_batch(my_ids)
     n_streams = model.streams = auto_streams(len(my_ids))
+    model._serial_groups = bool(args.serial_groups)
     model.tail_split = n_streams == 1   # pinned, so that the instrumented (single-stream) step launches the timed kernels
     SPLIT_MODE[0] = n_streams == 1
     log(f"inputs resident ({len(my_ids)} clips on this rank, {n_streams} stream(s)); warm-up")
@@ -555,40 +570,32 @@ def main():
         model.streams = n_streams
         del o_batch
 
-    # ---- rooflines: one extra, instrumented step (HIP events on the launch stream) ----------------------------
+    # ---- rooflines: one extra, instrumented step (HIP events on the launch stream) --------------------------------
+    # The instrumented step issues EXACTLY the launches of the timed steps (same row groups, same tile policy and options);
+    # only their scheduling differs: the row groups run one after the other on one stream, so that an event pair brackets a
+    # kernel that has the GPU to itself.
     roof = {"roofline": None, "roofline_hbm": None, "kernels": None}
     if rank == 0 and not args.no_roofline:
-        model.streams = 1  # events bracket single launches: keep the GPU to one stream while they are recorded
-        model.profile_begin()
+        model.profile_begin(serial_groups=True)
         step()
         roof = rooflines(model.profile_end())
-        if n_streams > 1 and roof["roofline"]:
-            # for reference: the same step as ONE row group with the tail split on (what a context that has the GPU to
-            # itself runs): whole rounds of 256x256 tiles under the 8-phase symbol, last partial rounds as 128x128 tiles
-            model.tail_split = True
-            model.profile_begin()
-            step()
-            alt = rooflines(model.profile_end())
-            model.tail_split = False
-            if alt["roofline"]:
-                a = alt["roofline"]
-                roof["roofline"]["single_group_tail_split"] = {
-                    "what": "the same step solved as one row group with SAMAUDIO_OPT_TAIL_SPLIT on (not the timed configuration)",
-                    "kernel": a["kernel"], "achieved": a["achieved"], "frac": a["frac"], "launches_per_step": a["launches_per_step"],
-                    "dit_gemm_all": a["dit_gemm_all"], "traffic": traffic_of(a["kernel"], split=True)[0],
-                    "tail_kernel": next(({"kernel": k["kernel"], "tflops": k["tflops"], "ms": k["ms"], "launches": k["launches"]}
-                                         for k in alt["kernels"] if k["kernel"].endswith("_tail")), None)}
-        model.streams = n_streams
         if roof["roofline"]:
             fl = sum(k["_flops"] for k in roof["_rows"])
+            ref_fl = reference_flops(cfg, len(my_ids), args.text_len) * (args.candidates if args.candidates > 1 else 1)
             roof["roofline"]["measured"] = (
-                "one extra instrumented step on ONE stream: HIP events bracket every launch on its launch stream, so "
-                "durations are those of a kernel that has the GPU to itself (= what rocprofv3 --kernel-trace of "
-                "`bench.py --streams 1` reports, profiles/); the timed steps run streams_per_gpu concurrent row groups")
+                f"one extra instrumented step issuing the launches of the timed steps ({n_streams} row group(s) of "
+                f"{len(my_ids) // n_streams} clips: M = {len(my_ids) // n_streams * 250} rows per DiT GEMM launch), the groups one "
+                "after the other on one stream: HIP events bracket every launch on its launch stream, so a duration is that "
+                "of a kernel that has the GPU to itself (= what rocprofv3 --kernel-trace of the serialised command reports, "
+                "profiles/); in the timed steps the row groups overlap - see whole_step for the figure that includes it")
             roof["roofline"]["whole_step"] = {
-                "what": "executed flops of ALL kernels of a step / the timed ms_per_step (concurrent streams included)",
-                "flops_per_step": fl, "achieved": round(fl / (elapsed / args.steps) / 1e12, 2), "unit": "TFLOP/s",
-                "frac": round(fl / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                "what": "flops of a whole step / the TIMED ms_per_step (concurrent row groups, codec and streaming kernels "
+                        "included): `executed` = what the kernels of this build run (hoisted conditioning, folded cross-"
+                        "attention), `as_reference` = the algorithmic flops of the reference's own op sequence (SURVEY.md 8d)",
+                "executed_flops_per_step": fl, "executed": round(fl / (elapsed / args.steps) / 1e12, 2),
+                "as_reference_flops_per_step": ref_fl, "as_reference": round(ref_fl / (elapsed / args.steps) / 1e12, 2),
+                "unit": "TFLOP/s", "frac_executed": round(fl / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "frac": round(ref_fl / (elapsed / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4)}
 
     # ---- visual prompting: the tower alone, HIP events around the frames of ONE video (250 frames) ---------------
     if rank == 0 and args.visual:

@@ -415,7 +415,10 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
     // a split launch (gemm.hip gemm_tail_split) is two kernels: each gets its own record, flops / bytes by tile share
     const double share = !full ? 1.0 : (part == 0 ? (double)full / tiles : 1.0 - (double)full / tiles);
     ProfRec r;
-    r.key = std::string(prof_cls_) + "/" + (part ? "gemm8s_bf16_128x128_tail" : gemm_variant_name(gemm_variant(p, bf16_), bf16_));
+    // implicit convolutions (kc < K) run the 8-phase kernels under their own instantiation (gemm8_kernel<true>): own record
+    const int variant = gemm_variant(p, bf16_);
+    const char* conv = (variant == 22 || variant == 27) && p.kc < p.K ? "_conv" : "";
+    r.key = std::string(prof_cls_) + "/" + (part ? "gemm8s_bf16_128x128_tail" : gemm_variant_name(variant, bf16_)) + conv;
     r.flops = flops * share;
     r.bytes = bytes * share;
     SA_TRY(prof_event(&r.e0));

@@ -119,6 +119,7 @@ class SAMAudio:
         # the same kernels as the timed ones)
         self.tail_split: Optional[bool] = None
         self._lanes: List[_Lane] = []
+        self._profiling = self._serial_groups = False
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
             precision=hip.precision_code(precision), dim=t.dim, n_heads=t.n_heads,
@@ -257,18 +258,33 @@ class SAMAudio:
         return self._tensors
 
     # ------------------------------------------------------------------ measurement (bench.py)
-    def profile_begin(self) -> None:
-        """Bracket every GEMM launch with a hipEvent pair on the launch stream until profile_end()."""
-        hip.check(self._lib.samaudio_profile_begin(self._ctx))
+    def profile_begin(self, serial_groups: bool = True) -> None:
+        """Bracket every kernel launch with a hipEvent pair on its launch stream until profile_end(), on every engine
+        context of the model (the row groups of `streams` > 1 have one each).  `serial_groups`: while profiling, the row
+        groups run ONE AFTER THE OTHER on the caller's stream, so that an event pair times a kernel that has the GPU to
+        itself - the launches (shapes, tile policy, options) are exactly those of the concurrent run."""
+        self._profiling, self._serial_groups = True, bool(serial_groups)
+        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+            hip.check(self._lib.samaudio_profile_begin(ctx))
 
     def profile_end(self) -> List[Dict[str, Any]]:
-        """[{name, launches, flops, bytes, ms}] per (class, kernel) since profile_begin() (synchronises).  name =
-        "dit/<kernel>" | "codec/<kernel>" | "prep/<kernel>"; flops / bytes are algorithmic (see include/samaudio.h)."""
-        buf = (hip.KernelStat * 64)()
-        n = C.c_int(0)
-        hip.check(self._lib.samaudio_profile_end(self._ctx, buf, 64, C.byref(n)))
-        return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), flops=float(buf[i].flops),
-                     bytes=float(buf[i].bytes), ms=float(buf[i].ms)) for i in range(n.value)]
+        """[{name, launches, flops, bytes, ms}] per (class, kernel) since profile_begin() (synchronises), summed over the
+        contexts.  name = "dit/<kernel>" | "codec/<kernel>" | "prep/<kernel>"; flops / bytes are algorithmic (see
+        include/samaudio.h)."""
+        merged: Dict[str, Dict[str, Any]] = {}
+        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+            buf = (hip.KernelStat * 64)()
+            n = C.c_int(0)
+            hip.check(self._lib.samaudio_profile_end(ctx, buf, 64, C.byref(n)))
+            for i in range(n.value):
+                name = buf[i].name.decode()
+                row = merged.setdefault(name, dict(name=name, launches=0, flops=0.0, bytes=0.0, ms=0.0))
+                row["launches"] += int(buf[i].launches)
+                row["flops"] += float(buf[i].flops)
+                row["bytes"] += float(buf[i].bytes)
+                row["ms"] += float(buf[i].ms)
+        self._profiling = self._serial_groups = False
+        return list(merged.values())
 
     # ------------------------------------------------------------------ workspace
     def _ensure_workspace(self, rows: int, frames: int, text_len: int, codec_items: int, samples: int,
@@ -419,6 +435,8 @@ class SAMAudio:
                 if decode else None)
         while len(self._lanes) < groups - 1:
             self._lanes.append(_Lane(self))
+            if self._profiling:
+                hip.check(self._lib.samaudio_profile_begin(self._lanes[-1]._ctx))
         self._apply_options(groups)
         main = torch.cuda.current_stream(self.device)
         errors: List[BaseException] = []
@@ -428,7 +446,7 @@ class SAMAudio:
                 rr = shard_range(rows, i, groups)
                 sl = slice(rr.start, rr.stop)
                 part = [None if c is None else c[sl] for c in cond]
-                stream = main if lane is None else lane.stream
+                stream = main if (lane is None or self._serial_groups) else lane.stream
                 with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(stream):
                     self._prepare(*part, lane=lane)
                     ctx = self._ctx if lane is None else lane._ctx
@@ -441,15 +459,19 @@ class SAMAudio:
             except BaseException as exc:  # re-raised on the caller's thread
                 errors.append(exc)
 
-        for lane in self._lanes[:groups - 1]:
-            lane.stream.wait_stream(main)
-        threads = [threading.Thread(target=work, args=(i, None if i == 0 else self._lanes[i - 1])) for i in range(groups)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        for lane in self._lanes[:groups - 1]:
-            main.wait_stream(lane.stream)
+        if self._serial_groups:   # profiling: the same launches, one group after the other on the caller's stream
+            for i in range(groups):
+                work(i, None if i == 0 else self._lanes[i - 1])
+        else:
+            for lane in self._lanes[:groups - 1]:
+                lane.stream.wait_stream(main)
+            threads = [threading.Thread(target=work, args=(i, None if i == 0 else self._lanes[i - 1])) for i in range(groups)]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            for lane in self._lanes[:groups - 1]:
+                main.wait_stream(lane.stream)
         if errors:
             raise errors[0]
         return (state, wavs.view(rows, 2, -1)) if decode else state
