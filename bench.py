@@ -514,6 +514,11 @@ def main():
 
         def step():
             # noise=None: drawn on device inside, like the reference (model.py:274-275)
+            if args.predict_spans:
+                # predict_spans() writes the predicted anchors into the batch (reference model.py:245, processor.py:122-123)
+                # and a batch that already has anchors skips the predictor: every step starts from the un-anchored batch
+                batch.process_anchors(None)
+                batch.anchor_ids, batch.anchor_alignment = batch.anchor_ids.to(dev), batch.anchor_alignment.to(dev)
             return model.separate(batch, reranking_candidates=args.candidates, predict_spans=args.predict_spans)
 
         for i in range(warmup):
@@ -551,6 +556,44 @@ def main():
     elapsed, step = timed(batch, args.steps, args.warmup, args.scaling)
     value = clips_total * CLIP_SECONDS * args.steps / elapsed
     log(f"timed {args.steps} steps in {elapsed:.3f} s -> {value:.2f} s-audio/s")
+
+    # ---- configs[3]: what the span predictor and the Judge reranker cost, by difference ---------------------------------
+    breakdown = None
+    if rank == 0 and (args.candidates > 1 or args.predict_spans):
+        ranker, predictor = model.text_ranker, model.span_predictor
+        b_steps = max(2, min(args.steps, 4))
+
+        def run(spans, rerank):
+            model.text_ranker = ranker if rerank else None
+            model.span_predictor = predictor if spans else None
+            import warnings
+
+            def once():
+                batch.process_anchors(None)
+                batch.anchor_ids, batch.anchor_alignment = batch.anchor_ids.to(dev), batch.anchor_alignment.to(dev)
+                model.separate(batch, reranking_candidates=args.candidates, predict_spans=spans)
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                once()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(b_steps):
+                    once()
+                torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / b_steps
+
+        ms_core = run(False, False)
+        ms_spans = run(args.predict_spans, False) if args.predict_spans else ms_core
+        ms_all = run(args.predict_spans, True)
+        model.text_ranker, model.span_predictor = ranker, predictor
+        breakdown = {"what": "ms per step by difference: separate() with candidates but no span predictor and no reranker (DAC "
+                             "encode, ODE over batch x candidates rows, DAC decode of every candidate) | + PE-A-Frame span "
+                             "predictor | + Judge reranker (DAC encodes of mixture and candidates, two PE-AV transformers, "
+                             "ModernBERT text tower)",
+                     "encode_ode_decode_ms": round(ms_core, 2), "span_predictor_ms": round(ms_spans - ms_core, 2),
+                     "judge_reranker_ms": round(ms_all - ms_spans, 2), "steps": b_steps}
+        log(f"breakdown: {breakdown}")
 
     # ---- N > 1: the other scaling mode in the same invocation (strong is the line's value, weak the side key, or v.v.) ----
     strong = None
@@ -690,7 +733,8 @@ def main():
             },
             "vision_tower": vision,
             "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,
-            "parity_check": parity, "parity_mode": pmode, "other_scaling": strong, "kernels": roof.get("kernels"),
+            "parity_check": parity, "parity_mode": pmode, "other_scaling": strong, "rerank_breakdown": breakdown,
+            "kernels": roof.get("kernels"),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -205,7 +205,16 @@ class SAMAudio:
             from .vision_encoder import PerceptionEncoder
             self.vision_encoder = PerceptionEncoder(self.cfg.vision_encoder, device=self.device, precision=self.precision)
         if vis and hasattr(self.vision_encoder, "load_state_dict"):
-            self.vision_encoder.load_state_dict(vis, strict=strict)
+            # The tower's key list is restated from the published PE-Core architecture (perception_models is not
+            # importable offline), so it is validated for what the engine NEEDS, not for what a genuine checkpoint may carry
+            # on top (buffers, layer-scale or text-side keys under `visual.`): missing tensors still fail a strict load,
+            # extra ones are reported - an unverified key list must not make a whole SAMAudio checkpoint unloadable.
+            v_missing, v_unexpected = self.vision_encoder.load_state_dict(vis, strict=False)
+            if strict and v_missing:
+                raise RuntimeError(f"Missing keys: {['vision_encoder.' + k for k in v_missing]}")
+            if v_unexpected:
+                warnings.warn(f"vision_encoder: {len(v_unexpected)} checkpoint tensors are not consumed by the PE-Core tower "
+                              f"engine (first: {v_unexpected[:3]})")
         with torch.cuda.device(self.device):
             if not dit_missing:
                 self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device))

@@ -39,7 +39,8 @@ class T5TextEncoder:
         self.cfg = cfg or T5EncoderConfig()
         if backend not in (None, "hip", "torch"):
             raise ValueError("backend must be 'hip' or 'torch'")
-        self.backend = backend            # None: decided by the first .to(device): "hip" on a GPU, "torch" on the CPU
+        self._requested = backend         # what the caller asked for; None = automatic
+        self.backend = backend            # the RESOLVED backend: re-decided by every .to(device) when automatic
         self.precision = precision
         self._hip = None                  # T5EncoderHIP, built when the weights move to the GPU
         self.pad_mode = self.cfg.pad_mode
@@ -68,8 +69,18 @@ class T5TextEncoder:
             self.to(device=device, dtype=dtype)
 
     def to(self, device=None, dtype=None):
+        """Automatic backend (backend=None at construction): "hip" whenever the encoder is on a GPU, "torch" on the CPU,
+        re-resolved on EVERY device move (a CPU stop-over does not pin the torch module for a later .to('cuda')).  An
+        explicit backend="hip" cannot live on the CPU: the move is refused."""
         dev = torch.device(device) if device is not None else None
-        backend = self.backend or ("hip" if dev is not None and dev.type == "cuda" else "torch")
+        if dev is None:                   # dtype-only request: the device, hence the automatic choice, is unchanged
+            backend = self.backend or self._requested or "torch"
+        else:
+            backend = self._requested or ("hip" if dev.type == "cuda" else "torch")
+        if backend == "hip" and dev is not None and dev.type != "cuda":
+            from . import hip
+            raise hip.SamAudioHipError("T5TextEncoder(backend='hip') cannot move to the CPU: there is no CPU fallback "
+                                       "(construct it with backend=None or 'torch' for CPU use)")
         if backend == "hip" and dev is not None:
             # the HIP stack takes its own (re-laid out) copy of the weights; the torch module stays where it is
             from .t5_encoder import T5Dims, T5EncoderHIP
@@ -81,7 +92,8 @@ class T5TextEncoder:
             pass                          # dtype-only request: the HIP stack's operand format is `precision`
         else:
             self.model = self.model.to(device=device, dtype=dtype)
-            self._hip = None
+            self._hip = None              # a stale device copy must not outlive the move
+            self._device = None
         self.backend = backend
         return self
 

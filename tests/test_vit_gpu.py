@@ -194,6 +194,12 @@ def test_separate_with_the_hip_tower_from_a_checkpoint(gpu):
     assert (lat_ref - lat_novid).abs().max() > 1e-3, "the video term must matter for this check to mean anything"
     model = SAMAudio(cfg, precision="fp32", device=str(gpu))
     assert model.vision_encoder is None
+    # a genuine pe.CLIP state_dict may carry tensors under `visual.` that the restated key list does not know (buffers,
+    # layer-scale): a strict load must report them, not fail on them
+    extra = dict(full)
+    extra["vision_encoder.model.visual.some_buffer_the_engine_does_not_use"] = torch.zeros(3)
+    with pytest.warns(UserWarning, match="not consumed by the PE-Core tower"):
+        model.load_state_dict(extra, strict=True)
     model.load_state_dict(full, strict=True)
     assert model.vision_encoder is not None and model.vision_encoder.tower.__class__.__name__ == "PEVisionTower"
     model.separate(batch.to(gpu), noise=noise.to(gpu))
