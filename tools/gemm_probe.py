@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """A few launches of chosen GEMM variants on the real DiT shapes, for rocprofv3 --pmc passes
-(tools/pmc_gemm.sh).  usage: python tools/gemm_probe.py [variant:shape ...]  e.g. 22:w13 22:c_wq"""
+(tools/pmc_gemm.sh).  usage: [PROBE_ROWS=4000] python tools/gemm_probe.py [variant:shape ...]  e.g. 22:w13 22:c_wq
+PROBE_ROWS: rows per launch (default 8000 = one row group of 32 clips; 4000 = the two-group launches bench.py times)."""
 import os
 import sys
 
@@ -13,8 +14,8 @@ from sam_audio_amd.config import preset_config  # noqa: E402
 from tests import util  # noqa: E402
 
 t = preset_config("large*").transformer
-D, Fh, M = t.dim, t.ffn_hidden, 8000
-SHAPES = {"w13": (M, 2 * Fh, D, 1), "c_wq": (M, D, D, 0), "qkv": (M, 3 * D, D, 0), "w2": (M, D, Fh, 0)}
+D, Fh, M = t.dim, t.ffn_hidden, int(os.environ.get("PROBE_ROWS", "8000"))
+SHAPES = {"w13": (M, 2 * Fh, D, 1), "c_wq": (M, D, D, 0), "wo": (M, D, D, 0), "qkv": (M, 3 * D, D, 0), "w2": (M, D, Fh, 0)}
 dev = torch.device("cuda:0")
 for spec in (sys.argv[1:] or ["22:w13", "22:c_wq", "22:qkv", "22:w2"]):
     v, name = spec.split(":")
