@@ -63,12 +63,9 @@ __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha)
 // chunks XOR-swizzled with the row): after it a lane owns 4 consecutive columns and the 16 lanes of a row group cover
 // 256 contiguous bytes, so residual / gate loads and fp32 / bf16 stores move whole cache lines per row
 // (MI355X_MICROARCH.md "store-ISSUE-bound" epilogues, cdna_hip_programming.md T21).
-// MF: 16-row fragments of the (single) half that exist - 4, or 3 for the 96-row tile of gemm8s (48 rows per wave; the
-// staged image keeps its 64-row pitch and rows 48 .. 63 are neither written nor read).
-template <int NH, int MF = 4>
-__device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH * MF][4], char* const stg, const int b,
+template <int NH>
+__device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH * 4][4], char* const stg, const int b,
                                           const int m_wave0, const int n_wave0, const int lane) {
-  static_assert(MF == 4 || NH == 1, "partial halves only for one-half tiles");
   const int lr = lane & 15, lg = lane >> 4;
   const long bM = (long)b * p.M;
   const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
@@ -91,14 +88,14 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
   for (int half = 0; half < NH; ++half) {
     // write phase: rows half*64 + i*16 + lr of the wave's rows
 #pragma unroll
-    for (int i = 0; i < MF; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int row = i * 16 + lr;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4_t a = acc[half * MF + i][j];
+        const f32x4_t a = acc[half * 4 + i][j];
         if (p.swiglu) {  // odd fragments hold the w3 rows matching the previous fragment's w1 rows
           if (j & 1) continue;
-          const f32x4_t g = acc[half * MF + i][j | 1];
+          const f32x4_t g = acc[half * 4 + i][j | 1];
           const int chunk = (j >> 1) * 4 + lg;
           *(float4*)(stg + row * 256 + ((chunk ^ (row & 15)) << 4)) =
               make_float4(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1], silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
@@ -133,8 +130,8 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
       const int row = it * rows_per_it + rsub;
       const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
       const int m = m_wave0 + half * 64 + row;
-      const bool m_ok = m < p.M && (MF == 4 || row < MF * 16);
-      const int mc = m < p.M ? m : p.M - 1;
+      const bool m_ok = m < p.M;
+      const int mc = m_ok ? m : p.M - 1;
       float v[4] = {sv.x, sv.y, sv.z, sv.w};
       if (has_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
       if (has_gate) {
@@ -409,15 +406,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // fragment sets: the LDS reads of K-tile t+1 are issued BEFORE the MFMAs of K-tile t and complete underneath them, one
 // barrier per K-tile.  Same MFMA order per output element: bitwise identical to the plain form and to gemm8_kernel.
 // CONV as in gemm8_kernel: plain GEMMs (kc == K) compile the tap walk out of the staging step.
-// MF (round 3): 16-row fragments per wave = 4 (128 x 128 tile) or 3 (96 x 128: a wave owns 48 x 64).  Launches with few
-// rows are one partial round of the chip whatever the tile, so what counts is how many CUs get a tile: 1000 rows x
-// N = 2816 are 8 x 22 = 176 tiles of 128 rows (69 % of the CUs) but 11 x 22 = 242 of 96 rows (95 %).  Same MFMA, same
-// fragment <-> k mapping, same K order: bitwise the 128-row result.  (The weight tile keeps its 128 rows; the activation
-// tile keeps its 16 KiB slot and stages 96 rows = 3 instead of 4 wave-instructions per wave and K-tile.)
-template <bool PIPE, bool CONV, int MF = 4>
+template <bool PIPE, bool CONV>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
-  constexpr int BM = 32 * MF, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile slot (128 rows x 128 B)
-  constexpr int AQ = MF;                                           // activation staging instructions per wave and K-tile
+  constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 3 : 2;
   __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
 
@@ -444,9 +435,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     n0 = tn * BN;
   }
 
-  // staging: wave w moves rows 32w .. 32w+31 of the weight tile and rows 8 MF w .. 8 MF (w+1) - 1 of the activation tile as
-  // 4 + MF wave instructions of 8 rows (1 KiB each): lane -> row r0 + 8q + (lane>>3), 16-byte slot lane&7, which must hold
-  // source chunk slot ^ ((row>>1)&7).
+  // staging: wave w moves rows 32w .. 32w+31 of both tiles as 4 + 4 wave instructions of 8 rows (1 KiB each):
+  // lane -> row 32w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
   const int r8 = lane >> 3;
   const bf16_t* a_row[4];
   const bf16_t* w_row[4];
@@ -459,15 +449,13 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     for (int q = 0; q < 4; ++q) {
       const int row = wave * 32 + q * 8 + r8;
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      int m = m0 + row;
+      m = m < p.M ? m : p.M - 1;
+      a_row[q] = A + (long)m * p.lda;
       int n = n0 + row;
       n = n < p.N ? n : p.N - 1;
       w_row[q] = W + (long)n * p.K + chunk * 8;
-      const int arow = wave * (8 * AQ) + q * 8 + r8;   // MF = 4: the same row
-      const int achunk = (lane & 7) ^ ((arow >> 1) & 7);
-      int m = m0 + arow;
-      m = m < p.M ? m : p.M - 1;
-      a_row[q] = A + (long)m * p.lda;
-      a_in[q] = achunk * 8;
+      a_in[q] = chunk * 8;
       a_tap[q] = 0;
       if constexpr (CONV)
         while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
@@ -475,11 +463,11 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
   }
   const int nt = p.K / BK;
   auto stage = [&](int buf, int kt) {  // K-tile kt (the a_in / a_tap state points at it) -> stage buf
-    char* dst = smem + buf * (2 * TB);
+    char* dst = smem + buf * (2 * TB) + wave * 4096;
 #pragma unroll
-    for (int q = 0; q < AQ; ++q) dma16_8(a_row[q] + a_tap[q] + a_in[q], dst + wave * (1024 * AQ) + q * 1024);
+    for (int q = 0; q < 4; ++q) dma16_8(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dma16_8(w_row[q] + (long)kt * BK, dst + TB + wave * 4096 + q * 1024);
+    for (int q = 0; q < 4; ++q) dma16_8(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       a_in[q] += BK;
@@ -488,22 +476,17 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     }
   };
 
-  constexpr int LOADS = AQ + 4;   // staging instructions of one K-tile per wave: what a counted vmcnt leaves in flight
-  f32x4_t acc[MF][4];
+  f32x4_t acc[4][4];
 #pragma unroll
-  for (int i = 0; i < MF; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   auto frag = [&](const char* tile_base, int row, int ks) -> bf16x8_t {
     return *(const bf16x8_t*)(tile_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
   };
-  auto wait_landed = [&]() {  // everything but the youngest K-tile's loads has landed
-    if constexpr (LOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  };
 
   if constexpr (PIPE) {
-    bf16x8_t af[2][MF][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
+    bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
     auto read_frags = [&](int buf, auto SET) {
       const char* At = smem + buf * (2 * TB);
       const char* Wt = At + TB;
@@ -511,7 +494,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          if (i < MF) af[SET()][i][ks] = frag(At, wr * (16 * MF) + i * 16 + lr, ks);
+          af[SET()][i][ks] = frag(At, wr * 64 + i * 16 + lr, ks);
           wf[SET()][i][ks] = frag(Wt, wc * 64 + i * 16 + lr, ks);
         }
     };
@@ -522,7 +505,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       // K-tile t+2 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
       if (t + 2 < nt) stage((t + 2) % 3, t + 2);
       if constexpr (decltype(NEXT)::value) {
-        if (t + 2 < nt) wait_landed();   // K-tile t+1 has landed (t+2 may be in flight)
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile t+1 has landed (t+2 may be in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();
@@ -533,7 +516,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < MF; ++i)
+          for (int i = 0; i < 4; ++i)
             acc[i][j] = SA_MFMA_16x16x32(wf[SET()][j][ks], af[SET()][i][ks], acc[i][j]);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -541,7 +524,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     stage(0, 0);
     if (nt > 1) {
       stage(1, 1);
-      wait_landed();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -559,7 +542,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       step(t, I0{}, std::false_type{});
     }
     __syncthreads();
-    epilogue8<1, MF>(p, acc, smem + wave * 16384, b, m0 + wr * (16 * MF), n0 + wc * 64, lane);
+    epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
     return;
   }
   stage(0, 0);
@@ -567,19 +550,19 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     const int cb = t & 1;
     if (t + 1 < nt) {
       stage(cb ^ 1, t + 1);
-      wait_landed();  // the loads just issued stay in flight; K-tile t has landed
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the 8 loads just issued stay in flight; K-tile t has landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     const char* At = smem + cb * (2 * TB);
     const char* Wt = At + TB;
-    bf16x8_t af[MF][2], wf[4][2];
+    bf16x8_t af[4][2], wf[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if (i < MF) af[i][ks] = frag(At, wr * (16 * MF) + i * 16 + lr, ks);
+        af[i][ks] = frag(At, wr * 64 + i * 16 + lr, ks);
         wf[i][ks] = frag(Wt, wc * 64 + i * 16 + lr, ks);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -589,14 +572,18 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < MF; ++i)
+        for (int i = 0; i < 4; ++i)
           acc[i][j] = SA_MFMA_16x16x32(wf[j][ks], af[i][ks], acc[i][j]);
   }
   __syncthreads();
-  epilogue8<1, MF>(p, acc, smem + wave * 16384, b, m0 + wr * (16 * MF), n0 + wc * 64, lane);
+  epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
+// (Round 3, GPU call 8: the same kernel on 96 x 128 tiles - 242 instead of 176 workgroups at 1000 rows x N = 2816, bitwise
+// identical - ran exactly as fast: c_wq 36.0 vs 35.3 us, 4 clips 114.8 vs 115.1 s-audio/s, small* 423 vs 424.  With few
+// rows a launch lasts nt x ~0.8 us whatever its workgroup count: it is bound by the depth of the K-tile prefetch (two K-tiles
+// of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2

@@ -214,44 +214,6 @@ def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
         assert torch.equal(outs["pipelined"][1].view(torch.int16), outs[other][1].view(torch.int16))
 
 
-@pytest.mark.parametrize("M,N,K,swiglu", [(1000, 2816, 256, 0), (500, 1536, 320, 0), (760, 1280, 192, 1), (200, 2816, 128, 0)])
-def test_gemm8s_96_row_tile_is_bitwise_identical(gpu, M, N, K, swiglu):
-    """Round 3: launches with few rows run gemm8s on 96 x 128 tiles when that puts markedly more CUs to work inside one
-    round (1000 rows x 2816 columns: 11 x 22 = 242 workgroups instead of 176).  A wave owns 48 x 64; the activation tile
-    stages 3 instead of 4 instructions per wave and K-tile (counted vmcnt 7 instead of 8).  Same MFMA and K order: the
-    result must equal the 128-row form (debug flag 21 = plain double buffer, 128 rows) and the 256x256 kernel bit for bit;
-    ragged last M-tile (1000 = 10 x 96 + 40), gated-residual and SwiGLU epilogues, 2 .. 5 K-tiles."""
-    A, W = _mk((M, K), 81), _mk((N, K), 82, 1 / math.sqrt(K))
-    n_out = N // 2 if swiglu else N
-    tab, gate, res = _mk((n_out,), 83), _mk((1, n_out), 84), _mk((M, n_out), 85)
-    keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
-    assert (M + 95) // 96 * ((N + 127) // 128) <= 256 and (M + 95) // 96 * 100 >= (M + 127) // 128 * 115   # the 96-row form is what runs
-    outs = {}
-    try:
-        for name, variant, flag in (("96", 27, 0), ("128", 27, 1), ("256", 22, 0)):
-            hip.lib().samaudio_debug_force_gemm_variant(variant)
-            hip.lib().samaudio_debug_set_flag(21, flag)
-            out_act = torch.zeros(M, n_out, device=gpu, dtype=torch.bfloat16)
-            if swiglu:
-                util.gemm("bf16", keep[0], keep[1], M, N, K, swiglu=1, out_act=out_act, act_geom=(0, n_out, 0))
-                outs[name] = (out_act.cpu().float(), out_act.cpu())
-            else:
-                out = torch.full((M, N), float("nan"), device=gpu)
-                util.gemm("bf16", keep[0], keep[1], M, N, K, gate_tab=keep[2], gate=keep[3], gate_ld=N, rows_per_gate=M,
-                          res=keep[4], res_geom=(0, N, 0), out_f32=out, f32_geom=(0, N, 0), out_act=out_act, act_geom=(0, N, 0))
-                outs[name] = (out.cpu(), out_act.cpu())
-    finally:
-        hip.lib().samaudio_debug_set_flag(21, 0)
-        hip.lib().samaudio_debug_force_gemm_variant(-1)
-    assert torch.isfinite(outs["96"][0]).all()
-    if not swiglu:
-        want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
-        util.report(f"gemm8s 96-row {M}x{N}x{K}", outs["96"][0], want, 5e-4)
-    for other in ("128", "256"):
-        assert torch.equal(outs["96"][0], outs[other][0])
-        assert torch.equal(outs["96"][1].view(torch.int16), outs[other][1].view(torch.int16))
-
-
 @pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10)])
 def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
     """8-phase launches whose last round of 256x256 tiles is mostly empty run as two kernels (gemm.hip gemm_tail_split:
