@@ -402,14 +402,18 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // DMA of K-tile t+1 is issued before the reads of K-tile t, one counted vmcnt and two barriers per K-tile.
 // PIPE: the form for launches that cannot give a CU a second workgroup (<= 256 workgroups: 176 at M = 1000, N = D).  Alone
 // on its CU the double-buffered loop runs read fragments -> barrier -> MFMA strictly in sequence - one wave per SIMD, nothing
-// to overlap with: ~1 200 cycles per K-tile for 512 cycles of MFMA work.  PIPE keeps a 3-stage ring (96 KiB) and two
+// to overlap with: ~1 200 cycles per K-tile for 512 cycles of MFMA work.  PIPE keeps a 4-stage ring (128 KiB) and two
 // fragment sets: the LDS reads of K-tile t+1 are issued BEFORE the MFMAs of K-tile t and complete underneath them, one
 // barrier per K-tile.  Same MFMA order per output element: bitwise identical to the plain form and to gemm8_kernel.
 // CONV as in gemm8_kernel: plain GEMMs (kc == K) compile the tap walk out of the staging step.
+// The pipelined form's ring has 4 stages (128 KiB: as deep as LDS allows) = 3 K-tiles of L2 latency in flight: a launch of
+// <= 256 workgroups lasts nt x (a per-K-tile time set by that depth) whatever its workgroup count (round 3, GPU call 8).
+// 3 -> 4 stages: c_wq at 1000 rows 36.9 -> 34.9 us, w2 83.4 -> 79.0; 4 clips per GPU 114.5 -> 119.8 s-audio/s, small* 8 clips
+// 424.0 -> 435.3 (profiles/r3_call9/).
 template <bool PIPE, bool CONV>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
-  constexpr int S = PIPE ? 3 : 2;
+  constexpr int S = PIPE ? 4 : 2;
   __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
 
   const int tid = threadIdx.x;
@@ -502,14 +506,16 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     // EVERY outstanding LDS read before the MFMAs (it cannot keep a per-path count), which serialises read and multiply again.
     auto step = [&](int t, auto SET, auto NEXT) {   // fragments of K-tile t are set SET (reads issued one step earlier)
       constexpr int OTHER = 1 - decltype(SET)::value;
-      // K-tile t+2 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
-      if (t + 2 < nt) stage((t + 2) % 3, t + 2);
+      // K-tile t+S-1 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
+      if (t + S - 1 < nt) stage((t + S - 1) % S, t + S - 1);
       if constexpr (decltype(NEXT)::value) {
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // K-tile t+1 has landed (t+2 may be in flight)
+        // K-tile t+1 has landed; the younger ones (t+2 .. t+S-1, as far as they exist) may be in flight
+        if (S == 4 && t + 3 < nt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();
-        read_frags((t + 1) % 3, std::integral_constant<int, OTHER>{});      // in flight underneath the MFMAs below
+        read_frags((t + 1) % S, std::integral_constant<int, OTHER>{});      // in flight underneath the MFMAs below
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -522,12 +528,12 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     stage(0, 0);
-    if (nt > 1) {
-      stage(1, 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (nt > 1) stage(1, 1);
+    if (S == 4 && nt > 2) stage(2, 2);
+    // K-tile 0 has landed; up to S - 2 younger ones stay in flight
+    if (S == 4 && nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(0, I0{});
     int t = 0;
