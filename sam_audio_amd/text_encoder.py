@@ -77,10 +77,10 @@ class T5TextEncoder:
             backend = self.backend or self._requested or "torch"
         else:
             backend = self._requested or ("hip" if dev.type == "cuda" else "torch")
-        if backend == "hip" and dev is not None and dev.type != "cuda":
+        if backend == "hip" and dev is not None:
             from . import hip
-            raise hip.SamAudioHipError("T5TextEncoder(backend='hip') cannot move to the CPU: there is no CPU fallback "
-                                       "(construct it with backend=None or 'torch' for CPU use)")
+            # an explicit backend="hip" cannot live on the CPU: raises "... needs a ROCm GPU: there is no CPU fallback"
+            hip.require_gpu(dev, "T5TextEncoder(backend='hip') (construct it with backend=None or 'torch' for CPU use)")
         if backend == "hip" and dev is not None:
             # the HIP stack takes its own (re-laid out) copy of the weights; the torch module stays where it is
             from .t5_encoder import T5Dims, T5EncoderHIP
