@@ -214,7 +214,10 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 // (Round 3, GPU call 3: issuing the second staging instruction of every phase from inside the wave's own MFMA cluster -
 // to shorten the read sections, which carry 2 global_load_lds at 100 - 185 issue cycles each - measured 4 - 7 % SLOWER on
 // every DiT shape than this loop (profiles/r3_call3/gemm_bench_r3.log); removed.  Compiling the tap walk out of plain
-// GEMMs measured 3 - 5 % faster and is what CONV = false is.)
+// GEMMs measured 3 - 5 % faster and is what CONV = false is.  GPU call 10: issuing a phase's staging instructions BEFORE its
+// ds_reads, and merging the four phases into two super-phases (32-MFMA clusters, 4 barriers per K-tile instead of 8), both
+// measured within +-1 % of this loop on every shape (profiles/r3_call10/): neither the barrier count nor the order inside
+// a read section is what bounds it.)
 template <bool CONV>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
   constexpr bool STAGGER = true, PRIO = true;

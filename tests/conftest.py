@@ -51,6 +51,9 @@ def _enable_emu_dryrun():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     hip._lib = lib
+    for kv in filter(None, os.environ.get("SAMAUDIO_DEBUG_FLAGS", "").split(",")):   # as hip.lib() does for the real library
+        k, v = kv.split("=")
+        lib.samaudio_debug_set_flag(int(k), int(v))
     hip.require_gpu = lambda device, who: None
     hip.current_stream_ptr = lambda: C.c_void_p(0)
     # `x.to(gpu)` is a copy on a real GPU; tests rely on that (a kernel that works in place must not change the CPU
