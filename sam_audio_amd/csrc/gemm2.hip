@@ -616,6 +616,186 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParam
   gemm_epilogue_lds<FM, FN>(q, acc, b, m0 + wm * WTM, wn * WTN, lane, smem + wave * (FN * 4096));
 }
 
+// ------------------------------------------------------------------------------------------------
+// resws_kernel: the same residual unit, WEIGHT-STATIONARY and persistent, for launches with many tiles (C = 64 / 96 / 128).
+// resunit_kernel at 8 x 480 000 samples spends ~34 us per 128-row tile for ~2 us of MFMA work: 14 K-tiles of 12 MFMAs each
+// behind a barrier + DMA wait, then an epilogue whose residual reads the compiler cannot hoist over the stores of the
+// previous iteration (they alias: the fp32 stream is updated in place), i.e. one memory round trip per 64 x 16 bytes - the
+// kernel has too few bytes in flight to load HBM (2.2 TB/s, profiles/r3_call5/op_bench_prev.log).  Here
+//   * one workgroup per CU, C/32 waves, wave w owns output channels [32 w, 32 w + 32) of ALL 128 rows of a tile and keeps
+//     its slice of W7 (7 C / 16 fragments) and W1 (C / 16) in REGISTERS for the whole launch (<= 256 VGPRs): no weight
+//     ring, no per-K-tile barrier - phase 1 is one straight run of 4 independent MFMAs per fragment;
+//   * the workgroup walks tiles; the halo tile of tile t+1 streams into the second halo buffer while tile t computes, and
+//     the fp32 residual rows of tile t (16 x 16 bytes per lane) are requested at the top of the tile, ~3 us before the
+//     epilogue consumes them: ~90 KiB in flight per CU;
+//   * 3 barriers per tile (halo landed | phase-1 reads done | intermediate published).
+// Arithmetic, K order and rounding points are those of the two launches: bitwise identical (tests/test_gemm2_gpu.py).
+// ------------------------------------------------------------------------------------------------
+template <int C, int TAG>
+__global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams p, const GemmParams q) {
+  constexpr int NW = C / 32, BM = 128, FM = 4, MAXD = 9;
+  constexpr int HS = C * 2 + 16;
+  constexpr int CPRH = HS / 16;
+  constexpr int HROWS = BM + 6 * MAXD;
+  constexpr int HALO_B = (HROWS * HS + 1023) / 1024 * 1024;
+  constexpr int K7S = 7 * C / 16, K1S = C / 16;
+  static_assert(C % 32 == 0 && 2 * HALO_B + NW * 4096 + 2 * C * 4 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HALO_B + NW * 4096];
+  __shared__ __attribute__((aligned(16))) float colv[2 * C];   // phase 1's bias | Snake alpha
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int dil = (int)(p.tap_stride / C);
+  const int tiles_m = (p.M + BM - 1) / BM, total = tiles_m * p.nbatch;
+  const int bid = blockIdx.x, G = gridDim.x;
+  // a full grid gives every XCD (workgroup id mod 8) 32 consecutive tiles per sweep: neighbours share halo rows in one L2
+  auto tile_of = [&](int it) { return G == 256 ? it * 256 + (bid & 7) * 32 + (bid >> 3) : it * G + bid; };
+  if (tid < C / 4) {   // published by the first tile's barrier
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av = bv;
+    if (p.bias) bv = ((const float4*)p.bias)[tid];
+    if (p.act == ACT_SNAKE) av = ((const float4*)p.act_alpha)[tid];
+    ((float4*)colv)[tid] = bv;
+    ((float4*)colv)[C / 4 + tid] = av;
+  }
+  const int rows_used = BM + 6 * dil, last_row = p.M - 1 + 6 * dil, chunks = rows_used * CPRH;
+  auto issue_halo = [&](int L, char* dst) {   // as conv7h_kernel; rows past the clip re-read its last halo row
+    const int hb = L / tiles_m, hm0 = (L - hb * tiles_m) * BM;
+    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)hb * p.a_bstride;
+    for (int c0 = wave * 64; c0 < chunks; c0 += NW * 64) {
+      const int g = c0 + lane;
+      const int row = g / CPRH;
+      int cc = g - row * CPRH;
+      if (cc >= C / 8) cc = 0;
+      int mr = hm0 + row;
+      mr = mr < last_row ? mr : last_row;
+      dma16(A + (long)mr * C + cc * 8, dst + c0 * 16);
+    }
+  };
+  if (tile_of(0) < total) issue_halo(tile_of(0), smem);
+
+  bf16x8_t w7[K7S], w1[K1S];
+  {
+    const bf16_t* W7 = (const bf16_t*)p.W + (long)(wave * 32 + l31) * p.K + lh * 8;
+    const bf16_t* W1 = (const bf16_t*)q.W + (long)(wave * 32 + l31) * q.K + lh * 8;
+#pragma unroll
+    for (int kk = 0; kk < K7S; ++kk) w7[kk] = *(const bf16x8_t*)(W7 + kk * 16);
+#pragma unroll
+    for (int kk = 0; kk < K1S; ++kk) w1[kk] = *(const bf16x8_t*)(W1 + kk * 16);
+  }
+  // q's epilogue operands: a lane keeps columns ncol .. ncol+3 in every staged slice
+  const int ncol = wave * 32 + (lane & 7) * 4, erow = lane >> 3;
+  const bool q_bias = q.bias != nullptr, q_res = q.res != nullptr, p_bias = p.bias != nullptr, p_snake = p.act == ACT_SNAKE;
+  float4 qb = make_float4(0.f, 0.f, 0.f, 0.f), qsa = qb;
+  if (q_bias) qb = *(const float4*)(q.bias + ncol);
+  if (q.act == ACT_SNAKE) qsa = *(const float4*)(q.act_alpha + ncol);
+  char* const stg = smem + 2 * HALO_B + wave * 4096;
+  const int dilHS = dil * HS;
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  int cur = 0;
+  for (int it = 0;; ++it, cur ^= 1) {
+    const int L = tile_of(it);
+    if (L >= total) break;   // uniform; tile_of grows with it
+    __syncthreads();         // vmcnt(0): this tile's halo has landed (and the previous tile's stores are acknowledged)
+    const int Ln = tile_of(it + 1);
+    if (Ln < total) issue_halo(Ln, smem + (cur ^ 1) * HALO_B);
+    const int b = L / tiles_m, m0 = (L - b * tiles_m) * BM;
+    float4 pre[FM * 4];
+    if (q_res) {
+      const float* R = q.res + q.res_off + (long)b * q.res_bstride + ncol;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int m = m0 + i * 32 + t * 8 + erow;
+          pre[i * 4 + t] = *(const float4*)(R + (long)(m < p.M ? m : p.M - 1) * q.res_ld);
+        }
+    }
+    char* const hb = smem + cur * HALO_B;
+    const char* const a_lane = hb + l31 * HS + lh * 16;
+    f32x16_t acc[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i] = zero16;
+    // ---- phase 1: k = 7 dilated convolution, K order tap-major as the ring kernels ------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < K7S; ++kk) {
+      const int tap = kk * 16 / C, c = kk * 16 - tap * C;
+      const char* a_k = a_lane + tap * dilHS + c * 2;
+      bf16x8_t af[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(a_k + i * 32 * HS);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i] = SA_MFMA_32x32x16(w7[kk], af[i], acc[i]);
+    }
+    __builtin_amdgcn_s_barrier();   // every wave is through with the halo tile (raw: the prefetches stay in flight)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- between the phases: y = snake(acc + bias) rounded to bf16 -> rows 0 .. BM-1 of this tile's halo buffer --------
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = wave * 32 + 8 * g + 4 * lh;
+        const float4 bb = *(const float4*)(colv + n), sa = *(const float4*)(colv + C + n);
+        float v[4] = {acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+        if (p_bias) { v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        const float sv[4] = {sa.x, sa.y, sa.z, sa.w};
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sn = __sinf(sv[e] * v[e]);
+          a[e] = p_snake ? v[e] + sn * sn / (sv[e] + 1e-9f) : v[e];
+        }
+        store4<bf16_t>((bf16_t*)(hb + (i * 32 + l31) * HS) + n, a[0], a[1], a[2], a[3]);
+      }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) acc[i] = zero16;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- phase 2: k = 1 convolution of the intermediate --------------------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < K1S; ++kk) {
+      bf16x8_t af[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(a_lane + kk * 32 + i * 32 * HS);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i] = SA_MFMA_32x32x16(w1[kk], af[i], acc[i]);
+    }
+    // ---- q's epilogue (gemm_epilogue_lds with FN = 1, its operands already in registers) --------------------------------
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(stg + l31 * 128 + (((2 * g + lh) ^ (l31 & 7)) << 4)) =
+            make_float4(acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 8 + erow;
+        const float4 sv = *(const float4*)(stg + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+        const int m = m0 + i * 32 + row;
+        float v[4] = {sv.x, sv.y, sv.z, sv.w};
+        if (q_bias) { v[0] += qb.x; v[1] += qb.y; v[2] += qb.z; v[3] += qb.w; }
+        if (q_res) { const float4 rr = pre[i * 4 + t]; v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+        const float a0 = act_apply(v[0], q.act, qsa.x), a1 = act_apply(v[1], q.act, qsa.y),
+                    a2 = act_apply(v[2], q.act, qsa.z), a3 = act_apply(v[3], q.act, qsa.w);
+        if (m < p.M) {
+          if (q.out_f32) {
+            float* frow = q.out_f32 + q.f32_off + (long)b * q.f32_bstride + (long)m * q.f32_ld;
+            *(float4*)(frow + ncol) = q.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v[0], v[1], v[2], v[3]);
+          }
+          bf16_t* arow = (bf16_t*)q.out_act + q.act_off + (long)b * q.act_bstride + (long)m * q.act_ld;
+          store4<bf16_t>(arow + ncol, a0, a1, a2, a3);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 // the launches conv7h covers: k = 7 'same' convolution of C -> C channels as the engine issues it (conv_same(): kc = lda =
 // C, tap_stride = dil * C, W tap-major with K = 7 C rounded up to 64), dilation <= 9, bf16, no per-batch weights
 bool conv7h_ok(const GemmParams& p) {
@@ -670,7 +850,33 @@ static hipError_t launch_ru(const GemmParams& p, const GemmParams& q, hipStream_
   return hipGetLastError();
 }
 
+template <int C>
+static hipError_t launch_ws(const GemmParams& p, const GemmParams& q, long tiles, hipStream_t st) {
+  const long cap = debug_flag(19) == 3 ? 3 : 256;                // one workgroup per CU, walking tiles
+  const unsigned grid = (unsigned)(tiles < cap ? tiles : cap);
+  if (p.tag == 1)
+    hipLaunchKernelGGL((resws_kernel<C, 1>), dim3(grid), dim3(C / 32 * 64), 0, st, p, q);
+  else
+    hipLaunchKernelGGL((resws_kernel<C, 0>), dim3(grid), dim3(C / 32 * 64), 0, st, p, q);
+  return hipGetLastError();
+}
+
+// launches of >= 1024 tiles of 128 rows (four sweeps of the chip) run the weight-stationary kernel; flag 19 = whatever
+// the launch size (its tests; 3 = the same on a grid of 3 workgroups, so that small cases walk several tiles), 2 = never
+bool resunit_ws(const GemmParams& p) {
+  if (!(p.N == 64 || p.N == 96 || p.N == 128) || debug_flag(19) == 2) return false;
+  return (long)((p.M + 127) / 128) * p.nbatch >= 1024 || debug_flag(19) == 1 || debug_flag(19) == 3;
+}
+
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st) {
+  if (resunit_ws(p)) {
+    const long tiles = (long)((p.M + 127) / 128) * p.nbatch;
+    switch (p.N) {
+      case 64: return launch_ws<64>(p, q, tiles, st);
+      case 96: return launch_ws<96>(p, q, tiles, st);
+      default: return launch_ws<128>(p, q, tiles, st);
+    }
+  }
   switch (p.N) {  // tile shapes of launch_conv7h
     case 64: return launch_ru<64, 256, 8, 1, 3>(p, q, st);
     // 96 channels: 128-row tiles on 4 waves and a 2-stage ring = 72 KiB, two workgroups per CU, so that one workgroup's

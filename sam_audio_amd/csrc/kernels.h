@@ -13,6 +13,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 11: k7 convolutions as implicit GEMMs (no conv7h kernel) - the bitwise-equality tests of conv7h
 //   flag 16: DAC residual units as two launches (k7 + k1) instead of the fused resunit kernel - its bitwise-equality tests
 //   flag 18: fuse residual units whatever the launch size (tests: small launches otherwise stay two launches)
+//   flag 19: 1 = residual units on the weight-stationary kernel whatever the launch size (its tests; otherwise >= 1024
+//            tiles), 3 = the same on 3 workgroups (small cases then walk several tiles each), 2 = never (ring kernel: A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined form)
 void set_debug_flag(int flag, int value);
 int debug_flag(int flag);
@@ -37,6 +39,7 @@ bool conv7h_ok(const GemmParams& p);
 hipError_t launch_conv7h(const GemmParams& p, hipStream_t st);
 // one DAC residual unit (k7 launch p + k1 launch q on its output) as ONE kernel, bitwise equal to the two launches
 bool resunit_ok(const GemmParams& p, const GemmParams& q);
+bool resunit_ws(const GemmParams& p);   // launch_resunit would run the weight-stationary kernel for this k7 launch
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st);
 // gemm8.hip: one GEMM as two launches - part 0: gemm8 on the first `full` 256x256 tiles (whole rounds of the chip),
 // part 1: the rest as 128x128 quadrants on gemm8s.  gemm_tail_split() = `full` for a launch (0: no split).

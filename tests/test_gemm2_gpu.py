@@ -307,13 +307,16 @@ def test_conv7h_is_bitwise_the_implicit_gemm(gpu, C, dil, T, items):
 
 
 @pytest.mark.parametrize("C,dil,T,items", [(64, 1, 700, 3), (96, 3, 530, 2), (96, 9, 300, 3), (128, 9, 520, 2), (192, 3, 300, 3),
-                                           (192, 1, 130, 2), (96, 1, 256, 1), (96, 1, 128, 2)])
+                                           (192, 1, 130, 2), (96, 1, 256, 1), (96, 1, 128, 2), (128, 1, 1100, 2),
+                                           (64, 3, 128 * 90 + 17, 3)])
 def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
     """resunit (one DAC residual unit per launch: k7 convolution -> Snake -> bf16 intermediate kept in LDS -> k1 convolution
     + fp32 residual, fp32 stream and Snake'd bf16 copy out) against the two launches the engine otherwise issues, on identical
     operands: identical bits in both outputs, halo rows of the output activation untouched, the input activation untouched;
-    every channel count / dilation the DAC stages use, M not a multiple of the row tile, several items.  The two-launch
-    form itself is checked against torch (conv1d + Snake + conv1d + residual)."""
+    every channel count / dilation the DAC stages use, M not a multiple of the row tile, several items.  Both fused kernels:
+    the ring kernel (one tile per workgroup) and, for C <= 128, the weight-stationary persistent kernel that large launches
+    use (debug flag 19: one tile per workgroup, and 3 workgroups walking all tiles; the last case has > 256 tiles = the
+    full-grid tile order).  The two-launch form itself is checked against torch (conv1d + Snake + conv1d + residual)."""
     halo = 40
     x = _mk((items, C, T), 71)
     xb = torch.zeros(items, T + 2 * halo, C)
@@ -344,22 +347,29 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
 
     import ctypes as CT
     res = {}
-    for fused in (False, True):
-        mid = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
-        out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
-        raw = raw0.to(gpu)
-        p7, p1 = params(mid, raw, out)
-        if fused:
-            util.resunit(p7, p1)
-            assert float(mid.float().abs().max()) == 0          # the intermediate never reaches memory
-        else:
-            for p in (p7, p1):
-                hip.check(hip.lib().samaudio_op_gemm(CT.byref(p), CT.sizeof(p), hip.BF16, util.stream()))
-        res[fused] = (raw.cpu(), out.cpu())
+    forms = [(False, 2), (True, 2)] + ([(True, 1), (True, 3)] if C <= 128 else [])   # (fused, debug flag 19)
+    try:
+        for fused, ws in forms:
+            hip.lib().samaudio_debug_set_flag(19, ws)
+            mid = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+            out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+            raw = raw0.to(gpu)
+            p7, p1 = params(mid, raw, out)
+            if fused:
+                util.resunit(p7, p1)
+                assert float(mid.float().abs().max()) == 0          # the intermediate never reaches memory
+            else:
+                for p in (p7, p1):
+                    hip.check(hip.lib().samaudio_op_gemm(CT.byref(p), CT.sizeof(p), hip.BF16, util.stream()))
+            res[(fused, ws)] = (raw.cpu(), out.cpu())
+    finally:
+        hip.lib().samaudio_debug_set_flag(19, 0)
     assert torch.equal(xin.cpu().view(torch.int16), util.as_act(xb, "bf16", "cpu").view(torch.int16))
-    assert torch.equal(res[True][0].view(torch.int32), res[False][0].view(torch.int32))
-    assert torch.equal(res[True][1].view(torch.int16), res[False][1].view(torch.int16))
-    assert float(res[True][1][:, :halo].abs().max()) == 0 and float(res[True][1][:, halo + T:].abs().max()) == 0
+    for form in forms[1:]:
+        assert torch.equal(res[form][0].view(torch.int32), res[(False, 2)][0].view(torch.int32)), form
+        assert torch.equal(res[form][1].view(torch.int16), res[(False, 2)][1].view(torch.int16)), form
+        assert float(res[form][1][:, :halo].abs().max()) == 0 and float(res[form][1][:, halo + T:].abs().max()) == 0
+    res = {True: res[forms[-1]], False: res[(False, 2)]}
     snake = lambda y, a: y + torch.sin(a[None, :, None] * y) ** 2 / (a[None, :, None] + 1e-9)   # noqa: E731
     y = util.rounded(snake(F.conv1d(util.rounded(x, "bf16"), util.rounded(w7, "bf16"), b7, dilation=dil, padding=3 * dil), a7), "bf16")
     want_raw = raw0[:, halo:halo + T] + (F.conv1d(y, util.rounded(w1, "bf16")[:, :, None], b1)).transpose(1, 2)

@@ -96,8 +96,8 @@ def test_codec_chunked_equals_unchunked(gpu, monkeypatch):
 
 def test_codec_fused_residual_units_equal_the_two_launch_form(gpu):
     """DAC residual units as one kernel each (resunit, debug flag 18 = at any launch size; the activation buffers of a
-    stage swap roles per fused unit) against the two launches per unit (flag 16): identical latents and waveforms, also
-    when the batch is split into chunks."""
+    stage swap roles per fused unit; flag 19 = 3: the weight-stationary persistent kernel of large launches, on 3 workgroups)
+    against the two launches per unit (flag 16): identical latents and waveforms."""
     cfg = preset_config("tiny")
     sd = init_state_dict(cfg, seed=6)
     hop = cfg.audio_codec.hop_length
@@ -107,7 +107,7 @@ def test_codec_fused_residual_units_equal_the_two_launch_form(gpu):
     from sam_audio_amd import hip
     outs = {}
     try:
-        for name, flags in (("two", {16: 1, 18: 0}), ("fused", {16: 0, 18: 1})):
+        for name, flags in (("two", {16: 1, 18: 0, 19: 0}), ("fused", {16: 0, 18: 1, 19: 2}), ("ws", {16: 0, 18: 1, 19: 3})):
             for k, v in flags.items():
                 hip.lib().samaudio_debug_set_flag(k, v)
             if gpu.type == "cuda":     # the per-kernel records say which form ran (hipEvents: hardware only)
@@ -115,11 +115,12 @@ def test_codec_fused_residual_units_equal_the_two_launch_form(gpu):
             outs[name] = (model.encode_audio(wav).clone(), model.decode_audio(lat).clone())
             if gpu.type == "cuda":
                 ran = [r["name"] for r in model.profile_end()]
-                assert any("resunit" in r for r in ran) == (name == "fused"), ran
+                assert any("resunit" in r for r in ran) == (name != "two"), ran
     finally:
-        hip.lib().samaudio_debug_set_flag(16, 0)
-        hip.lib().samaudio_debug_set_flag(18, 0)
-    assert torch.equal(outs["two"][0], outs["fused"][0]) and torch.equal(outs["two"][1], outs["fused"][1])
+        for k in (16, 18, 19):
+            hip.lib().samaudio_debug_set_flag(k, 0)
+    for name in ("fused", "ws"):
+        assert torch.equal(outs["two"][0], outs[name][0]) and torch.equal(outs["two"][1], outs[name][1]), name
     with torch.inference_mode():
         w_ref = O.dac_decode(sd, cfg.audio_codec, lat.transpose(1, 2)).squeeze(1)
     util.report("codec decode bf16, fused residual units", outs["fused"][1], w_ref, 2e-3)

@@ -92,4 +92,8 @@ for Cc, Tc, items in ((64, 480000, 8), (96, 480000, 8), (128, 240000, 8), (192, 
         for pp in (p7, p1):
             hip.check(L.samaudio_op_gemm(C.byref(pp), C.sizeof(pp), hip.BF16, st()))
     timeit(f"residual unit C={Cc} dil 3 [two launches]", two, unit_bytes, iters=5)
-    timeit(f"residual unit C={Cc} dil 3 [fused resunit]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
+    L.samaudio_debug_set_flag(19, 2)
+    timeit(f"residual unit C={Cc} dil 3 [fused, ring kernel]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
+    L.samaudio_debug_set_flag(19, 0)
+    if Cc <= 128:
+        timeit(f"residual unit C={Cc} dil 3 [fused, weight-stationary]", lambda: util.resunit(p7, p1), unit_bytes, iters=5)
