@@ -24,6 +24,9 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       # the simulator's call; everything else in the file is compiled as it stands
       sed 's|asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");|simt::wait_vmcnt(N);|' $src > $OUT/gemm2_simt.hip
       grep -q "simt::wait_vmcnt(N);" $OUT/gemm2_simt.hip || { echo "gemm2.hip: wait_vmcnt<N> statement not found"; exit 1; }
+      # and the direct-to-LDS load, inline assembly with operands in the product (see dma16a), becomes the builtin the stub emulates
+      sed -i 's|^.*// SIMT-DMA$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0); (void)lds;|' $OUT/gemm2_simt.hip
+      grep -q "(void)lds;" $OUT/gemm2_simt.hip || { echo "gemm2.hip: dma16a asm statement not found"; exit 1; }
       src=$OUT/gemm2_simt.hip
     fi
     $CXX $FLAGS $EXTRA -c $src -o $OUT/$f.o &

@@ -186,6 +186,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
 }
 inline void __builtin_amdgcn_s_barrier() { simt::block_sync(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline void __builtin_amdgcn_s_setprio(int) {}
 
 // global -> LDS DMA (global_load_lds_dwordx4): lane i's 16 bytes land at (wave-uniform LDS base) + 16*i; the base is the

@@ -448,8 +448,7 @@ Status Engine::res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, doub
   const int ci = p.N == 64 ? 0 : p.N == 96 ? 1 : p.N == 128 ? 2 : p.N == 192 ? 3 : -1;
   // fused where it measured faster than the two launches (profiles/r2_call20/op_bench.log, 8 waveforms: C = 64 844 vs
   // 1028 us, C = 96 2127 vs 2236; C = 128 1419 vs 1395 and C = 192 2825 vs 2772 stay two launches)
-  // The weight-stationary kernel (gemm2.hip resws_kernel, C <= 128, launches of >= 1024 tiles) beats both on all three.
-  const int excluded = resunit_ws(fp) ? 8 : 4 | 8;
+  const int excluded = 4 | 8;
   const bool fuse = bf16_ && ci >= 0 && !debug_flag(16) && !(excluded & kMask[ci]) && resunit_ok(fp, fq) &&
                     ((long)((p.M + 255) / 256) * p.nbatch >= 256 || debug_flag(18));
   if (!fuse) {

@@ -28,9 +28,20 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 namespace {
 
+// Direct-to-LDS load of 16 bytes per lane (lane i lands at lds_wave_base + 16 i).
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// The same as inline assembly, for the residual-unit kernels.  They also WRITE the DMA-filled LDS region with ordinary
+// stores (the intermediate activation), and for such a kernel the compiler makes every LDS read that follows a
+// direct-to-LDS load it knows about wait for that load: s_waitcnt vmcnt(0) in front of the ds_reads of the next k-step,
+// i.e. issue -> wait -> compute instead of a ring (gemm2_kernel / conv7h_kernel, which only read their LDS, do not get
+// these waits).  Completion is ordered by the explicit s_waitcnt vmcnt / barriers of the kernel - a __syncthreads() does
+// NOT imply vmcnt(0) for loads the compiler cannot see.  M0 = LDS base; one wait state between the M0 write and the DMA.
+__device__ __forceinline__ void dma16a(const void* gsrc, char* lds_wave_base) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParam
       if (cc >= C / 8) cc = 0;
       int mr = m0 + row;
       mr = mr < last_row ? mr : last_row;
-      dma16(A + (long)mr * C + cc * 8, halo + c0 * 16);
+      dma16a(A + (long)mr * C + cc * 8, halo + c0 * 16);
     }
   }
   // ---- weight ring: the K-tiles of W7 (p.W, row stride p.K) followed by those of W1 (q.W, row stride q.K) ----------
@@ -521,16 +532,12 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParam
   int issued = 0;
   auto issue = [&](int stage) {
     char* sB = ring + stage * TILE_W;
-    if (issued < nslab1) {  // uniform
+    const bool first = issued < nslab1;  // uniform
 #pragma unroll
-      for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (wave + NW * i) * 1024);
-#pragma unroll
-      for (int i = 0; i < BI; ++i) w_rows[i] += 64;
-    } else {
-#pragma unroll
-      for (int i = 0; i < BI; ++i) dma16(w2_rows[i], sB + (wave + NW * i) * 1024);
-#pragma unroll
-      for (int i = 0; i < BI; ++i) w2_rows[i] += 64;
+    for (int i = 0; i < BI; ++i) {
+      dma16a(first ? w_rows[i] : w2_rows[i], sB + (wave + NW * i) * 1024);
+      w_rows[i] += first ? 64 : 0;
+      w2_rows[i] += first ? 0 : 64;
     }
     ++issued;
   };
@@ -626,9 +633,11 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParam
 //     its slice of W7 (7 C / 16 fragments) and W1 (C / 16) in REGISTERS for the whole launch (<= 256 VGPRs): no weight
 //     ring, no per-K-tile barrier - phase 1 is one straight run of 4 independent MFMAs per fragment;
 //   * the workgroup walks tiles; the halo tile of tile t+1 streams into the second halo buffer while tile t computes, and
-//     the fp32 residual rows of tile t (16 x 16 bytes per lane) are requested at the top of the tile, ~3 us before the
-//     epilogue consumes them: ~90 KiB in flight per CU;
+//     the fp32 residual rows of tile t are requested at the top of the tile, ~3 us before the epilogue consumes them, by
+//     DMA into a wave-private LDS area in exactly the (lane, step) order the epilogue reads them back (in registers the
+//     compiler shuffled them through AGPR copies that waited for the loads at once): ~90 KiB in flight per CU;
 //   * 3 barriers per tile (halo landed | phase-1 reads done | intermediate published).
+// C = 128 does not fit (2 halo buffers + 64 KiB of residual rows > 160 KiB) and stays on the ring kernel / two launches.
 // Arithmetic, K order and rounding points are those of the two launches: bitwise identical (tests/test_gemm2_gpu.py).
 // ------------------------------------------------------------------------------------------------
 template <int C, int TAG>
@@ -639,8 +648,9 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
   constexpr int HROWS = BM + 6 * MAXD;
   constexpr int HALO_B = (HROWS * HS + 1023) / 1024 * 1024;
   constexpr int K7S = 7 * C / 16, K1S = C / 16;
-  static_assert(C % 32 == 0 && 2 * HALO_B + NW * 4096 + 2 * C * 4 <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) char smem[2 * HALO_B + NW * 4096];
+  constexpr int RES_B = BM * 32 * 4;   // one wave's residual rows: 128 rows x 32 channels of fp32
+  static_assert(C % 32 == 0 && 2 * HALO_B + NW * (4096 + RES_B) + 2 * C * 4 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[2 * HALO_B + NW * (4096 + RES_B)];
   __shared__ __attribute__((aligned(16))) float colv[2 * C];   // phase 1's bias | Snake alpha
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
       if (cc >= C / 8) cc = 0;
       int mr = hm0 + row;
       mr = mr < last_row ? mr : last_row;
-      dma16(A + (long)mr * C + cc * 8, dst + c0 * 16);
+      dma16a(A + (long)mr * C + cc * 8, dst + c0 * 16);
     }
   };
   if (tile_of(0) < total) issue_halo(tile_of(0), smem);
@@ -685,11 +695,13 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
   }
   // q's epilogue operands: a lane keeps columns ncol .. ncol+3 in every staged slice
   const int ncol = wave * 32 + (lane & 7) * 4, erow = lane >> 3;
-  const bool q_bias = q.bias != nullptr, q_res = q.res != nullptr, p_bias = p.bias != nullptr, p_snake = p.act == ACT_SNAKE;
+  const bool q_bias = q.bias != nullptr, q_res = q.res != nullptr, p_bias = p.bias != nullptr, p_snake = p.act == ACT_SNAKE,
+             q_snake = q.act == ACT_SNAKE;
   float4 qb = make_float4(0.f, 0.f, 0.f, 0.f), qsa = qb;
   if (q_bias) qb = *(const float4*)(q.bias + ncol);
   if (q.act == ACT_SNAKE) qsa = *(const float4*)(q.act_alpha + ncol);
   char* const stg = smem + 2 * HALO_B + wave * 4096;
+  char* const resb = smem + 2 * HALO_B + NW * 4096 + wave * RES_B;
   const int dilHS = dil * HS;
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -697,19 +709,19 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
   for (int it = 0;; ++it, cur ^= 1) {
     const int L = tile_of(it);
     if (L >= total) break;   // uniform; tile_of grows with it
-    __syncthreads();         // vmcnt(0): this tile's halo has landed (and the previous tile's stores are acknowledged)
+    wait_vmcnt<0>();         // this tile's halo has landed (the compiler does not see dma16's loads: explicit) ...
+    __syncthreads();         // ... in every wave
     const int Ln = tile_of(it + 1);
     if (Ln < total) issue_halo(Ln, smem + (cur ^ 1) * HALO_B);
     const int b = L / tiles_m, m0 = (L - b * tiles_m) * BM;
-    float4 pre[FM * 4];
-    if (q_res) {
+    if (q_res) {   // step (i, t) of the epilogue: lane's row i*32 + t*8 + erow, columns ncol .. ncol+3 -> resb + ((4i + t) * 64 + lane) * 16
       const float* R = q.res + q.res_off + (long)b * q.res_bstride + ncol;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int m = m0 + i * 32 + t * 8 + erow;
-          pre[i * 4 + t] = *(const float4*)(R + (long)(m < p.M ? m : p.M - 1) * q.res_ld);
+          dma16a(R + (long)(m < p.M ? m : p.M - 1) * q.res_ld, resb + (i * 4 + t) * 1024);
         }
     }
     char* const hb = smem + cur * HALO_B;
@@ -718,15 +730,26 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
 #pragma unroll
     for (int i = 0; i < FM; ++i) acc[i] = zero16;
     // ---- phase 1: k = 7 dilated convolution, K order tap-major as the ring kernels ------------------------------------
-#pragma unroll
-    for (int kk = 0; kk < K7S; ++kk) {
+    // One wave per SIMD: nothing but this wave's own instruction stream hides the LDS latency, and left alone the compiler
+    // issues read -> wait -> MFMA one at a time (12 us per tile).  Fragments are requested two k-steps ahead into a rotating
+    // register set and the scheduler is told the interleave: 4 reads, 4 MFMAs.
+    auto halo_frags = [&](int kk, bf16x8_t (&af)[FM]) {
       const int tap = kk * 16 / C, c = kk * 16 - tap * C;
       const char* a_k = a_lane + tap * dilHS + c * 2;
-      bf16x8_t af[FM];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(a_k + i * 32 * HS);
+    };
+    bf16x8_t af[3][FM];
+    halo_frags(0, af[0]);
+    halo_frags(1, af[1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * FM, 0);   // the two steps requested ahead form a group of their own
 #pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i] = SA_MFMA_32x32x16(w7[kk], af[i], acc[i]);
+    for (int kk = 0; kk < K7S; ++kk) {
+      if (kk + 2 < K7S) halo_frags(kk + 2, af[(kk + 2) % 3]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i] = SA_MFMA_32x32x16(w7[kk], af[kk % 3][i], acc[i]);
+      __builtin_amdgcn_sched_group_barrier(0x100, FM, 0);   // DS reads of step kk+2
+      __builtin_amdgcn_sched_group_barrier(0x008, FM, 0);   // MFMAs of step kk
     }
     __builtin_amdgcn_s_barrier();   // every wave is through with the halo tile (raw: the prefetches stay in flight)
     __builtin_amdgcn_sched_barrier(0);
@@ -756,15 +779,23 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // ---- phase 2: k = 1 convolution of the intermediate --------------------------------------------------------------
+    auto mid_frags = [&](int kk, bf16x8_t (&mf)[FM]) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) mf[i] = *(const bf16x8_t*)(a_lane + kk * 32 + i * 32 * HS);
+    };
+    mid_frags(0, af[0]);
+    mid_frags(1, af[1]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * FM, 0);
 #pragma unroll
     for (int kk = 0; kk < K1S; ++kk) {
-      bf16x8_t af[FM];
+      if (kk + 2 < K1S) mid_frags(kk + 2, af[(kk + 2) % 3]);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8_t*)(a_lane + kk * 32 + i * 32 * HS);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i] = SA_MFMA_32x32x16(w1[kk], af[i], acc[i]);
+      for (int i = 0; i < FM; ++i) acc[i] = SA_MFMA_32x32x16(w1[kk], af[kk % 3][i], acc[i]);
+      __builtin_amdgcn_sched_group_barrier(0x100, FM, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, FM, 0);
     }
-    // ---- q's epilogue (gemm_epilogue_lds with FN = 1, its operands already in registers) --------------------------------
+    // ---- q's epilogue (gemm_epilogue_lds with FN = 1, its operands already on chip) -----------------------------------
+    wait_vmcnt<0>();   // this wave's residual rows (and its share of the next halo tile) have landed
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -779,9 +810,19 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
         const int m = m0 + i * 32 + row;
         float v[4] = {sv.x, sv.y, sv.z, sv.w};
         if (q_bias) { v[0] += qb.x; v[1] += qb.y; v[2] += qb.z; v[3] += qb.w; }
-        if (q_res) { const float4 rr = pre[i * 4 + t]; v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-        const float a0 = act_apply(v[0], q.act, qsa.x), a1 = act_apply(v[1], q.act, qsa.y),
-                    a2 = act_apply(v[2], q.act, qsa.z), a3 = act_apply(v[3], q.act, qsa.w);
+        if (q_res) {
+          const float4 rr = *(const float4*)(resb + ((i * 4 + t) * 64 + lane) * 16);
+          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        // q.act is ACT_SNAKE or ACT_NONE (resunit_ws): act_apply's Snake expression without its other branches
+        const float qs[4] = {qsa.x, qsa.y, qsa.z, qsa.w};
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float sn = __sinf(qs[e] * v[e]);
+          a[e] = q_snake ? v[e] + sn * sn / (qs[e] + 1e-9f) : v[e];
+        }
+        const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
         if (m < p.M) {
           if (q.out_f32) {
             float* frow = q.out_f32 + q.f32_off + (long)b * q.f32_bstride + (long)m * q.f32_ld;
@@ -863,19 +904,16 @@ static hipError_t launch_ws(const GemmParams& p, const GemmParams& q, long tiles
 
 // launches of >= 1024 tiles of 128 rows (four sweeps of the chip) run the weight-stationary kernel; flag 19 = whatever
 // the launch size (its tests; 3 = the same on a grid of 3 workgroups, so that small cases walk several tiles), 2 = never
-bool resunit_ws(const GemmParams& p) {
-  if (!(p.N == 64 || p.N == 96 || p.N == 128) || debug_flag(19) == 2) return false;
+static bool resunit_ws(const GemmParams& p, const GemmParams& q) {
+  if (!(p.N == 64 || p.N == 96) || debug_flag(19) == 2) return false;
+  if (q.act != ACT_SNAKE && q.act != ACT_NONE) return false;
   return (long)((p.M + 127) / 128) * p.nbatch >= 1024 || debug_flag(19) == 1 || debug_flag(19) == 3;
 }
 
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st) {
-  if (resunit_ws(p)) {
+  if (resunit_ws(p, q)) {
     const long tiles = (long)((p.M + 127) / 128) * p.nbatch;
-    switch (p.N) {
-      case 64: return launch_ws<64>(p, q, tiles, st);
-      case 96: return launch_ws<96>(p, q, tiles, st);
-      default: return launch_ws<128>(p, q, tiles, st);
-    }
+    return p.N == 64 ? launch_ws<64>(p, q, tiles, st) : launch_ws<96>(p, q, tiles, st);
   }
   switch (p.N) {  // tile shapes of launch_conv7h
     case 64: return launch_ru<64, 256, 8, 1, 3>(p, q, st);

@@ -39,7 +39,6 @@ bool conv7h_ok(const GemmParams& p);
 hipError_t launch_conv7h(const GemmParams& p, hipStream_t st);
 // one DAC residual unit (k7 launch p + k1 launch q on its output) as ONE kernel, bitwise equal to the two launches
 bool resunit_ok(const GemmParams& p, const GemmParams& q);
-bool resunit_ws(const GemmParams& p);   // launch_resunit would run the weight-stationary kernel for this k7 launch
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st);
 // gemm8.hip: one GEMM as two launches - part 0: gemm8 on the first `full` 256x256 tiles (whole rounds of the chip),
 // part 1: the rest as 128x128 quadrants on gemm8s.  gemm_tail_split() = `full` for a launch (0: no split).
