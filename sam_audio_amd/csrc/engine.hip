@@ -444,12 +444,11 @@ Status Engine::res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, doub
   GemmParams fp = p, fq = q;
   fq.out_act = alt;
   fp.tag = fq.tag = prof_cls_[0] == 'c' ? 1 : 0;
-  static const int kMask[4] = {1, 2, 4, 8};
-  const int ci = p.N == 64 ? 0 : p.N == 96 ? 1 : p.N == 128 ? 2 : p.N == 192 ? 3 : -1;
-  // fused where it measured faster than the two launches (profiles/r2_call20/op_bench.log, 8 waveforms: C = 64 844 vs
-  // 1028 us, C = 96 2127 vs 2236; C = 128 1419 vs 1395 and C = 192 2825 vs 2772 stay two launches)
-  const int excluded = 4 | 8;
-  const bool fuse = bf16_ && ci >= 0 && !debug_flag(16) && !(excluded & kMask[ci]) && resunit_ok(fp, fq) &&
+  const bool covered = p.N == 64 || p.N == 96 || p.N == 128 || p.N == 192;
+  // fused for all four channel counts: since the residual-unit kernels issue their direct-to-LDS loads as inline assembly
+  // (gemm2.hip dma16a) the fused form is the faster one everywhere (profiles/r3_call12/op_bench.log, 8 waveforms, fused vs
+  // two launches: C = 64 923 vs 1193 us, C = 96 1697 vs 2269, C = 128 1353 vs 1391, C = 192 2515 vs 2784)
+  const bool fuse = bf16_ && covered && !debug_flag(16) && resunit_ok(fp, fq) &&
                     ((long)((p.M + 255) / 256) * p.nbatch >= 256 || debug_flag(18));
   if (!fuse) {
     SA_TRY(gemm(p, st, flops7));

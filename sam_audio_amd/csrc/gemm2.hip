@@ -902,12 +902,15 @@ static hipError_t launch_ws(const GemmParams& p, const GemmParams& q, long tiles
   return hipGetLastError();
 }
 
-// launches of >= 1024 tiles of 128 rows (four sweeps of the chip) run the weight-stationary kernel; flag 19 = whatever
+// 96-channel launches of >= 1024 tiles of 128 rows (four sweeps of the chip) run the weight-stationary kernel; flag 19 = whatever
 // the launch size (its tests; 3 = the same on a grid of 3 workgroups, so that small cases walk several tiles), 2 = never
 static bool resunit_ws(const GemmParams& p, const GemmParams& q) {
   if (!(p.N == 64 || p.N == 96) || debug_flag(19) == 2) return false;
   if (q.act != ACT_SNAKE && q.act != ACT_NONE) return false;
-  return (long)((p.M + 127) / 128) * p.nbatch >= 1024 || debug_flag(19) == 1 || debug_flag(19) == 3;
+  if (debug_flag(19) == 1 || debug_flag(19) == 3) return true;
+  // 96 channels: 1 697 vs 1 939 us for 8 waveforms (ring kernel), profiles/r3_call12/op_bench.log.  64 channels would run
+  // two waves per CU - too few to cover its LDS / VALU latencies: 1 564 vs 923 us - and stays on the ring kernel.
+  return p.N == 96 && (long)((p.M + 127) / 128) * p.nbatch >= 1024;
 }
 
 hipError_t launch_resunit(const GemmParams& p, const GemmParams& q, hipStream_t st) {

@@ -216,14 +216,19 @@ class SAMAudio:
                 warnings.warn(f"vision_encoder: {len(v_unexpected)} checkpoint tensors are not consumed by the PE-Core tower "
                               f"engine (first: {v_unexpected[:3]})")
         with torch.cuda.device(self.device):
+            self._lanes = []   # extra stream contexts borrow the weight tensors registered below: rebuilt on demand
+            # register everything first: replacing a tensor the engine already holds (a second load_state_dict) marks BOTH
+            # weight sets as not finalized, so each set the model has is finalized again afterwards
             if not dit_missing:
                 self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device))
-                hip.check(self._lib.samaudio_finalize(self._ctx, 0))
                 self._has_dit = True
             if not codec_missing:
                 self._register(convert_codec(state_dict, self.cfg, self.act_dtype, self.device))
-                hip.check(self._lib.samaudio_finalize(self._ctx, 1))
                 self._has_codec = True
+            if self._has_dit and not (dit_missing and codec_missing):
+                hip.check(self._lib.samaudio_finalize(self._ctx, 0))
+            if self._has_codec and not (dit_missing and codec_missing):
+                hip.check(self._lib.samaudio_finalize(self._ctx, 1))
         return missing, unexpected
 
     def _covers_vision_tower(self, vis: Dict[str, torch.Tensor]) -> bool:

@@ -237,3 +237,29 @@ def test_concurrent_streams_are_bitwise_equal_to_one_stream(gpu):
         torch.cuda.synchronize()
         assert torch.equal(two.last_latent, ref)
     assert all(torch.isfinite(w).all() for w in res.target)
+
+
+def test_load_state_dict_twice_replaces_the_weights(gpu):
+    """nn.Module semantics (reference model.py loads checkpoints through load_state_dict): a second load replaces every
+    weight - both weight sets are finalized again, stream lanes that borrowed the old tensors are rebuilt - and the model
+    then equals a fresh one loaded with the second checkpoint, bit for bit."""
+    cfg = preset_config("tiny")
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 4 * hop) for i in range(3)]
+    text, tmask = synthetic_text_features(3, 4)
+    proc = SAMAudioProcessor.from_config(cfg)
+    batch = proc(descriptions=["x"] * 3, audios=clips, text_features=text, text_mask=tmask).to(gpu)
+    noise = synthetic_noise(3, 4).to(gpu)
+    sd_a, sd_b = init_state_dict(cfg, seed=21), init_state_dict(cfg, seed=22)
+    fresh = _model(cfg, sd_b, "bf16", gpu)
+    want = fresh.separate(batch, noise=noise)
+    want_lat = fresh.last_latent.clone()
+    twice = SAMAudio(cfg, precision="bf16", device=str(gpu), streams=2 if gpu.type == "cuda" else 1)   # (dry run: no streams)
+    twice.load_state_dict(sd_a, strict=False)
+    first = twice.separate(batch, noise=noise)
+    assert not torch.equal(twice.last_latent, want_lat)
+    twice.load_state_dict(sd_b, strict=False)
+    got = twice.separate(batch, noise=noise)
+    assert torch.equal(twice.last_latent, want_lat)
+    assert all(torch.equal(a, b) for a, b in zip(got.target, want.target))
+    assert all(torch.isfinite(w).all() for w in first.target)
