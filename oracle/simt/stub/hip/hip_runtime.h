@@ -147,6 +147,7 @@ inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; 
 inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 inline float __expf(float x) { return std::exp(x); }
 inline float __sinf(float x) { return std::sin(x); }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __cosf(float x) { return std::cos(x); }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 

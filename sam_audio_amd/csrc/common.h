@@ -85,6 +85,14 @@ __device__ __forceinline__ float snake_f(float x, float a) {
   float s = sinf(a * x);
   return x + s * s / (a + 1e-9f);
 }
+// Snake in the epilogues of the 16-bit GEMM / convolution kernels, whose result is rounded to a 16-bit operand (or is the
+// fp32 copy of one): hardware sine and hardware reciprocal (v_sin_f32 / v_rcp_f32, 1 ulp each).  An IEEE division costs
+// ~10 VALU instructions per element, and the DAC residual-unit kernels were VALU-bound on it (two Snakes per element).
+// Every 16-bit kernel uses this one expression, so fused and unfused forms of a convolution stay bitwise identical.
+__device__ __forceinline__ float snake16_f(float x, float a) {
+  const float s = __sinf(a * x);
+  return x + s * s * __builtin_amdgcn_rcpf(a + 1e-9f);
+}
 
 // Reductions over the 16 lanes of one DPP row (lanes 16k .. 16k+15) on the VALU: v_max / v_add with a row_ror
 // DPP modifier, no LDS round trip (__shfl_xor lowers to ds_bpermute_b32: ~100 cycles of lgkmcnt wait per step, which

@@ -54,10 +54,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float snake_alpha) 
   if (act == ACT_RELU) return relu_f(v);
   if (act == ACT_GELU_TANH) return gelu_tanh_f(v);
   if (act == ACT_TANH) return tanhf(v);
-  if (act == ACT_SNAKE) {  // x + sin^2(a x) / a; the result feeds a bf16 operand, so the hardware sine suffices
-    const float sn = __sinf(snake_alpha * v);
-    return v + sn * sn / (snake_alpha + 1e-9f);
-  }
+  if (act == ACT_SNAKE) return snake16_f(v, snake_alpha);  // x + sin^2(a x) / a
   return v;
 }
 
@@ -582,10 +579,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParam
             const float sv[4] = {sa.x, sa.y, sa.z, sa.w};
             float a[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float sn = __sinf(sv[e] * v[e]);
-              a[e] = snake_on ? v[e] + sn * sn / (sv[e] + 1e-9f) : v[e];
-            }
+            for (int e = 0; e < 4; ++e) a[e] = snake_on ? snake16_f(v[e], sv[e]) : v[e];
             store4<bf16_t>((bf16_t*)(halo + (wm * WTM + i * 32 + l31) * HS) + n, a[0], a[1], a[2], a[3]);
             acc[i][j][4 * g + 0] = 0.f; acc[i][j][4 * g + 1] = 0.f; acc[i][j][4 * g + 2] = 0.f; acc[i][j][4 * g + 3] = 0.f;
           }
@@ -767,10 +761,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
         const float sv[4] = {sa.x, sa.y, sa.z, sa.w};
         float a[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sn = __sinf(sv[e] * v[e]);
-          a[e] = p_snake ? v[e] + sn * sn / (sv[e] + 1e-9f) : v[e];
-        }
+        for (int e = 0; e < 4; ++e) a[e] = p_snake ? snake16_f(v[e], sv[e]) : v[e];
         store4<bf16_t>((bf16_t*)(hb + (i * 32 + l31) * HS) + n, a[0], a[1], a[2], a[3]);
       }
 #pragma unroll
@@ -818,10 +809,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
         const float qs[4] = {qsa.x, qsa.y, qsa.z, qsa.w};
         float a[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float sn = __sinf(qs[e] * v[e]);
-          a[e] = q_snake ? v[e] + sn * sn / (qs[e] + 1e-9f) : v[e];
-        }
+        for (int e = 0; e < 4; ++e) a[e] = q_snake ? snake16_f(v[e], qs[e]) : v[e];
         const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
         if (m < p.M) {
           if (q.out_f32) {

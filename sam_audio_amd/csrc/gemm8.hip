@@ -48,10 +48,7 @@ __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha)
   if (act == ACT_RELU) return relu_f(v);
   if (act == ACT_GELU_TANH) return gelu_tanh_f(v);
   if (act == ACT_TANH) return tanhf(v);
-  if (act == ACT_SNAKE) {
-    const float sn = __sinf(snake_alpha * v);
-    return v + sn * sn / (snake_alpha + 1e-9f);
-  }
+  if (act == ACT_SNAKE) return snake16_f(v, snake_alpha);
   return v;
 }
 
