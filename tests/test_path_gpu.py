@@ -232,10 +232,15 @@ def test_concurrent_streams_are_bitwise_equal_to_one_stream(gpu):
     ref = one.last_latent.clone()
     two = SAMAudio(cfg, precision="bf16", device=str(gpu), streams=2)
     two.load_state_dict(sd, strict=False)
-    for _ in range(2):
+    for rep in range(2):
         res = two.separate(batch, noise=noise, ode_opt=opt)
         torch.cuda.synchronize()
-        assert torch.equal(two.last_latent, ref)
+        if not torch.equal(two.last_latent, ref):   # say where (failed once in round 3, GPU call 11; not reproduced since)
+            d = (two.last_latent.float() - ref.float()).abs()
+            per_clip = d.flatten(1).max(dim=1).values.tolist()
+            raise AssertionError(f"two-stream latent differs from the one-stream one in repetition {rep}: max |diff| per clip "
+                                 f"{per_clip}, {int((d > 0).sum())} of {d.numel()} elements, "
+                                 f"finite={bool(torch.isfinite(two.last_latent).all())}")
     assert all(torch.isfinite(w).all() for w in res.target)
 
 
