@@ -179,53 +179,89 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::run(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::run(bfr[j], af[i], acc[i][j]);   // swapped: see the epilogue
     }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  // C/D layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  // The operands go into the MFMA swapped (W fragment first): per fragment D = (A W^T)^T, i.e. a lane holds row m = lane & 15
+  // of m-fragment i and the FOUR CONSECUTIVE columns n = 16 j + 4 (lane >> 4) .. + 3 of n-fragment j.  Bias / gate / residual
+  // are 16-byte loads and the outputs 16- / 8-byte stores wherever the addresses allow it (the plain layout - one column,
+  // four rows per lane - moved every element on its own: the 2816-wide fp32 input projection of the 16-bit modes ran at
+  // 16 TF/s, 355 us for 68 MB of output; profiles/r3_call14/bench.log).  Element arithmetic and its order are unchanged.
   const long bM = (long)b * p.M;
+  const int n_out = p.swiglu ? p.N >> 1 : p.N;
+  auto finish = [&](float v, const float bias, const float gate, const float res, const float sa, float& a) -> float {
+    v += bias;
+    if (p.gate) v *= gate;
+    v *= p.alpha;
+    v += res;
+    a = v;
+    if (p.act == ACT_SNAKE) a = snake_f(v, sa);
+    else if (p.act == ACT_TANH) a = tanhf(v);
+    else if (p.act == ACT_SILU) a = silu_f(v);
+    else if (p.act == ACT_GELU) a = gelu_f(v);
+    else if (p.act == ACT_QUICK_GELU) a = quick_gelu_f(v);
+    else if (p.act == ACT_RELU) a = relu_f(v);
+    else if (p.act == ACT_GELU_TANH) a = gelu_tanh_f(v);
+    return v;
+  };
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + lr;
+    if (m >= p.M) continue;
+    const float* grow = nullptr;
+    if (p.gate) grow = p.gate + ((bM + m) / p.rows_per_gate) * p.gate_ld;
+    const float* rrow = p.res ? p.res + p.res_off + (long)b * p.res_bstride + (long)m * p.res_ld : nullptr;
+    float* frow = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + (long)m * p.f32_ld : nullptr;
+    T* arow = p.out_act ? (T*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)m * p.act_ld : nullptr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * WTM + i * 16 + lg * 4 + r;
-      if (m >= p.M) continue;
-      const float* grow = nullptr;
-      if (p.gate) grow = p.gate + ((bM + m) / p.rows_per_gate) * p.gate_ld;
+    for (int j = 0; j < FN; ++j) {
+      if (p.swiglu && (j & 1)) continue;
+      f32x4_t v4 = acc[i][j];
+      int n = n0 + wn * WTN + j * 16 + lg * 4;
+      if (p.swiglu) {  // w1 / w3 rows interleaved in 16-row blocks: fragment j | 1 holds the matching w3 columns
+        const f32x4_t g = acc[i][j | 1];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        int n = n0 + wn * WTN + j * 16 + lr;
-        float v = acc[i][j][r];
-        if (p.swiglu) {
-          if (j & 1) continue;
-          if (n >= p.N) continue;
-          const float g = acc[i][j | 1][r];  // matching w3 column (weights interleaved in 16-row blocks)
-          v = silu_f(v) * g;
-          n = ((n0 + wn * WTN) >> 1) + (j >> 1) * 16 + lr;
-        } else {
-          if (n >= p.N) continue;
-        }
-        const int ch = p.chan_mod ? n % p.chan_mod : n;
-        if (p.bias) v += p.bias[ch];
-        if (grow) v *= (p.gate_tab ? p.gate_tab[n] : 0.f) + grow[n];
-        v *= p.alpha;
-        const long erel = (long)m * p.c_ld_rel + n;
+        for (int e = 0; e < 4; ++e) v4[e] = silu_f(v4[e]) * g[e];
+        n = ((n0 + wn * WTN) >> 1) + (j >> 1) * 16 + lg * 4;
+      }
+      if (n >= n_out) continue;
+      // 16-byte path: all four columns exist, no per-element channel folding / output window, every operand aligned
+      size_t al = 0;
+      if (p.bias) al |= (size_t)(p.bias + n);
+      if (grow) al |= (size_t)(grow + n);
+      if (p.gate_tab) al |= (size_t)(p.gate_tab + n);
+      if (rrow) al |= (size_t)(rrow + n);
+      if (p.act == ACT_SNAKE) al |= (size_t)(p.act_alpha + n);
+      if (frow) al |= (size_t)(frow + n);
+      if (arow) al |= (size_t)(arow + n) * (16 / (4 * sizeof(T)));   // 4 elements of T: 16 bytes (fp32) or 8 (16-bit)
+      if (n + 4 <= n_out && !p.chan_mod && !p.c_ld_rel && (al & 15) == 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 bb = p.bias ? *(const float4*)(p.bias + n) : z;
+        float4 gg = grow ? *(const float4*)(grow + n) : z;
+        if (grow && p.gate_tab) { const float4 tt = *(const float4*)(p.gate_tab + n); gg.x += tt.x; gg.y += tt.y; gg.z += tt.z; gg.w += tt.w; }
+        const float4 rr = rrow ? *(const float4*)(rrow + n) : z;
+        const float4 sa = p.act == ACT_SNAKE ? *(const float4*)(p.act_alpha + n) : z;
+        float a0, a1, a2, a3;
+        const float v0 = finish(v4[0], bb.x, gg.x, rr.x, sa.x, a0), v1 = finish(v4[1], bb.y, gg.y, rr.y, sa.y, a1),
+                    v2 = finish(v4[2], bb.z, gg.z, rr.z, sa.z, a2), v3 = finish(v4[3], bb.w, gg.w, rr.w, sa.w, a3);
+        if (frow) *(float4*)(frow + n) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v0, v1, v2, v3);
+        if (arow) store4<T>(arow + n, a0, a1, a2, a3);
+        continue;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ne = n + e;
+        if (ne >= n_out) continue;
+        const int ch = p.chan_mod ? ne % p.chan_mod : ne;
+        const long erel = (long)m * p.c_ld_rel + ne;
         if (p.c_ld_rel && (erel < p.c_lo || erel >= p.c_hi)) continue;
-        if (p.res) v += p.res[p.res_off + (long)b * p.res_bstride + (long)m * p.res_ld + n];
-        float a = v;
-        if (p.act == ACT_SNAKE) a = snake_f(v, p.act_alpha[ch]);
-        else if (p.act == ACT_TANH) a = tanhf(v);
-        else if (p.act == ACT_SILU) a = silu_f(v);
-        else if (p.act == ACT_GELU) a = gelu_f(v);
-        else if (p.act == ACT_QUICK_GELU) a = quick_gelu_f(v);
-        else if (p.act == ACT_RELU) a = relu_f(v);
-        else if (p.act == ACT_GELU_TANH) a = gelu_tanh_f(v);
-        if (p.out_f32)
-          p.out_f32[p.f32_off + (long)b * p.f32_bstride + (long)m * p.f32_ld + n] = p.f32_act ? a : v;
-        if (p.out_act)
-          Elem<T>::store((T*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)m * p.act_ld + n, a);
+        float a;
+        const float v = finish(v4[e], p.bias ? p.bias[ch] : 0.f, grow ? (p.gate_tab ? p.gate_tab[ne] : 0.f) + grow[ne] : 0.f,
+                               rrow ? rrow[ne] : 0.f, p.act == ACT_SNAKE ? p.act_alpha[ch] : 0.f, a);
+        if (frow) frow[ne] = p.f32_act ? a : v;
+        if (arow) Elem<T>::store(arow + ne, a);
       }
     }
   }
