@@ -119,7 +119,6 @@ class SAMAudio:
         # the same kernels as the timed ones)
         self.tail_split: Optional[bool] = None
         self._lanes: List[_Lane] = []
-        self.stagger = not os.environ.get("SAMAUDIO_NO_STAGGER")   # groups encode their own rows, one codec phase apart
         self._profiling = self._serial_groups = False
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
@@ -328,10 +327,9 @@ class SAMAudio:
         rem = wavs.size(-1) % hop
         return wavs if rem == 0 else torch.nn.functional.pad(wavs, (0, hop - rem), mode="reflect")
 
-    def encode_audio(self, audios: torch.Tensor, lane: Optional[_Lane] = None) -> torch.Tensor:
+    def encode_audio(self, audios: torch.Tensor) -> torch.Tensor:
         """audios [B,1,Tw] -> mean latent, channels-last [B, T, codebook_dim] (reference codec.py:65-78;
-        the reference returns [B, C, T] and transposes at model.py:183).  `lane`: run on that lane's context (and on the
-        current stream)."""
+        the reference returns [B, C, T] and transposes at model.py:183)."""
         if not self._has_codec:
             raise RuntimeError("audio_codec weights are not loaded")
         wav = self._pad_to_hop(audios.to(self.device, torch.float32)).squeeze(1).contiguous()
@@ -339,9 +337,8 @@ class SAMAudio:
         frames = samples // self.cfg.audio_codec.hop_length
         z = torch.empty(items, frames, self.cfg.audio_codec.codebook_dim, device=self.device)
         with torch.cuda.device(self.device):
-            self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples, lane=lane)
-            ctx = self._ctx if lane is None else lane._ctx
-            hip.check(self._lib.samaudio_codec_encode(ctx, hip.ptr(wav), items, samples, hip.ptr(z),
+            self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples)
+            hip.check(self._lib.samaudio_codec_encode(self._ctx, hip.ptr(wav), items, samples, hip.ptr(z),
                                                       hip.current_stream_ptr()))
         return z
 
@@ -437,15 +434,11 @@ class SAMAudio:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_TAIL_SPLIT, split))
 
     def _solve_concurrent(self, noise: torch.Tensor, ode_opt: Dict[str, Any], cond: List[Optional[torch.Tensor]],
-                          groups: int, decode: bool = False, audios: Optional[torch.Tensor] = None):
+                          groups: int, decode: bool = False):
         """prepare + ODE solve (+ DAC-VAE decode of target and residual when `decode`) of `groups` contiguous row groups,
         each on its own engine context and HIP stream, driven by one host thread per group (the C calls release the GIL).
         Rows are independent, so the result equals the single-stream one bit for bit.  Returns the
-        latent state, and with `decode` also the waveforms [rows, 2, samples] (model.py:291-295).
-        `audios` [rows, 1, samples] (then cond[0] is None): every group also ENCODES its own rows, and group i starts its
-        encode when group i-1 has finished encoding.  The groups then run one codec phase apart for the whole call: a
-        group's HBM-bound encode / decode runs beside the other group's DiT GEMMs (on the CUs their partial tile rounds
-        leave idle) instead of beside the other group's encode / decode, which competes for the same HBM bandwidth."""
+        latent state, and with `decode` also the waveforms [rows, 2, samples] (model.py:291-295)."""
         import threading
         from .dist import shard_range
         method, grid = ode_grid(ode_opt)
@@ -461,8 +454,6 @@ class SAMAudio:
         self._apply_options(groups)
         main = torch.cuda.current_stream(self.device)
         errors: List[BaseException] = []
-        encoded = [threading.Event() for _ in range(groups)]   # host side: group i has enqueued its encode ...
-        encoded_ev = [torch.cuda.Event() for _ in range(groups)]   # ... and this marks its end on the device
 
         def work(i: int, lane: Optional[_Lane]):
             try:
@@ -471,16 +462,6 @@ class SAMAudio:
                 part = [None if c is None else c[sl] for c in cond]
                 stream = main if (lane is None or self._serial_groups) else lane.stream
                 with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(stream):
-                    if audios is not None:
-                        if i > 0 and not self._serial_groups:
-                            encoded[i - 1].wait()
-                            stream.wait_event(encoded_ev[i - 1])
-                        try:
-                            z = self.encode_audio(audios[sl], lane=lane)
-                            part[0] = torch.cat([z, z], dim=2)                   # model.py:182-184
-                            encoded_ev[i].record(stream)
-                        finally:
-                            encoded[i].set()   # also on failure: the next group must not wait for ever
                     self._prepare(*part, lane=lane)
                     ctx = self._ctx if lane is None else lane._ctx
                     hip.check(self._lib.samaudio_ode_solve(ctx, hip.ptr(state[sl]), method, g, len(grid),
@@ -539,18 +520,9 @@ class SAMAudio:
             raise RuntimeError("load_state_dict() first")
         cand = int(reranking_candidates)
         with torch.cuda.device(self.device):
-            # several row groups, one candidate, no span predictor (it reads the features): every group encodes its own
-            # rows, one codec phase behind the previous group (_solve_concurrent)
-            own_encode = (self.streams > 1 and cand == 1 and batch.audios.size(0) > 1 and self.stagger
-                          and not (predict_spans and batch.anchors is None and self.span_predictor is not None))
-            if own_encode:
-                hop = self.cfg.audio_codec.hop_length
-                feats = None
-                B, T, C2 = batch.audios.size(0), -(-batch.audios.size(-1) // hop), 2 * self.cfg.audio_codec.codebook_dim
-            else:
-                z = self.encode_audio(batch.audios)                              # [B, T, 128]
-                feats = torch.cat([z, z], dim=2)                                 # model.py:182-184
-                B, T, C2 = feats.shape
+            z = self.encode_audio(batch.audios)                                  # [B, T, 128]
+            feats = torch.cat([z, z], dim=2)                                     # model.py:182-184
+            B, T, C2 = feats.shape
             text, text_mask = self._text(batch)
             video = None
             if batch.masked_video is not None:                                   # model.py:186-191
@@ -572,19 +544,18 @@ class SAMAudio:
                         anchor_ids, anchor_alignment = batch.anchor_ids, batch.anchor_alignment
             feats_r = self._repeat(feats, cand)
             if noise is None:
-                noise = torch.randn(B * cand, T, C2, device=self.device)         # model.py:274-275
-            assert tuple(noise.shape) == (B * cand, T, C2), "noise must be [B*candidates, T, 256]"
+                noise = torch.randn_like(feats_r)                                # model.py:274-275
+            assert noise.shape == feats_r.shape, "noise must be [B*candidates, T, 256]"
             cond = [feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), self._repeat(video, cand),
                     self._repeat(anchor_ids, cand), self._repeat(anchor_alignment, cand),
                     self._repeat(batch.audio_pad_mask, cand)]
-            groups = min(self.streams, B * cand)
+            groups = min(self.streams, feats_r.size(0))
             wavs = None
             if groups > 1:
                 cond = [None if c is None else c.to(self.device) for c in cond]
                 # each group also decodes its own rows on its stream: the codec's HBM-bound convolutions of one group run
                 # beside the other group's kernels instead of after both solves
-                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True,
-                                                      audios=batch.audios.to(self.device) if own_encode else None)
+                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True)
             else:
                 self._apply_options(1)
                 self._prepare(*cond)
