@@ -331,11 +331,13 @@ typedef struct {
   double ms;
 } samaudio_kernel_stat;
 int samaudio_profile_begin(samaudio_ctx* ctx);
-/* Tuning / test hook: force the GEMM kernel variant (-1 automatic; 0..2 the 128-row tiles of gemm.hip;
- * 3 = 256x128 3-stage ring, 4 = 256x128 2-stage ring, 5 = 256x256 2-stage ring, 9 = 256x256 role-split of
- * gemm2.hip where eligible). */
+/* Test hook: force the GEMM kernel variant (-1 automatic; 0..2 the 128-row tiles of gemm.hip; 22 = gemm8 256x256 8-phase,
+ * 27 = gemm8s 128x128, 25 / 26 / 28 / 29 / 32 / 33 / 34 = the 32x32x16-family tiles, 35 = conv7h; csrc/gemm.hip
+ * gemm_variant_name).  A launch the forced kernel does not cover falls back to gemm.hip's tiles. */
 void samaudio_debug_force_gemm_variant(int variant);
-/* Tuning hook: A/B switches between kernel generations (flag 1 = first-generation bf16 qkv_prep); 0 = shipped. */
+/* Test hooks (csrc/kernels.h lists them; 0 = shipped behaviour): 11 = k7 convolutions as implicit GEMMs, 16 = DAC residual
+ * units as two launches, 18 = fuse residual units whatever the launch size, 19 = residual-unit kernel form (1 / 3 = weight-
+ * stationary, 2 = ring), 21 = gemm8s always in its plain double-buffered form. */
 void samaudio_debug_set_flag(int flag, int value);
 /* Test aid: leave the LDS of every CU filled with NaN bit patterns (LDS is not cleared between kernels), so that a
  * kernel consuming LDS it never wrote fails deterministically. */
