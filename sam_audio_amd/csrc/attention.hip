@@ -604,8 +604,12 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
                                   int H, hipStream_t st) {
   if ((H * 128) % 64 || (LtP != 8 && LtP != 16) || KP % 8 || KP < H * LtP) return hipErrorInvalidValue;
   const int groups = (KP + 8 * LtP - 1) / (8 * LtP);   // 8-head groups covering the padded row
-  // batch splits: enough workgroups for two per CU, at least 4 items each (a trip handles 4)
-  int zs = (512 + (H * 128 / 64) * groups - 1) / ((H * 128 / 64) * groups);
+  // batch splits, at least 4 items each (a trip handles 4).  Every split re-reads Wo, and the kernel is bound by the sum of its
+  // L2 traffic, not by how many CUs hold a workgroup: up to 16 items no split at all (132 workgroups walking 4 trips: 23.3 vs
+  // 27.1 us for 528 one-trip workgroups), beyond that ~384 workgroups (32 items: 35.6 vs 41.3 us; profiles/r3_call21/, where
+  // requesting the V fragments one trip ahead also measured no better).
+  const int target = B <= 16 ? 1 : 384;
+  int zs = (target + (H * 128 / 64) * groups - 1) / ((H * 128 / 64) * groups);
   const int zmax = (B + 3) / 4;
   zs = zs < 1 ? 1 : zs > zmax ? zmax : zs;
   hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, groups, zs), dim3(512), 0, st, (const bf16_t*)wo,
