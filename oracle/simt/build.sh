@@ -29,14 +29,6 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       grep -q "(void)lds;" $OUT/gemm2_simt.hip || { echo "gemm2.hip: dma16a asm statement not found"; exit 1; }
       src=$OUT/gemm2_simt.hip
     fi
-    if [ $f = gemm8 ]; then
-      # gemm8w's inline-assembly direct-to-LDS load and MFMA (operands the preprocessor cannot see) become the builtins
-      sed -e 's|^.*// SIMT-DMA$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0); (void)lds;|' \
-          -e 's|^.*// SIMT-MFMA$|  acc = SA_MFMA_16x16x32(w, a, acc);|' $src > $OUT/gemm8_simt.hip
-      grep -q "acc = SA_MFMA_16x16x32(w, a, acc);" $OUT/gemm8_simt.hip || { echo "gemm8.hip: mfma_acc asm statement not found"; exit 1; }
-      EXTRA="-I $SRC"
-      src=$OUT/gemm8_simt.hip
-    fi
     $CXX $FLAGS $EXTRA -c $src -o $OUT/$f.o &
     pids+=($!)
   fi

@@ -26,7 +26,6 @@ __device__ __forceinline__ float h16_hi(unsigned w) { return bf2f((unsigned shor
 typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_t;
 #define SA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #define SA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#define SA_MFMA_16x16x32_MNEMONIC "v_mfma_f32_16x16x32_f16"
 #else
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {  // round-to-nearest-even
@@ -39,7 +38,6 @@ __device__ __forceinline__ float h16_hi(unsigned w) { return __uint_as_float(w &
 typedef __attribute__((ext_vector_type(8))) __bf16 h16x8_t;
 #define SA_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define SA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#define SA_MFMA_16x16x32_MNEMONIC "v_mfma_f32_16x16x32_bf16"
 #endif
 
 template <typename T> struct Elem;

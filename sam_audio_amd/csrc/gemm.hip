@@ -355,7 +355,6 @@ const char* gemm_variant_name(int v, bool is_bf16) {
     case 33: return "gemm2_bf16_64x128_k32_s3";
     case 34: return "gemm2_bf16_128x192_k32_s3";
     case 35: return "conv7h_bf16";
-    case 36: return "gemm8w_bf16_256x256_4wave";
     default: return "";
   }
 }

@@ -968,7 +968,6 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st) {
     case 30: return launch2<64, 128, 1, 4, 3, 32>(p, st);   // 36 KiB => four workgroups per CU
     case 31: return launch2<128, 192, 2, 2, 3, 32>(p, st);  // N = 192 in one tile, 60 KiB => two workgroups per CU
     case 32: return launch_conv7h(p, st);  // k7 convolution with the halo tile resident in LDS (conv7h_ok launches only)
-    case 33: return launch_gemm8w(p, st);  // gemm8.hip: the 256x256 tile on 4 waves of 128x128 (plain GEMMs; else gemm8)
     default: return hipErrorInvalidValue;
   }
 }

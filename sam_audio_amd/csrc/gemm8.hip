@@ -610,163 +610,6 @@ hipError_t launch_gemm8(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------------
-// gemm8w_kernel: the 256 x 256 tile on FOUR waves, 2 (M) x 2 (N), 128 x 128 outputs each (plain GEMMs only).
-// gemm8_kernel's 128 x 64 wave tiles read 192 KiB of LDS per 64-deep K-tile and CU (A 16 + W 8 KiB per wave, 8 waves) and
-// its read sections outlast the 16-MFMA clusters they hide behind.  Square 128 x 128 wave tiles need
-// 128 KiB - a third less LDS traffic per flop - at the price of one wave per SIMD: nothing hides a stall, the K loop must be
-// software-pipelined inside the wave, and the 64 accumulator fragments (256 registers) must stay put.  hipcc left to itself
-// shuffles them between VGPRs and AGPRs inside the loop (110 spills), so here
-//   * every MFMA is an inline-assembly statement whose accumulator is a "+a" operand: 64 fragments x 4 AGPRs, the whole
-//     accumulation file, assigned once; the order of the statements is the schedule (sched_barrier(0) between groups);
-//   * K walked in stages of 32 (one MFMA k-step), ring of 4 stages x 32 KiB (A 256 rows x 64 B | W 256 rows x 64 B, 16-byte
-//     chunks XOR-swizzled with (row >> 2) & 3: a 16-row fragment read covers 1 KiB and hits every bank once);
-//   * stage s: 16 groups of 4 MFMAs on fragment set s & 1; between the groups, the 16 ds_read_b128 that fill set (s+1) & 1
-//     from stage s+1 (in the order stage s+1 consumes them) and the 8 direct-to-LDS loads (inline assembly as gemm2.hip's
-//     dma16a: the compiler must not see them, or every fragment read waits for vmcnt(0)) that refill stage s-1's buffer
-//     with stage s+3;
-//   * one counted vmcnt(8) + one barrier per stage: two stages (2 x 1024 MFMA cycles) of DMA latency in flight.
-// Fragment <-> k mapping, MFMA shape and the order of the k-steps are gemm8_kernel's: bitwise identical results.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dma16_8a(const void* gsrc, char* lds_wave_base) {
-  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA
-}
-__device__ __forceinline__ void mfma_acc(f32x4_t& acc, const bf16x8_t& w, const bf16x8_t& a) {
-  asm volatile(SA_MFMA_16x16x32_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(a));  // SIMT-MFMA
-}
-
-__global__ __launch_bounds__(256, 1) void gemm8w_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, KS = 32, NS = 4, SB = 2 * 256 * 64;  // SB: bytes of one stage (A part | W part)
-  __shared__ __attribute__((aligned(16))) char smem[NS * SB];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int lr = lane & 15, lg = lane >> 4;
-  int b, tm, tn;
-  tile_raster8(p, BM, BN, b, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- staging: wave w fills rows 64w .. 64w+63 of both parts, 4 + 4 wave-instructions of 16 rows x 64 B per stage --------
-  const int r4 = lane >> 2, c4 = (lane & 3) ^ ((r4 >> 2) & 3);   // row inside the instruction, SOURCE chunk of the lane's slot
-  const bf16_t* a_ptr[4];
-  const bf16_t* w_ptr[4];
-  {
-    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
-    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = wave * 64 + q * 16 + r4;
-      int m = m0 + row, n = n0 + row;
-      m = m < p.M ? m : p.M - 1;
-      n = n < p.N ? n : p.N - 1;
-      a_ptr[q] = A + (long)m * p.lda + c4 * 8;
-      w_ptr[q] = W + (long)n * p.K + c4 * 8;
-    }
-  }
-  // one staging instruction: u = 0..3 -> A rows, 4..7 -> W rows of stage s (buffer s & 3)
-#define SA_GEMM8W_DMA(S, U)                                                                                       \
-  dma16_8a(((U) < 4 ? a_ptr[(U) & 3] : w_ptr[(U) & 3]) + (long)(S) * KS,                                          \
-           smem + ((S) & (NS - 1)) * SB + wave * 4096 + ((U) < 4 ? 0 : 16384) + ((U) & 3) * 1024)
-
-  f32x4_t acc[2][8][4];   // [64-column half][m-fragment][n-fragment of the half]: the shape epilogue8<2> takes per half
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t af[2][8], wf[2][8];
-  const int a_off = (wr * 128 + lr) * 64 + ((lg ^ (lr >> 2)) << 4);
-  const int w_off = 16384 + (wc * 128 + lr) * 64 + ((lg ^ (lr >> 2)) << 4);
-  // fragment read number R (0..15) of stage S into set SET, in the order a stage consumes them: W 0-3, A 0, W 4-7, A 1..7
-#define SA_GEMM8W_READ1(SET, S, R)                                                                                \
-  do {                                                                                                            \
-    const char* base_ = smem + ((S) & (NS - 1)) * SB;                                                             \
-    if ((R) < 4) wf[SET][R] = *(const bf16x8_t*)(base_ + w_off + (R) * 1024);                                     \
-    else if ((R) == 4) af[SET][0] = *(const bf16x8_t*)(base_ + a_off);                                            \
-    else if ((R) < 9) wf[SET][(R) - 1] = *(const bf16x8_t*)(base_ + w_off + ((R) - 1) * 1024);                    \
-    else af[SET][(R) - 8] = *(const bf16x8_t*)(base_ + a_off + ((R) - 8) * 1024);                                 \
-  } while (0)
-  // MFMA group G (0..15) of a stage: m-fragment G / 2, n-fragments 4 (G % 2) .. + 3
-#define SA_GEMM8W_MMA4(SET, G)                                                                                    \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                                              \
-      mfma_acc(acc[(G) & 1][(G) >> 1][jj], wf[SET][((G) & 1) * 4 + jj], af[SET][(G) >> 1]);                       \
-  } while (0)
-
-  const int ns = p.K / KS;   // even: K is a multiple of 64
-#define SA_GEMM8W_STAGE_ALL(S) do { _Pragma("unroll") for (int u = 0; u < 8; ++u) SA_GEMM8W_DMA(S, u); } while (0)
-  SA_GEMM8W_STAGE_ALL(0);
-  if (ns > 1) SA_GEMM8W_STAGE_ALL(1);
-  if (ns > 2) SA_GEMM8W_STAGE_ALL(2);
-  if (ns > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (ns > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) SA_GEMM8W_READ1(0, 0, r);
-  // steady-state stage: everything unconditional and in exactly this order
-#define SA_GEMM8W_STEADY(SET, S)                                                                                  \
-  do {                                                                                                            \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* stage S+1 has landed (this wave's part) */                \
-    __builtin_amdgcn_s_barrier();                    /* ... every wave's; and every wave is through stage S-1 */   \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) {                                                              \
-      SA_GEMM8W_MMA4(SET, g);                                                                                     \
-      if (g < 8) SA_GEMM8W_DMA((S) + 3, g);                                                                       \
-      /* 16 reads over groups 0 .. 11 (two each in the first four): the last one is issued 4 groups = 256 MFMA cycles   \
-         before the stage ends, so the lgkmcnt(0) the compiler puts at the top of the next stage costs nothing */        \
-      if (g < 4) { SA_GEMM8W_READ1((SET) ^ 1, (S) + 1, 2 * g); SA_GEMM8W_READ1((SET) ^ 1, (S) + 1, 2 * g + 1); }          \
-      else if (g < 12) SA_GEMM8W_READ1((SET) ^ 1, (S) + 1, g + 4);                                                \
-      __builtin_amdgcn_sched_barrier(0);                                                                          \
-    }                                                                                                             \
-  } while (0)
-  int s = 0;
-  for (; s + 4 < ns; s += 2) {   // both stages of a trip have a stage s+3 to fetch
-    SA_GEMM8W_STEADY(0, s);
-    SA_GEMM8W_STEADY(1, s + 1);
-  }
-  // the last (up to four) stages: the same steps under their conditions
-#define SA_GEMM8W_TAIL(SET, S)                                                                                    \
-  do {                                                                                                            \
-    if ((S) + 1 < ns) {                                                                                           \
-      if ((S) + 2 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                          \
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
-      __builtin_amdgcn_s_barrier();                                                                               \
-      if ((S) + 3 < ns) SA_GEMM8W_STAGE_ALL((S) + 3);                                                             \
-      _Pragma("unroll") for (int r = 0; r < 16; ++r) SA_GEMM8W_READ1((SET) ^ 1, (S) + 1, r);                      \
-    }                                                                                                             \
-    _Pragma("unroll") for (int g = 0; g < 16; ++g) SA_GEMM8W_MMA4(SET, g);                                        \
-  } while (0)
-  for (; s < ns; s += 2) {
-    SA_GEMM8W_TAIL(0, s);
-    SA_GEMM8W_TAIL(1, s + 1);
-  }
-#undef SA_GEMM8W_DMA
-#undef SA_GEMM8W_READ1
-#undef SA_GEMM8W_MMA4
-#undef SA_GEMM8W_STAGE_ALL
-#undef SA_GEMM8W_STEADY
-#undef SA_GEMM8W_TAIL
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");   // the last MFMAs' results (the compiler does not know the
-                                                                 // statements above are MFMAs: no hazard slots of its own)
-  __syncthreads();   // every wave is through with the ring (no DMA in flight): the epilogue stages through it
-  epilogue8<2>(p, acc[0], smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 128, lane);
-  __syncthreads();   // the staging area is reused: the first half's reads precede the second half's writes
-  epilogue8<2>(p, acc[1], smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 128 + 64, lane);
-}
-
-// launches gemm8w covers: plain GEMMs (no tap walk) of the 16x16x32 family's operand model
-bool gemm8w_ok(const GemmParams& p) { return gemm2_ok(p) && p.kc >= p.K; }
-hipError_t launch_gemm8w(const GemmParams& p, hipStream_t st) {
-  if (!gemm8w_ok(p)) return launch_gemm8(p, st);
-  const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
-  hipLaunchKernelGGL(gemm8w_kernel, dim3((unsigned)tiles), dim3(256), 0, st, p);
-  return hipGetLastError();
-}
-
 // Tile-quantisation split: 256x256 tiles fill the chip only in whole rounds of 256 workgroups (one per CU); the last,
 // partial round of a launch leaves CUs idle for a full tile time (352 tiles at N = D: 2 rounds for 1.375 rounds of
 // work).  part 0 = the 8-phase kernel on the first `full` tiles of the raster order, part 1 = the remaining tiles as

@@ -23,7 +23,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 37;  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 36;  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
                                    // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family;
                                    // 28 = 256x64 tile of the 32x32x16 family for 64-channel convolutions
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)
@@ -31,7 +31,6 @@ bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 // gemm8.hip: 256x256 8-phase kernel (variant 22); needs gemm2_ok(p)
 hipError_t launch_gemm8(const GemmParams& p, hipStream_t st);
-hipError_t launch_gemm8w(const GemmParams& p, hipStream_t st);   // 4-wave form (plain GEMMs; falls back to gemm8 otherwise)
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in

@@ -23,7 +23,7 @@ from tests import util  # noqa: E402
 RASTER = [0]
 BLAS = [False]
 # the kernels the tile policy picks from for a DiT-class GEMM (gemm.hip gemm_variant numbering)
-VARIANTS = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128", 36: "4-wave 256x256 (gemm8w)"}
+VARIANTS = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128"}
 
 
 def interleave16(w1, w3):
