@@ -52,6 +52,32 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
   }
+  // Validity of this lane's keys (key = 64 t + 16 nb + lr: exists and is not masked) for every K-tile, as one bit each,
+  // gathered BEFORE the loop, 16 byte-loads in flight at a time.  Loaded where it is used - under `key < T &&`, after the
+  // S MFMAs - each of a tile's four mask bytes was a branch around a dependent global load with its own s_waitcnt vmcnt(0):
+  // four L2 round trips in series in every K-tile.  (Tp > 1024: more tiles than bits - the in-loop loads remain.)
+  const int ntile = Tp >> 6;
+  const bool bits_ok = ntile <= 16;
+  unsigned long long vbits = 0;
+  if (bits_ok) {
+    for (int t0 = 0; t0 < ntile; t0 += 4) {
+      unsigned char mk[4][4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int key = (t0 + tt) * 64 + nb * 16 + lr;
+          mk[tt][nb] = key_mask[(long)b * T + (key < T ? key : T - 1)];
+        }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int key = (t0 + tt) * 64 + nb * 16 + lr;
+          if (t0 + tt < ntile && key < T && mk[tt][nb] != 0) vbits |= 1ull << ((t0 + tt) * 4 + nb);
+        }
+    }
+  }
   float m_i[4], l_i[4];
   f32x4_t o[NF];
 #pragma unroll
@@ -93,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       const int key = kt + nb * 16 + lr;
-      valid[nb] = key < T && key_mask[(long)b * T + key] != 0;
+      valid[nb] = bits_ok ? ((vbits >> ((kt >> 6) * 4 + nb)) & 1ull) != 0 : (key < T && key_mask[(long)b * T + key] != 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -141,15 +167,28 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
       }
     }
   }
+  // Output: a lane holds column n*16 + lr of rows lg*4 + r - stored from there, every element is a 2-byte store and an
+  // instruction covers four 32-byte pieces.  The wave's 16 x HD tile goes through LDS instead (a private slice of the K / V^T
+  // staging area, free after the loop) and leaves as 16-byte stores, 16 lanes per 256-byte row.
   const int D = H * HD;
+  __syncthreads();   // every wave is through with Ks / Vs
+  constexpr int SLICE = 16 * HD * 2;   // one wave's tile: Ks holds four of them, Vs the other four (NW = 8)
+  static_assert(4 * SLICE == 64 * HD * 2 && 4 * SLICE <= HD * 128 && NW <= 8, "output staging fits the K / V^T staging areas");
+  char* mine = wave < 4 ? Ks + wave * SLICE : Vs + (wave - 4) * SLICE;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int q = q0 + wave * 16 + lg * 4 + r;
-    if (q >= T) continue;
     const float inv = 1.f / l_i[r];
-    bf16_t* orow = out + ((long)b * T + q) * D + h * HD;
+    const int q = lg * 4 + r;
 #pragma unroll
-    for (int n = 0; n < NF; ++n) orow[n * 16 + lr].v = f2bf(o[n][r] * inv);
+    for (int n = 0; n < NF; ++n) *(unsigned short*)(mine + q * (HD * 2) + (n * 16 + lr) * 2) = f2bf(o[n][r] * inv);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: only wave-level ordering is needed
+  constexpr int CPRO = HD / 8;   // 16-byte chunks per output row
+#pragma unroll
+  for (int u = lane; u < 16 * CPRO; u += 64) {
+    const int row = u / CPRO, c = u % CPRO;
+    const int q = q0 + wave * 16 + row;
+    if (q < T) *(uint4*)(out + ((long)b * T + q) * D + h * HD + c * 8) = *(const uint4*)(mine + row * (HD * 2) + c * 16);
   }
 }
 
