@@ -26,7 +26,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // buffering with one barrier per tile and the key mask staged through LDS (79 vs 68 us), and both together.  At T = 250
 // the kernel moves 275 MB for 23.6 GFLOP in 68 us = 4 TB/s: it is bandwidth-bound, not latency-bound.)
 template <int NW, int HD>
-__global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(NW * 64, 4) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt,
                                                                  const unsigned char* __restrict__ key_mask,
                                                                  bf16_t* __restrict__ out, int T, int Tp, int H) {
@@ -52,32 +52,16 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8_t*)(qrow + (ks * 4 + lg) * 8);
   }
-  // Validity of this lane's keys (key = 64 t + 16 nb + lr: exists and is not masked) for every K-tile, as one bit each,
-  // gathered BEFORE the loop, 16 byte-loads in flight at a time.  Loaded where it is used - under `key < T &&`, after the
+  // Key validity (the key exists and is not masked) for the whole (padded) sequence goes to LDS once, coalesced, and the K
+  // loop reads its four bytes per lane from there.  Read from global memory where it is used - under `key < T &&`, after the
   // S MFMAs - each of a tile's four mask bytes was a branch around a dependent global load with its own s_waitcnt vmcnt(0):
-  // four L2 round trips in series in every K-tile.  (Tp > 1024: more tiles than bits - the in-loop loads remain.)
-  const int ntile = Tp >> 6;
-  const bool bits_ok = ntile <= 16;
-  unsigned long long vbits = 0;
-  if (bits_ok) {
-    for (int t0 = 0; t0 < ntile; t0 += 4) {
-      unsigned char mk[4][4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const int key = (t0 + tt) * 64 + nb * 16 + lr;
-          mk[tt][nb] = key_mask[(long)b * T + (key < T ? key : T - 1)];
-        }
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          const int key = (t0 + tt) * 64 + nb * 16 + lr;
-          if (t0 + tt < ntile && key < T && mk[tt][nb] != 0) vbits |= 1ull << ((t0 + tt) * 4 + nb);
-        }
-    }
-  }
+  // four L2 round trips in series in every K-tile.  (Sequences beyond MAXT keys keep the global reads.)
+  constexpr int MAXT = 2048;
+  __shared__ unsigned char Ms[MAXT];
+  const bool mask_in_lds = Tp <= MAXT;   // uniform
+  if (mask_in_lds)
+    for (int i = tid; i < Tp; i += NW * 64) Ms[i] = (i < T && key_mask[(long)b * T + (i < T ? i : 0)] != 0) ? 1 : 0;
+  // (published by the two barriers every K-tile starts with)
   float m_i[4], l_i[4];
   f32x4_t o[NF];
 #pragma unroll
@@ -119,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void self_attn_bf16_kernel(const bf16_t* _
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       const int key = kt + nb * 16 + lr;
-      valid[nb] = bits_ok ? ((vbits >> ((kt >> 6) * 4 + nb)) & 1ull) != 0 : (key < T && key_mask[(long)b * T + key] != 0);
+      valid[nb] = mask_in_lds ? Ms[key] != 0 : (key < T && key_mask[(long)b * T + key] != 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
