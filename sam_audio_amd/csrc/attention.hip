@@ -351,7 +351,13 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
   }
   // K fragments: rows = tokens
   bf16x8_t kf[4];
-  const bool tok_ok = r < Lt && mask[(long)b * Lt + (r < Lt ? r : 0)] != 0;
+  // mask bytes are loaded unconditionally (clamped index) and up front: under `tok < Lt &&` each was a branch around a
+  // dependent global load that had to land before the next instruction - one L2 round trip each, in series
+  const unsigned char mask_r = mask[(long)b * Lt + (r < Lt ? r : 0)];
+  unsigned char mask_e[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) mask_e[e] = mask[(long)b * Lt + (g * 4 + e < Lt ? g * 4 + e : 0)];
+  const bool tok_ok = r < Lt && mask_r != 0;
   {
     const bf16_t* krow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + h * 128 + g * 8;
 #pragma unroll
@@ -381,14 +387,27 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
       }
     }
   }
+  // q-norm weights of the lane's 32 channels: requested together with the operands and pinned there (an empty asm that
+  // "uses" them) - left alone the compiler sinks each of these loads to its k-step, behind a vmcnt(0) of its own
+  f32x4_t wq[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    wq[ks][0] = *(const f32x4_t*)(qw + ks * 32 + g * 8);
+    wq[ks][1] = *(const f32x4_t*)(qw + ks * 32 + g * 8 + 4);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    asm volatile("" : "+v"(wq[ks][0]));
+    asm volatile("" : "+v"(wq[ks][1]));
+  }
   ss += __shfl_xor(ss, 16, 64);
   ss += __shfl_xor(ss, 32, 64);
   const float inv = rsqrtf(ss / 128.f + eps);
   f32x4_t sT = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const float4 w0 = *(const float4*)(qw + ks * 32 + g * 8), w1 = *(const float4*)(qw + ks * 32 + g * 8 + 4);
-    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const f32x4_t w0 = wq[ks][0], w1 = wq[ks][1];
+    const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
     unsigned pk[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -402,7 +421,7 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_kernel(const bf16_t* __re
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int tok = g * 4 + e;
-    const bool ok = tok < Lt && mask[(long)b * Lt + (tok < Lt ? tok : 0)] != 0;
+    const bool ok = tok < Lt && mask_e[e] != 0;
     p[e] = ok ? sT[e] * scale : -INFINITY;
     mx = fmaxf(mx, p[e]);
   }
@@ -474,7 +493,13 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
   const int r = lane & 15, g = lane >> 4;
   const int D = H * 128;
   bf16x8_t kf[4];
-  const bool tok_ok = r < Lt && mask[(long)b * Lt + (r < Lt ? r : 0)] != 0;
+  // mask bytes are loaded unconditionally (clamped index) and up front: under `tok < Lt &&` each was a branch around a
+  // dependent global load that had to land before the next instruction - one L2 round trip each, in series
+  const unsigned char mask_r = mask[(long)b * Lt + (r < Lt ? r : 0)];
+  unsigned char mask_e[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) mask_e[e] = mask[(long)b * Lt + (g * 4 + e < Lt ? g * 4 + e : 0)];
+  const bool tok_ok = r < Lt && mask_r != 0;
   {
     const bf16_t* krow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + h * 128 + g * 8;
 #pragma unroll
@@ -503,14 +528,27 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
       }
     }
   }
+  // q-norm weights of the lane's 32 channels: requested together with the operands and pinned there (an empty asm that
+  // "uses" them) - left alone the compiler sinks each of these loads to its k-step, behind a vmcnt(0) of its own
+  f32x4_t wq[4][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    wq[ks][0] = *(const f32x4_t*)(qw + ks * 32 + g * 8);
+    wq[ks][1] = *(const f32x4_t*)(qw + ks * 32 + g * 8 + 4);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    asm volatile("" : "+v"(wq[ks][0]));
+    asm volatile("" : "+v"(wq[ks][1]));
+  }
   ss += __shfl_xor(ss, 16, 64);
   ss += __shfl_xor(ss, 32, 64);
   const float inv = rsqrtf(ss / 128.f + eps);
   f32x4_t sT = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const float4 w0 = *(const float4*)(qw + ks * 32 + g * 8), w1 = *(const float4*)(qw + ks * 32 + g * 8 + 4);
-    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const f32x4_t w0 = wq[ks][0], w1 = wq[ks][1];
+    const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
     unsigned pk[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -523,7 +561,7 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int tok = g * 4 + e;
-    const bool ok = tok < Lt && mask[(long)b * Lt + (tok < Lt ? tok : 0)] != 0;
+    const bool ok = tok < Lt && mask_e[e] != 0;
     p[e] = ok ? sT[e] * scale : -INFINITY;
     mx = fmaxf(mx, p[e]);
   }
