@@ -127,6 +127,30 @@ def test_self_attention(gpu, prec, T):
     # bf16: P is rounded to bf16 before P@V (2^-9 relative on weights that sum to 1) and so is the output
     util.report(f"self_attention {prec} T{T}", out, want, 2e-5 if prec == "fp32" else 2e-2)
 
+def test_self_attention_long_sequence(gpu):
+    """More keys than the bf16 kernel's LDS-resident validity table holds (2048): the K loop reads the key mask from global
+    memory instead - same result as torch on a 2100-frame (84 s) sequence with a masked tail and a masked stretch inside."""
+    prec, B, H, T = "bf16", 1, 1, 2100
+    Tp = (T + 127) // 128 * 128
+    D = H * 128
+    q, k, v = _mk((B, H, T, 128), 23) * 1.5, _mk((B, H, T, 128), 24), _mk((B, H, T, 128), 25)
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[0, T - 70:] = False
+    mask[0, 1000:1040] = False
+    pad = lambda z: torch.nn.functional.pad(z, (0, 0, 0, Tp - T))
+    qd, kd = util.as_act(pad(q), prec, gpu), util.as_act(pad(k), prec, gpu)
+    vtd = util.as_act(pad(v).transpose(2, 3), prec, gpu)
+    out = torch.empty(B * T, D, device=gpu, dtype=util.ACT_DT[prec])
+    hip.check(hip.lib().samaudio_op_self_attention(hip.ptr(qd), hip.ptr(kd), hip.ptr(vtd),
+                                                   P(mask.to(gpu).to(torch.uint8)), hip.ptr(out), util.PREC[prec],
+                                                   B, T, Tp, H, util.stream()))
+    qq, kk, vv = util.rounded(q, prec), util.rounded(k, prec), util.rounded(v, prec)
+    s = (qq @ kk.transpose(-1, -2)) / math.sqrt(128)
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    want = (torch.softmax(s, -1) @ vv).permute(0, 2, 1, 3).reshape(B * T, D)
+    util.report(f"self_attention {prec} T{T} (mask from global memory)", out, want, 2e-2)
+
+
 @pytest.mark.parametrize("prec", PRECS)
 def test_cross_attention(gpu, prec):
     B, T, Lt, H = 2, 40, 6, 2
@@ -163,7 +187,7 @@ def test_layernorm_accum(gpu):
 
 
 @pytest.mark.parametrize("Lt,ltp,B,H", [(3, 8, 3, 4), (8, 8, 3, 4), (11, 16, 3, 4), (8, 8, 6, 6), (16, 16, 5, 2), (8, 8, 5, 22),
-                                        (8, 8, 33, 10), (13, 16, 9, 22)])
+                                        (8, 8, 33, 10), (13, 16, 9, 22), (8, 8, 16, 22), (8, 8, 13, 4)])
 def test_cross_attn_fold_operand(gpu, Lt, ltp, B, H):
     """U^T of the folded cross-attention output projection against an fp32 einsum.  A workgroup writes the runs of 8
     consecutive heads: H = 4 / 6 / 2 / 10 / 22 exercise partial last head groups (whose missing heads must come out as the
