@@ -409,7 +409,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // The pipelined form's ring has 4 stages (128 KiB: as deep as LDS allows) = 3 K-tiles of L2 latency in flight: a launch of
 // <= 256 workgroups lasts nt x (a per-K-tile time set by that depth) whatever its workgroup count (round 3, GPU call 8).
 // 3 -> 4 stages: c_wq at 1000 rows 36.9 -> 34.9 us, w2 83.4 -> 79.0; 4 clips per GPU 114.5 -> 119.8 s-audio/s, small* 8 clips
-// 424.0 -> 435.3 (profiles/r3_call9/).
+// 424.0 -> 435.3 (profiles/r3_call9/).  A 5-stage ring (160 KiB, all of the CU's LDS) measured slower again: c_wq 35.9 vs 34.9 us, w2
+// 80.5 vs 76.2, 4 clips 120.7 vs 121.5 (profiles/r3_call28/) - three K-tiles in flight already cover the latency.
 template <bool PIPE, bool CONV>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
