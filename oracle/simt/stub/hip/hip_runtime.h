@@ -185,6 +185,25 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   std::memcpy(&r, x + (size_t)from * 8, 4);
   return r;
 }
+// v_permlane16_swap_b32: the odd 16-lane rows of `vdst` swap with the even rows of `src` (lane l of an odd row <-> lane
+// l - 16); returns {new vdst, new src}.  Every lane of the wave takes part (as on the hardware: EXEC-masked lanes read
+// garbage there).
+struct simt_u32x2 {
+  unsigned v[2];
+  unsigned operator[](int i) const { return v[i]; }
+};
+inline simt_u32x2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src, bool fi, bool bound_ctrl) {
+  (void)fi; (void)bound_ctrl;
+  const unsigned both[2] = {vdst, src};
+  const unsigned char* x = simt::wave_publish(both, 8);
+  const int l = simt::cur->lane;
+  unsigned other[2];
+  std::memcpy(other, x + (size_t)(l ^ 16) * simt::XBYTES, 8);
+  simt_u32x2 r;
+  if ((l >> 4) & 1) { r.v[0] = other[1]; r.v[1] = src; }   // odd row: vdst <- the even partner's src
+  else { r.v[0] = vdst; r.v[1] = other[0]; }                // even row: src <- the odd partner's vdst
+  return r;
+}
 inline void __builtin_amdgcn_s_barrier() { simt::block_sync(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}

@@ -40,6 +40,19 @@ typedef __attribute__((ext_vector_type(8))) __bf16 h16x8_t;
 #define SA_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #endif
 
+// two fp32 values -> one packed word of the 16-bit operand format, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 /
+// v_cvt_f16_f32 x 2): the same bits as f2bf() for every finite value
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#ifdef SA_OPERAND_FP16
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2_t;
+#else
+typedef __attribute__((ext_vector_type(2))) __bf16 h16x2_t;
+#endif
+__device__ __forceinline__ unsigned pack_h16x2(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2_t));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }
@@ -171,7 +184,8 @@ struct GemmParams {
   int raster_gm;           // gemm2/gemm3 tile raster: M-tiles per group (0 = default 8)
   int flags;               // launch switches: bit 0 (set by launch_gemm2) accumulator-layout epilogue; bit 1 (set by the
                            // caller) never split the launch into whole rounds + tail (gemm.hip gemm_tail_split);
-                           // bits 2-3 / 4-5 (fp32 kernel only): round the A / W operand to bf16 (1) or fp16 (2) first
+                           // bits 2-3 / 4-5 (fp32 kernel only): round the A / W operand to bf16 (1) or fp16 (2) first;
+                           // bit 6 (set by the gemm8.hip launchers): linear epilogue (gemm8_linear_epilogue)
   int tag;                 // 1: DAC-VAE launch - same code under its own kernel symbol (rocprofv3 / roofline attribution)
 };
 

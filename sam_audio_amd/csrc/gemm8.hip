@@ -173,6 +173,121 @@ __device__ __forceinline__ void epilogue8(const GemmParams& p, f32x4_t (&acc)[NH
   }
 }
 
+// The LINEAR epilogue (p.flags bit 6, set by gemm8_linear_epilogue() on the host): what every Linear of the DiT needs -
+// bias, adaLN gate, alpha, residual, fp32 and / or 16-bit output, SwiGLU - and nothing else (no activation, no per-channel
+// period, no window mask, N a multiple of 64), straight from the accumulator layout.  Round 4, GPU call 1
+// (profiles/r4_call1/ksweep.log): one 256 x 256 tile of the general epilogue above costs 24 us (plain 16-bit output) to 32 us
+// (gated residual) on top of its K loop - as much as 22 - 30 K-tiles, a third of a K = 2816 launch - because the general
+// contract is evaluated per element: 64-bit divisions for the gate row, 64-bit multiplies per address, seven activation
+// branches, two LDS passes and two barriers per 64-row half.  Here a lane keeps the 4 consecutive columns the swapped MFMA
+// gives it (16 bytes of fp32: residual / gate loads and fp32 stores are 16-byte accesses as they stand), the 16-bit
+// output pairs two column blocks with v_permlane16_swap so that a lane stores 8 consecutive columns (16 bytes) - no LDS,
+// no barrier, ~25 VALU instructions per 16 x 16 fragment.  Row operands are requested two row blocks ahead of their use,
+// before the stores of the current block (vmcnt retires in order: a load issued behind a store waits for the store).
+// Same expression order as the general epilogue, contraction off: both give the same bits.
+template <int NH>
+__device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&acc)[NH * 4][4], const int b,
+                                                 const int m_wave0, const int n_wave0, const int lane) {
+#pragma clang fp contract(off)
+  constexpr int NI = NH * 4;
+  const int lr = lane & 15, lg = lane >> 4;
+  if (n_wave0 >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
+  const long bM = (long)b * p.M;
+  const int m_last = p.M - 1;
+  bf16_t* const act0 = p.out_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride : nullptr;
+  if (p.swiglu) {
+    // fragments (j, j | 1) = the w1 / w3 rows of 16 outputs: block jp = j >> 1 -> output columns (n_wave0 >> 1) + 16 jp
+    const int c_own = (n_wave0 >> 1) + lg * 4;                              // + 16 jp: the lane's own 4 outputs
+    const int c_st = (n_wave0 >> 1) + (lg & 1) * 16 + (lg >> 1) * 8;        // after the swap: 8 consecutive outputs
+    (void)c_own;
+#pragma unroll
+    for (int I = 0; I < NI; ++I) {
+      const int m = m_wave0 + I * 16 + lr;
+      unsigned lo[2], hi[2];
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const f32x4_t a = acc[I][2 * jp], g = acc[I][2 * jp + 1];
+        lo[jp] = pack_h16x2(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1]);
+        hi[jp] = pack_h16x2(silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
+      }
+      const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], lo[1], false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(hi[0], hi[1], false, false);
+      if (m <= m_last) *(uint4*)(act0 + (long)m * p.act_ld + c_st) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
+    return;
+  }
+  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
+             has_res = p.res != nullptr, has_f32 = p.out_f32 != nullptr, has_act = p.out_act != nullptr;
+  const int ncol = n_wave0 + lg * 4;   // + 16 j
+  // column-only operand: the bias, or the gate table (never both: gemm8_linear_epilogue)
+  float4 cc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    cc[j] = has_bias ? *(const float4*)(p.bias + ncol + 16 * j)
+                     : (has_tab ? *(const float4*)(p.gate_tab + ncol + 16 * j) : make_float4(0.f, 0.f, 0.f, 0.f));
+  const float* const res0 = has_res ? p.res + p.res_off + (long)b * p.res_bstride + ncol : nullptr;
+  float* const f320 = has_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + ncol : nullptr;
+  const float* const gate0 = has_gate ? p.gate + ncol : nullptr;
+  const unsigned rpg = (unsigned)p.rows_per_gate;
+  const int c_st = n_wave0 + (lg & 1) * 16 + (lg >> 1) * 8;   // + 32 jp: 8 consecutive columns after the swap
+  // one step = one row block I x one pair of column blocks jp; the row operands of step s + 2 are requested before the
+  // stores of step s
+  constexpr int NS = NI * 2;
+  float4 rr[2][2], gg[2][2];
+  auto request = [&](const int s_, float4 (&r)[2], float4 (&g)[2]) {
+    const int I = s_ >> 1, jp = s_ & 1;
+    int m = m_wave0 + I * 16 + lr;
+    m = m <= m_last ? m : m_last;   // rows past M: clamped loads, masked stores
+    if (has_res) {
+      const float* rrow = res0 + (long)m * p.res_ld + 32 * jp;
+      r[0] = *(const float4*)rrow;
+      r[1] = *(const float4*)(rrow + 16);
+    }
+    if (has_gate) {
+      const float* grow = gate0 + (long)((unsigned)(bM + m) / rpg) * p.gate_ld + 32 * jp;
+      g[0] = *(const float4*)grow;
+      g[1] = *(const float4*)(grow + 16);
+    }
+  };
+  request(0, rr[0], gg[0]);
+  request(1, rr[1], gg[1]);
+#pragma unroll
+  for (int s_ = 0; s_ < NS; ++s_) {
+    const int I = s_ >> 1, jp = s_ & 1;
+    const int m = m_wave0 + I * 16 + lr;
+    const bool m_ok = m <= m_last;
+    float v[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * jp + h;
+      const float4 r = rr[s_ & 1][h];
+      float4 g = gg[s_ & 1][h];
+      v[h][0] = acc[I][j][0]; v[h][1] = acc[I][j][1]; v[h][2] = acc[I][j][2]; v[h][3] = acc[I][j][3];
+      if (has_bias) { v[h][0] += cc[j].x; v[h][1] += cc[j].y; v[h][2] += cc[j].z; v[h][3] += cc[j].w; }
+      if (has_gate) {
+        if (has_tab) { g.x += cc[j].x; g.y += cc[j].y; g.z += cc[j].z; g.w += cc[j].w; }
+        v[h][0] *= g.x; v[h][1] *= g.y; v[h][2] *= g.z; v[h][3] *= g.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[h][e] *= p.alpha;
+      if (has_res) { v[h][0] += r.x; v[h][1] += r.y; v[h][2] += r.z; v[h][3] += r.w; }
+    }
+    if (s_ + 2 < NS) request(s_ + 2, rr[s_ & 1], gg[s_ & 1]);   // ahead of this step's stores
+    if (has_f32 && m_ok) {
+      float* frow = f320 + (long)m * p.f32_ld + 32 * jp;
+      *(float4*)frow = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+      *(float4*)(frow + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+    }
+    if (has_act) {
+      const unsigned lo0 = pack_h16x2(v[0][0], v[0][1]), hi0 = pack_h16x2(v[0][2], v[0][3]);
+      const unsigned lo1 = pack_h16x2(v[1][0], v[1][1]), hi1 = pack_h16x2(v[1][2], v[1][3]);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
+      if (m_ok) *(uint4*)(act0 + (long)m * p.act_ld + c_st + 32 * jp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    }
+  }
+}
+
 // workgroup -> tile: contiguous run of tiles per XCD, GM M-tiles x all N-tiles per group (as gemm2.hip).
 // `L` = position in the linear raster order; tile_of() maps it to (batch, M-tile, N-tile).
 __device__ __forceinline__ void tile_of(const GemmParams& p, const int BM, const int BN, const int L, int& b, int& tm, int& tn) {
@@ -388,6 +503,209 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 #undef SA_GEMM8_READ_W
 
   // ---- epilogue (contract of GemmParams, common.h): shared with gemm8s_kernel below ----------------------------
+  if (p.flags & 64) {   // the linear epilogue needs no LDS: no barrier either
+    epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
+    return;
+  }
+  __syncthreads();
+  epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+// gemm8d: gemm8_kernel's tile, MFMA order and epilogue (bitwise the same results) with a DEEPER staging pipeline.
+// gemm8_kernel stages HA(t+1) in P1 / P2 of K-tile t and waits for it in P4: a half-tile has as little as two phases
+// (~1 200 cycles) to arrive, which an L2 hit makes and a miss to the Infinity Cache / HBM under a chip-wide GEMM does not.
+// Here the four half-tiles of a K-tile are composed so that EVERY wave consumes them in the same order:
+//   HA_s = rows  (r >> 6) * 128 + s * 64 + (r & 63)   of the tile  (s = 0, 1: the s-th 64-row half of BOTH wave rows)
+//   HB_s = cols  (r >> 5) * 64  + s * 32 + (r & 31)                (the s-th 32-column half of ALL FOUR wave columns)
+// (a row permutation of the DMA's per-lane source rows: free).  Phase reads:  P1 HB0 + HA0 | P2 HB1 | P3 HA1 | P4 -,
+// so a slot is free right after that phase and is restaged with the data of TWO K-tiles ahead:
+//   P1(t): HA1(t+1)   P2(t): HA0(t+2)   P3(t): HB0(t+2)   P4(t): HB1(t+2)        (issue order HA0 HB0 HB1 HA1 per K-tile =
+// the order of consumption).  Every half-tile has >= 6 phases to arrive; the counted waits leave FIVE half-tiles (10 DMA
+// instructions per wave, 80 KiB per CU) in flight:  P4(t) retires HA0 / HB0(t+1), P1(t) HB1(t), P2(t) HA1(t) - each read
+// one phase after the wait (the lagging group's waves wait one barrier before the leading group's read).  HA0 is restaged in
+// the phase after its last read, so P1 retires its LDS reads BEFORE its first barrier (as gemm8_kernel's P2 does for HB).
+template <bool CONV>
+__global__ __launch_bounds__(512) void gemm8d_kernel(const GemmParams p, const int tile_count) {
+  constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  int b, tm, tn;
+  if (tile_count > 0) tile_of(p, BM, BN, xcd_run_pos(tile_count), b, tm, tn);
+  else tile_raster8(p, BM, BN, b, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging: wave w moves half-tile rows 16w .. 16w+15 as two instructions of 8 rows --------------------------
+  const int r8 = lane >> 3;
+  const bf16_t* a_row[2][2];  // [s][q]; plain GEMMs: incl. the lane's chunk
+  const bf16_t* w_row[2][2];
+  int chunk[2];
+  {
+    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = wave * 16 + q * 8 + r8;
+      chunk[q] = (lane & 7) ^ ((row >> 1) & 7);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        int m = m0 + (row >> 6) * 128 + s * 64 + (row & 63);
+        m = m < p.M ? m : p.M - 1;
+        a_row[s][q] = A + (long)m * p.lda + (CONV ? 0 : chunk[q] * 8);
+        int n = n0 + (row >> 5) * 64 + s * 32 + (row & 31);
+        n = n < p.N ? n : p.N - 1;
+        w_row[s][q] = W + (long)n * p.K + chunk[q] * 8;
+      }
+    }
+  }
+  // CONV: position of the lane's chunk in the (tap, offset) structure of A's k axis, per half-tile stream s (HA0 and HA1
+  // of one K-tile are staged three phases apart) and q; advances by one K-tile per stage_a(s, ..)
+  int a_in[2][2];
+  long a_tap[2][2];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        a_in[s][q] = chunk[q] * 8;
+        a_tap[s][q] = 0;
+        while (a_in[s][q] >= p.kc) { a_in[s][q] -= p.kc; a_tap[s][q] += p.tap_stride; }
+      }
+  }
+  const int nt = p.K / BK;
+  auto stage_a = [&](int s, int buf, int kt) {  // HA_s of K-tile kt (CONV: the K-tile stream s points at)
+    char* dst = smem + buf * (4 * HT) + s * HT + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if constexpr (CONV) {
+        dma16_8(a_row[s][q] + a_tap[s][q] + a_in[s][q], dst + q * 1024);
+        a_in[s][q] += BK;
+        while (a_in[s][q] >= p.kc) { a_in[s][q] -= p.kc; a_tap[s][q] += p.tap_stride; }
+      } else {
+        dma16_8(a_row[s][q] + (long)kt * BK, dst + q * 1024);
+      }
+    }
+  };
+  auto stage_w = [&](int s, int buf, int kt) {
+    char* dst = smem + buf * (4 * HT) + (2 + s) * HT + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16_8(w_row[s][q] + (long)kt * BK, dst + q * 1024);
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4][2];
+  bf16x8_t wf[2][2][2];
+
+  auto frag = [&](const char* half_base, int row, int ks) -> bf16x8_t {
+    return *(const bf16x8_t*)(half_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
+  };
+  auto read_a = [&](int buf, int sub) {  // the wave's rows of HA_sub
+    const char* base = smem + buf * (4 * HT) + sub * HT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = frag(base, wr * 64 + i * 16 + lr, ks);
+  };
+#define SA_GEMM8_READ_W(BUF, SUB)                                                                                 \
+  do {                                                                                                            \
+    const char* base_ = smem + (BUF) * (4 * HT) + (2 + (SUB)) * HT;                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+        wf[SUB][j][ks] = frag(base_, wc * 32 + j * 16 + lr, ks);                                                  \
+  } while (0)
+#define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
+  do {                                                                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
+          acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = SA_MFMA_16x16x32(                                                 \
+              wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+  } while (0)
+
+  // ---- prologue: K-tile 0 and HA0 / HB0 / HB1 of K-tile 1, in the canonical order ----------------------------------
+  stage_a(0, 0, 0);
+  stage_w(0, 0, 0);
+  stage_w(1, 0, 0);
+  stage_a(1, 0, 0);
+  if (nt > 1) {
+    stage_a(0, 1, 1);
+    stage_w(0, 1, 1);
+    stage_w(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HA0 / HB0 of K-tile 0 have landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+  for (int t = 0; t < nt; ++t) {
+    const int cb = t & 1, nb = cb ^ 1;
+    const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
+    // P1: reads HB0, HA0 (their last reads: retired before the barrier, HA0 is restaged in P2)
+    SA_GEMM8_READ_W(cb, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(cb, 0);
+    if (s1) {
+      stage_a(1, nb, t + 1);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HB1(t) has landed (read in P2)
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    SA_GEMM8_MMA(0, 0);
+    __builtin_amdgcn_s_barrier();
+    // P2: reads HB1
+    SA_GEMM8_READ_W(cb, 1);
+    if (s2) {
+      stage_a(0, cb, t + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HA1(t) has landed (read in P3)
+    } else if (s1) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SA_GEMM8_MMA(0, 1);
+    __builtin_amdgcn_s_barrier();
+    // P3: reads HA1
+    read_a(cb, 1);
+    if (s2) stage_w(0, cb, t + 2);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SA_GEMM8_MMA(1, 1);
+    __builtin_amdgcn_s_barrier();
+    // P4: no reads
+    if (s2) {
+      stage_w(1, cb, t + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HA0 / HB0 of K-tile t+1 have landed (read in its P1)
+    } else if (s1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    SA_GEMM8_MMA(1, 0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef SA_GEMM8_MMA
+#undef SA_GEMM8_READ_W
+
+  if (p.flags & 64) {   // the linear epilogue needs no LDS: no barrier either
+    epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
+    return;
+  }
   __syncthreads();
   epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
 }
@@ -548,6 +866,10 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     } else {
       step(t, I0{}, std::false_type{});
     }
+    if (p.flags & 64) {
+      epilogue8_linear<1>(p, acc, b, m0 + wr * 64, n0 + wc * 64, lane);
+      return;
+    }
     __syncthreads();
     epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
     return;
@@ -582,8 +904,34 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
         for (int i = 0; i < 4; ++i)
           acc[i][j] = SA_MFMA_16x16x32(wf[j][ks], af[i][ks], acc[i][j]);
   }
+  if (p.flags & 64) {
+    epilogue8_linear<1>(p, acc, b, m0 + wr * 64, n0 + wc * 64, lane);
+    return;
+  }
   __syncthreads();
   epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
+}
+
+// The launches whose epilogue is "linear" (epilogue8_linear): every Linear of the DiT / the towers.  Debug flag 24 = 1:
+// never (the general epilogue for everything - the bitwise-equality tests of the linear one).
+static bool gemm8_linear_epilogue(const GemmParams& p) {
+  if (debug_flag(24)) return false;
+  if (p.act != ACT_NONE || p.chan_mod || p.c_ld_rel || (p.flags & 1) || p.N % 64) return false;
+  if (!p.out_act && !p.out_f32) return false;
+  if (p.swiglu && (!p.out_act || p.out_f32 || p.bias || p.gate || p.res)) return false;
+  if (p.bias && (p.gate || p.gate_tab)) return false;
+  if (p.gate_tab && !p.gate) return false;
+  auto al = [](long v, long a) { return v % a == 0; };
+  if (p.out_act && !(al(p.act_ld, 8) && al(p.act_off, 8) && al(p.act_bstride, 8) && ((uintptr_t)p.out_act & 15) == 0))
+    return false;
+  if (p.gate && (p.rows_per_gate <= 0 || (long)p.M * p.nbatch >= (1L << 31))) return false;
+  return true;   // 16-byte alignment of the fp32 operands: gemm2_ok(), checked by the policy for every launch of this file
+}
+static GemmParams with_epilogue_choice(const GemmParams& p) {
+  GemmParams q = p;
+  if (gemm8_linear_epilogue(p)) q.flags |= 64;
+  else q.flags &= ~64;
+  return q;
 }
 
 // eligibility: the vectorised-epilogue conditions of gemm2_ok() (checked by the caller) - any M, N, K % 64 == 0
@@ -591,7 +939,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 // identical - ran exactly as fast: c_wq 36.0 vs 35.3 us, 4 clips 114.8 vs 115.1 s-audio/s, small* 423 vs 424.  With few
 // rows a launch lasts nt x ~0.8 us whatever its workgroup count: it is bound by the depth of the K-tile prefetch (two K-tiles
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
-hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
+hipError_t launch_gemm8s(const GemmParams& p_in, hipStream_t st) {
+  const GemmParams p = with_epilogue_choice(p_in);
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
   const bool pipe = tiles <= 256 && !debug_flag(21), conv = p.kc < p.K;
@@ -603,11 +952,21 @@ hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_gemm8(const GemmParams& p, hipStream_t st) {
+// flag 23 (A/B): 1 = the deep-pipeline form (gemm8d_kernel), 0 = gemm8_kernel; bitwise the same results
+static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, hipStream_t st) {
+  const bool conv = p.kc < p.K, deep = debug_flag(23) != 0;
+  const dim3 block(512);
+  if (deep && conv) hipLaunchKernelGGL((gemm8d_kernel<true>), grid, block, 0, st, p, tile_count);
+  else if (deep) hipLaunchKernelGGL((gemm8d_kernel<false>), grid, block, 0, st, p, tile_count);
+  else if (conv) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
+  else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
+}
+
+hipError_t launch_gemm8(const GemmParams& p_in, hipStream_t st) {
+  const GemmParams p = with_epilogue_choice(p_in);
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   const dim3 grid((unsigned)tiles), block(512);
-  if (p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, 0);
-  else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, 0);
+  launch_gemm8_tiles(p, grid, 0, st);
   return hipGetLastError();
 }
 
@@ -615,11 +974,11 @@ hipError_t launch_gemm8(const GemmParams& p, hipStream_t st) {
 // partial round of a launch leaves CUs idle for a full tile time (352 tiles at N = D: 2 rounds for 1.375 rounds of
 // work).  part 0 = the 8-phase kernel on the first `full` tiles of the raster order, part 1 = the remaining tiles as
 // 128x128 quadrants on gemm8s_kernel (two workgroups per CU, 4x finer granularity).  Bitwise the same results.
-hipError_t launch_gemm8_split(const GemmParams& p, int full, int part, hipStream_t st) {
+hipError_t launch_gemm8_split(const GemmParams& p_in, int full, int part, hipStream_t st) {
+  const GemmParams p = with_epilogue_choice(p_in);
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   if (full <= 0 || full >= tiles) return hipErrorInvalidValue;
-  if (part == 0 && p.kc < p.K) hipLaunchKernelGGL((gemm8_kernel<true>), dim3((unsigned)full), dim3(512), 0, st, p, full);
-  else if (part == 0) hipLaunchKernelGGL((gemm8_kernel<false>), dim3((unsigned)full), dim3(512), 0, st, p, full);
+  if (part == 0) launch_gemm8_tiles(p, dim3((unsigned)full), full, st);
   else {
     const bool pipe = (tiles - full) * 4 <= 256 && !debug_flag(21);   // a tail that cannot give a CU two workgroups
     const bool conv = p.kc < p.K;

@@ -378,3 +378,59 @@ def test_fused_residual_unit_is_bitwise_the_two_launches(gpu, C, dil, T, items):
     # the output activation must not alias the input (neighbouring tiles read input halo rows): rejected, not raced
     p7, p1 = params(torch.zeros_like(xin), raw0.to(gpu), xin)
     assert hip.lib().samaudio_op_resunit(CT.byref(p7), CT.byref(p1), CT.sizeof(p7), util.stream()) == hip.ERR_ARG
+
+
+@pytest.mark.parametrize("variant", [22, 27])
+@pytest.mark.parametrize("kind", ["act", "f32", "gated_dual", "gated_f32", "swiglu", "bias_res_batched", "alpha_res"])
+def test_linear_epilogue_is_bitwise_the_general_one(gpu, variant, kind):
+    """gemm8.hip epilogue8_linear (the DiT's Linears: bias | gate + table, alpha, residual, fp32 / 16-bit outputs, SwiGLU,
+    straight from the accumulator layout) against the general LDS-staged epilogue (debug flag 24) on the same launch:
+    identical bits; ragged M (masked rows inside a tile), N with waves wholly outside the problem, batch strides."""
+    M, N, K, nb = 333, 448, 192, 1
+    kw = {}
+    g = lambda *shape, seed: _mk(shape, seed).to(gpu)   # noqa: E731
+    if kind == "bias_res_batched":
+        M, N, K, nb = 250, 320, 128, 3
+    A, W = _mk((nb, M, K), 61), _mk((N, K), 62, 1 / math.sqrt(K))
+    n_out = N // 2 if kind == "swiglu" else N
+    outs = {}
+    keep = dict(A=util.as_act(A, "bf16", gpu), W=util.as_act(W, "bf16", gpu), tab=g(N, seed=63), gate=g(4, N, seed=64),
+                res=g(nb, M, N, seed=65), bias=g(N, seed=66))
+    try:
+        for flag in (0, 1):
+            hip.lib().samaudio_debug_force_gemm_variant(variant)
+            hip.lib().samaudio_debug_set_flag(24, flag)
+            o32 = torch.full((nb, M, N), float("nan"), device=gpu)
+            o16 = torch.zeros(nb, M, n_out, device=gpu, dtype=torch.bfloat16)
+            if kind == "act":
+                kw = dict(out_act=o16, act_geom=(M * N, N, 0))
+            elif kind == "f32":
+                kw = dict(out_f32=o32, f32_geom=(M * N, N, 0))
+            elif kind in ("gated_dual", "gated_f32"):
+                kw = dict(gate_tab=keep["tab"], gate=keep["gate"], gate_ld=N, rows_per_gate=100, res=keep["res"],
+                          res_geom=(M * N, N, 0), out_f32=o32, f32_geom=(M * N, N, 0))
+                if kind == "gated_dual":
+                    kw.update(out_act=o16, act_geom=(M * N, N, 0))
+            elif kind == "swiglu":
+                kw = dict(swiglu=1, out_act=o16, act_geom=(M * n_out, n_out, 0))
+            elif kind == "bias_res_batched":
+                kw = dict(bias=keep["bias"], res=keep["res"], res_geom=(M * N, N, 0), out_f32=o32, f32_geom=(M * N, N, 0),
+                          out_act=o16, act_geom=(M * N, N, 0), nbatch=nb, a_bstride=M * K)
+            else:
+                kw = dict(alpha=0.37, res=keep["res"], res_geom=(M * N, N, 0), out_f32=o32, f32_geom=(M * N, N, 0))
+            util.gemm("bf16", keep["A"], keep["W"], M, N, K, **kw)
+            outs[flag] = (o32.cpu(), o16.cpu())
+    finally:
+        hip.lib().samaudio_debug_set_flag(24, 0)
+        hip.lib().samaudio_debug_force_gemm_variant(-1)
+    uses32, uses16 = "out_f32" in kw, "out_act" in kw
+    if uses32:
+        assert torch.isfinite(outs[0][0][: (nb if kind == "bias_res_batched" else 1)]).all()
+        assert torch.equal(outs[0][0][:nb if kind == "bias_res_batched" else 1], outs[1][0][:nb if kind == "bias_res_batched" else 1])
+    if uses16:
+        assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+        assert outs[0][1].float().abs().sum() > 0
+    # and against the fp32 reference of the simplest forms
+    if kind == "f32":
+        want = util.rounded(A[0], "bf16") @ util.rounded(W, "bf16").T
+        util.report(f"linear epilogue v{variant} f32", outs[0][0][0], want, 5e-4)

@@ -24,6 +24,8 @@ RASTER = [0]
 BLAS = [False]
 # the kernels the tile policy picks from for a DiT-class GEMM (gemm.hip gemm_variant numbering)
 VARIANTS = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128"}
+# A/B of a debug flag on the forced 8-phase kernel: --ab FLAG adds a column "8-phase, flag FLAG = 1"
+AB_FLAG = [None]
 
 
 def interleave16(w1, w3):
@@ -66,8 +68,13 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
             outs = [("f32", out, ref, 2e-3), ("act", out_act, ref, 1e-1)]
     kw["raster_gm"] = RASTER[0]
     line = f"{name:>22s} M={M} N={N} K={K} {kind:7s} gm={RASTER[0]}"
-    for v, vname in VARIANTS.items():
+    cols = [(v, vname, None) for v, vname in VARIANTS.items()]
+    if AB_FLAG[0] is not None:
+        cols += [(22, f"8-phase flag {AB_FLAG[0]}=1", AB_FLAG[0]), (-1, f"auto flag {AB_FLAG[0]}=1", AB_FLAG[0])]
+    for v, vname, flag in cols:
         hip.lib().samaudio_debug_force_gemm_variant(v)
+        if flag is not None:
+            hip.lib().samaudio_debug_set_flag(flag, 1)
         for _, o, _, _ in outs:
             o.fill_(float("nan"))
         util.gemm("bf16", A, W, M, N, K, **kw)
@@ -86,6 +93,8 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
         line += f" | {vname}: {us:8.1f} us {flops / us / 1e6:7.1f} TF {'ok' if ok else 'WRONG'} ({', '.join(errs)})"
+        if flag is not None:
+            hip.lib().samaudio_debug_set_flag(flag, 0)
     hip.lib().samaudio_debug_force_gemm_variant(-1)
     if BLAS[0]:   # yardstick: hipBLASLt through torch.matmul on the same operands (plain product, 16-bit output, no epilogue)
         for _ in range(2):
@@ -109,10 +118,12 @@ def main():
     ap.add_argument("--quick", action="store_true", help="only the small correctness shapes")
     ap.add_argument("--no-blas", action="store_true", help="skip the hipBLASLt (torch.matmul) column")
     ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size of the 8-phase kernel")
+    ap.add_argument("--ab", type=int, default=None, help="debug flag to A/B on the forced 8-phase kernel and the policy")
     ap.add_argument("--vit", action="store_true", help="the PE-Core-L14-336 tower's GEMM shapes (250 frames x 577 tokens)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     BLAS[0] = not args.no_blas
+    AB_FLAG[0] = args.ab
     if args.vit:
         Mv = 250 * 577
         run_case("vit qkv (bias)", Mv, 3072, 1024, "plain", dev, 5)
