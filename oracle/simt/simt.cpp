@@ -174,7 +174,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
       const unsigned bx = (unsigned)(blk_id % grid.x), by = (unsigned)((blk_id / grid.x) % grid.y),
                      bz = (unsigned)(blk_id / ((long)grid.x * grid.y));
 #ifdef SIMT_POISON
-      std::memset(__start_simt_lds, 0xFF, (size_t)(__stop_simt_lds - __start_simt_lds));
+      // SAMAUDIO_SIMT_POISON_BYTE: the fill byte (default 0xFF = NaN; a finite pattern such as 0x3F shows reads of unwritten
+      // LDS that NaN-ignoring operations - fmaxf, selects - hide)
+      static const int fill = [] { const char* e = std::getenv("SAMAUDIO_SIMT_POISON_BYTE"); return e ? (int)std::strtol(e, nullptr, 0) : 0xFF; }();
+      std::memset(__start_simt_lds, fill, (size_t)(__stop_simt_lds - __start_simt_lds));
 #endif
       Block blk;
       blk.live = nthreads;

@@ -32,6 +32,7 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
 inline hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
@@ -139,6 +140,7 @@ struct ushort4 { unsigned short x, y, z, w; };
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 // ---------------------------------------------------------------------------------------------------- device math
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }

@@ -99,6 +99,7 @@ class Engine {
   template <class F>
   Status op(const char* name, double alg_bytes, double alg_flops, hipStream_t st, F&& launch);
   Status res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, double flops7, double flops1, hipStream_t st);
+  void* hash_ = nullptr;   // SAMAUDIO_TRACE_HASH recorder (engine.hip HashTrace; debugging aid)
   bool prof_on_ = false;
   std::vector<ProfRec> prof_;
   std::vector<hipEvent_t> ev_pool_;

@@ -29,7 +29,65 @@ static bool trace_on() {
   static const bool on = std::getenv("SAMAUDIO_TRACE") != nullptr;
   return on;
 }
+// SAMAUDIO_TRACE_HASH=1: the same stages, WITHOUT synchronising: a checksum kernel per stage writes one 64-bit word per batch
+// item into a debug buffer on the launch stream; ode_solve / forward print them afterwards ("[samaudio hash] <context>
+// <sequence> <stage> item <b> <hex>").  Two runs whose rows must agree (one stream vs two streams, whole batch vs shards)
+// are compared stage by stage offline (tools/diag_hash.py): the first stage whose checksums differ names the kernel.
+// Debugging aid; the only place the library allocates device memory (hipMalloc of 8 MiB, on first use).
+__global__ __launch_bounds__(256) void hash_items_kernel(const unsigned* x, size_t words, unsigned long long* out) {
+  const unsigned* src = x + (size_t)blockIdx.x * words;
+  unsigned long long h = 0;
+  for (size_t i = threadIdx.x; i < words; i += 256) h += (unsigned long long)(src[i] ^ (unsigned)(i * 0x9E3779B1u)) * (2 * i + 1);
+  __shared__ unsigned long long part[256];
+  part[threadIdx.x] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+struct HashTrace {
+  struct Rec { std::string name; int items; size_t slot; };
+  unsigned long long* dev = nullptr;
+  size_t used = 0, seq = 0;
+  std::vector<Rec> recs;
+  static constexpr size_t CAP = 1 << 20;
+};
+static bool hash_on() {
+  static const bool on = std::getenv("SAMAUDIO_TRACE_HASH") != nullptr;
+  return on;
+}
+static thread_local HashTrace* g_hash = nullptr;   // the running context's recorder (set by eval_field)
+static thread_local int g_hash_items = 1;
+static void hash_stage(const char* name, const void* dev, size_t bytes, hipStream_t st) {
+  HashTrace* h = g_hash;
+  if (!h || !dev || bytes < 4) return;
+  if (!h->dev && hipMalloc(&h->dev, HashTrace::CAP * 8) != hipSuccess) return;
+  int items = g_hash_items;
+  if (items <= 0 || (bytes / 4) % (size_t)items) items = 1;
+  if (h->used + items > HashTrace::CAP) return;
+  hipLaunchKernelGGL(hash_items_kernel, dim3(items), dim3(256), 0, st, (const unsigned*)dev, bytes / 4 / items, h->dev + h->used);
+  h->recs.push_back({name, items, h->used});
+  h->used += items;
+}
+static void hash_flush(HashTrace* h, const void* ctx, hipStream_t st) {
+  if (!h || !h->dev || h->recs.empty()) return;
+  (void)hipStreamSynchronize(st);
+  std::vector<unsigned long long> host(h->used);
+  if (hipMemcpy(host.data(), h->dev, h->used * 8, hipMemcpyDeviceToHost) == hipSuccess)
+    for (const auto& r : h->recs) {
+      for (int b = 0; b < r.items; ++b)
+        std::fprintf(stderr, "[samaudio hash] %p %zu %s item %d of %d %016llx\n", ctx, h->seq, r.name.c_str(), b, r.items,
+                     host[r.slot + b]);
+      ++h->seq;
+    }
+  h->recs.clear();
+  h->used = 0;
+}
+
 static void trace(const char* name, const void* dev, size_t count, bool is_bf16, hipStream_t st) {
+  if (hash_on()) hash_stage(name, dev, count * (is_bf16 ? 2 : 4), st);
   if (!trace_on() || !dev || !count) return;
   (void)hipStreamSynchronize(st);
   std::vector<unsigned char> host(count * (is_bf16 ? 2 : 4));
@@ -640,6 +698,12 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   const long t6 = nt == 1 ? 0 : 6L * D, t1 = nt == 1 ? 0 : (long)D;
   prof_cls_ = "dit";
   const double MD = (double)M * D;
+  if (hash_on()) {
+    if (!hash_) hash_ = new HashTrace();
+    g_hash = (HashTrace*)hash_;
+    g_hash_items = rows;
+    hash_stage("noisy", noisy, (size_t)M * C2 * 4, st);
+  }
 
   // aligned = noisy @ Wy^T + cond                                   (model.py:116-125, columns 0..255)
   {
@@ -783,6 +847,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
     }
     trace("  h after wo", d_.h, (size_t)M * D, false, st);
+    trace("  hbf", d_.hbf, (size_t)M * D, bf16_, st);
     // cross-attention branch: h = h + CA(h, y)   (no norm, no gate: quirk Q4)
     {
       GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
@@ -807,6 +872,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.res_bstride = (long)T * D;
       out_f32(p, d_.h, D);
       p.f32_bstride = (long)T * D;
+      trace("  probs", d_.probs, (size_t)M * fold_kp_, bf16_, st);
+      trace("  ut", d_.ut, (size_t)rows * D * fold_kp_, bf16_, st);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
       SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
@@ -829,11 +896,14 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.swiglu = 1;
       out_act(p, d_.u, F);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
+      trace("  xn (ffn)", d_.xn, (size_t)M * D, bf16_, st);
+      trace("  u", d_.u, (size_t)M * F, bf16_, st);
       p = lin(d_.u, F, w.w2, M, D, F);  // out = h + gate_mlp * ff
       p.gate_tab = tab + 5 * D; p.gate = d_.t0 + 5 * D; p.gate_ld = t6; p.rows_per_gate = T;
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W2));
+      trace("  h after ffn", d_.h, (size_t)M * D, false, st);
     }
   }
   trace("h after layers", d_.h, (size_t)M * D, false, st);
@@ -849,12 +919,18 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     out_f32(p, out, C2);
     SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_OUT, f));
   }
+  if (hash_on()) {
+    hash_stage("field out", out, (size_t)M * C2 * 4, st);
+    g_hash = nullptr;
+  }
   return Status{};
 }
 
 Status Engine::forward(const float* noisy, const float* time, int n_time, float* out, hipStream_t st) {
   if (!noisy || !time || !out) return fail(SAMAUDIO_ERR_ARG, "forward: null pointer");
-  return eval_field(noisy, time, n_time, out, nullptr, 1.f, st);
+  const Status s = eval_field(noisy, time, n_time, out, nullptr, 1.f, st);
+  if (hash_on()) hash_flush((HashTrace*)hash_, this, st);
+  return s;
 }
 
 Status Engine::ode_solve(float* y, int method, const float* grid, int n_grid, hipStream_t st) {
@@ -879,6 +955,7 @@ Status Engine::ode_solve(float* y, int method, const float* grid, int n_grid, hi
       SA_TRY(eval_field(d_.ymid, d_.times + 2 * k + 1, 1, y, y, dt, st));
     }
   }
+  if (hash_on()) hash_flush((HashTrace*)hash_, this, st);
   return Status{};
 }
 

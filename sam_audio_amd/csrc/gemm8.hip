@@ -268,8 +268,6 @@ __device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&
         if (has_tab) { g.x += cc[j].x; g.y += cc[j].y; g.z += cc[j].z; g.w += cc[j].w; }
         v[h][0] *= g.x; v[h][1] *= g.y; v[h][2] *= g.z; v[h][3] *= g.w;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[h][e] *= p.alpha;
       if (has_res) { v[h][0] += r.x; v[h][1] += r.y; v[h][2] += r.z; v[h][3] += r.w; }
     }
     if (s_ + 2 < NS) request(s_ + 2, rr[s_ & 1], gg[s_ & 1]);   // ahead of this step's stores
@@ -285,6 +283,88 @@ __device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&
       const auto s1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
       if (m_ok) *(uint4*)(act0 + (long)m * p.act_ld + c_st + 32 * jp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
     }
+  }
+}
+
+// The same contract as epilogue8_linear for launches WITH an fp32 output / residual (the adaLN-gated residual updates of
+// the DiT: wo, w2, the folded cross-attention projection, the patcher): those move 10 bytes per element and are bound by
+// memory transactions, and the accumulator layout gives a wave instruction 16 rows x 64 bytes - sixteen half lines (round 4,
+// GPU call 2: 5 us per tile slower than the general epilogue).  So the tile goes through the wave's private LDS area as in
+// the general epilogue - a lane then owns 4 consecutive columns and 16 lanes cover a row's 256 contiguous bytes - but with
+// the lean arithmetic of the linear contract: no activation chain, 32-bit gate-row division, row pointers advanced by
+// addition, operands of row block it + 4 requested ahead of the stores of block it.
+template <int NH>
+__device__ __forceinline__ void epilogue8_rows(const GemmParams& p, f32x4_t (&acc)[NH * 4][4], char* const stg, const int b,
+                                               const int m_wave0, const int n_wave0, const int lane) {
+#pragma clang fp contract(off)
+  const int lr = lane & 15, lg = lane >> 4;
+  const long bM = (long)b * p.M;
+  const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
+             has_res = p.res != nullptr, has_f32 = p.out_f32 != nullptr, has_act = p.out_act != nullptr;
+  const int rsub = lane >> 4, csub = lane & 15;   // read phase: 4 rows x 16 chunks of 4 columns per wave instruction
+  const int n = n_wave0 + csub * 4;
+  const bool n_ok = n_wave0 < p.N;                // N % 64 == 0
+  float4 cc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n_ok && has_bias) cc = *(const float4*)(p.bias + n);
+  if (n_ok && has_tab) cc = *(const float4*)(p.gate_tab + n);
+  const int m_last = p.M - 1;
+  const unsigned rpg = (unsigned)p.rows_per_gate;
+  const float* const res0 = has_res ? p.res + p.res_off + (long)b * p.res_bstride + n : nullptr;
+  float* const f320 = has_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + n : nullptr;
+  bf16_t* const act0 = has_act ? (bf16_t*)p.out_act + p.act_off + (long)b * p.act_bstride + n : nullptr;
+  const float* const gate0 = has_gate ? p.gate + n : nullptr;
+#pragma unroll
+  for (int half = 0; half < NH; ++half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t a = acc[half * 4 + i][j];
+        *(float4*)(stg + row * 256 + (((j * 4 + lg) ^ (row & 15)) << 4)) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging area is private to the wave: no barrier
+    float4 r0, r1, r2, r3, g0, g1, g2, g3;
+    auto request = [&](const int it, float4& rr, float4& gg) {
+      int m = m_wave0 + half * 64 + it * 4 + rsub;
+      m = m <= m_last ? m : m_last;
+      if (has_res) rr = *(const float4*)(res0 + (long)m * p.res_ld);
+      if (has_gate) gg = *(const float4*)(gate0 + (long)((unsigned)(bM + m) / rpg) * p.gate_ld);
+    };
+    auto body = [&](const int it, float4& rslot, float4& gslot) {
+      const float4 rr = rslot;
+      float4 gg = gslot;
+      if (it + 4 < 16) request(it + 4, rslot, gslot);
+      const int row = it * 4 + rsub;
+      const float4 sv = *(const float4*)(stg + row * 256 + ((csub ^ (row & 15)) << 4));
+      const int m = m_wave0 + half * 64 + row;
+      float v0 = sv.x, v1 = sv.y, v2 = sv.z, v3 = sv.w;
+      if (has_bias) { v0 += cc.x; v1 += cc.y; v2 += cc.z; v3 += cc.w; }
+      if (has_gate) {
+        if (has_tab) { gg.x += cc.x; gg.y += cc.y; gg.z += cc.z; gg.w += cc.w; }
+        v0 *= gg.x; v1 *= gg.y; v2 *= gg.z; v3 *= gg.w;
+      }
+      if (has_res) { v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w; }
+      if (m <= m_last) {
+        if (has_f32) *(float4*)(f320 + (long)m * p.f32_ld) = make_float4(v0, v1, v2, v3);
+        if (has_act) *(uint2*)(act0 + (long)m * p.act_ld) = make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
+      }
+    };
+    if (n_ok) {
+      request(0, r0, g0);
+      request(1, r1, g1);
+      request(2, r2, g2);
+      request(3, r3, g3);
+#pragma unroll
+      for (int it = 0; it < 16; it += 4) {
+        body(it, r0, g0);
+        body(it + 1, r1, g1);
+        body(it + 2, r2, g2);
+        body(it + 3, r3, g3);
+      }
+    }
+    if (half + 1 < NH) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this half's reads precede the next half's writes
   }
 }
 
@@ -330,9 +410,14 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 // ds_reads, and merging the four phases into two super-phases (32-MFMA clusters, 4 barriers per K-tile instead of 8), both
 // measured within +-1 % of this loop on every shape (profiles/r3_call10/): neither the barrier count nor the order inside
 // a read section is what bounds it.)
-template <bool CONV>
+// ABL (only instantiated with -DSAMAUDIO_GEMM8_ABL, tools/build_abl.sh; timing experiments, wrong results): 1 = no DMA inside the K
+// loop, 2 = no LDS fragment reads inside the K loop, 3 = no MFMA, 4 = no barriers, 5 = no s_setprio, 9 = correct results +
+// s_memtime stamps of (entry, prologue done, K loop done, epilogue done) written per tile to p.act_alpha
+template <bool CONV, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
-  constexpr bool STAGGER = true, PRIO = true;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if constexpr (ABL == 9) ts0 = __builtin_readcyclecounter();
+  constexpr bool STAGGER = true, PRIO = ABL != 5;
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;  // HT: bytes of one half-tile
   __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
 
@@ -436,6 +521,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   // registers (a run-time quadrant index sends the whole accumulator to scratch).
 #define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
   do {                                                                                                            \
+    if constexpr (ABL == 3) {                                                                                     \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(wf[WSUB][j][ks]));                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(af[i][ks]));                          \
+      }                                                                                                           \
+      break;                                                                                                      \
+    }                                                                                                             \
     if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
@@ -445,6 +537,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
     if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 
+#define SA_BAR()                                   \
+  do {                                             \
+    if constexpr (ABL != 4) __builtin_amdgcn_s_barrier(); \
+  } while (0)
   // ---- prologue: K-tile 0 complete, HB0 / HB1 of K-tile 1 in flight (what the steady state expects) ----------
   stage_w(0, 0, 0);
   stage_w(1, 0, 0);
@@ -461,54 +557,74 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
 
+  if constexpr (ABL == 2) {
+    SA_GEMM8_READ_W(0, 0);
+    SA_GEMM8_READ_W(0, 1);
+    read_a(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if constexpr (ABL == 9) ts1 = __builtin_readcyclecounter();
   for (int t = 0; t < nt; ++t) {
     const int cb = t & 1, nb = cb ^ 1;
     const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
     // P1
-    SA_GEMM8_READ_W(cb, 0);
+    if constexpr (ABL != 2) SA_GEMM8_READ_W(cb, 0);
     __builtin_amdgcn_sched_barrier(0);
-    read_a(cb, 0);
-    if (s1) stage_a(0, nb);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL != 2) read_a(cb, 0);
+    if (ABL != 1 && s1) stage_a(0, nb);
+    SA_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SA_GEMM8_MMA(0, 0);
-    __builtin_amdgcn_s_barrier();
+    SA_BAR();
     // P2
-    SA_GEMM8_READ_W(cb, 1);
-    if (s1) { stage_a(1, nb); advance_a(); }
+    if constexpr (ABL != 2) SA_GEMM8_READ_W(cb, 1);
+    if (ABL != 1 && s1) { stage_a(1, nb); advance_a(); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // HB(t) is restaged in the next phase: its reads end here
-    __builtin_amdgcn_s_barrier();
+    SA_BAR();
     SA_GEMM8_MMA(0, 1);
-    __builtin_amdgcn_s_barrier();
+    SA_BAR();
     // P3
-    read_a(cb, 1);
-    if (s2) stage_w(0, cb, t + 2);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL != 2) read_a(cb, 1);
+    if (ABL != 1 && s2) stage_w(0, cb, t + 2);
+    SA_BAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     SA_GEMM8_MMA(1, 1);
-    __builtin_amdgcn_s_barrier();
+    SA_BAR();
     // P4
-    if (s2) {
+    if (ABL == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (s2) {
       stage_w(1, cb, t + 2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // HB0 / HB1 of t+2 stay in flight; K-tile t+1 has landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+    SA_BAR();
     SA_GEMM8_MMA(1, 0);
-    __builtin_amdgcn_s_barrier();
+    SA_BAR();
   }
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();  // every wave passes the same number of barriers
 #undef SA_GEMM8_MMA
 #undef SA_GEMM8_READ_W
+#undef SA_BAR
+  if constexpr (ABL == 9) ts2 = __builtin_readcyclecounter();
 
   // ---- epilogue (contract of GemmParams, common.h): shared with gemm8s_kernel below ----------------------------
   if (p.flags & 64) {   // the linear epilogue needs no LDS: no barrier either
     epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
-    return;
+  } else {
+    __syncthreads();
+    if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+    else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
   }
-  __syncthreads();
-  epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+  if constexpr (ABL == 9) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left the wave
+    const unsigned long long ts3 = __builtin_readcyclecounter();
+    if (lane == 0) {
+      unsigned long long* o = (unsigned long long*)p.act_alpha + ((size_t)blockIdx.x * 8 + wave) * 4;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3;
+    }
+  }
 }
 
 // gemm8d: gemm8_kernel's tile, MFMA order and epilogue (bitwise the same results) with a DEEPER staging pipeline.
@@ -707,7 +823,8 @@ __global__ __launch_bounds__(512) void gemm8d_kernel(const GemmParams p, const i
     return;
   }
   __syncthreads();
-  epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+  if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+  else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
 // gemm8s: the SAME arithmetic as gemm8_kernel on a 128 x 128 tile - 16x16x32 MFMA with swapped operands, identical
@@ -871,7 +988,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       return;
     }
     __syncthreads();
-    epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
+    if (p.flags & 128) epilogue8_rows<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
+    else epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
     return;
   }
   stage(0, 0);
@@ -909,28 +1027,34 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     return;
   }
   __syncthreads();
-  epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
+  if (p.flags & 128) epilogue8_rows<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
+  else epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
-// The launches whose epilogue is "linear" (epilogue8_linear): every Linear of the DiT / the towers.  Debug flag 24 = 1:
-// never (the general epilogue for everything - the bitwise-equality tests of the linear one).
-static bool gemm8_linear_epilogue(const GemmParams& p) {
-  if (debug_flag(24)) return false;
-  if (p.act != ACT_NONE || p.chan_mod || p.c_ld_rel || (p.flags & 1) || p.N % 64) return false;
-  if (!p.out_act && !p.out_f32) return false;
-  if (p.swiglu && (!p.out_act || p.out_f32 || p.bias || p.gate || p.res)) return false;
-  if (p.bias && (p.gate || p.gate_tab)) return false;
-  if (p.gate_tab && !p.gate) return false;
+// The launches whose epilogue is "linear" (every Linear of the DiT / the towers): bit 6 = epilogue8_linear (16-bit output
+// only: straight from the accumulator layout), bit 7 = epilogue8_rows (fp32 output / residual: through the wave's LDS area).
+// Debug flag 24: 1 = the general epilogue for everything (the bitwise-equality tests), 2 / 3 = the register / LDS form for
+// every eligible launch (A/B).
+static int gemm8_linear_epilogue(const GemmParams& p) {
+  const int mode = debug_flag(24);
+  if (mode == 1) return 0;
+  if (p.act != ACT_NONE || p.chan_mod || p.c_ld_rel || (p.flags & 1) || p.N % 64 || p.alpha != 1.f) return 0;
+  if (!p.out_act && !p.out_f32) return 0;
+  if (p.swiglu && (!p.out_act || p.out_f32 || p.bias || p.gate || p.res)) return 0;
+  if (p.bias && (p.gate || p.gate_tab)) return 0;
+  if (p.gate_tab && !p.gate) return 0;
   auto al = [](long v, long a) { return v % a == 0; };
   if (p.out_act && !(al(p.act_ld, 8) && al(p.act_off, 8) && al(p.act_bstride, 8) && ((uintptr_t)p.out_act & 15) == 0))
-    return false;
-  if (p.gate && (p.rows_per_gate <= 0 || (long)p.M * p.nbatch >= (1L << 31))) return false;
-  return true;   // 16-byte alignment of the fp32 operands: gemm2_ok(), checked by the policy for every launch of this file
+    return 0;
+  if (p.gate && (p.rows_per_gate <= 0 || (long)p.M * p.nbatch >= (1L << 31))) return 0;
+  // 16-byte alignment of the fp32 operands: gemm2_ok(), checked by the policy for every launch of this file
+  if (p.swiglu || mode == 2) return 64;
+  if (mode == 3) return 128;
+  return p.out_f32 || p.res ? 128 : 64;
 }
 static GemmParams with_epilogue_choice(const GemmParams& p) {
   GemmParams q = p;
-  if (gemm8_linear_epilogue(p)) q.flags |= 64;
-  else q.flags &= ~64;
+  q.flags = (q.flags & ~192) | gemm8_linear_epilogue(p);
   return q;
 }
 
@@ -959,6 +1083,14 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   if (deep && conv) hipLaunchKernelGGL((gemm8d_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (deep) hipLaunchKernelGGL((gemm8d_kernel<false>), grid, block, 0, st, p, tile_count);
   else if (conv) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
+#ifdef SAMAUDIO_GEMM8_ABL   // timing experiments (tools/build_abl.sh): debug flag 25 selects the ablation
+  else if (debug_flag(25) == 1) hipLaunchKernelGGL((gemm8_kernel<false, 1>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(25) == 2) hipLaunchKernelGGL((gemm8_kernel<false, 2>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(25) == 3) hipLaunchKernelGGL((gemm8_kernel<false, 3>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(25) == 4) hipLaunchKernelGGL((gemm8_kernel<false, 4>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(25) == 5) hipLaunchKernelGGL((gemm8_kernel<false, 5>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(25) == 9) hipLaunchKernelGGL((gemm8_kernel<false, 9>), grid, block, 0, st, p, tile_count);
+#endif
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
 }
 

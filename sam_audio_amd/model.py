@@ -310,7 +310,8 @@ class SAMAudio:
             if os.environ.get("SAMAUDIO_POISON"):
                 # test aid: every byte 0xFF = NaN in fp32 and bf16, so a kernel that reads scratch nobody wrote shows up
                 # as NaN deterministically instead of depending on what the allocator handed out
-                own._workspace = torch.full((need + 256,), 255, dtype=torch.uint8, device=self.device)
+                fill = int(os.environ.get("SAMAUDIO_POISON_BYTE", "255"), 0)   # a finite pattern (e.g. 0x3F) shows reads
+                own._workspace = torch.full((need + 256,), fill, dtype=torch.uint8, device=self.device)  # that NaN-ignoring ops hide
             else:
                 own._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = own._workspace.data_ptr()

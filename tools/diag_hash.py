@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Where does a two-stream solve first differ from the one-stream solve?  Runs the configuration of
+tests/test_path_gpu.py::test_concurrent_streams_are_bitwise_equal_to_one_stream with SAMAUDIO_TRACE_HASH=1 (engine.hip: one
+checksum per stage and batch item, written on the launch stream WITHOUT synchronising - the concurrency under test stays
+intact), `--reps` times, and compares the per-clip checksum sequence of every two-stream run with the one-stream run.
+Prints the first stage / clip whose checksum differs for each repetition that ends with different latents.
+
+    SAMAUDIO_TRACE_HASH=1 python tools/diag_hash.py [--reps 40] 2> hash.log     (stderr carries the checksums; this script
+    re-reads them through a pipe it sets up itself when run without the redirect)
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CHILD = r'''
+import sys, os
+sys.path.insert(0, %(root)r)
+import torch
+from sam_audio_amd import SAMAudio, SAMAudioProcessor, hip, preset_config
+from sam_audio_amd.synthetic import init_state_dict, synthetic_clip, synthetic_noise, synthetic_text_features
+gpu = torch.device("cuda:0")
+cfg = preset_config("mini")
+sd = init_state_dict(cfg, seed=11)
+hop = cfg.audio_codec.hop_length
+clips = [synthetic_clip(i, 12 * hop) for i in range(5)]
+text, tmask = synthetic_text_features(5, 6, ragged=True)
+proc = SAMAudioProcessor.from_config(cfg)
+batch = proc(descriptions=["x"] * 5, audios=clips, text_features=text, text_mask=tmask).to(gpu)
+noise = synthetic_noise(5, 12).to(gpu)
+opt = {"method": "midpoint", "options": {"step_size": 0.25}}
+def model(streams):
+    m = SAMAudio(cfg, precision="bf16", device=str(gpu), streams=streams)
+    m.load_state_dict(sd, strict=False)
+    return m
+one = model(1)
+print("RUN one", file=sys.stderr, flush=True)
+one.separate(batch, noise=noise, ode_opt=opt); torch.cuda.synchronize()
+ref = one.last_latent.clone()
+two = model(2)
+for rep in range(%(reps)d):
+    print(f"RUN two {rep}", file=sys.stderr, flush=True)
+    two.separate(batch, noise=noise, ode_opt=opt); torch.cuda.synchronize()
+    d = (two.last_latent.float() - ref.float()).abs().flatten(1).max(dim=1).values.tolist()
+    print(f"RESULT {rep} " + " ".join("%%.3g" %% x for x in d), file=sys.stderr, flush=True)
+'''
+
+
+def parse(lines):
+    """-> {run name: {context: [(seq, stage, item, items, hash)]}}, {rep: diffs}"""
+    runs, results, cur = {}, {}, None
+    for ln in lines:
+        if ln.startswith("RUN "):
+            cur = ln.split(None, 1)[1].strip()
+            runs[cur] = {}
+        elif ln.startswith("RESULT "):
+            parts = ln.split()
+            results[int(parts[1])] = [float(x) for x in parts[2:]]
+        else:
+            m = re.match(r"\[samaudio hash\] (\S+) (\d+) (.*) item (\d+) of (\d+) ([0-9a-f]{16})", ln)
+            if m and cur is not None:
+                ctx, seq, stage, item, items, h = m.groups()
+                runs[cur].setdefault(ctx, []).append((int(seq), stage, int(item), int(items), h))
+    return runs, results
+
+
+def per_clip(run):
+    """{clip: {(stage, occurrence): (seq, hash)}}: contexts ordered by size (the 3-clip group holds clips 0-2, the 2-clip
+    group clips 3-4); only stages recorded once per batch item of the context are comparable between shardings"""
+    ctxs = sorted(run.items(), key=lambda kv: -max(r[3] for r in kv[1]))
+    out, base = {}, 0
+    for _, recs in ctxs:
+        n = max(r[3] for r in recs)
+        seen = {}
+        for seq, stage, item, items, h in recs:
+            if items != n:
+                continue
+            k = seen.get((stage, item), 0)
+            seen[(stage, item)] = k + 1
+            out.setdefault(base + item, {})[(stage, k)] = (seq, h)
+        base += n
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=40)
+    args = ap.parse_args()
+    env = dict(os.environ, SAMAUDIO_TRACE_HASH="1")
+    p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, reps=args.reps)], env=env, capture_output=True, text=True)
+    lines = p.stderr.splitlines()
+    runs, results = parse(lines)
+    if "one" not in runs:
+        print(p.stderr[-3000:])
+        sys.exit(1)
+    ref = per_clip(runs["one"])
+    bad = 0
+    for rep in sorted(results):
+        diffs = results[rep]
+        got = per_clip(runs.get(f"two {rep}", {}))
+        first = None
+        for clip in sorted(ref):
+            a, b = ref[clip], got.get(clip, {})
+            for key in sorted(a, key=lambda k: a[k][0]):   # in the order the reference run recorded them
+                if key in b and a[key][1] != b[key][1]:
+                    cand = (a[key][0], clip, key)
+                    if first is None or cand[0] < first[0]:
+                        first = cand
+                    break
+        status = "DIFF" if any(d > 0 for d in diffs) else "same"
+        if status == "DIFF" or first is not None:
+            bad += 1
+            print(f"rep {rep}: latents {status} {diffs}; first differing checksum: {first}")
+    print(f"{len(results)} two-stream repetitions, {bad} with differences; stages per clip in the reference: "
+          f"{len(next(iter(ref.values())))}")
+
+
+if __name__ == "__main__":
+    main()
