@@ -433,6 +433,16 @@ hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, co
   return hipSuccess;
 }
 
+hipError_t launch_hash_items(const unsigned* x, size_t words, int items, unsigned long long* out, hipStream_t) {
+  for (int b = 0; b < items; ++b) {
+    unsigned long long h = 0;
+    for (size_t i = 0; i < words; ++i) h += (unsigned long long)(x[(size_t)b * words + i] ^ (unsigned)(i * 0x9E3779B1u)) * (2 * i + 1);
+    out[b] = h;
+  }
+  return hipSuccess;
+}
+void* debug_device_alloc(size_t bytes) { return std::malloc(bytes); }
+
 hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_col0, void* out, long out_bstride,
                          bool bf16, int B, long T, int C_in, int C_out, int halo, hipStream_t) {
   if (out_bstride == 0) out_bstride = (T + 2L * halo) * C_out;

@@ -29,6 +29,13 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       grep -q "(void)lds;" $OUT/gemm2_simt.hip || { echo "gemm2.hip: dma16a asm statement not found"; exit 1; }
       src=$OUT/gemm2_simt.hip
     fi
+    if [ $f = gemm8 ]; then
+      # gemm8.hip's scalar-base DMA (dma16s: inline assembly with operands) becomes the builtin the stub emulates
+      sed 's|^.*// SIMT-DMA8$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)sbase + voff), (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); (void)lds;|' $src > $OUT/gemm8_simt.hip
+      grep -q "(void)lds;" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16s asm statement not found"; exit 1; }
+      EXTRA="-I $SRC"
+      src=$OUT/gemm8_simt.hip
+    fi
     $CXX $FLAGS $EXTRA -c $src -o $OUT/$f.o &
     pids+=($!)
   fi

@@ -206,6 +206,7 @@ inline simt_u32x2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src, 
   else { r.v[0] = vdst; r.v[1] = other[0]; }                // even row: src <- the odd partner's vdst
   return r;
 }
+inline void __builtin_amdgcn_s_waitcnt(int) { simt::wave_sync(); }   // lgkmcnt forms only (gemm8.hip)
 inline void __builtin_amdgcn_s_barrier() { simt::block_sync(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}

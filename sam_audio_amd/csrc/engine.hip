@@ -34,19 +34,6 @@ static bool trace_on() {
 // <sequence> <stage> item <b> <hex>").  Two runs whose rows must agree (one stream vs two streams, whole batch vs shards)
 // are compared stage by stage offline (tools/diag_hash.py): the first stage whose checksums differ names the kernel.
 // Debugging aid; the only place the library allocates device memory (hipMalloc of 8 MiB, on first use).
-__global__ __launch_bounds__(256) void hash_items_kernel(const unsigned* x, size_t words, unsigned long long* out) {
-  const unsigned* src = x + (size_t)blockIdx.x * words;
-  unsigned long long h = 0;
-  for (size_t i = threadIdx.x; i < words; i += 256) h += (unsigned long long)(src[i] ^ (unsigned)(i * 0x9E3779B1u)) * (2 * i + 1);
-  __shared__ unsigned long long part[256];
-  part[threadIdx.x] = h;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
-}
 struct HashTrace {
   struct Rec { std::string name; int items; size_t slot; };
   unsigned long long* dev = nullptr;
@@ -63,11 +50,11 @@ static thread_local int g_hash_items = 1;
 static void hash_stage(const char* name, const void* dev, size_t bytes, hipStream_t st) {
   HashTrace* h = g_hash;
   if (!h || !dev || bytes < 4) return;
-  if (!h->dev && hipMalloc(&h->dev, HashTrace::CAP * 8) != hipSuccess) return;
+  if (!h->dev && !(h->dev = (unsigned long long*)debug_device_alloc(HashTrace::CAP * 8))) return;
   int items = g_hash_items;
   if (items <= 0 || (bytes / 4) % (size_t)items) items = 1;
   if (h->used + items > HashTrace::CAP) return;
-  hipLaunchKernelGGL(hash_items_kernel, dim3(items), dim3(256), 0, st, (const unsigned*)dev, bytes / 4 / items, h->dev + h->used);
+  (void)launch_hash_items((const unsigned*)dev, bytes / 4 / items, items, h->dev + h->used, st);
   h->recs.push_back({name, items, h->used});
   h->used += items;
 }

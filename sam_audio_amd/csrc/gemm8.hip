@@ -41,6 +41,17 @@ __device__ __forceinline__ void dma16_8(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same DMA with the source as (wave-uniform base, per-lane 32-bit byte offset) and issued as inline assembly
+// (gemm8p_kernel).  Two reasons: the scalar-base form needs no 64-bit address arithmetic per issue and half the address
+// registers; and hipcc treats a global_load_lds it can see as a "flat" access pending on BOTH counters - while one is in
+// flight every LDS fragment read is waited for with lgkmcnt(0) (and every ordinary load with vmcnt(0)), whatever the order
+// of issue, so a kernel cannot start its MFMAs on the fragments that have already arrived.  Invisible to the compiler,
+// the DMA is ordered by the kernel's own counted s_waitcnt vmcnt + barriers alone (a __syncthreads() implies NO wait for
+// it).  M0 = LDS base; one wait state between the M0 write and the DMA.
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, size_t lds_wave_addr) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");  // SIMT-DMA8
+}
 __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha) {
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_GELU) return gelu_f(v);
@@ -827,6 +838,257 @@ __global__ __launch_bounds__(512) void gemm8d_kernel(const GemmParams p, const i
   else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
 }
 
+// gemm8p: gemm8_kernel with two changes to the READ side of its phases (same tile, MFMA order, epilogue: same bits).
+// Round 4, GPU call 4 (profiles/r4_call4/ablate.log): a K-tile of gemm8_kernel takes 2 533 cycles for 2 048 cycles of MFMA
+// work; without the DMA instructions 2 105, without the LDS fragment reads 2 006, without barriers / priorities no less -
+// the read sections (12 / 4 / 8 / 0 ds_read_b128 + 2 DMA instructions per phase) are the longer leg of the heavy phases.
+//   SCHED >= 2  the fragment reads of a phase are issued k-step 0 first and the DMA as inline assembly (dma16s): hipcc then
+//               counts the LDS reads itself (lgkmcnt(7), (6), ...) and a phase's MFMAs start as their own fragments arrive -
+//               with a DMA it can see in flight it waits lgkmcnt(0) in front of the first MFMA of every phase.
+//   SCHED == 3  additionally the W fragments Bs0 of K-tile t+1 are read in P4 of K-tile t (whose read section is empty),
+//               into the register set Bs1 has just left: 8 / 4 / 8 / 4 reads per phase.  The two W register sets swap roles
+//               every K-tile, so the loop is unrolled by two (which also makes the buffer offsets constants).  HB(t+1)
+//               must have landed one phase earlier than in gemm8_kernel: a counted wait in P3.
+template <bool CONV, int SCHED>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const int tile_count) {
+  constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;
+  constexpr bool PRE = SCHED == 3;
+  // [HA0, HA1, HB0, HB1][K-tile buffer]: the two buffers of a half-tile are 16 KiB apart, so that every fragment read of a wave
+  // is one of four lane base addresses + an immediate offset (a buffer-major layout puts buffer 1 beyond the 64 KiB
+  // immediate range: eight more address registers in the loop unrolled by two)
+  __shared__ __attribute__((aligned(16))) char smem[4 * 2 * HT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  int b, tm, tn;
+  if (tile_count > 0) tile_of(p, BM, BN, xcd_run_pos(tile_count), b, tm, tn);
+  else tile_raster8(p, BM, BN, b, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging: plain GEMMs address a row as (uniform base advancing 128 bytes per K-tile) + (per-lane 32-bit byte offset)
+  // (launch_gemm8_tiles checks that every offset fits 32 bits); implicit convolutions keep per-lane 64-bit pointers and the
+  // tap walk of gemm8_kernel
+  const int r8 = lane >> 3;
+  const bf16_t* a_row[2][2];
+  const bf16_t* w_row[2][2];
+  unsigned a_off[2][2], w_off[2][2];
+  int chunk[2];
+  const bf16_t* const A0 = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+  const bf16_t* const W0 = (const bf16_t*)p.W + (long)b * p.w_bstride;
+  {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int row = wave * 16 + q * 8 + r8;
+      chunk[q] = (lane & 7) ^ ((row >> 1) & 7);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int m = m0 + h * 128 + row;
+        m = m < p.M ? m : p.M - 1;
+        a_row[h][q] = A0 + (long)m * p.lda;
+        a_off[h][q] = (unsigned)(((long)m * p.lda + chunk[q] * 8) * 2);
+        int n = n0 + h * 128 + row;
+        n = n < p.N ? n : p.N - 1;
+        w_row[h][q] = W0 + (long)n * p.K + chunk[q] * 8;
+        w_off[h][q] = (unsigned)(((long)n * p.K + chunk[q] * 8) * 2);
+      }
+    }
+  }
+  int a_in[2];
+  long a_tap[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    a_in[q] = chunk[q] * 8;
+    a_tap[q] = 0;
+    if constexpr (CONV)
+      while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+  }
+  const int nt = p.K / BK;
+  const char* a_base = (const char*)A0;   // the K-tile the next stage_a() stages
+  const size_t lds0 = (size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of the tile buffers
+  auto stage_a = [&](int h, int buf) {
+    char* dst = smem + (h * 2 + buf) * HT + wave * 2048;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if constexpr (CONV) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
+      else dma16s(a_base, a_off[h][q], lds0 + (size_t)((h * 2 + buf) * HT + wave * 2048 + q * 1024));
+    }
+  };
+  auto advance_a = [&]() {
+    a_base += BK * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      a_in[q] += BK;
+      if constexpr (CONV)
+        while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+    }
+  };
+  auto stage_w = [&](int h, int buf, int kt) {
+    char* dst = smem + ((2 + h) * 2 + buf) * HT + wave * 2048;
+    const char* w_base = (const char*)W0 + (long)kt * (BK * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if constexpr (CONV) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
+      else dma16s(w_base, w_off[h][q], lds0 + (size_t)(((2 + h) * 2 + buf) * HT + wave * 2048 + q * 1024));
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4][2];      // [m-fragment][k-step]
+  bf16x8_t wf[2][2][2];   // [register set][n-fragment][k-step]
+
+  auto frag = [&](const char* half_base, int row, int ks) -> bf16x8_t {
+    return *(const bf16x8_t*)(half_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
+  };
+  // fragment reads of ONE k-step (KS compile-time): A rows 64*sub .. +63 of HA_wr; W rows of the 32-column half SUB
+#define SA_G8P_READ_A(BUF, ASUB, KS)                                                                              \
+  do {                                                                                                            \
+    const char* base_ = smem + (wr * 2 + (BUF)) * HT;                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i][KS] = frag(base_, (ASUB) * 64 + i * 16 + lr, KS);        \
+  } while (0)
+#define SA_G8P_READ_W(BUF, SUB, SET, KS)                                                                          \
+  do {                                                                                                            \
+    const char* base_ = smem + ((2 + (wc >> 1)) * 2 + (BUF)) * HT;                                           \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      wf[SET][j][KS] = frag(base_, (wc & 1) * 64 + (SUB) * 32 + j * 16 + lr, KS);                                 \
+  } while (0)
+  // the 8 MFMAs of one k-step of a C quadrant (same order as gemm8_kernel: ks outer, j, i)
+#define SA_G8P_MMA(ASUB, WSUB, SET, KS)                                                                           \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        acc[(ASUB) * 4 + i][(WSUB) * 2 + j] =                                                                     \
+            SA_MFMA_16x16x32(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                     \
+  } while (0)
+  // one K-tile; CB = its buffer (compile-time), S0 / S1 = the register sets of Bs0 / Bs1 for this K-tile.  STEADY: K-tiles
+  // t+1 and t+2 exist - no branch between the fragment reads and the MFMAs (at a control-flow merge hipcc waits for EVERY
+  // outstanding LDS read before the first MFMA; without one it counts them itself)
+#define SA_G8P_TILE(CB, S0, S1, STEADY)                                                                                  \
+  do {                                                                                                            \
+    constexpr int NB = (CB) ^ 1;                                                                                  \
+    const bool s1 = (STEADY) || t + 1 < nt, s2 = (STEADY) || t + 2 < nt;                                                                \
+    /* P1: (Bs0,) As0 */                                                                                          \
+    if constexpr (!PRE) SA_G8P_READ_W(CB, 0, S0, 0);                                                              \
+    SA_G8P_READ_A(CB, 0, 0);                                                                                      \
+    if constexpr (!PRE) SA_G8P_READ_W(CB, 0, S0, 1);                                                              \
+    SA_G8P_READ_A(CB, 0, 1);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (s1) stage_a(0, NB);                                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8P_MMA(0, 0, S0, 0);                                                                                      \
+    SA_G8P_MMA(0, 0, S0, 1);                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    /* P2: Bs1 (HB(t) is restaged in P3: its reads end before the barrier) */                                     \
+    SA_G8P_READ_W(CB, 1, S1, 0);                                                                                  \
+    SA_G8P_READ_W(CB, 1, S1, 1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (s1) { stage_a(1, NB); advance_a(); }                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8P_MMA(0, 1, S1, 0);                                                                                      \
+    SA_G8P_MMA(0, 1, S1, 1);                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    /* P3: As1 */                                                                                                 \
+    SA_G8P_READ_A(CB, 1, 0);                                                                                      \
+    SA_G8P_READ_A(CB, 1, 1);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (s2) stage_w(0, CB, t + 2);                                                                                \
+    if constexpr (PRE) {   /* HB0 / HB1 of K-tile t+1 have landed (a wave's Bs0 lives in HB_(wc>>1)): read in P4 */ \
+      if (s2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                    \
+      else if (s1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                               \
+    }                                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8P_MMA(1, 1, S1, 0);                                                                                      \
+    SA_G8P_MMA(1, 1, S1, 1);                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    /* P4: (Bs0 of K-tile t+1 into the set Bs1 has left) */                                                       \
+    if constexpr (PRE) {                                                                                          \
+      if (s1) {                                                                                                   \
+        SA_G8P_READ_W(NB, 0, S1, 0);                                                                              \
+        SA_G8P_READ_W(NB, 0, S1, 1);                                                                              \
+      }                                                                                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }                                                                                                             \
+    if (s2) {                                                                                                     \
+      stage_w(1, CB, t + 2);                                                                                      \
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                            \
+    } else {                                                                                                      \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+    }                                                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8P_MMA(1, 0, S0, 0);                                                                                      \
+    SA_G8P_MMA(1, 0, S0, 1);                                                                                      \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    if constexpr (PRE) __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0), as the builtin: hipcc then knows that   \
+                                                              nothing is pending at the loop's back edge */     \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+  } while (0)
+
+  // ---- prologue (as gemm8_kernel) ---------------------------------------------------------------------------------
+  stage_w(0, 0, 0);
+  stage_w(1, 0, 0);
+  stage_a(0, 0);
+  stage_a(1, 0);
+  advance_a();
+  if (nt > 1) {
+    stage_w(0, 1, 1);
+    stage_w(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+  if constexpr (PRE) {
+    SA_G8P_READ_W(0, 0, 0, 0);
+    SA_G8P_READ_W(0, 0, 0, 1);
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the kernel arguments and Bs0(0) - nothing pending at the loop entry
+
+  int t = 0;
+  for (; t + 3 < nt; t += 2) {   // both K-tiles of a trip have two successors
+    SA_G8P_TILE(0, 0, 1, true);
+    ++t;
+    if constexpr (PRE) SA_G8P_TILE(1, 1, 0, true); else SA_G8P_TILE(1, 0, 1, true);
+    --t;
+  }
+  // the last one to three K-tiles (t is even here): straight-line code, so that the roles of the W register sets stay static
+  SA_G8P_TILE(0, 0, 1, false);
+  ++t;
+  if (t < nt) {
+    if constexpr (PRE) SA_G8P_TILE(1, 1, 0, false); else SA_G8P_TILE(1, 0, 1, false);
+    ++t;
+    if (t < nt) SA_G8P_TILE(0, 0, 1, false);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef SA_G8P_TILE
+#undef SA_G8P_MMA
+#undef SA_G8P_READ_W
+#undef SA_G8P_READ_A
+
+  if (p.flags & 64) {
+    epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
+    return;
+  }
+  __syncthreads();
+  if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+  else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
 // gemm8s: the SAME arithmetic as gemm8_kernel on a 128 x 128 tile - 16x16x32 MFMA with swapped operands, identical
 // fragment <-> k mapping, K walked in slabs of 64 with the two k-steps of a slab in the same order - so an output element
 // is accumulated bit for bit as the 256 x 256 kernel accumulates it.  The tile policy (gemm.hip gemm_variant) may
@@ -1078,9 +1340,16 @@ hipError_t launch_gemm8s(const GemmParams& p_in, hipStream_t st) {
 
 // flag 23 (A/B): 1 = the deep-pipeline form (gemm8d_kernel), 0 = gemm8_kernel; bitwise the same results
 static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, hipStream_t st) {
-  const bool conv = p.kc < p.K, deep = debug_flag(23) != 0;
+  const bool conv = p.kc < p.K, deep = debug_flag(23) == 1;
   const dim3 block(512);
-  if (deep && conv) hipLaunchKernelGGL((gemm8d_kernel<true>), grid, block, 0, st, p, tile_count);
+  // gemm8p addresses plain operands with 32-bit byte offsets from the batch item's base
+  const bool off32 = conv || ((long)p.M * p.lda * 2 < (1L << 32) && (long)p.N * p.K * 2 < (1L << 32));
+  if (!off32) { /* fall through to gemm8_kernel */ }
+  else if (debug_flag(23) == 2 && conv) hipLaunchKernelGGL((gemm8p_kernel<true, 2>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(23) == 2) hipLaunchKernelGGL((gemm8p_kernel<false, 2>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(23) == 3 && conv) hipLaunchKernelGGL((gemm8p_kernel<true, 3>), grid, block, 0, st, p, tile_count);
+  else if (debug_flag(23) == 3) hipLaunchKernelGGL((gemm8p_kernel<false, 3>), grid, block, 0, st, p, tile_count);
+  else if (deep && conv) hipLaunchKernelGGL((gemm8d_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (deep) hipLaunchKernelGGL((gemm8d_kernel<false>), grid, block, 0, st, p, tile_count);
   else if (conv) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
 #ifdef SAMAUDIO_GEMM8_ABL   // timing experiments (tools/build_abl.sh): debug flag 25 selects the ablation

@@ -17,6 +17,9 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            tiles), 3 = the same on 3 workgroups (small cases then walk several tiles each), 2 = never (ring kernel: A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined form)
 void set_debug_flag(int flag, int value);
+// SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library
+hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st);
+void* debug_device_alloc(size_t bytes);
 int debug_flag(int flag);
 
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);

@@ -693,4 +693,27 @@ hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo
   return hipGetLastError();
 }
 
+// SAMAUDIO_TRACE_HASH (engine.hip): one 64-bit checksum per batch item of a stage's buffer, on the launch stream
+__global__ __launch_bounds__(256) void hash_items_kernel(const unsigned* x, size_t words, unsigned long long* out) {
+  const unsigned* src = x + (size_t)blockIdx.x * words;
+  unsigned long long h = 0;
+  for (size_t i = threadIdx.x; i < words; i += 256) h += (unsigned long long)(src[i] ^ (unsigned)(i * 0x9E3779B1u)) * (2 * i + 1);
+  __shared__ unsigned long long part[256];
+  part[threadIdx.x] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st) {
+  hipLaunchKernelGGL(hash_items_kernel, dim3(items), dim3(256), 0, st, x, words_per_item, out);
+  return hipGetLastError();
+}
+void* debug_device_alloc(size_t bytes) {   // debugging aids only: the product path never allocates device memory
+  void* p = nullptr;
+  return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+}
+
 }  // namespace sa

@@ -23,12 +23,14 @@ def main():
     ap.add_argument("--flags", nargs="*", default=["23=0", "23=1"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--variant", type=int, default=22)
+    ap.add_argument("--kinds", nargs="*", default=["plain", "gated"])
+    ap.add_argument("--shapes", nargs="*", default=["4000x2816", "4096x4096", "4000x8448", "8000x2816"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
     Ks = [64, 128, 256, 512, 1024, 2048, 2816, 4096, 5632, 8448]
-    for (M, N) in [(4000, 2816), (4096, 4096), (4000, 8448), (8000, 2816)]:
-        for kind in ("plain", "gated"):
+    for (M, N) in [tuple(int(v) for v in sh.split("x")) for sh in args.shapes]:
+        for kind in args.kinds:
             rows = {}
             for K in Ks:
                 A = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
