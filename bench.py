@@ -67,8 +67,10 @@ def parse(argv=None):
     ap.add_argument("--no-other-scaling", "--no-strong", dest="no_other", action="store_true",
                     help="N > 1: skip the extra measurement of the other scaling mode")
     ap.add_argument("--text-len", type=int, default=8)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
-                    help="bf16 (default) | fp16 = the same kernels on IEEE fp16 operands (libsamaudio_hip_f16.so) | fp32 parity mode")
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="16-bit GEMM-operand format of the timed model: fp16 (default: the mode whose full solve stays inside "
+                         "the 1e-3 parity bound - same kernels and MFMA rate as bf16, libsamaudio_hip_f16.so) | bf16 | fp32 "
+                         "(exact-fp32 parity mode).  The other 16-bit format is timed side by side (--no-parity-mode skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip parity_check (it shares the oracle run with cpu_baseline)")
@@ -103,6 +105,13 @@ def parse(argv=None):
                     help="functional check of the N-rank path on a box with ONE GPU: every rank uses cuda:0 and the process "
                          "group runs on gloo (RCCL refuses two ranks on one device); the ranks time-share the GPU, so the "
                          "value is NOT a scaling number")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default invocation (N = 1, every workload flag at its default) also runs short lines of BASELINE "
+                         "configs[1], [3], [4] and the 4-clips-per-GPU share of configs[2] as sub-processes and reports them "
+                         "under other_configs; this switch skips them")
+    ap.add_argument("--oracle-cache", default=None,
+                    help="file holding / receiving the CPU oracle's result for this (size, sample): sub-runs of other_configs "
+                         "on the same weights reuse the main run's oracle pass for their parity_check")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU-only: exercise the self-launch + sharding + gather plumbing on gloo (tests/test_bench_spawn_cpu.py)")
     return ap.parse_args(argv)
@@ -247,6 +256,57 @@ def parity_check(model, sub, noise, ref, R, dev, precision):
         "ode_latent_err": e_lat, "ode_latent_ref_max": float(ref["lat"].abs().max()),
         "waveform_err": e_wav, "waveform_ref_max": float(ref["wav"].abs().max()),
     }
+
+
+def default_workload(args):
+    return (args.size == "large*" and args.batch == 32 and args.candidates == 1 and not args.predict_spans and not args.visual
+            and not args.t5 and args.streams == 0 and not args.serial_groups and args.text_len == 8)
+
+
+def other_configs(args):
+    """Short lines of the other BASELINE.json configurations, each a sub-process of this script on the same GPU after the
+    main measurement (the model of the main run has been released): configs[1] small* 8 clips, configs[3] large* 8 clips x 8
+    candidates with the span predictor and the Judge reranker, configs[4] large* 4 clips with visual prompts through the
+    PE-Core tower, and the 4-clips-per-GPU share of configs[2] (what one of 8 GPUs runs under strong scaling).  Every
+    sub-line carries its own `roofline` and `parity_check` (the 2-clip full solve of its dims and precision against the CPU
+    oracle; the large* ones reuse the main run's oracle pass through --oracle-cache)."""
+    import subprocess
+    import tempfile
+    large = args.oracle_cache or os.path.join(tempfile.gettempdir(), f"samaudio_oracle_{os.getpid()}_large.pt")
+    small = large.replace("_large.pt", "") + "_small.pt"
+    common = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--verify", "--no-other-configs", "--no-parity-mode", "--precision", args.precision]
+    runs = [
+        ("configs[1] small* 8 clips", ["--size", "small*", "--batch", "8", "--oracle-cache", small]),
+        ("configs[2] share of one of 8 GPUs: 4 clips", ["--batch", "4", "--oracle-cache", large]),
+        ("configs[3] 8 clips x 8 candidates, span predictor + Judge", ["--batch", "8", "--candidates", "8", "--predict-spans",
+                                                                       "--oracle-cache", large]),
+        ("configs[4] 4 clips, visual prompts", ["--batch", "4", "--visual", "--oracle-cache", large]),
+    ]
+    out = []
+    for name, extra in runs:
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(common + extra, capture_output=True, text=True, timeout=900)
+            rows = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not rows:
+                out.append({"config": name, "error": (p.stderr or p.stdout)[-400:]})
+                continue
+            sub = json.loads(rows[-1])
+            keep = {k: sub.get(k) for k in ("value", "unit", "ms_per_step", "steps", "dtype", "config", "parity_check",
+                                            "rerank_breakdown", "vision_tower")}
+            r = sub.get("roofline") or {}
+            keep["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "launches_per_step",
+                                                       "avg_launch_us")} if r else None
+            if r.get("whole_step"):
+                keep["whole_step_frac"] = r["whole_step"].get("frac")
+            keep["config_name"] = name
+            keep["wall_s"] = round(time.perf_counter() - t0, 1)
+            out.append(keep)
+            log(f"other_configs: {name}: {keep['value']} {keep['unit']} in {keep['wall_s']} s")
+        except Exception as exc:   # a sub-line must never cost the main line
+            out.append({"config": name, "error": repr(exc)[:400]})
+    return out
 
 
 def hip_classes():
@@ -399,6 +459,9 @@ def rooflines(stats):
 
 def main():
     args = parse()
+    if args.oracle_cache is None and default_workload(args):
+        import tempfile
+        args.oracle_cache = os.path.join(tempfile.gettempdir(), f"samaudio_oracle_{os.getpid()}_large.pt")
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
     maybe_self_launch(args)
@@ -445,7 +508,8 @@ def main():
 
     model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=max(args.streams, 2))
     model.load_state_dict(sd, strict=False)
-    want_parity_mode = (args.precision == "bf16" and not args.no_parity_mode and not args.visual and args.candidates == 1
+    side = {"fp16": "bf16", "bf16": "fp16"}.get(args.precision)   # the other 16-bit operand format, timed side by side
+    want_parity_mode = (side is not None and not args.no_parity_mode and not args.visual and args.candidates == 1
                         and not args.predict_spans and not args.t5)
     sd_keep = sd if want_parity_mode else None   # the parity-mode model is built from the same weights after the timed run
     del sd
@@ -661,10 +725,10 @@ def main():
                           "(all GEMMs + attention) / HIP-event time on the current stream"}
         log(f"vision tower: {vision['ms']} ms per 250 frames, {vision['achieved']} TFLOP/s")
 
-    # ---- the parity mode, side by side: the same steps on IEEE fp16 operands --------------------------------------------
+    # ---- the other 16-bit operand format, side by side: the same steps ----------------------------------------------------
     pmodel = pmode = None
     if want_parity_mode:
-        pmodel = SAMAudio(cfg, precision="fp16", device=str(dev), streams=max(args.streams, 2))
+        pmodel = SAMAudio(cfg, precision=side, device=str(dev), streams=max(args.streams, 2))
         pmodel.load_state_dict(sd_keep, strict=False)
         del sd_keep
         torch.cuda.empty_cache()
@@ -685,12 +749,12 @@ def main():
             t = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             p_elapsed = float(t.item())
-        pmode = {"precision": "fp16", "what": "the same workload and streams with IEEE fp16 GEMM operands (libsamaudio_hip_f16.so: "
-                 "same kernels, same MFMA rate) - the mode whose full-solve latent and waveform stay inside the 1e-3 bound "
-                 "(tests/test_large_gpu.py::test_full_solve_and_decode asserts it)",
+        pmode = {"precision": side, "what": f"the same workload and streams with {side} GEMM operands (same kernels, same MFMA "
+                 "rate; fp16 = the mode whose full-solve latent and waveform stay inside the 1e-3 bound, bf16 does not: "
+                 "tests/test_large_gpu.py::test_full_solve_and_decode, DESIGN.md section 4)",
                  "value": round(clips_total * CLIP_SECONDS * p_steps / p_elapsed, 3), "unit": "s-audio/s", "steps": p_steps,
                  "ms_per_step": round(1e3 * p_elapsed / p_steps, 2), "parity_check": None}
-        log(f"parity mode (fp16): {p_steps} steps in {p_elapsed:.3f} s -> {pmode['value']:.2f} s-audio/s")
+        log(f"side by side ({side}): {p_steps} steps in {p_elapsed:.3f} s -> {pmode['value']:.2f} s-audio/s")
 
     cpu = parity = None
     if want_cpu or want_verify:
@@ -698,14 +762,28 @@ def main():
         threads = args.cpu_threads or usable_cores()
         g = torch.Generator().manual_seed(99)
         noise = torch.randn(R, n_samples // cfg.audio_codec.hop_length, tcfg.out_channels, generator=g)
-        cpu, ref = oracle_sample(cfg, sd_cpu, torch.stack(clips[:R]), text[:R], tmask[:R], noise, threads)
+        cache = args.oracle_cache
+        key = [args.size, R, float(torch.stack(clips[:R]).double().sum()), float(text[:R].double().sum()), float(noise.double().sum())]
+        ref = None
+        if cache and os.path.exists(cache) and not want_cpu:
+            ref = torch.load(cache)
+            if ref.get("key") != key:   # another sample / size: not this run's oracle result
+                ref = None
+            else:
+                cpu = None
+                log(f"oracle result of this sample read from {cache}")
+        if ref is None:
+            cpu, ref = oracle_sample(cfg, sd_cpu, torch.stack(clips[:R]), text[:R], tmask[:R], noise, threads)
+            if cache:
+                ref["key"] = key
+                torch.save(ref, cache)
         if want_verify:
             sub = proc(descriptions=["sound"] * R, audios=clips[:R], text_features=text[:R], text_mask=tmask[:R]).to(dev)
             parity = parity_check(model, sub, noise, ref, R, dev, args.precision)
             log(f"parity_check: {parity}")
             if pmodel is not None and rank == 0:
-                pmode["parity_check"] = parity_check(pmodel, sub, noise, ref, R, dev, "fp16")
-                log(f"parity_check (parity mode): {pmode['parity_check']}")
+                pmode["parity_check"] = parity_check(pmodel, sub, noise, ref, R, dev, side)
+                log(f"parity_check ({side}): {pmode['parity_check']}")
         if not want_cpu:
             cpu = None
 
@@ -733,9 +811,11 @@ def main():
             },
             "vision_tower": vision,
             "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,
-            "parity_check": parity, "parity_mode": pmode, "other_scaling": strong, "rerank_breakdown": breakdown,
+            "parity_check": parity, ("parity_mode" if side == "fp16" else "bf16_mode"): pmode, "other_scaling": strong, "rerank_breakdown": breakdown,
             "kernels": roof.get("kernels"),
         }
+        if default_workload(args) and world == 1 and not args.no_other_configs:
+            line["other_configs"] = other_configs(args)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -33,6 +33,8 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       # gemm8.hip's scalar-base DMA (dma16s: inline assembly with operands) becomes the builtin the stub emulates
       sed 's|^.*// SIMT-DMA8$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)sbase + voff), (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); (void)lds;|' $src > $OUT/gemm8_simt.hip
       grep -q "(void)lds;" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16s asm statement not found"; exit 1; }
+      sed -i 's|^.*// SIMT-DMA8V$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); (void)lds; /*v*/|' $OUT/gemm8_simt.hip
+      grep -q "(void)lds; /\*v\*/" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16v asm statement not found"; exit 1; }
       EXTRA="-I $SRC"
       src=$OUT/gemm8_simt.hip
     fi

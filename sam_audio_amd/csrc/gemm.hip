@@ -370,7 +370,7 @@ static hipError_t launch_t(const GemmParams& p, int variant, hipStream_t st) {
 
 // 8-phase launches whose last round of 256x256 tiles would be mostly empty are split (gemm8.hip launch_gemm8_split):
 // returns the number of tiles the main launch keeps, 0 = one launch.  Only when the policy (not a forced variant) chose
-// the kernel; the tail must be worth a launch (>= 16 tiles) and the last round must be at most 3/4 full.
+// the kernel; the tail must be worth a launch (>= 16 tiles) and the last round must be at most half full.
 int gemm_tail_split(const GemmParams& p, bool is_bf16) {
   if (g_force >= 0 || (p.flags & 2) || gemm_variant(p, is_bf16) != 22) return 0;
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
@@ -378,7 +378,9 @@ int gemm_tail_split(const GemmParams& p, bool is_bf16) {
   // ... and only for launches of a few rounds: with many rounds the idle part of the last one is a small share of the
   // launch and the second kernel costs more than it recovers (vision tower, M = 144 250: qkv 749 -> 646 TF/s, out_proj
   // 557 -> 500 with the split; profiles/r2_call15/)
-  return full >= 256 && full <= 1024 && rem >= 16 && rem <= 192 ? (int)full : 0;
+  // (round 4: with the lean epilogues a last round that is half full is cheaper as it stands - w13 at 4000 rows, 944 tiles = 3 x 256
+  // + 176: 249 us in one launch, 268 split; qkv, 528 = 2 x 256 + 16: 179 vs 160 split; profiles/r4_call5/gemm_bench_f3.log)
+  return full >= 256 && full <= 1024 && rem >= 16 && rem <= 128 ? (int)full : 0;
 }
 hipError_t launch_gemm_part(const GemmParams& p, bool is_bf16, int part, hipStream_t st) {
   return launch_gemm8_split(p, gemm_tail_split(p, is_bf16), part, st);

@@ -497,6 +497,7 @@ __global__ __launch_bounds__(WM_ * WN_ * 64) void resunit_kernel(const GemmParam
     ((float4*)colv)[threadIdx.x] = bv;
     ((float4*)colv)[C / 4 + threadIdx.x] = av;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is IN LDS before the (raw) barrier that publishes it
 
   {  // halo tile of the input activation (as conv7h_kernel)
     const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(C / 32 * 64, 1) void resws_kernel(const GemmParams 
     ((float4*)colv)[tid] = bv;
     ((float4*)colv)[C / 4 + tid] = av;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is IN LDS before the (raw) barrier that publishes it
   const int rows_used = BM + 6 * dil, last_row = p.M - 1 + 6 * dil, chunks = rows_used * CPRH;
   auto issue_halo = [&](int L, char* dst) {   // as conv7h_kernel; rows past the clip re-read its last halo row
     const int hb = L / tiles_m, hm0 = (L - hb * tiles_m) * BM;

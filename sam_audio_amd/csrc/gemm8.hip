@@ -42,7 +42,7 @@ __device__ __forceinline__ void dma16_8(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 // The same DMA with the source as (wave-uniform base, per-lane 32-bit byte offset) and issued as inline assembly
-// (gemm8p_kernel).  Two reasons: the scalar-base form needs no 64-bit address arithmetic per issue and half the address
+// (gemm8_kernel, gemm8s_kernel).  Two reasons: the scalar-base form needs no 64-bit address arithmetic per issue and half the address
 // registers; and hipcc treats a global_load_lds it can see as a "flat" access pending on BOTH counters - while one is in
 // flight every LDS fragment read is waited for with lgkmcnt(0) (and every ordinary load with vmcnt(0)), whatever the order
 // of issue, so a kernel cannot start its MFMAs on the fragments that have already arrived.  Invisible to the compiler,
@@ -51,6 +51,11 @@ __device__ __forceinline__ void dma16_8(const void* gsrc, char* lds_wave_base) {
 __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, size_t lds_wave_addr) {
   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");  // SIMT-DMA8
+}
+// the same with a per-lane 64-bit source pointer (implicit convolutions: the tap walk; operands beyond 4 GiB)
+__device__ __forceinline__ void dma16v(const void* gsrc, size_t lds_wave_addr) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA8V
 }
 __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha) {
   if (act == ACT_SILU) return silu_f(v);
@@ -410,6 +415,10 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 
 }  // namespace
 
+#ifdef SAMAUDIO_GEMM8_ABL
+// gemm8o: the round-2 / round-3 form of the 8-phase loop (DMA through the builtin, buffer-major LDS layout), kept for the
+// ablation build only (tools/build_abl.sh, tools/gemm8_ablate.py): its ablations are what located the read side as the
+// longer leg (profiles/r4_call4/ablate.log).  The shipped kernel is gemm8_kernel below.
 // The two wave groups run one barrier apart and every MFMA cluster runs under s_setprio 1 (round-2 A/B builds of the
 // template on one box: without the stagger -11 %, without the priority -9 %; profiles/r2_call3/).
 // CONV: A's k axis is split into taps (implicit convolutions: kc < K); plain GEMMs compile the per-K-tile tap walk - a
@@ -425,7 +434,7 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
 // loop, 2 = no LDS fragment reads inside the K loop, 3 = no MFMA, 4 = no barriers, 5 = no s_setprio, 9 = correct results +
 // s_memtime stamps of (entry, prologue done, K loop done, epilogue done) written per tile to p.act_alpha
 template <bool CONV, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
+__global__ __launch_bounds__(512) void gemm8o_kernel(const GemmParams p, const int tile_count) {
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
   if constexpr (ABL == 9) ts0 = __builtin_readcyclecounter();
   constexpr bool STAGGER = true, PRIO = ABL != 5;
@@ -638,221 +647,28 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   }
 }
 
-// gemm8d: gemm8_kernel's tile, MFMA order and epilogue (bitwise the same results) with a DEEPER staging pipeline.
-// gemm8_kernel stages HA(t+1) in P1 / P2 of K-tile t and waits for it in P4: a half-tile has as little as two phases
-// (~1 200 cycles) to arrive, which an L2 hit makes and a miss to the Infinity Cache / HBM under a chip-wide GEMM does not.
-// Here the four half-tiles of a K-tile are composed so that EVERY wave consumes them in the same order:
-//   HA_s = rows  (r >> 6) * 128 + s * 64 + (r & 63)   of the tile  (s = 0, 1: the s-th 64-row half of BOTH wave rows)
-//   HB_s = cols  (r >> 5) * 64  + s * 32 + (r & 31)                (the s-th 32-column half of ALL FOUR wave columns)
-// (a row permutation of the DMA's per-lane source rows: free).  Phase reads:  P1 HB0 + HA0 | P2 HB1 | P3 HA1 | P4 -,
-// so a slot is free right after that phase and is restaged with the data of TWO K-tiles ahead:
-//   P1(t): HA1(t+1)   P2(t): HA0(t+2)   P3(t): HB0(t+2)   P4(t): HB1(t+2)        (issue order HA0 HB0 HB1 HA1 per K-tile =
-// the order of consumption).  Every half-tile has >= 6 phases to arrive; the counted waits leave FIVE half-tiles (10 DMA
-// instructions per wave, 80 KiB per CU) in flight:  P4(t) retires HA0 / HB0(t+1), P1(t) HB1(t), P2(t) HA1(t) - each read
-// one phase after the wait (the lagging group's waves wait one barrier before the leading group's read).  HA0 is restaged in
-// the phase after its last read, so P1 retires its LDS reads BEFORE its first barrier (as gemm8_kernel's P2 does for HB).
+#endif  // SAMAUDIO_GEMM8_ABL
+
+// gemm8_kernel (round 4): the 8-phase loop above with the DMA issued as inline assembly.  GPU call 4
+// (profiles/r4_call4/ablate.log): a K-tile of the round-3 loop took 2 533 cycles for 2 048 cycles of MFMA work; without its
+// DMA instructions 2 105, without its LDS fragment reads 2 006, without barriers / priorities no less - the read side of the
+// heavy phases was the longer leg, and the ISA showed why: hipcc treats a global_load_lds it can see as a "flat" access
+// pending on both counters, so every MFMA cluster began with s_waitcnt lgkmcnt(0) - all 12 fragment reads of a phase
+// landed before its first MFMA issued.  With the DMA invisible to it (dma16s / dma16v) the compiler counts the reads itself
+// (lgkmcnt(9), (8), ... in front of the MFMAs that need them): the fragments of k-step 1 land underneath the MFMAs of
+// k-step 0.  Reads are issued k-step-major for that; the steady-state loop is unrolled by two K-tiles and free of branches
+// (buffer offsets become immediates; the LDS layout is half-tile-major so that both buffers are within the 64 KiB
+// immediate range of one lane base address); the last one to three K-tiles run a copy with the end-of-K conditions.
+// Plain operands are addressed as (uniform base advancing 128 bytes per K-tile) + (32-bit lane offset): no vector address
+// arithmetic in the loop at all - its VALU content is the 128 MFMAs.  GPU call 5 (profiles/r4_call5/): 1.091 -> 0.999 us
+// per K-tile at 176 tiles, 1.398 -> 1.311 at 256; 4096^3 1 101 -> 1 388 TF/s (the guide's template: 1 320 - 1 340);
+// end to end 234.5 -> 240.7 s-audio/s.  Also measured there and dropped: reading the next K-tile's first W fragments in P4
+// (8 / 4 / 8 / 4 reads per phase instead of 12 / 4 / 8 / 0; +-0.5 %), and in call 1 a deeper staging pipeline (five
+// half-tiles in flight instead of two: 1 - 3 % slower - load latency was never the limiter).
+// Same tile, MFMA order and epilogues as gemm8o / gemm8s: the same bits.
 template <bool CONV>
-__global__ __launch_bounds__(512) void gemm8d_kernel(const GemmParams p, const int tile_count) {
+__global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * HT];  // [K-tile buffer][HA0, HA1, HB0, HB1]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-  const int lr = lane & 15, lg = lane >> 4;
-
-  int b, tm, tn;
-  if (tile_count > 0) tile_of(p, BM, BN, xcd_run_pos(tile_count), b, tm, tn);
-  else tile_raster8(p, BM, BN, b, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- staging: wave w moves half-tile rows 16w .. 16w+15 as two instructions of 8 rows --------------------------
-  const int r8 = lane >> 3;
-  const bf16_t* a_row[2][2];  // [s][q]; plain GEMMs: incl. the lane's chunk
-  const bf16_t* w_row[2][2];
-  int chunk[2];
-  {
-    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
-    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int row = wave * 16 + q * 8 + r8;
-      chunk[q] = (lane & 7) ^ ((row >> 1) & 7);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        int m = m0 + (row >> 6) * 128 + s * 64 + (row & 63);
-        m = m < p.M ? m : p.M - 1;
-        a_row[s][q] = A + (long)m * p.lda + (CONV ? 0 : chunk[q] * 8);
-        int n = n0 + (row >> 5) * 64 + s * 32 + (row & 31);
-        n = n < p.N ? n : p.N - 1;
-        w_row[s][q] = W + (long)n * p.K + chunk[q] * 8;
-      }
-    }
-  }
-  // CONV: position of the lane's chunk in the (tap, offset) structure of A's k axis, per half-tile stream s (HA0 and HA1
-  // of one K-tile are staged three phases apart) and q; advances by one K-tile per stage_a(s, ..)
-  int a_in[2][2];
-  long a_tap[2][2];
-  if constexpr (CONV) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        a_in[s][q] = chunk[q] * 8;
-        a_tap[s][q] = 0;
-        while (a_in[s][q] >= p.kc) { a_in[s][q] -= p.kc; a_tap[s][q] += p.tap_stride; }
-      }
-  }
-  const int nt = p.K / BK;
-  auto stage_a = [&](int s, int buf, int kt) {  // HA_s of K-tile kt (CONV: the K-tile stream s points at)
-    char* dst = smem + buf * (4 * HT) + s * HT + wave * 2048;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if constexpr (CONV) {
-        dma16_8(a_row[s][q] + a_tap[s][q] + a_in[s][q], dst + q * 1024);
-        a_in[s][q] += BK;
-        while (a_in[s][q] >= p.kc) { a_in[s][q] -= p.kc; a_tap[s][q] += p.tap_stride; }
-      } else {
-        dma16_8(a_row[s][q] + (long)kt * BK, dst + q * 1024);
-      }
-    }
-  };
-  auto stage_w = [&](int s, int buf, int kt) {
-    char* dst = smem + buf * (4 * HT) + (2 + s) * HT + wave * 2048;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) dma16_8(w_row[s][q] + (long)kt * BK, dst + q * 1024);
-  };
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t af[4][2];
-  bf16x8_t wf[2][2][2];
-
-  auto frag = [&](const char* half_base, int row, int ks) -> bf16x8_t {
-    return *(const bf16x8_t*)(half_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
-  };
-  auto read_a = [&](int buf, int sub) {  // the wave's rows of HA_sub
-    const char* base = smem + buf * (4 * HT) + sub * HT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[i][ks] = frag(base, wr * 64 + i * 16 + lr, ks);
-  };
-#define SA_GEMM8_READ_W(BUF, SUB)                                                                                 \
-  do {                                                                                                            \
-    const char* base_ = smem + (BUF) * (4 * HT) + (2 + (SUB)) * HT;                                               \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
-        wf[SUB][j][ks] = frag(base_, wc * 32 + j * 16 + lr, ks);                                                  \
-  } while (0)
-#define SA_GEMM8_MMA(ASUB, WSUB)                                                                                  \
-  do {                                                                                                            \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                              \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                             \
-          acc[(ASUB) * 4 + i][(WSUB) * 2 + j] = SA_MFMA_16x16x32(                                                 \
-              wf[WSUB][j][ks], af[i][ks], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                                   \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
-  } while (0)
-
-  // ---- prologue: K-tile 0 and HA0 / HB0 / HB1 of K-tile 1, in the canonical order ----------------------------------
-  stage_a(0, 0, 0);
-  stage_w(0, 0, 0);
-  stage_w(1, 0, 0);
-  stage_a(1, 0, 0);
-  if (nt > 1) {
-    stage_a(0, 1, 1);
-    stage_w(0, 1, 1);
-    stage_w(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HA0 / HB0 of K-tile 0 have landed
-  } else {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
-
-  for (int t = 0; t < nt; ++t) {
-    const int cb = t & 1, nb = cb ^ 1;
-    const bool s1 = t + 1 < nt, s2 = t + 2 < nt;
-    // P1: reads HB0, HA0 (their last reads: retired before the barrier, HA0 is restaged in P2)
-    SA_GEMM8_READ_W(cb, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(cb, 0);
-    if (s1) {
-      stage_a(1, nb, t + 1);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HB1(t) has landed (read in P2)
-    } else {
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    SA_GEMM8_MMA(0, 0);
-    __builtin_amdgcn_s_barrier();
-    // P2: reads HB1
-    SA_GEMM8_READ_W(cb, 1);
-    if (s2) {
-      stage_a(0, cb, t + 2);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HA1(t) has landed (read in P3)
-    } else if (s1) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SA_GEMM8_MMA(0, 1);
-    __builtin_amdgcn_s_barrier();
-    // P3: reads HA1
-    read_a(cb, 1);
-    if (s2) stage_w(0, cb, t + 2);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    SA_GEMM8_MMA(1, 1);
-    __builtin_amdgcn_s_barrier();
-    // P4: no reads
-    if (s2) {
-      stage_w(1, cb, t + 2);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // HA0 / HB0 of K-tile t+1 have landed (read in its P1)
-    } else if (s1) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    SA_GEMM8_MMA(1, 0);
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef SA_GEMM8_MMA
-#undef SA_GEMM8_READ_W
-
-  if (p.flags & 64) {   // the linear epilogue needs no LDS: no barrier either
-    epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
-    return;
-  }
-  __syncthreads();
-  if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
-  else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
-}
-
-// gemm8p: gemm8_kernel with two changes to the READ side of its phases (same tile, MFMA order, epilogue: same bits).
-// Round 4, GPU call 4 (profiles/r4_call4/ablate.log): a K-tile of gemm8_kernel takes 2 533 cycles for 2 048 cycles of MFMA
-// work; without the DMA instructions 2 105, without the LDS fragment reads 2 006, without barriers / priorities no less -
-// the read sections (12 / 4 / 8 / 0 ds_read_b128 + 2 DMA instructions per phase) are the longer leg of the heavy phases.
-//   SCHED >= 2  the fragment reads of a phase are issued k-step 0 first and the DMA as inline assembly (dma16s): hipcc then
-//               counts the LDS reads itself (lgkmcnt(7), (6), ...) and a phase's MFMAs start as their own fragments arrive -
-//               with a DMA it can see in flight it waits lgkmcnt(0) in front of the first MFMA of every phase.
-//   SCHED == 3  additionally the W fragments Bs0 of K-tile t+1 are read in P4 of K-tile t (whose read section is empty),
-//               into the register set Bs1 has just left: 8 / 4 / 8 / 4 reads per phase.  The two W register sets swap roles
-//               every K-tile, so the loop is unrolled by two (which also makes the buffer offsets constants).  HB(t+1)
-//               must have landed one phase earlier than in gemm8_kernel: a counted wait in P3.
-template <bool CONV, int SCHED>
-__global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const int tile_count) {
-  constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;
-  constexpr bool PRE = SCHED == 3;
   // [HA0, HA1, HB0, HB1][K-tile buffer]: the two buffers of a half-tile are 16 KiB apart, so that every fragment read of a wave
   // is one of four lane base addresses + an immediate offset (a buffer-major layout puts buffer 1 beyond the 64 KiB
   // immediate range: eight more address registers in the loop unrolled by two)
@@ -910,11 +726,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const i
   const char* a_base = (const char*)A0;   // the K-tile the next stage_a() stages
   const size_t lds0 = (size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of the tile buffers
   auto stage_a = [&](int h, int buf) {
-    char* dst = smem + (h * 2 + buf) * HT + wave * 2048;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      if constexpr (CONV) dma16_8(a_row[h][q] + a_tap[q] + a_in[q], dst + q * 1024);
-      else dma16s(a_base, a_off[h][q], lds0 + (size_t)((h * 2 + buf) * HT + wave * 2048 + q * 1024));
+      const size_t dst = lds0 + (size_t)((h * 2 + buf) * HT + wave * 2048 + q * 1024);
+      if constexpr (CONV) dma16v(a_row[h][q] + a_tap[q] + a_in[q], dst);
+      else dma16s(a_base, a_off[h][q], dst);
     }
   };
   auto advance_a = [&]() {
@@ -927,12 +743,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const i
     }
   };
   auto stage_w = [&](int h, int buf, int kt) {
-    char* dst = smem + ((2 + h) * 2 + buf) * HT + wave * 2048;
     const char* w_base = (const char*)W0 + (long)kt * (BK * 2);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      if constexpr (CONV) dma16_8(w_row[h][q] + (long)kt * BK, dst + q * 1024);
-      else dma16s(w_base, w_off[h][q], lds0 + (size_t)(((2 + h) * 2 + buf) * HT + wave * 2048 + q * 1024));
+      const size_t dst = lds0 + (size_t)(((2 + h) * 2 + buf) * HT + wave * 2048 + q * 1024);
+      if constexpr (CONV) dma16v(w_row[h][q] + (long)kt * BK, dst);
+      else dma16s(w_base, w_off[h][q], dst);
     }
   };
 
@@ -975,9 +791,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const i
     constexpr int NB = (CB) ^ 1;                                                                                  \
     const bool s1 = (STEADY) || t + 1 < nt, s2 = (STEADY) || t + 2 < nt;                                                                \
     /* P1: (Bs0,) As0 */                                                                                          \
-    if constexpr (!PRE) SA_G8P_READ_W(CB, 0, S0, 0);                                                              \
+    SA_G8P_READ_W(CB, 0, S0, 0);                                                                               \
     SA_G8P_READ_A(CB, 0, 0);                                                                                      \
-    if constexpr (!PRE) SA_G8P_READ_W(CB, 0, S0, 1);                                                              \
+    SA_G8P_READ_W(CB, 0, S0, 1);                                                                               \
     SA_G8P_READ_A(CB, 0, 1);                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if (s1) stage_a(0, NB);                                                                                       \
@@ -1004,24 +820,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const i
     SA_G8P_READ_A(CB, 1, 1);                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     if (s2) stage_w(0, CB, t + 2);                                                                                \
-    if constexpr (PRE) {   /* HB0 / HB1 of K-tile t+1 have landed (a wave's Bs0 lives in HB_(wc>>1)): read in P4 */ \
-      if (s2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                    \
-      else if (s1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                               \
-    }                                                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8P_MMA(1, 1, S1, 0);                                                                                      \
     SA_G8P_MMA(1, 1, S1, 1);                                                                                      \
     __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    /* P4: (Bs0 of K-tile t+1 into the set Bs1 has left) */                                                       \
-    if constexpr (PRE) {                                                                                          \
-      if (s1) {                                                                                                   \
-        SA_G8P_READ_W(NB, 0, S1, 0);                                                                              \
-        SA_G8P_READ_W(NB, 0, S1, 1);                                                                              \
-      }                                                                                                           \
-      __builtin_amdgcn_sched_barrier(0);                                                                          \
-    }                                                                                                             \
+    /* P4: no reads */                                                                                            \
     if (s2) {                                                                                                     \
       stage_w(1, CB, t + 2);                                                                                      \
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                            \
@@ -1033,8 +838,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const i
     SA_G8P_MMA(1, 0, S0, 0);                                                                                      \
     SA_G8P_MMA(1, 0, S0, 1);                                                                                      \
     __builtin_amdgcn_s_setprio(0);                                                                                \
-    if constexpr (PRE) __builtin_amdgcn_s_waitcnt(0xC07F);   /* lgkmcnt(0), as the builtin: hipcc then knows that   \
-                                                              nothing is pending at the loop's back edge */     \
     __builtin_amdgcn_s_barrier();                                                                                 \
   } while (0)
 
@@ -1053,24 +856,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const GemmParams p, const i
   }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();
-  if constexpr (PRE) {
-    SA_G8P_READ_W(0, 0, 0, 0);
-    SA_G8P_READ_W(0, 0, 0, 1);
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the kernel arguments and Bs0(0) - nothing pending at the loop entry
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), as the builtin: hipcc then knows that nothing is pending at the loop entry
 
   int t = 0;
   for (; t + 3 < nt; t += 2) {   // both K-tiles of a trip have two successors
     SA_G8P_TILE(0, 0, 1, true);
     ++t;
-    if constexpr (PRE) SA_G8P_TILE(1, 1, 0, true); else SA_G8P_TILE(1, 0, 1, true);
+    SA_G8P_TILE(1, 0, 1, true);
     --t;
   }
   // the last one to three K-tiles (t is even here): straight-line code, so that the roles of the W register sets stay static
   SA_G8P_TILE(0, 0, 1, false);
   ++t;
   if (t < nt) {
-    if constexpr (PRE) SA_G8P_TILE(1, 1, 0, false); else SA_G8P_TILE(1, 0, 1, false);
+    SA_G8P_TILE(1, 0, 1, false);
     ++t;
     if (t < nt) SA_G8P_TILE(0, 0, 1, false);
   }
@@ -1142,21 +941,24 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
   const int r8 = lane >> 3;
   const bf16_t* a_row[4];
   const bf16_t* w_row[4];
+  unsigned a_off[4], w_off[4];   // plain GEMMs: 32-bit byte offsets from the batch item's base (as gemm8_kernel)
   int a_in[4];
   long a_tap[4];
+  const bf16_t* const A0 = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+  const bf16_t* const W0 = (const bf16_t*)p.W + (long)b * p.w_bstride;
   {
-    const bf16_t* A = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
-    const bf16_t* W = (const bf16_t*)p.W + (long)b * p.w_bstride;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = wave * 32 + q * 8 + r8;
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       int m = m0 + row;
       m = m < p.M ? m : p.M - 1;
-      a_row[q] = A + (long)m * p.lda;
+      a_row[q] = A0 + (long)m * p.lda;
+      a_off[q] = (unsigned)(((long)m * p.lda + chunk * 8) * 2);
       int n = n0 + row;
       n = n < p.N ? n : p.N - 1;
-      w_row[q] = W + (long)n * p.K + chunk * 8;
+      w_row[q] = W0 + (long)n * p.K + chunk * 8;
+      w_off[q] = (unsigned)(((long)n * p.K + chunk * 8) * 2);
       a_in[q] = chunk * 8;
       a_tap[q] = 0;
       if constexpr (CONV)
@@ -1164,17 +966,29 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     }
   }
   const int nt = p.K / BK;
-  auto stage = [&](int buf, int kt) {  // K-tile kt (the a_in / a_tap state points at it) -> stage buf
-    char* dst = smem + buf * (2 * TB) + wave * 4096;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma16_8(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma16_8(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
+  const size_t lds0 = (size_t)(__attribute__((address_space(3))) char*)smem;
+  // DMA as inline assembly (dma16s / dma16v, see there): the compiler then counts the fragment reads itself, which is what
+  // lets the pipelined form's reads of K-tile t+1 really complete underneath the MFMAs of K-tile t
+  auto stage = [&](int buf, int kt) {  // K-tile kt (CONV: the a_in / a_tap state points at it) -> stage buf
+    const size_t dst = lds0 + (size_t)(buf * (2 * TB) + wave * 4096);
+    const char* a_base = (const char*)A0 + (long)kt * (BK * 2);
+    const char* w_base = (const char*)W0 + (long)kt * (BK * 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      a_in[q] += BK;
-      if constexpr (CONV)
+      if constexpr (CONV) dma16v(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
+      else dma16s(a_base, a_off[q], dst + q * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (CONV) dma16v(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
+      else dma16s(w_base, w_off[q], dst + TB + q * 1024);
+    }
+    if constexpr (CONV) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a_in[q] += BK;
         while (a_in[q] >= p.kc) { a_in[q] -= p.kc; a_tap[q] += p.tap_stride; }
+      }
     }
   };
 
@@ -1293,6 +1107,11 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
   else epilogue8<1>(p, acc, smem + wave * 16384, b, m0 + wr * 64, n0 + wc * 64, lane);
 }
 
+// CONV instantiation = per-lane 64-bit source pointers: implicit convolutions, and plain operands whose byte offsets from the
+// batch item's base do not fit 32 bits
+static bool gemm8_wide(const GemmParams& p) {
+  return p.kc < p.K || (long)p.M * p.lda * 2 >= (1L << 32) || (long)p.N * p.K * 2 >= (1L << 32);
+}
 // The launches whose epilogue is "linear" (every Linear of the DiT / the towers): bit 6 = epilogue8_linear (16-bit output
 // only: straight from the accumulator layout), bit 7 = epilogue8_rows (fp32 output / residual: through the wave's LDS area).
 // Debug flag 24: 1 = the general epilogue for everything (the bitwise-equality tests), 2 / 3 = the register / LDS form for
@@ -1329,7 +1148,7 @@ hipError_t launch_gemm8s(const GemmParams& p_in, hipStream_t st) {
   const GemmParams p = with_epilogue_choice(p_in);
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
-  const bool pipe = tiles <= 256 && !debug_flag(21), conv = p.kc < p.K;
+  const bool pipe = tiles <= 256 && !debug_flag(21), conv = gemm8_wide(p);
   const dim3 grid((unsigned)tiles), block(256);
   if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, -1);
   else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, -1);
@@ -1338,28 +1157,21 @@ hipError_t launch_gemm8s(const GemmParams& p_in, hipStream_t st) {
   return hipGetLastError();
 }
 
-// flag 23 (A/B): 1 = the deep-pipeline form (gemm8d_kernel), 0 = gemm8_kernel; bitwise the same results
 static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, hipStream_t st) {
-  const bool conv = p.kc < p.K, deep = debug_flag(23) == 1;
   const dim3 block(512);
-  // gemm8p addresses plain operands with 32-bit byte offsets from the batch item's base
-  const bool off32 = conv || ((long)p.M * p.lda * 2 < (1L << 32) && (long)p.N * p.K * 2 < (1L << 32));
-  if (!off32) { /* fall through to gemm8_kernel */ }
-  else if (debug_flag(23) == 2 && conv) hipLaunchKernelGGL((gemm8p_kernel<true, 2>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(23) == 2) hipLaunchKernelGGL((gemm8p_kernel<false, 2>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(23) == 3 && conv) hipLaunchKernelGGL((gemm8p_kernel<true, 3>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(23) == 3) hipLaunchKernelGGL((gemm8p_kernel<false, 3>), grid, block, 0, st, p, tile_count);
-  else if (deep && conv) hipLaunchKernelGGL((gemm8d_kernel<true>), grid, block, 0, st, p, tile_count);
-  else if (deep) hipLaunchKernelGGL((gemm8d_kernel<false>), grid, block, 0, st, p, tile_count);
-  else if (conv) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
-#ifdef SAMAUDIO_GEMM8_ABL   // timing experiments (tools/build_abl.sh): debug flag 25 selects the ablation
-  else if (debug_flag(25) == 1) hipLaunchKernelGGL((gemm8_kernel<false, 1>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(25) == 2) hipLaunchKernelGGL((gemm8_kernel<false, 2>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(25) == 3) hipLaunchKernelGGL((gemm8_kernel<false, 3>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(25) == 4) hipLaunchKernelGGL((gemm8_kernel<false, 4>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(25) == 5) hipLaunchKernelGGL((gemm8_kernel<false, 5>), grid, block, 0, st, p, tile_count);
-  else if (debug_flag(25) == 9) hipLaunchKernelGGL((gemm8_kernel<false, 9>), grid, block, 0, st, p, tile_count);
+#ifdef SAMAUDIO_GEMM8_ABL   // timing experiments (tools/build_abl.sh): debug flag 25 selects an ablation of the round-3 loop
+  if (!(p.kc < p.K)) switch (debug_flag(25)) {
+    case 1: hipLaunchKernelGGL((gemm8o_kernel<false, 1>), grid, block, 0, st, p, tile_count); return;
+    case 2: hipLaunchKernelGGL((gemm8o_kernel<false, 2>), grid, block, 0, st, p, tile_count); return;
+    case 3: hipLaunchKernelGGL((gemm8o_kernel<false, 3>), grid, block, 0, st, p, tile_count); return;
+    case 4: hipLaunchKernelGGL((gemm8o_kernel<false, 4>), grid, block, 0, st, p, tile_count); return;
+    case 5: hipLaunchKernelGGL((gemm8o_kernel<false, 5>), grid, block, 0, st, p, tile_count); return;
+    case 8: hipLaunchKernelGGL((gemm8o_kernel<false, 0>), grid, block, 0, st, p, tile_count); return;
+    case 9: hipLaunchKernelGGL((gemm8o_kernel<false, 9>), grid, block, 0, st, p, tile_count); return;
+    default: break;
+  }
 #endif
+  if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
 }
 
@@ -1382,7 +1194,7 @@ hipError_t launch_gemm8_split(const GemmParams& p_in, int full, int part, hipStr
   if (part == 0) launch_gemm8_tiles(p, dim3((unsigned)full), full, st);
   else {
     const bool pipe = (tiles - full) * 4 <= 256 && !debug_flag(21);   // a tail that cannot give a CU two workgroups
-    const bool conv = p.kc < p.K;
+    const bool conv = gemm8_wide(p);
     const dim3 grid((unsigned)((tiles - full) * 4)), block(256);
     if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, full);
     else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, full);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""What the 8-phase K loop spends its time on: the ablation builds of gemm8_kernel (tools/build_abl.sh; debug flag 25: 1 = no
+"""What the 8-phase K loop spends its time on: the ablation builds of the round-3 loop gemm8o_kernel (tools/build_abl.sh; debug flag 25: 8 = that loop unchanged, 1 = no
 DMA in the loop, 2 = no LDS fragment reads, 3 = no MFMA, 4 = no barriers, 5 = no s_setprio) timed against K at fixed (M, N)
 - slope = time per K-tile of what is left - and the s_memtime stamps of the real kernel (flag 25 = 9): cycles from kernel
 entry to the end of the prologue, through the K loop, through the epilogue, per tile.
@@ -17,7 +17,8 @@ import torch  # noqa: E402
 from sam_audio_amd import hip  # noqa: E402
 from tests import util  # noqa: E402
 
-NAMES = {0: "full kernel", 1: "no DMA in loop", 2: "no LDS reads in loop", 3: "no MFMA", 4: "no barriers", 5: "no setprio"}
+NAMES = {0: "shipped kernel", 8: "round-3 loop", 1: "r3 loop, no DMA", 2: "r3 loop, no LDS reads", 3: "r3 loop, no MFMA",
+         4: "r3 loop, no barriers", 5: "r3 loop, no setprio"}
 
 
 def timeit(fn, iters=20):
@@ -40,7 +41,7 @@ def main():
     Ks = [1024, 2816, 5632, 8448]
     for (M, N) in [(4000, 2816), (4096, 4096)]:
         print(f"M={M} N={N} plain 16-bit output; us per launch at K = {Ks}; slope over K")
-        for abl in (0, 1, 2, 3, 4, 5):
+        for abl in (0, 8, 1, 2, 3, 4, 5):
             us = []
             for K in Ks:
                 A = torch.randn(M, K, device=dev).to(torch.bfloat16)
