@@ -16,6 +16,10 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 19: 1 = residual units on the weight-stationary kernel whatever the launch size (its tests; otherwise >= 1024
 //            tiles), 3 = the same on 3 workgroups (small cases then walk several tiles each), 2 = never (ring kernel: A/B)
 //   flag 21: gemm8s always in its plain double-buffered form (launches of <= 256 workgroups use the pipelined form)
+//   flag 24: epilogue of the 8-phase family: 0 = shipped choice (register form for 16-bit-only outputs, LDS-staged lean form
+//            for fp32 output / residual, general contract for everything else), 1 = the general epilogue for every launch
+//            (bitwise-equality tests of the lean forms), 2 / 3 = the register / LDS form for every eligible launch (A/B)
+//   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library
 hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st);

@@ -64,7 +64,9 @@ QUANT_FORMATS = {"bf16": 1, "fp16": 2}
 
 
 def class_mask(classes) -> int:
-    """'time,out' | ['time', 'out'] | int -> bit mask of SAMAUDIO_CLS_* ("all" = every class)."""
+    """'time,out' | ['time', 'out'] | int | None -> bit mask of SAMAUDIO_CLS_* ("all" = every class, None = none)."""
+    if classes is None:
+        return 0
     if isinstance(classes, int):
         return classes
     if isinstance(classes, str):
