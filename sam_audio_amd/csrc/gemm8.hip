@@ -408,6 +408,11 @@ __device__ __forceinline__ int xcd_run_pos(const int total) {
   const int xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+__device__ __forceinline__ int xcd_run_pos_of(const int total, const int bid) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, const int BN, int& b, int& tm, int& tn) {
   const int total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
   tile_of(p, BM, BN, xcd_run_pos(total), b, tm, tn);
@@ -680,9 +685,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   const int wr = wave >> 2, wc = wave & 3;
   const int lr = lane & 15, lg = lane >> 4;
 
+  // PERSISTENT (grid < tiles: launch_gemm8_tiles): a workgroup walks the tiles vb = blockIdx.x, + gridDim.x, ...
+  // of the XCD-contiguous raster (gridDim.x is a multiple of 8, so every tile of a workgroup lies in its XCD's run).  The
+  // 16-bit epilogue's stores are not waited for: they drain underneath the next tile's prologue loads, which in turn are in
+  // flight while the stores are issued.
+  const int total = tile_count > 0 ? tile_count : ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
   int b, tm, tn;
-  if (tile_count > 0) tile_of(p, BM, BN, xcd_run_pos(tile_count), b, tm, tn);
-  else tile_raster8(p, BM, BN, b, tm, tn);
+  tile_of(p, BM, BN, xcd_run_pos_of(total, vb), b, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging: plain GEMMs address a row as (uniform base advancing 128 bytes per K-tile) + (per-lane 32-bit byte offset)
@@ -881,11 +891,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 
   if (p.flags & 64) {
     epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
-    return;
+  } else {
+    __syncthreads();
+    if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+    else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+    if (vb + (int)gridDim.x < total) __syncthreads();   // the staging area is the next tile's K-tile buffers
   }
-  __syncthreads();
-  if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
-  else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+  }   // tiles of this workgroup
 }
 
 // gemm8s: the SAME arithmetic as gemm8_kernel on a 128 x 128 tile - 16x16x32 MFMA with swapped operands, identical
@@ -1171,6 +1183,12 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
     default: break;
   }
 #endif
+  // Persistent above one round of the chip: at most one workgroup per CU, each walking its XCD's run of tiles (debug flag 26 =
+  // 1: one workgroup per tile, as in round 3).  Per launch the walk is worth 1 - 4 % (w13 at 4 000 rows 259 -> 254 us: the
+  // epilogue stores drain under the next prologue); end to end, with two row groups on two streams, 223.5 -> 234.2 s-audio/s
+  // (+4.7 %, profiles/r4_call7/): a launch now keeps its CUs for its whole duration instead of re-competing for them with
+  // the other group's launch after every tile.
+  if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
   if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
 }

@@ -437,3 +437,37 @@ def test_linear_epilogue_is_bitwise_the_general_one(gpu, variant, kind):
     if kind == "f32":
         want = util.rounded(A[0], "bf16") @ util.rounded(W, "bf16").T
         util.report(f"linear epilogue v{variant} f32", outs[0][0][0], want, 5e-4)
+
+
+@pytest.mark.parametrize("kind", ["act", "gated"])
+def test_persistent_tile_walk_is_bitwise_invisible(gpu, kind):
+    """gemm8_kernel is a persistent kernel above 256 tiles (at most 256 workgroups, each walking its XCD's run of tiles): a
+    launch of 306 tiles - 50 workgroups compute two tiles, the 16-bit epilogue's stores draining under the next tile's
+    prologue, the LDS-staged epilogue followed by a barrier - against the one-tile-per-workgroup launch (debug flag 26 = 1):
+    identical bits."""
+    M, N, K = 4400, 4352, 192
+    A, W = _mk((M, K), 71), _mk((N, K), 72, 1 / math.sqrt(K))
+    keep = dict(A=util.as_act(A, "bf16", gpu), W=util.as_act(W, "bf16", gpu), tab=_mk((N,), 73).to(gpu),
+                gate=_mk((1, N), 74).to(gpu), res=_mk((M, N), 75).to(gpu))
+    outs = {}
+    try:
+        for flag in (0, 1):
+            hip.lib().samaudio_debug_force_gemm_variant(22)
+            hip.lib().samaudio_debug_set_flag(26, flag)
+            o32 = torch.full((M, N), float("nan"), device=gpu)
+            o16 = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
+            kw = dict(out_act=o16, act_geom=(0, N, 0))
+            if kind == "gated":
+                kw.update(gate_tab=keep["tab"], gate=keep["gate"], gate_ld=N, rows_per_gate=M, res=keep["res"], res_geom=(0, N, 0),
+                          out_f32=o32, f32_geom=(0, N, 0))
+            util.gemm("bf16", keep["A"], keep["W"], M, N, K, **kw)
+            outs[flag] = (o32.cpu(), o16.cpu())
+    finally:
+        hip.lib().samaudio_debug_set_flag(26, 0)
+        hip.lib().samaudio_debug_force_gemm_variant(-1)
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+    if kind == "gated":
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.isfinite(outs[0][0]).all()
+    want = util.rounded(A, "bf16") @ util.rounded(W, "bf16").T
+    if kind == "act":
+        util.report("persistent walk, 16-bit output", outs[1][1], want, 3.2e-2)
