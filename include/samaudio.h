@@ -337,7 +337,9 @@ int samaudio_profile_begin(samaudio_ctx* ctx);
 void samaudio_debug_force_gemm_variant(int variant);
 /* Test hooks (csrc/kernels.h lists them; 0 = shipped behaviour): 11 = k7 convolutions as implicit GEMMs, 16 = DAC residual
  * units as two launches, 18 = fuse residual units whatever the launch size, 19 = residual-unit kernel form (1 / 3 = weight-
- * stationary, 2 = ring), 21 = gemm8s always in its plain double-buffered form. */
+ * stationary, 2 = ring), 21 = gemm8s always in its plain double-buffered form, 24 = epilogue form of the 8-phase family (1 = the
+ * general one for every launch, 2 / 3 = one lean form for every eligible launch), 26 = 1: one workgroup per tile (shipped:
+ * persistent above 256 tiles). */
 void samaudio_debug_set_flag(int flag, int value);
 /* Test aid: leave the LDS of every CU filled with NaN bit patterns (LDS is not cleared between kernels), so that a
  * kernel consuming LDS it never wrote fails deterministically. */

@@ -41,6 +41,8 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 hipError_t launch_gemm8(const GemmParams& p, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
+// gemm8.hip: GemmParams.flags bit 8 (q|k|v epilogue) is well-formed; only the 8-phase family (variants 22 / 27) implements it
+bool gemm8_qkv_ok(const GemmParams& p);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
 // LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
 bool conv7h_ok(const GemmParams& p);
