@@ -614,7 +614,8 @@ def main():
     batch, clips, text, tmask = make_batch(my_ids)
     n_streams = model.streams = auto_streams(len(my_ids))
     model._serial_groups = bool(args.serial_groups)
-    model.tail_split = n_streams == 1   # pinned, so that the instrumented (single-stream) step launches the timed kernels
+    # pinned, so that the instrumented (single-stream) step launches the timed kernels; SAMAUDIO_BENCH_TAIL_SPLIT=0/1: A/B
+    model.tail_split = (n_streams == 1) if os.environ.get("SAMAUDIO_BENCH_TAIL_SPLIT") is None else bool(int(os.environ["SAMAUDIO_BENCH_TAIL_SPLIT"]))
     SPLIT_MODE[0] = n_streams == 1
     log(f"inputs resident ({len(my_ids)} clips on this rank, {n_streams} stream(s)); warm-up")
     elapsed, step = timed(batch, args.steps, args.warmup, args.scaling)

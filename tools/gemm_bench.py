@@ -154,6 +154,7 @@ def main():
             run_case("c_wq", M, D, D, "plain", dev, args.iters)
             run_case("w13 swiglu", M, 2 * Fh, D, "swiglu", dev, args.iters)
             run_case("w2 (gate+res)", M, D, Fh, "gated", dev, args.iters)
+            run_case("w2 shape, plain (as hipBLASLt)", M, D, Fh, "plain", dev, args.iters)
             run_case("patcher conv-as-gemm shape", M, D, 3 * D, "plain", dev, args.iters)
 
 
