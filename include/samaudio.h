@@ -99,6 +99,14 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
 #define SAMAUDIO_OPT_F32_CLASSES 2
 #define SAMAUDIO_OPT_QUANT_CLASSES 3
 #define SAMAUDIO_OPT_QUANT_FORMAT 4
+/*   SAMAUDIO_OPT_ALT16_CLASSES (16-bit contexts; value = mask of the five big GEMM classes of the DiT layers - QKV, WO, CWQ, W13,
+ *   W2 -, default 0): precision "mixed".  The named classes read their operands in the library's OTHER 16-bit format - bfloat16
+ *   in libsamaudio_hip_f16.so - i.e. BASELINE's dtype for 96 % of the flops, IEEE fp16 for the classes that carry the error
+ *   (DESIGN.md section 4); their weight tensors are registered in that format (same dtype code: a 16-bit tensor is bits), and
+ *   the kernels that produce their activation operands (RMSNorm + modulate, self-attention, the wo / w13 epilogues) write that
+ *   format.  In libsamaudio_hip.so both formats are bfloat16 and the option changes nothing. */
+#define SAMAUDIO_OPT_ALT16_CLASSES 5
+#define SAMAUDIO_CLS_ALT16_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
 #define SAMAUDIO_CLS_TIME (1 << 0)   /* t_embedder MLP + t_block (transformer.py:236-257,462-467): 1 row per time value */
 #define SAMAUDIO_CLS_OUT (1 << 1)    /* DiT output projection D -> 256 (transformer.py:519): feeds the ODE state */
 #define SAMAUDIO_CLS_IN (1 << 2)     /* proj, noisy-audio columns (model.py:116-125): reads the ODE state */

@@ -159,7 +159,7 @@ hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec,
   return hipSuccess;
 }
 hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
-                             float eps, hipStream_t) {
+                             float eps, hipStream_t, bool) {
   for (int row = 0; row < M; ++row) {
     const float* xr = x + (long)row * D;
     double ss = 0;
@@ -309,7 +309,7 @@ static void self_attn_t(const TA* Q, const TA* K, const TA* Vt, const unsigned c
     }
 }
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask, void* out,
-                                 bool bf16, int B, int T, int Tp, int H, hipStream_t) {
+                                 bool bf16, int B, int T, int Tp, int H, hipStream_t, bool) {
   if (bf16) self_attn_t<bf16_t>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, B, T, Tp, H);
   else self_attn_t<float>((const float*)Q, (const float*)K, (const float*)Vt, key_mask, (float*)out, B, T, Tp, H);
   return hipSuccess;

@@ -25,7 +25,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // a register prefetch of the next K / V^T tile - the compiler sinks the loads back behind the barrier -, DMA double
 // buffering with one barrier per tile and the key mask staged through LDS (79 vs 68 us), and both together.  At T = 250
 // the kernel moves 275 MB for 23.6 GFLOP in 68 us = 4 TB/s: it is bandwidth-bound, not latency-bound.)
-template <int NW, int HD>
+// OUT_ALT: the context rows leave in the alt 16-bit format (mixed mode: they feed the wo GEMM on bf16 operands)
+template <int NW, int HD, bool OUT_ALT = false>
 __global__ __launch_bounds__(NW * 64, 4) void self_attn_bf16_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                  const bf16_t* __restrict__ Vt,
                                                                  const unsigned char* __restrict__ key_mask,
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(NW * 64, 4) void self_attn_bf16_kernel(const bf16_t
     const float inv = 1.f / l_i[r];
     const int q = lg * 4 + r;
 #pragma unroll
-    for (int n = 0; n < NF; ++n) *(unsigned short*)(mine + q * (HD * 2) + (n * 16 + lr) * 2) = f2bf(o[n][r] * inv);
+    for (int n = 0; n < NF; ++n)
+      *(unsigned short*)(mine + q * (HD * 2) + (n * 16 + lr) * 2) = OUT_ALT ? f2alt(o[n][r] * inv) : f2bf(o[n][r] * inv);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: only wave-level ordering is needed
   constexpr int CPRO = HD / 8;   // 16-byte chunks per output row
@@ -263,8 +265,16 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
 
 template <int HD>
 static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
-                                          void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
-  if (bf16 && Tp % 128 == 0)
+                                          void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st, bool out_alt = false) {
+  if (bf16 && out_alt && HD == 128 && Tp % 128 == 0)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<8, 128, true>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else if (bf16 && out_alt && HD == 128)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<4, 128, true>), dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
+                       (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
+  else if (out_alt)
+    return hipErrorInvalidValue;
+  else if (bf16 && Tp % 128 == 0)
     hipLaunchKernelGGL((self_attn_bf16_kernel<8, HD>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
   else if (bf16)
@@ -277,8 +287,8 @@ static hipError_t launch_self_attention_t(const void* Q, const void* K, const vo
 }
 
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
-                                 void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st) {
-  return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st);
+                                 void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st, bool out_alt) {
+  return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st, out_alt);
 }
 hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                     void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st) {

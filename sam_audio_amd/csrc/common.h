@@ -53,6 +53,24 @@ __device__ __forceinline__ unsigned pack_h16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2_t));
 }
 
+// ---- the OTHER 16-bit format (mixed mode) ------------------------------------------------------------------------------
+// precision = "mixed" runs on the fp16 build of the library with the five big GEMM classes of the DiT (qkv, wo, c_wq, w13, w2:
+// 96 % of the flops, 2e-4 of the error each in bf16 - DESIGN.md section 4) on bfloat16 operands, i.e. BASELINE's dtype where
+// the time is and fp16 where the error is.  "alt" = the format that is not the library's own: bf16 in the fp16 build.  In the
+// bf16 build alt is bf16 as well (the mode is the plain bf16 mode there).
+struct alt16_t {
+  unsigned short v;
+};
+typedef __attribute__((ext_vector_type(2))) __bf16 alt16x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 alt16x8_t;
+__device__ __forceinline__ unsigned pack_alt16x2(float a, float b) {   // v_cvt_pk_bf16_f32
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, alt16x2_t));
+}
+__device__ __forceinline__ unsigned short f2alt(float f) { return (unsigned short)(pack_alt16x2(f, 0.f) & 0xffffu); }
+#define SA_MFMA_16x16x32_ALT(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(alt16x8_t, a), __builtin_bit_cast(alt16x8_t, b), c, 0, 0, 0)
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }
@@ -71,6 +89,9 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
   ushort4 v;
   v.x = f2bf(a); v.y = f2bf(b); v.z = f2bf(c); v.w = f2bf(d);
   *(ushort4*)p = v;
+}
+template <> __device__ __forceinline__ void store4<alt16_t>(alt16_t* p, float a, float b, float c, float d) {
+  *(uint2*)p = make_uint2(pack_alt16x2(a, b), pack_alt16x2(c, d));
 }
 template <typename T> __device__ __forceinline__ void load2(const T* p, float& a, float& b);
 template <> __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b) {

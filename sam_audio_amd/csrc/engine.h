@@ -88,6 +88,7 @@ class Engine {
   // 16-bit context (SAMAUDIO_OPT_F32_CLASSES - the caller hands fp32 A / W / out_act pointers)
   Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0, int cls = 0, bool f32 = false);
   bool f32c(int cls) const { return bf16_ && (f32_classes_ & cls) != 0; }
+  bool alt16(int cls) const { return bf16_ && (alt_classes_ & cls) != 0; }   // SAMAUDIO_OPT_ALT16_CLASSES (mixed mode)
   const void* opt(const std::string& name, std::vector<int64_t> shape) const;  // optional fp32 tensor, null if absent / mis-shaped
   struct ProfRec {
     std::string key;
@@ -112,6 +113,7 @@ class Engine {
   bool bf16_;
   bool tail_split_ = true;  // SAMAUDIO_OPT_TAIL_SPLIT
   int f32_classes_ = 0;     // SAMAUDIO_OPT_F32_CLASSES (16-bit contexts)
+  int alt_classes_ = 0;     // SAMAUDIO_OPT_ALT16_CLASSES (16-bit contexts)
   int quant_classes_ = 0, quant_fmt_ = 0;  // SAMAUDIO_OPT_QUANT_CLASSES / _FORMAT (fp32 contexts)
   size_t esz_;  // bytes per activation / GEMM-operand element
   int at_dtype_;

@@ -424,6 +424,13 @@ Status Engine::set_option(int option, int value) {
     f32_classes_ = value;
     return Status{};
   }
+  if (option == SAMAUDIO_OPT_ALT16_CLASSES) {
+    if (value && !bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_ALT16_CLASSES applies to 16-bit contexts");
+    if (value & ~SAMAUDIO_CLS_ALT16_CAPABLE)
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_ALT16_CLASSES: only the five big GEMM classes of the DiT layers (qkv, wo, cwq, w13, w2)");
+    alt_classes_ = value;
+    return Status{};
+  }
   if (option == SAMAUDIO_OPT_QUANT_CLASSES || option == SAMAUDIO_OPT_QUANT_FORMAT) {
     if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_QUANT_*: operand-rounding emulation needs an fp32 context");
     if (option == SAMAUDIO_OPT_QUANT_FORMAT && (value < 0 || value > 2))
@@ -437,7 +444,9 @@ Status Engine::set_option(int option, int value) {
 Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, bool f32) {
   GemmParams p = p_in;
   p.tag = prof_cls_[0] == 'c' ? 1 : 0;  // codec launches run under their own kernel symbols
-  p.flags = tail_split_ ? 0 : 2;        // bit 1: no tail split (gemm.hip gemm_tail_split)
+  // bit 1: no tail split (gemm.hip gemm_tail_split); bit 9 (from the caller): 16-bit output in the alt format; bit 10: operands
+  // in the alt format (SAMAUDIO_OPT_ALT16_CLASSES, mixed mode)
+  p.flags = (p_in.flags & 512) | (tail_split_ ? 0 : 2) | (alt16(cls) && !f32 ? 1024 : 0);
   if (p.tag) cls = SAMAUDIO_CLS_CODEC;
   if (f32) {  // a class of SAMAUDIO_OPT_F32_CLASSES: exact-fp32 kernel inside a 16-bit context
     if (!p.W) return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_F32_CLASSES: the class's \"<name>.f32\" weight copy is not registered");
@@ -745,6 +754,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   }
   // RMSNorm + modulate operands of this evaluation, pre-combined for every layer's two norms (kernels.hip mod_tables)
   const bool mod_gs = 2 * cfg_.n_layers <= kMaxModNorms && cfg_.n_layers > 0 && D <= 256 * 12;
+  if (alt_classes_ && bf16_ && !mod_gs)
+    return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_ALT16_CLASSES: the mixed mode needs the pre-combined RMSNorm operands (<= 48 layers, D <= 3072)");
   const long gs_ld = nt == 1 ? 0 : 2L * D;
   if (mod_gs) {
     ModTables mt;
@@ -803,7 +814,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     // self-attention branch
     SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
       if (mod_gs)
-        return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st);
+        return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st,
+                                 alt16(SAMAUDIO_CLS_QKV));
       return launch_rmsnorm_mod(d_.h, w.attn_norm, tab + 0 * D, tab + 1 * D, d_.t0, t6, 0 * D, 1 * D, d_.xn, bf16_, (int)M, D,
                                 T, eps, st);
     }));
@@ -822,7 +834,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     trace("  K", d_.K, (size_t)rows * H * Tp * 128, bf16_, st);
     trace("  Vt", d_.Vt, (size_t)rows * H * Tp * 128, bf16_, st);
     SA_TRY(op("self_attention", 4 * MD * esz_, 4.0 * T * T * 128 * H * rows, st, [&] {
-      return launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st);
+      return launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st, alt16(SAMAUDIO_CLS_WO));
     }));
     trace("  attn", d_.attn, (size_t)M * D, bf16_, st);
     {
@@ -831,6 +843,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
       out_act(p, d_.hbf, D);
+      if (alt16(SAMAUDIO_CLS_CWQ)) p.flags |= 512;   // hbf is c_wq's operand
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
     }
     trace("  h after wo", d_.h, (size_t)M * D, false, st);
@@ -874,7 +887,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     // feed-forward branch
     SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
       if (mod_gs)
-        return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l + 1) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st);
+        return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l + 1) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st,
+                                 alt16(SAMAUDIO_CLS_W13));
       return launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_, (int)M, D,
                                 T, eps, st);
     }));
@@ -882,6 +896,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       GemmParams p = lin(d_.xn, D, w.w13, M, 2 * F, D);
       p.swiglu = 1;
       out_act(p, d_.u, F);
+      if (alt16(SAMAUDIO_CLS_W2)) p.flags |= 512;    // u is w2's operand
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
       trace("  xn (ffn)", d_.xn, (size_t)M * D, bf16_, st);
       trace("  u", d_.u, (size_t)M * F, bf16_, st);

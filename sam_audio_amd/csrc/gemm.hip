@@ -406,6 +406,11 @@ const char* gemm_check(const GemmParams& p, bool is_bf16) {
     return "gemm: A strides/offsets must be 16-byte aligned";
   if (p.swiglu && (p.N % 32)) return "gemm: swiglu needs N % 32 == 0";
   if (p.gate && p.rows_per_gate <= 0) return "gemm: rows_per_gate";
+  if (p.flags & (512 | 1024)) {   // mixed mode: alt-format output / operands exist in the 8-phase family only
+    if (!is_bf16 || !gemm2_ok(p) || !gemm8_alt_ok(p)) return "gemm: alt 16-bit format: plain 16-bit launches with a lean epilogue only";
+    const int v = gemm_variant(p, is_bf16);
+    if (v != 22 && v != 27) return "gemm: alt 16-bit format: the tile policy did not pick the 8-phase family for this launch";
+  }
   return nullptr;
 }
 

@@ -207,6 +207,8 @@ __device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&
 #pragma clang fp contract(off)
   constexpr int NI = NH * 4;
   const int lr = lane & 15, lg = lane >> 4;
+  const bool out_alt = (p.flags & 512) != 0;   // mixed mode: the 16-bit output feeds a GEMM on alt-format operands
+  auto pack = [&](float x, float y) { return out_alt ? pack_alt16x2(x, y) : pack_h16x2(x, y); };
   if (n_wave0 >= p.N) return;   // N % 64 == 0: a wave's 64 columns are all inside or all outside
   const long bM = (long)b * p.M;
   const int m_last = p.M - 1;
@@ -223,8 +225,8 @@ __device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         const f32x4_t a = acc[I][2 * jp], g = acc[I][2 * jp + 1];
-        lo[jp] = pack_h16x2(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1]);
-        hi[jp] = pack_h16x2(silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
+        lo[jp] = pack(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1]);
+        hi[jp] = pack(silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
       }
       const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], lo[1], false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(hi[0], hi[1], false, false);
@@ -293,8 +295,8 @@ __device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&
       *(float4*)(frow + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
     }
     if (has_act) {
-      const unsigned lo0 = pack_h16x2(v[0][0], v[0][1]), hi0 = pack_h16x2(v[0][2], v[0][3]);
-      const unsigned lo1 = pack_h16x2(v[1][0], v[1][1]), hi1 = pack_h16x2(v[1][2], v[1][3]);
+      const unsigned lo0 = pack(v[0][0], v[0][1]), hi0 = pack(v[0][2], v[0][3]);
+      const unsigned lo1 = pack(v[1][0], v[1][1]), hi1 = pack(v[1][2], v[1][3]);
       const auto s0 = __builtin_amdgcn_permlane16_swap(lo0, lo1, false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(hi0, hi1, false, false);
       if (m_ok) *(uint4*)(act0 + (long)m * p.act_ld + c_st + 32 * jp) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
@@ -314,6 +316,7 @@ __device__ __forceinline__ void epilogue8_rows(const GemmParams& p, f32x4_t (&ac
                                                const int m_wave0, const int n_wave0, const int lane) {
 #pragma clang fp contract(off)
   const int lr = lane & 15, lg = lane >> 4;
+  const bool out_alt = (p.flags & 512) != 0;
   const long bM = (long)b * p.M;
   const bool has_bias = p.bias != nullptr, has_gate = p.gate != nullptr, has_tab = p.gate_tab != nullptr,
              has_res = p.res != nullptr, has_f32 = p.out_f32 != nullptr, has_act = p.out_act != nullptr;
@@ -364,7 +367,7 @@ __device__ __forceinline__ void epilogue8_rows(const GemmParams& p, f32x4_t (&ac
       if (has_res) { v0 += rr.x; v1 += rr.y; v2 += rr.z; v3 += rr.w; }
       if (m <= m_last) {
         if (has_f32) *(float4*)(f320 + (long)m * p.f32_ld) = make_float4(v0, v1, v2, v3);
-        if (has_act) *(uint2*)(act0 + (long)m * p.act_ld) = make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
+        if (has_act) *(uint2*)(act0 + (long)m * p.act_ld) = out_alt ? make_uint2(pack_alt16x2(v0, v1), pack_alt16x2(v2, v3)) : make_uint2(pack_h16x2(v0, v1), pack_h16x2(v2, v3));
       }
     };
     if (n_ok) {
@@ -671,7 +674,8 @@ __global__ __launch_bounds__(512) void gemm8o_kernel(const GemmParams p, const i
 // (8 / 4 / 8 / 4 reads per phase instead of 12 / 4 / 8 / 0; +-0.5 %), and in call 1 a deeper staging pipeline (five
 // half-tiles in flight instead of two: 1 - 3 % slower - load latency was never the limiter).
 // Same tile, MFMA order and epilogues as gemm8o / gemm8s: the same bits.
-template <bool CONV>
+// ALT: the operands are in the alt 16-bit format (mixed mode: bf16 inside the fp16 build) - the MFMA opcode is the only difference
+template <bool CONV, bool ALT = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, BK = 64, HT = 128 * 128;
   // [HA0, HA1, HB0, HB1][K-tile buffer]: the two buffers of a half-tile are 16 KiB apart, so that every fragment read of a wave
@@ -791,7 +795,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
         acc[(ASUB) * 4 + i][(WSUB) * 2 + j] =                                                                     \
-            SA_MFMA_16x16x32(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                     \
+            ALT ? SA_MFMA_16x16x32_ALT(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j])            \
+                : SA_MFMA_16x16x32(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);              \
   } while (0)
   // one K-tile; CB = its buffer (compile-time), S0 / S1 = the register sets of Bs0 / Bs1 for this K-tile.  STEADY: K-tiles
   // t+1 and t+2 exist - no branch between the fragment reads and the MFMAs (at a control-flow merge hipcc waits for EVERY
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // 3 -> 4 stages: c_wq at 1000 rows 36.9 -> 34.9 us, w2 83.4 -> 79.0; 4 clips per GPU 114.5 -> 119.8 s-audio/s, small* 8 clips
 // 424.0 -> 435.3 (profiles/r3_call9/).  A 5-stage ring (160 KiB, all of the CU's LDS) measured slower again: c_wq 35.9 vs 34.9 us, w2
 // 80.5 vs 76.2, 4 clips 120.7 vs 121.5 (profiles/r3_call28/) - three K-tiles in flight already cover the latency.
-template <bool PIPE, bool CONV>
+template <bool PIPE, bool CONV, bool ALT = false>
 __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 4 : 2;
@@ -1047,7 +1052,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            acc[i][j] = SA_MFMA_16x16x32(wf[SET()][j][ks], af[SET()][i][ks], acc[i][j]);
+            acc[i][j] = ALT ? SA_MFMA_16x16x32_ALT(wf[SET()][j][ks], af[SET()][i][ks], acc[i][j])
+                            : SA_MFMA_16x16x32(wf[SET()][j][ks], af[SET()][i][ks], acc[i][j]);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[i][j] = SA_MFMA_16x16x32(wf[j][ks], af[i][ks], acc[i][j]);
+          acc[i][j] = ALT ? SA_MFMA_16x16x32_ALT(wf[j][ks], af[i][ks], acc[i][j]) : SA_MFMA_16x16x32(wf[j][ks], af[i][ks], acc[i][j]);
   }
   if (p.flags & 64) {
     epilogue8_linear<1>(p, acc, b, m0 + wr * 64, n0 + wc * 64, lane);
@@ -1156,16 +1162,32 @@ static GemmParams with_epilogue_choice(const GemmParams& p) {
 // identical - ran exactly as fast: c_wq 36.0 vs 35.3 us, 4 clips 114.8 vs 115.1 s-audio/s, small* 423 vs 424.  With few
 // rows a launch lasts nt x ~0.8 us whatever its workgroup count: it is bound by the depth of the K-tile prefetch (two K-tiles
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
+// alt-format operands (flags bit 10, mixed mode) exist for plain GEMMs only - the DiT's Linears - gemm8_alt_ok()
+static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 grid, int skip256, hipStream_t st) {
+  const dim3 block(256);
+  const bool alt = (p.flags & 1024) != 0;
+  if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, skip256);
+  else if (pipe && alt) hipLaunchKernelGGL((gemm8s_kernel<true, false, true>), grid, block, 0, st, p, skip256);
+  else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, skip256);
+  else if (conv) hipLaunchKernelGGL((gemm8s_kernel<false, true>), grid, block, 0, st, p, skip256);
+  else if (alt) hipLaunchKernelGGL((gemm8s_kernel<false, false, true>), grid, block, 0, st, p, skip256);
+  else hipLaunchKernelGGL((gemm8s_kernel<false, false>), grid, block, 0, st, p, skip256);
+}
+// flags bits 9 / 10 are well-formed for this launch: plain operands within 32-bit offsets, a lean epilogue for an alt-format output
+bool gemm8_alt_ok(const GemmParams& p) {
+  if (!(p.flags & (512 | 1024))) return true;
+  if ((p.flags & 1024) && gemm8_wide(p)) return false;
+  if ((p.flags & 512) && (!p.out_act || gemm8_linear_epilogue(p) == 0)) return false;
+  return true;
+}
+
 hipError_t launch_gemm8s(const GemmParams& p_in, hipStream_t st) {
   const GemmParams p = with_epilogue_choice(p_in);
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
   const bool pipe = tiles <= 256 && !debug_flag(21), conv = gemm8_wide(p);
-  const dim3 grid((unsigned)tiles), block(256);
-  if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, -1);
-  else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, -1);
-  else if (conv) hipLaunchKernelGGL((gemm8s_kernel<false, true>), grid, block, 0, st, p, -1);
-  else hipLaunchKernelGGL((gemm8s_kernel<false, false>), grid, block, 0, st, p, -1);
+  const dim3 grid((unsigned)tiles);
+  launch_gemm8s_grid(p, pipe, conv, grid, -1, st);
   return hipGetLastError();
 }
 
@@ -1190,6 +1212,7 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   // the other group's launch after every tile.
   if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
   if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
+  else if (p.flags & 1024) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, tile_count);   // alt-format operands
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
 }
 
@@ -1213,11 +1236,8 @@ hipError_t launch_gemm8_split(const GemmParams& p_in, int full, int part, hipStr
   else {
     const bool pipe = (tiles - full) * 4 <= 256 && !debug_flag(21);   // a tail that cannot give a CU two workgroups
     const bool conv = gemm8_wide(p);
-    const dim3 grid((unsigned)((tiles - full) * 4)), block(256);
-    if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, full);
-    else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, full);
-    else if (conv) hipLaunchKernelGGL((gemm8s_kernel<false, true>), grid, block, 0, st, p, full);
-    else hipLaunchKernelGGL((gemm8s_kernel<false, false>), grid, block, 0, st, p, full);
+    const dim3 grid((unsigned)((tiles - full) * 4));
+    launch_gemm8s_grid(p, pipe, conv, grid, full, st);
   }
   return hipGetLastError();
 }

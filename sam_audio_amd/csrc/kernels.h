@@ -41,6 +41,9 @@ hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 hipError_t launch_gemm8(const GemmParams& p, hipStream_t st);
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
+// gemm8.hip: GemmParams.flags bits 9 / 10 (mixed mode: out_act written / operands read in the alt 16-bit format) are well-formed;
+// only the 8-phase family (variants 22 / 27) implements them
+bool gemm8_alt_ok(const GemmParams& p);
 // gemm8.hip: GemmParams.flags bit 8 (q|k|v epilogue) is well-formed; only the 8-phase family (variants 22 / 27) implements it
 bool gemm8_qkv_ok(const GemmParams& p);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
@@ -87,14 +90,14 @@ struct ModTables {
 hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec, long tvec_ld, int nt, float* gs, int D,
                              hipStream_t st);
 hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
-                             float eps, hipStream_t st);
+                             float eps, hipStream_t st, bool out_alt = false);   // out_alt: 16-bit output in the alt format (mixed mode)
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st);
 
 // self-attention over the padded layout above; key_mask [B,T] bytes (1 = attend); out [B*T, H*128]
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
-                                 void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st);
+                                 void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st, bool out_alt = false);
 
 // the same with head_dim 64 or 128 (Q, K [B,H,Tp,hd], Vt [B,H,hd,Tp], out [B*T, H*hd]; scale hd^-0.5)
 hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,

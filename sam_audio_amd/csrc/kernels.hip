@@ -161,10 +161,12 @@ __global__ __launch_bounds__(256) void rmsnorm_gs_reg_kernel(const float* __rest
 
 // gs = [g | s] of this norm for time value 0, gs_ld = floats between the time values (0: one time value for every row)
 hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
-                             float eps, hipStream_t st) {
+                             float eps, hipStream_t st, bool out_alt) {
   if (D > 256 * 12 || D % 4) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
-  if (bf16)
+  if (bf16 && out_alt)   // mixed mode: the row feeds a GEMM on alt-format operands
+    hipLaunchKernelGGL((rmsnorm_gs_reg_kernel<alt16_t, 12>), grid, block, 0, st, x, gs, gs_ld, (alt16_t*)out, M, D, rows_per_b, eps);
+  else if (bf16)
     hipLaunchKernelGGL((rmsnorm_gs_reg_kernel<bf16_t, 12>), grid, block, 0, st, x, gs, gs_ld, (bf16_t*)out, M, D, rows_per_b, eps);
   else
     hipLaunchKernelGGL((rmsnorm_gs_reg_kernel<float, 12>), grid, block, 0, st, x, gs, gs_ld, (float*)out, M, D, rows_per_b, eps);

@@ -18,12 +18,12 @@ LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libsamaudio_hip_f16.
 
 F32, BF16 = 0, 1             # precision codes of the C ABI: fp32 parity mode | 16-bit GEMM operands (bf16 or fp16 by library)
 DT_F32, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3   # DT_BF16 = "the library's 16-bit operand format"
-PRECISIONS = ("bf16", "fp16", "fp32")
+PRECISIONS = ("bf16", "fp16", "mixed", "fp32")
 
 
 def check_precision(precision: str) -> None:
     if precision not in PRECISIONS:
-        raise ValueError("precision must be 'bf16', 'fp16' or 'fp32'")
+        raise ValueError("precision must be 'bf16', 'fp16', 'mixed' or 'fp32'")
 
 
 def precision_code(precision: str) -> int:
@@ -32,25 +32,26 @@ def precision_code(precision: str) -> int:
 
 def operands_for(precision: str) -> str:
     """Which build of the library a host object of this precision talks to (fp32 mode lives in both; use the default)."""
-    return "fp16" if precision == "fp16" else "bf16"
+    return "fp16" if precision in ("fp16", "mixed") else "bf16"
 
 
 def act_dtype(precision: str):
     import torch
-    return {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[precision]
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "mixed": torch.float16, "fp32": torch.float32}[precision]
 
 
-def dtype_code(dtype, operands: Optional[str] = None) -> int:
+def dtype_code(dtype, operands: Optional[str] = None, alt_ok: bool = False) -> int:
     """C-ABI dtype code of a torch dtype.  `operands` ("bf16" | "fp16"): the build of the library the tensor is handed to -
-    a 16-bit tensor in the other build's format would be reinterpreted silently, so it is refused here."""
+    a 16-bit tensor in the other build's format would be reinterpreted silently, so it is refused here (`alt_ok`: the
+    tensor is the weight of a SAMAUDIO_OPT_ALT16_CLASSES class of a mixed-precision model, which IS in the other format)."""
     import torch
-    if operands is not None and dtype in (torch.bfloat16, torch.float16):
+    if operands is not None and not alt_ok and dtype in (torch.bfloat16, torch.float16):
         want = torch.float16 if operands == "fp16" else torch.bfloat16
         if dtype != want:
             raise TypeError(f"{dtype} tensor handed to the {operands}-operand build of libsamaudio_hip")
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
-OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT = 1, 2, 3, 4
+OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES = 1, 2, 3, 4, 5
 # GEMM classes of the DiT / codec (samaudio.h SAMAUDIO_CLS_*), in bit order
 CLASSES = ("time", "out", "in", "prep", "yemb", "ckv", "patch", "qkv", "wo", "cwq", "cwo", "w13", "w2", "codec")
 CLS = {name: 1 << i for i, name in enumerate(CLASSES)}
@@ -60,6 +61,10 @@ CLS_F32_CAPABLE = CLS["time"] | CLS["out"] | CLS["in"] | CLS["prep"] | CLS["yemb
 # |latent| <= 5.2): out 4.3e-3 / 6.0e-4, in 2.5e-3 / 3.5e-4, prep 2.6e-3 / 3.0e-4 against yemb 9.7e-4 / 1.3e-4 and
 # time 4.6e-4 / 5.9e-5 - the last two cost 1 ms per evaluation in fp32 and buy nothing measurable; they stay selectable.
 CLS_F32_DEFAULT = CLS["out"] | CLS["in"] | CLS["prep"]
+# precision="mixed": the five big GEMM classes of the DiT layers (96 % of the flops, <= 2e-4 of the error each on bf16 operands)
+# read bfloat16 operands inside the fp16 build; everything else stays fp16 (samaudio.h SAMAUDIO_OPT_ALT16_CLASSES)
+CLS_ALT16_MIXED = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["w13"] | CLS["w2"]
+ALT16_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "w13": "w13", "w2": "w2"}   # engine tensor L<i>.<name> -> class
 QUANT_FORMATS = {"bf16": 1, "fp16": 2}
 
 

@@ -58,7 +58,7 @@ class _Lane:
         self._ctx = C.c_void_p()
         hip.check(self.lib.samaudio_create(C.byref(model._hc), C.byref(self._ctx)))
         for name, t in model._tensors.items():
-            dt = hip.dtype_code(t.dtype, hip.operands_for(model.precision))
+            dt = hip.dtype_code(t.dtype, hip.operands_for(model.precision), alt_ok=model._alt16_weight(name))
             hip.check(self.lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(),
                                                    hip.shape_array(t.shape)))
         hip.check(self.lib.samaudio_finalize(self._ctx, 0))
@@ -91,6 +91,8 @@ class SAMAudio:
         self.f32_classes = 0 if precision == "fp32" else (
             hip.CLS_F32_DEFAULT if f32_classes == "auto" else hip.class_mask(f32_classes))
         self.quant_classes, self.quant_format = 0, 0   # fp32 engines: operand-rounding emulation (error budget)
+        # precision="mixed": bf16 operands for the five big GEMM classes inside the fp16 build (hip.CLS_ALT16_MIXED)
+        self.alt16_classes = hip.CLS_ALT16_MIXED if precision == "mixed" else 0
         self.device = torch.device(device) if device is not None else None
         self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])
         # rerankers (reference model.py:94-95): any callable with the reference's Ranker.forward keywords that returns
@@ -220,7 +222,8 @@ class SAMAudio:
             # register everything first: replacing a tensor the engine already holds (a second load_state_dict) marks BOTH
             # weight sets as not finalized, so each set the model has is finalized again afterwards
             if not dit_missing:
-                self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device))
+                alt = [leaf for leaf, c in hip.ALT16_WEIGHTS.items() if self.alt16_classes & hip.CLS[c]]
+                self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device, alt16_leaves=alt))
                 self._has_dit = True
             if not codec_missing:
                 self._register(convert_codec(state_dict, self.cfg, self.act_dtype, self.device))
@@ -240,6 +243,7 @@ class SAMAudio:
     def _set_precision_options(self, ctx) -> None:
         if self.precision != "fp32":
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_F32_CLASSES, self.f32_classes))
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ALT16_CLASSES, self.alt16_classes))
         else:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_CLASSES, self.quant_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_FORMAT, self.quant_format))
@@ -259,9 +263,14 @@ class SAMAudio:
         for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
             self._set_precision_options(ctx)
 
+    def _alt16_weight(self, name: str) -> bool:
+        """engine tensor `name` is the weight of a class that reads alt-format (bfloat16) operands in this model"""
+        leaf = name.rsplit(".", 1)[-1]
+        return name.startswith("L") and leaf in hip.ALT16_WEIGHTS and bool(self.alt16_classes & hip.CLS[hip.ALT16_WEIGHTS[leaf]])
+
     def _register(self, tensors: Dict[str, torch.Tensor]) -> None:
         for name, t in tensors.items():
-            dt = hip.dtype_code(t.dtype, hip.operands_for(self.precision))
+            dt = hip.dtype_code(t.dtype, hip.operands_for(self.precision), alt_ok=self._alt16_weight(name))
             if t.data_ptr() % 16:   # a view into a larger buffer: the library needs 16-byte aligned pointers
                 t = t.clone()
             self._tensors[name] = t  # keep alive: the library borrows the pointer

@@ -81,7 +81,9 @@ def expected_keys(cfg: SAMAudioConfig, with_codec: bool = True) -> List[str]:
 
 
 def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype,
-                device) -> Dict[str, torch.Tensor]:
+                device, alt16_leaves=()) -> Dict[str, torch.Tensor]:
+    """`alt16_leaves`: per-layer weight names (of "wqkv", "wo", "c_wq", "w13", "w2") whose GEMM class reads bfloat16
+    operands in a mixed-precision model (hip.ALT16_WEIGHTS): converted from fp32 to bfloat16 instead of `act_dtype`."""
     t = cfg.transformer
     D, H, F = t.dim, t.n_heads, t.ffn_hidden
     out: Dict[str, torch.Tensor] = {}
@@ -89,8 +91,9 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
     def f32(x):
         return x.detach().to(device=device, dtype=torch.float32).contiguous()
 
-    def op(x):  # GEMM operand
-        return x.detach().to(device=device, dtype=torch.float32).to(act_dtype).contiguous()
+    def op(x, leaf=None):  # GEMM operand
+        dt = torch.bfloat16 if leaf in alt16_leaves else act_dtype
+        return x.detach().to(device=device, dtype=torch.float32).to(dt).contiguous()
 
     def op_f32(name, x):
         """GEMM operand of a class that may run in exact fp32 inside a 16-bit engine (samaudio.h SAMAUDIO_OPT_F32_CLASSES):
@@ -111,12 +114,12 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
         out[E + "q_norm"] = f32(sd[L + "attention.q_norm.weight"])
         out[E + "k_norm"] = f32(sd[L + "attention.k_norm.weight"])
         out[E + "c_q_norm"] = f32(sd[L + "cross_attention.q_norm.weight"])
-        out[E + "wqkv"] = op(torch.cat([_head_major(W(L + f"attention.{n}.weight"), H) for n in ("wq", "wk", "wv")]))
-        out[E + "wo"] = op(W(L + "attention.wo.weight"))
-        out[E + "c_wq"] = op(_head_major(W(L + "cross_attention.wq.weight"), H))
+        out[E + "wqkv"] = op(torch.cat([_head_major(W(L + f"attention.{n}.weight"), H) for n in ("wq", "wk", "wv")]), "wqkv")
+        out[E + "wo"] = op(W(L + "attention.wo.weight"), "wo")
+        out[E + "c_wq"] = op(_head_major(W(L + "cross_attention.wq.weight"), H), "c_wq")
         out[E + "c_wo"] = op(W(L + "cross_attention.wo.weight"))
-        out[E + "w13"] = op(_interleave16(W(L + "feed_forward.w1.weight"), W(L + "feed_forward.w3.weight")))
-        out[E + "w2"] = op(W(L + "feed_forward.w2.weight"))
+        out[E + "w13"] = op(_interleave16(W(L + "feed_forward.w1.weight"), W(L + "feed_forward.w3.weight")), "w13")
+        out[E + "w2"] = op(W(L + "feed_forward.w2.weight"), "w2")
     # cross-attention K|V projections and k-norm weights of all layers, stacked: one GEMM per evaluation
     out["c_wkv_all"] = op(torch.cat([_head_major(W(f"{P}layers.{i}.cross_attention.{n}.weight"), H)
                                      for i in range(t.n_layers) for n in ("wk", "wv")]))

@@ -49,7 +49,7 @@ def small_full(gpu):
     return dict(cfg=cfg, sd=sd, batch=batch, noise=noise, lat=lat_ref, wav=t_ref + r_ref)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "mixed", "bf16"])
 def test_small_star_eight_clips_full_solve(gpu, small_full, prec):
     f = small_full
     model = SAMAudio(f["cfg"], precision=prec, device=str(gpu))

@@ -78,3 +78,66 @@ def test_separate_fp16_error_next_to_bf16(gpu):
     # bounds = 2 x measured, both inside the north_star's 1e-3 ... and 8x below bf16
     assert errs["fp16"][0] < 1.5e-3 and errs["fp16"][1] < 3.5e-4
     assert errs["fp16"][0] < errs["bf16"][0]
+
+
+@pytest.mark.parametrize("variant", [22, 27])
+@pytest.mark.parametrize("kind", ["act", "swiglu", "gated"])
+def test_mixed_mode_gemm_reads_and_writes_bfloat16_inside_the_fp16_library(gpu, variant, kind):
+    """precision="mixed" (samaudio.h SAMAUDIO_OPT_ALT16_CLASSES): the five big GEMM classes run on bfloat16 operands inside
+    the fp16 build.  GemmParams.flags bit 10: A and W are bfloat16 (the bf16 MFMA); bit 9: the 16-bit output is written as
+    bfloat16 (it feeds another such GEMM).  Against fp32 torch on the bf16-rounded operands; outputs decoded per flag."""
+    import ctypes as C
+    lib = hip.lib("fp16")
+    lib.samaudio_debug_force_gemm_variant(variant)
+    M, N, K = 333, 512, 320
+    A, W = _mk((M, K), 31), _mk((N, K), 32, 1 / math.sqrt(K))
+    Ab, Wb = A.to(torch.bfloat16).to(gpu), W.to(torch.bfloat16).to(gpu)
+    prod = A.to(torch.bfloat16).float() @ W.to(torch.bfloat16).float().T
+    for out_alt in (0, 1):
+        n_out = N // 2 if kind == "swiglu" else N
+        o16 = torch.zeros(M, n_out, device=gpu, dtype=torch.bfloat16 if out_alt else torch.float16)
+        o32 = torch.full((M, N), float("nan"), device=gpu)
+        kw = dict(out_act=o16, act_geom=(0, n_out, 0))
+        want = prod
+        if kind == "swiglu":
+            kw["swiglu"] = 1
+            w1 = prod.view(M, N // 32, 2, 16)[:, :, 0].reshape(M, N // 2)   # 16-row interleave of w1 / w3 (weights.py)
+            w3 = prod.view(M, N // 32, 2, 16)[:, :, 1].reshape(M, N // 2)
+            want = torch.nn.functional.silu(w1) * w3
+        elif kind == "gated":
+            tab, gate, res = _mk((N,), 33).to(gpu), _mk((1, N), 34).to(gpu), _mk((M, N), 35).to(gpu)
+            kw.update(gate_tab=tab, gate=gate, gate_ld=N, rows_per_gate=M, res=res, res_geom=(0, N, 0), out_f32=o32,
+                      f32_geom=(0, N, 0))
+            want = prod * (tab.cpu()[None] + gate.cpu()) + res.cpu()
+        p = util.gemm_params(Ab, Wb, M, N, K, **kw)
+        p.flags = 1024 | (512 if out_alt else 0)
+        hip.check(lib.samaudio_op_gemm(C.byref(p), C.sizeof(p), util.PREC["fp16"], util.stream()))
+        tol16 = want.abs().max().item() * (2.0 ** -8 if out_alt else 2.0 ** -11) * 1.02   # half an ulp of the output format
+        util.report(f"mixed gemm v{variant} {kind} out_alt={out_alt} 16-bit", o16, want, tol16)
+        if kind == "gated":
+            util.report(f"mixed gemm v{variant} {kind} out_alt={out_alt} f32", o32, want, 5e-4)
+
+
+def test_separate_mixed_precision_error_next_to_fp16(gpu):
+    """precision="mixed" end to end at 'mini' dims: bf16 operands on the five big GEMM classes of the DiT layers, fp16 elsewhere -
+    latent and waveform error against the fp32 CPU oracle, between the fp16 and the bf16 figures."""
+    cfg = preset_config("mini")
+    sd = init_state_dict(cfg, seed=8)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 25 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 5, ragged=True)
+    proc = SAMAudioProcessor.from_config(cfg)
+    batch = proc(descriptions=["x"] * 2, audios=clips, text_features=text, text_mask=tmask)
+    noise = synthetic_noise(2, 25)
+    with torch.inference_mode():
+        t_ref, r_ref, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise)
+    errs = {}
+    for prec in ("fp16", "mixed", "bf16"):
+        m = SAMAudio(cfg, precision=prec, device=str(gpu))
+        m.load_state_dict(sd, strict=False)
+        res = m.separate(batch.to(gpu), noise=noise.to(gpu))
+        errs[prec] = ((m.last_latent.cpu() - lat_ref).abs().max().item(),
+                      max((a.cpu() - b).abs().max().item() for a, b in zip(res.target + res.residual, t_ref + r_ref)))
+        print(f"mini separate {prec}: latent err {errs[prec][0]:.3e}, waveform err {errs[prec][1]:.3e}")
+    assert errs["mixed"][0] < errs["bf16"][0] and errs["mixed"][0] < 5 * errs["fp16"][0] + 1e-3
+    assert errs["mixed"][1] < 2 * errs["fp16"][1] + 1e-4

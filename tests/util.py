@@ -5,8 +5,8 @@ import torch
 
 from sam_audio_amd import hip
 
-PREC = {"fp32": hip.F32, "bf16": hip.BF16, "fp16": hip.BF16}   # fp16: the 16-bit mode of libsamaudio_hip_f16.so
-ACT_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+PREC = {"fp32": hip.F32, "bf16": hip.BF16, "fp16": hip.BF16, "mixed": hip.BF16}   # fp16 / mixed: libsamaudio_hip_f16.so
+ACT_DT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "mixed": torch.float16}
 
 
 def stream():
