@@ -34,7 +34,11 @@ The JSON line also carries
   cpu_baseline   - the CPU oracle (oracle/samaudio_oracle.py, a torch fp32 restatement of the reference algorithm)
                    timed on this box's host cores on a bounded sample (2 clips, the whole path; rank 0, N=1 only);
   parity_check   - the same sample (2 clips, fixed noise, the full 16-step solve) run through the HIP path in the benchmarked
-                   precision and compared with the oracle's result: encode latent, ODE latent and waveform max-abs error.
+                   precision and compared with the oracle's result: encode latent, ODE latent and waveform max-abs error;
+  bf16_mode      - the same steps timed with bfloat16 operands everywhere (BASELINE's nominal dtype), with its own parity_check
+                   (outside the 1e-3 bound; the headline mode `mixed` keeps bf16 where the flops are and is inside it);
+  other_configs  - short lines of BASELINE configs[1], [3], [4] and of one GPU's share of configs[2] under strong scaling, each
+                   a sub-process after the main measurement, with its own roofline and parity_check (default invocation only).
 """
 from __future__ import annotations
 
@@ -372,8 +376,9 @@ def build_span_predictor(cfg, precision, dev):
 
 # rocprofv3 kernel symbols of the profile names (profiles/r2_traffic.json is keyed by symbol)
 SYMBOLS = {
-    "gemm8_bf16_256x256_8phase": "sa::gemm8_kernel<false>",        # plain GEMMs: every Linear of the DiT
-    "gemm8_bf16_256x256_8phase_conv": "sa::gemm8_kernel<true>",    # implicit convolutions (patcher, wide codec stages)
+    "gemm8_bf16_256x256_8phase": "sa::gemm8_kernel<false",         # plain GEMMs: every Linear of the DiT (<false, true>: the
+                                                                   # bf16-operand instantiation of the mixed mode)
+    "gemm8_bf16_256x256_8phase_conv": "sa::gemm8_kernel<true",     # implicit convolutions (patcher, wide codec stages)
     "gemm8s_bf16_128x128": "sa::gemm8s_kernel<",
 }
 
@@ -389,8 +394,9 @@ def traffic_of(kernel: str, split: bool = False):
             continue
         key = SYMBOLS.get(kernel.split("/")[-1], "")
         hit = [v for k, v in table.items() if key and k.startswith(key)]
-        if hit:
-            return round(hit[0]["traffic_bytes_per_launch"]), f"HBM bytes per launch, rocprofv3 PMC passes (profiles/{fname})"
+        if hit:   # several instantiations of the symbol: the one with the most launches is the one the roofline is about
+            best = max(hit, key=lambda v: v.get("launches", 0))
+            return round(best["traffic_bytes_per_launch"]), f"HBM bytes per launch, rocprofv3 PMC passes (profiles/{fname})"
     return None, None
 
 

@@ -25,15 +25,15 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       sed 's|asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");|simt::wait_vmcnt(N);|' $src > $OUT/gemm2_simt.hip
       grep -q "simt::wait_vmcnt(N);" $OUT/gemm2_simt.hip || { echo "gemm2.hip: wait_vmcnt<N> statement not found"; exit 1; }
       # and the direct-to-LDS load, inline assembly with operands in the product (see dma16a), becomes the builtin the stub emulates
-      sed -i 's|^.*// SIMT-DMA$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0); (void)lds;|' $OUT/gemm2_simt.hip
+      sed -i 's|^.*// SIMT-DMA$|  simt::dma_asm = true; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0); simt::dma_asm = false; (void)lds;|' $OUT/gemm2_simt.hip
       grep -q "(void)lds;" $OUT/gemm2_simt.hip || { echo "gemm2.hip: dma16a asm statement not found"; exit 1; }
       src=$OUT/gemm2_simt.hip
     fi
     if [ $f = gemm8 ]; then
       # gemm8.hip's scalar-base DMA (dma16s: inline assembly with operands) becomes the builtin the stub emulates
-      sed 's|^.*// SIMT-DMA8$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)sbase + voff), (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); (void)lds;|' $src > $OUT/gemm8_simt.hip
+      sed 's|^.*// SIMT-DMA8$|  simt::dma_asm = true; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)sbase + voff), (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); simt::dma_asm = false; (void)lds;|' $src > $OUT/gemm8_simt.hip
       grep -q "(void)lds;" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16s asm statement not found"; exit 1; }
-      sed -i 's|^.*// SIMT-DMA8V$|  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); (void)lds; /*v*/|' $OUT/gemm8_simt.hip
+      sed -i 's|^.*// SIMT-DMA8V$|  simt::dma_asm = true; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); simt::dma_asm = false; (void)lds; /*v*/|' $OUT/gemm8_simt.hip
       grep -q "(void)lds; /\*v\*/" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16v asm statement not found"; exit 1; }
       EXTRA="-I $SRC"
       src=$OUT/gemm8_simt.hip

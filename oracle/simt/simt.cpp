@@ -111,6 +111,16 @@ void wait_vmcnt(int n) {
   }
 }
 
+thread_local bool dma_asm = false;
+void wait_vmcnt_if_visible() {
+  wave_sync();
+  Wave* w = cur->wave;
+  bool any = false;
+  for (const Wave::Dma& d : w->pending) any = any || d.visible;
+  if (any) wait_vmcnt(0);
+  else wave_sync();   // same number of wave-synchronous points on both paths
+}
+
 // `asm volatile("...")` statements of the kernels: a wave-synchronous point; `s_waitcnt vmcnt(<literal>)` retires DMAs.
 // (The one statement whose count is an asm operand, gemm2.hip wait_vmcnt<N>, is rewritten to simt::wait_vmcnt(N) by
 // oracle/simt/build.sh - the preprocessor cannot see an operand's value.)

@@ -63,7 +63,8 @@ struct Wave {
   alignas(64) unsigned char rbuf[2][WAVE][8];
   // global_load_lds instructions issued by this wave and not yet retired by one of its s_waitcnt vmcnt(N)
   // (only used in the "late" DMA mode, see dma_late())
-  struct Dma { char* base; unsigned char data[WAVE][16]; };
+  struct Dma { char* base; unsigned char data[WAVE][16]; bool visible = true; };   // visible: issued through the builtin (the compiler
+                                                                                   // knows it; an inline-assembly DMA it does not)
   std::deque<Dma> pending;
   unsigned long dma_first = 0;  // sequence number of pending.front()
 };
@@ -101,6 +102,8 @@ const unsigned char* row_publish(const void* data, size_t n);
 // make the real vmcnt(N) retire fewer DMAs than this model assumes.
 bool dma_late();
 void wait_vmcnt(int n);   // wave-synchronous
+void wait_vmcnt_if_visible();   // __syncthreads(): vmcnt(0) iff a compiler-visible DMA is pending
+extern thread_local bool dma_asm;   // the next global_load_lds stands for an inline-assembly DMA (set by the rewritten asm lines)
 void asm_stmt(const char* text);
 }  // namespace simt
 
@@ -126,7 +129,10 @@ void asm_stmt(const char* text);
 #define blockDim (simt::cur->bdim)
 #define gridDim (simt::cur->gdim)
 inline void __syncthreads() {
-  if (simt::dma_late()) simt::wait_vmcnt(0);  // hipcc emits s_waitcnt vmcnt(0) lgkmcnt(0) before the s_barrier
+  // hipcc emits s_waitcnt vmcnt(0) before the s_barrier ONLY for direct-to-LDS loads it can see (the builtin); a DMA issued as
+  // inline assembly (gemm2.hip dma16a, gemm8.hip dma16s / dma16v) is retired by the kernel's explicit s_waitcnt vmcnt alone
+  // (ADVICE round 3).  vmcnt retires in order, so one visible DMA in flight drains everything.
+  if (simt::dma_late()) simt::wait_vmcnt_if_visible();
   simt::block_sync();
 }
 
@@ -232,6 +238,7 @@ inline void __builtin_amdgcn_global_load_lds(const __attribute__((address_space(
   while (w->dma_first + w->pending.size() <= seq) {
     w->pending.emplace_back();
     w->pending.back().base = (char*)base + off;
+    w->pending.back().visible = !simt::dma_asm;
   }
   std::memcpy(w->pending[seq - w->dma_first].data[f->lane], (const void*)g, 16);
 }
