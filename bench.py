@@ -407,11 +407,15 @@ def reference_flops(cfg, clips, text_len):
     """Algorithmic FLOPs of one separate() over `clips` 10 s clips as the REFERENCE executes it:
     per evaluation L x (2T D^2 x 6 + 4 T^2 D + 6 T D F + cross K,V and scores) + patcher 12 T D^2 + the 768/1024/128/256-wide
     projections, x 32 evaluations; DAC-VAE encode 0.487 TF + decode 2 x 1.096 TF per clip (default codec dims)."""
-    t = cfg.transformer
-    D, F, L, T, Lt = t.dim, t.ffn_hidden, t.n_layers, 250, text_len
+    t, codec = cfg.transformer, cfg.audio_codec
+    T = int(round(CLIP_SECONDS * codec.sample_rate / codec.hop_length))   # 250 latent frames per 10 s clip
+    D, F, L, Lt = t.dim, t.ffn_hidden, t.n_layers, text_len
+    text_d, video_d, anchor_d, latent = cfg.text_encoder.dim, cfg.vision_encoder.dim, cfg.anchor_embedding_dim, t.out_channels
     layer = 2 * T * D * D * 6 + 4 * T * T * D + 6 * T * D * F + 2 * Lt * D * D * 2 + 4 * T * Lt * D
-    per_eval = L * layer + 12 * T * D * D + 2 * T * D * (768 + 1024 + 128 + 256) + 2 * Lt * D * 768 + 6 * Lt * D * D
-    return clips * (32.0 * per_eval + 0.487e12 + 2 * 1.096e12)
+    # input projection (3 x latent wide, model.py:116-125), video conv1x1, anchor projection, output projection (widths from cfg)
+    per_eval = (L * layer + 12 * T * D * D + 2 * T * D * (3 * latent + video_d + anchor_d + latent) + 2 * Lt * D * text_d
+                + 6 * Lt * D * D)
+    return clips * (32.0 * per_eval + 0.487e12 + 2 * 1.096e12)   # codec figures: SURVEY.md section 8(a2, a15), default codec dims
 
 
 def rooflines(stats):

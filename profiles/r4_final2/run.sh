@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 second closing set (final commit: mixed-precision headline, persistent kernels): the bench line as the driver runs it (fp16 headline, bf16 side by side, other_configs), stream
-# count A/B on the persistent kernels, rocprofv3 kernel stats of the serialised command, PMC passes restricted to the
+# Round-4 second closing set (mixed-precision headline, persistent kernels): the bench line as the driver runs it (mixed
+# headline, pure bf16 side by side, other_configs), quick lines of the pure fp16 / bf16 modes, rocprofv3 kernel stats of the serialised command, PMC passes restricted to the
 # dominant kernel's symbol (HBM traffic: FETCH_SIZE / WRITE_SIZE in separate runs; SQ counters), whole GPU suite.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r4_final2; mkdir -p $O
@@ -18,6 +18,6 @@ done
 python tools/pmc_traffic.py $O/a > $O/traffic_gemm8.json 2>$O/traffic.err; rm -rf $O/a
 ( PROBE_ROWS=4000 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $O/sq -o p -- python tools/gemm_probe.py 22:qkv 22:wo 22:c_wq 22:w13 22:w2 ) > $O/pmc_sq.log 2>&1
 f=$(find $O/sq -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f $O/pmc_sq_counters.csv; rm -rf $O/sq
-timeout 600 python tools/stress_determinism.py --reps 40 --config default --clips 4 --frames 250 --what forward > $O/stress_default_forward.log 2>&1; tail -1 $O/stress_default_forward.log
+timeout 600 python tools/stress_determinism.py --reps 40 --config default --clips 4 --frames 250 --what forward --precision mixed > $O/stress_default_forward.log 2>&1; tail -1 $O/stress_default_forward.log
 timeout 300 python tools/diag_rerun.py --runs 6 > $O/rerun_checksums.log 2>&1; tail -3 $O/rerun_checksums.log
 ( timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/gpu_tests.log 2>&1; echo "gpu suite exit=$?"; tail -2 $O/gpu_tests.log

@@ -292,14 +292,33 @@ class SAMAudioJudgeConfig:
     """reference config.py:234-251.  `text_model` stays a plain dict of ModernBertConfig arguments (the text tower
     runs on PyTorch-ROCm through transformers)."""
 
+    _warned_prenorm = False
+
     def __init__(self, audio_codec=None, transformer=None, text_model: Optional[Dict[str, Any]] = None,
                  finetune_transformer=None, nth_text_layer: Optional[int] = 22, bottleneck_dim: int = 256,
-                 last_text_layer_prenorm: bool = True):
+                 last_text_layer_prenorm: Optional[bool] = None):
         """`last_text_layer_prenorm` (no reference counterpart): what `hidden_states[nth_text_layer]` means when
         nth_text_layer == num_hidden_layers (the reference's default, 22 on a 22-layer tower, judge.py:74-88).  transformers
         4.48 - 4.5x - the generation the reference pins and the released Judge checkpoint was trained with - append the last
         layer's output BEFORE `final_norm`; transformers 5.x record the normalised tensor there.  True (default) = the 4.x
         meaning whatever transformers version is installed; False = the 5.x meaning (= last_hidden_state)."""
+        if last_text_layer_prenorm is None:   # left at its default (ADVICE round 3): say so once where the two meanings differ
+            last_text_layer_prenorm = True
+            layers = (text_model or {}).get("num_hidden_layers", 22)
+            if nth_text_layer == layers and not SAMAudioJudgeConfig._warned_prenorm:
+                try:
+                    import transformers
+                    major = int(transformers.__version__.split(".")[0])
+                except Exception:   # transformers absent: nothing to disagree with
+                    major = 0
+                if major >= 5:
+                    import warnings
+                    warnings.warn(
+                        f"SAMAudioJudgeConfig: nth_text_layer == num_hidden_layers ({layers}) and transformers {transformers.__version__} "
+                        "is installed - under transformers 5.x the reference's hidden_states[nth_text_layer] is the tensor AFTER "
+                        "final_norm, this build defaults to the 4.x meaning (before it, what the released Judge checkpoint was "
+                        "trained with).  Pass last_text_layer_prenorm=True / False to choose explicitly.")
+                    SAMAudioJudgeConfig._warned_prenorm = True
         self.last_text_layer_prenorm = bool(last_text_layer_prenorm)
         self.audio_codec = _build(DACVAEConfig, audio_codec)
         self.transformer = _build(PEAVTransformerConfig, transformer)
