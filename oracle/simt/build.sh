@@ -10,9 +10,16 @@ OUT=../_simt
 LIB=libsamaudio_simt.so
 POISON=""
 if [ "$1" = "poison" ]; then OUT=../_simt/poison; LIB=libsamaudio_simt_poison.so; POISON="-DSIMT_POISON"; fi
+# `build.sh asan`: the same sources under AddressSanitizer (libsamaudio_simt_asan.so).  "Device" memory is host heap memory on
+# the simulator, so a kernel that reads or writes past the end of a tensor it was handed - which on the GPU silently picks up
+# whatever the allocator left behind the buffer - is reported with the kernel's source line.  Run with
+#   LD_PRELOAD=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so ASAN_OPTIONS=detect_leaks=0:halt_on_error=0 \
+#   SAMAUDIO_EMU_DRYRUN=simt SAMAUDIO_SIMT_ASAN=1 python -m pytest tests/test_path_gpu.py -m gpu -k concurrent_streams
+SAN=""
+if [ "$1" = "asan" ]; then OUT=../_simt/asan; LIB=libsamaudio_simt_asan.so; SAN="-fsanitize=address -fsanitize-recover=address -fno-omit-frame-pointer -g1 -shared-libsan"; fi
 mkdir -p $OUT
 CXX=/opt/rocm/lib/llvm/bin/clang++
-FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp $POISON -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp $POISON $SAN -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
 pids=()
 for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 mbert api; do
   src=$SRC/$f.hip
@@ -45,6 +52,6 @@ done
 $CXX $FLAGS -c simt.cpp -o $OUT/simt.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$CXX -shared -fPIC -fopenmp $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/vit_kernels.o $OUT/t5_kernels.o $OUT/engine.o $OUT/peav.o $OUT/vit.o $OUT/t5.o $OUT/mbert.o $OUT/api.o $OUT/simt.o -o ../_simt/$LIB.tmp
+$CXX -shared -fPIC -fopenmp $SAN $OUT/gemm.o $OUT/gemm2.o $OUT/gemm8.o $OUT/kernels.o $OUT/attention.o $OUT/peav_kernels.o $OUT/vit_kernels.o $OUT/t5_kernels.o $OUT/engine.o $OUT/peav.o $OUT/vit.o $OUT/t5.o $OUT/mbert.o $OUT/api.o $OUT/simt.o -o ../_simt/$LIB.tmp
 mv -f ../_simt/$LIB.tmp ../_simt/$LIB   # atomic: a process that has the old library mapped keeps its inode
 echo "built ../_simt/$LIB"

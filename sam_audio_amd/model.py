@@ -324,6 +324,13 @@ class SAMAudio:
             else:
                 own._workspace = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = own._workspace.data_ptr()
+        # contexts never share scratch: the workspaces of the model and of its stream lanes are pairwise disjoint
+        for other in [self] + list(self._lanes):
+            ws = other._workspace
+            if other is not own and ws is not None:
+                lo, hi = ws.data_ptr(), ws.data_ptr() + ws.numel()
+                if base < hi and lo < base + own._workspace.numel():
+                    raise RuntimeError("engine contexts were handed overlapping workspaces")
         aligned = (base + 255) // 256 * 256
         hip.check(self._lib.samaudio_set_workspace(own._ctx, C.c_void_p(aligned),
                                                    own._workspace.numel() - (aligned - base)))
@@ -471,6 +478,14 @@ class SAMAudio:
                 sl = slice(rr.start, rr.stop)
                 part = [None if c is None else c[sl] for c in cond]
                 stream = main if (lane is None or self._serial_groups) else lane.stream
+                if stream is not main:
+                    # tensors allocated on the caller's stream and used on the lane's: tell the caching allocator, so that
+                    # none of their blocks is handed out again before the lane's work on them has finished (the explicit
+                    # wait_stream pair below already orders it for the tensors this frame holds; this covers the views
+                    # `_prepare` keeps in `lane._live` beyond this call)
+                    for t in [state, wavs] + list(cond):
+                        if t is not None and t.is_cuda:
+                            t.record_stream(stream)
                 with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(stream):
                     self._prepare(*part, lane=lane)
                     ctx = self._ctx if lane is None else lane._ctx

@@ -41,9 +41,11 @@ def _enable_emu_dryrun():
     from sam_audio_amd import hip
     which = "simt" if EMU_MODE == "simt" else "emu"
     poison = which == "simt" and os.environ.get("SAMAUDIO_SIMT_POISON") == "1"   # LDS poisoned before every workgroup
-    emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}{'_poison' if poison else ''}.so")
+    asan = which == "simt" and os.environ.get("SAMAUDIO_SIMT_ASAN") == "1"   # AddressSanitizer build (oracle/simt/build.sh)
+    emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}{'_poison' if poison else '_asan' if asan else ''}.so")
     if not os.environ.get("SAMAUDIO_EMU_NOBUILD"):
-        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")] + (["poison"] if poison else []))
+        subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")]
+                              + (["poison"] if poison else ["asan"] if asan else []))
     lib = C.CDLL(emu)
     for name, (res, args) in hip._PROTOS.items():
         if which == "emu" and name.startswith(("samaudio_vit_", "samaudio_t5_", "samaudio_mbert_")):
@@ -68,6 +70,28 @@ def _enable_emu_dryrun():
     torch.Tensor.to = to_copy
     torch.cuda.device = lambda *a, **k: contextlib.nullcontext()
     torch.cuda.current_stream = lambda *a, **k: None
+
+    class _NoStream:   # SAMAudio(streams=2): the row groups still run on two engine contexts from two host threads
+        def __init__(self, *a, **k):
+            pass
+
+        def wait_stream(self, other):
+            pass
+
+    torch.cuda.Stream = _NoStream
+    torch.cuda.stream = lambda *a, **k: contextlib.nullcontext()
+    torch.cuda.synchronize = lambda *a, **k: None
+    from sam_audio_amd import model as _model_mod
+    concurrent = _model_mod.SAMAudio._solve_concurrent
+
+    def one_group_after_the_other(self, *a, **k):   # the simulator runs one launch at a time (one kernel body per process)
+        keep, self._serial_groups = self._serial_groups, True
+        try:
+            return concurrent(self, *a, **k)
+        finally:
+            self._serial_groups = keep
+
+    _model_mod.SAMAudio._solve_concurrent = one_group_after_the_other
     if which == "emu":
         os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection's kernels are not emulated
         from sam_audio_amd import judge
