@@ -90,7 +90,8 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
 /* Precision of single GEMM classes (the reference computes everything in fp32: README.md:48, no autocast anywhere).
  *   SAMAUDIO_OPT_F32_CLASSES (16-bit contexts; value = mask of SAMAUDIO_CLS_* bits, default 0): the named classes run on
  *   exact-fp32 operands (v_mfma_f32_16x16x4f32) inside an otherwise 16-bit context.  Needs the class's weights registered
- *   a second time in fp32 under "<name>.f32" (samaudio_set_tensor); only the classes in SAMAUDIO_CLS_F32_CAPABLE - the
+ *   a second time in fp32 under "<name>.f32" (samaudio_set_tensor) - checked by samaudio_finalize(ctx, 0) and, on a finalized
+ *   context, by samaudio_set_option itself (SAMAUDIO_ERR_WEIGHT names the missing copy); only the classes in SAMAUDIO_CLS_F32_CAPABLE - the
  *   ones whose fp32 cost is < 1 % of a step - are accepted.
  *   SAMAUDIO_OPT_QUANT_CLASSES / SAMAUDIO_OPT_QUANT_FORMAT (fp32 contexts; measurement aid for the error budget of
  *   DESIGN.md section 4): the GEMMs of the named classes round BOTH operands to the 16-bit format (1 = bfloat16,

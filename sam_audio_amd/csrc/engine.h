@@ -50,6 +50,7 @@ class Engine {
   Status set_tensor(const char* name, const void* p, int dtype, int ndim, const int64_t* shape);
   Status finalize(int what);
   Status set_option(int option, int value);
+  Status check_f32_weights(int classes) const;   // every "<name>.f32" operand copy the classes read is registered
   size_t workspace_bytes(int rows, int frames, int text_len, int codec_items, int64_t samples);
   Status set_workspace(void* p, size_t bytes);
 

@@ -233,6 +233,7 @@ Status Engine::finalize(int what) {
       OPTF(y_w13, "y_w13", 2 * D, D);
       OPTF(y_w2, "y_w2", D, D);
 #undef OPTF
+      SA_TRY(check_f32_weights(f32_classes_));
     }
     dit_ready_ = true;
   } else {
@@ -412,6 +413,19 @@ static double gemm_alg_bytes(const GemmParams& p, size_t esz) {
   return b;
 }
 
+Status Engine::check_f32_weights(int classes) const {
+  const struct { int cls; const float* w; const char* name; } need[] = {
+      {SAMAUDIO_CLS_OUT, g32_.w_out, "w_out"},       {SAMAUDIO_CLS_TIME, g32_.t_w13, "t_w13"},   {SAMAUDIO_CLS_TIME, g32_.t_w2, "t_w2"},
+      {SAMAUDIO_CLS_TIME, g32_.tb_w, "tb_w"},        {SAMAUDIO_CLS_IN, g32_.proj_wy, "proj_wy"}, {SAMAUDIO_CLS_PREP, g32_.proj_wf, "proj_wf"},
+      {SAMAUDIO_CLS_PREP, g32_.mem_w, "mem_w"},      {SAMAUDIO_CLS_PREP, g32_.vid_w, "vid_w"},   {SAMAUDIO_CLS_PREP, g32_.anc_w, "anc_w"},
+      {SAMAUDIO_CLS_YEMB, g32_.y_w13, "y_w13"},      {SAMAUDIO_CLS_YEMB, g32_.y_w2, "y_w2"}};
+  for (const auto& n : need)
+    if ((classes & n.cls) && !n.w)
+      return fail(SAMAUDIO_ERR_WEIGHT, std::string("SAMAUDIO_OPT_F32_CLASSES: the fp32 operand copy '") + n.name +
+                                           ".f32' of a class that is switched to fp32 is not registered");
+  return Status{};
+}
+
 Status Engine::set_option(int option, int value) {
   if (option == SAMAUDIO_OPT_TAIL_SPLIT) {
     tail_split_ = value != 0;
@@ -421,6 +435,7 @@ Status Engine::set_option(int option, int value) {
     if (value && !bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_F32_CLASSES applies to 16-bit contexts (an fp32 context is exact already)");
     if (value & ~SAMAUDIO_CLS_F32_CAPABLE)
       return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_F32_CLASSES: only the classes of SAMAUDIO_CLS_F32_CAPABLE can run in fp32");
+    if (dit_ready_) SA_TRY(check_f32_weights(value));   // (before finalize(0): checked there)
     f32_classes_ = value;
     return Status{};
   }

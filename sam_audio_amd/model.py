@@ -20,7 +20,7 @@ import torch
 from . import hip
 from .config import SAMAudioConfig
 from .processor import Batch
-from .weights import convert_codec, convert_dit, split_missing_unexpected
+from .weights import F32_SOURCE_KEYS, convert_codec, convert_dit, convert_dit_f32, split_missing_unexpected
 
 DFLT_ODE_OPT = {"method": "midpoint", "options": {"step_size": 2 / 32}}  # reference model.py:22
 
@@ -121,6 +121,8 @@ class SAMAudio:
         # the same kernels as the timed ones)
         self.tail_split: Optional[bool] = None
         self._lanes: List[_Lane] = []
+        self._f32_have = 0                    # F32-capable classes whose fp32 operand copies are registered
+        self._f32_sd: Dict[str, torch.Tensor] = {}
         self._profiling = self._serial_groups = False
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
@@ -223,7 +225,12 @@ class SAMAudio:
             # weight sets as not finalized, so each set the model has is finalized again afterwards
             if not dit_missing:
                 alt = [leaf for leaf, c in hip.ALT16_WEIGHTS.items() if self.alt16_classes & hip.CLS[c]]
-                self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device, alt16_leaves=alt))
+                self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device, alt16_leaves=alt,
+                                           f32_classes=self.f32_classes))
+                # fp32 operand copies exist for the classes that run in fp32 now; set_f32_classes adds a class's later
+                # from these references to the checkpoint entries (no copy is made here)
+                self._f32_have = self.f32_classes
+                self._f32_sd = {k: state_dict[k] for k in F32_SOURCE_KEYS}
                 self._has_dit = True
             if not codec_missing:
                 self._register(convert_codec(state_dict, self.cfg, self.act_dtype, self.device))
@@ -250,7 +257,14 @@ class SAMAudio:
 
     def set_f32_classes(self, classes) -> None:
         """Switch the exact-fp32 GEMM classes of a 16-bit model (see __init__); takes effect from the next call."""
-        self.f32_classes = hip.class_mask(classes)
+        self.f32_classes = 0 if self.precision == "fp32" else hip.class_mask(classes)
+        need = self.f32_classes & ~self._f32_have
+        if need and self._has_dit:   # the classes switched on for the first time: their "<name>.f32" operand copies
+            with torch.cuda.device(self.device):
+                self._register(convert_dit_f32(self._f32_sd, self.cfg, self.device, need))
+                self._f32_have |= need
+                self._lanes = []   # stream lanes borrow the registered tensors: rebuilt on demand
+                hip.check(self._lib.samaudio_finalize(self._ctx, 0))   # binds the new names
         for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
             self._set_precision_options(ctx)
 

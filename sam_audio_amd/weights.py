@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import math
 import re
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -80,10 +80,49 @@ def expected_keys(cfg: SAMAudioConfig, with_codec: bool = True) -> List[str]:
     return list(init_state_dict(cfg, device="meta", with_codec=with_codec).keys())
 
 
+# the GEMM classes a 16-bit engine can run on exact-fp32 operands (hip.CLS_F32_CAPABLE) and the engine weights each reads
+F32_CLASS_WEIGHTS = {"out": ("w_out",), "time": ("t_w13", "t_w2", "tb_w"), "in": ("proj_wy",),
+                     "prep": ("proj_wf", "mem_w", "vid_w", "anc_w"), "yemb": ("y_w13", "y_w2")}
+_F32_WEIGHT_CLASS = {w: c for c, ws in F32_CLASS_WEIGHTS.items() for w in ws}
+# the checkpoint entries those weights are made of (SAMAudio keeps references to them so that set_f32_classes can add a
+# class's fp32 copies later without the whole checkpoint)
+F32_SOURCE_KEYS = tuple(["transformer.output.weight", "transformer.t_block.weight", "proj.weight", "memory_proj.weight",
+                         "align_masked_video.conv.weight", "embed_anchors.gate", "embed_anchors.proj.weight"]
+                        + [f"transformer.{e}.projection.{w}.weight" for e in ("y_embedder", "t_embedder") for w in ("w1", "w2", "w3")])
+
+
+def _f32_capable_sources(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, device) -> Dict[str, "callable"]:
+    """engine name -> thunk producing the fp32 operand of an F32-capable weight from the checkpoint"""
+    def W(key):
+        return sd[key].detach().to(device=device, dtype=torch.float32)
+
+    P, c2 = "transformer.", cfg.transformer.out_channels
+    src = {"w_out": lambda: W(P + "output.weight"), "tb_w": lambda: W(P + "t_block.weight"),
+           "proj_wy": lambda: W("proj.weight")[:, :c2], "proj_wf": lambda: W("proj.weight")[:, 2 * c2:],
+           "mem_w": lambda: W("memory_proj.weight"), "vid_w": lambda: W("align_masked_video.conv.weight").squeeze(-1),
+           "anc_w": lambda: torch.tanh(W("embed_anchors.gate")).reshape(1, 1) * W("embed_anchors.proj.weight")}
+    for pre, name in (("y", "y_embedder"), ("t", "t_embedder")):
+        Q = f"{P}{name}.projection."
+        src[f"{pre}_w13"] = lambda Q=Q: _interleave16(W(Q + "w1.weight"), W(Q + "w3.weight"))
+        src[f"{pre}_w2"] = lambda Q=Q: W(Q + "w2.weight")
+    return src
+
+
+def convert_dit_f32(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, device, classes: int) -> Dict[str, torch.Tensor]:
+    """Only the "<name>.f32" operand copies of the F32-capable classes in the mask `classes` (hip.CLS bits)."""
+    from . import hip
+    return {name + ".f32": make().contiguous() for name, make in _f32_capable_sources(sd, cfg, device).items()
+            if classes & hip.CLS[_F32_WEIGHT_CLASS[name]]}
+
+
 def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype,
-                device, alt16_leaves=()) -> Dict[str, torch.Tensor]:
+                device, alt16_leaves=(), f32_classes: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """`alt16_leaves`: per-layer weight names (of "wqkv", "wo", "c_wq", "w13", "w2") whose GEMM class reads bfloat16
-    operands in a mixed-precision model (hip.ALT16_WEIGHTS): converted from fp32 to bfloat16 instead of `act_dtype`."""
+    operands in a mixed-precision model (hip.ALT16_WEIGHTS): converted from fp32 to bfloat16 instead of `act_dtype`.
+    `f32_classes` (16-bit models): mask of the F32-capable classes whose weights also get an fp32 copy under
+    "<name>.f32" (None = all five, 0.5 GB at large* dims; SAMAudio passes the classes it will run in fp32)."""
+    from . import hip
+    want32 = hip.CLS_F32_CAPABLE if f32_classes is None else f32_classes
     t = cfg.transformer
     D, H, F = t.dim, t.n_heads, t.ffn_hidden
     out: Dict[str, torch.Tensor] = {}
@@ -97,9 +136,9 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
 
     def op_f32(name, x):
         """GEMM operand of a class that may run in exact fp32 inside a 16-bit engine (samaudio.h SAMAUDIO_OPT_F32_CLASSES):
-        the 16-bit copy under `name`, the fp32 one under `name + ".f32"` (0.5 GB at large* dims for all eleven)."""
+        the 16-bit copy under `name`, the fp32 one under `name + ".f32"` when its class is in `f32_classes`."""
         out[name] = op(x)
-        if act_dtype != torch.float32:
+        if act_dtype != torch.float32 and want32 & hip.CLS[_F32_WEIGHT_CLASS[name]]:
             out[name + ".f32"] = f32(x)
 
     def W(key):

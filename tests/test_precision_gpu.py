@@ -110,13 +110,36 @@ def test_option_validation(gpu, case):
         hip.check(m16._lib.samaudio_set_option(m16._ctx, hip.OPT_QUANT_CLASSES, 1))
     with pytest.raises(AssertionError):
         hip.check(m32._lib.samaudio_set_option(m32._ctx, hip.OPT_QUANT_FORMAT, 3))
-    # a class switched on without its fp32 weight copy fails loudly at the first launch, not silently in 16 bits
+    # a class switched on without its fp32 weight copy fails loudly when the weight set is finalized (naming the copy), not
+    # silently in 16 bits and not only at the class's first launch
     m = SAMAudio(case["cfg"], precision="bf16", device=str(gpu), f32_classes="out")
     from sam_audio_amd.weights import convert_dit
-    t = {k: v for k, v in convert_dit(case["sd"], case["cfg"], torch.bfloat16, gpu).items() if not k.endswith(".f32")}
+    t = convert_dit(case["sd"], case["cfg"], torch.bfloat16, gpu, f32_classes=0)
+    assert not any(k.endswith(".f32") for k in t)
     m._register(t)
-    hip.check(m._lib.samaudio_finalize(m._ctx, 0))
-    m._has_dit = True
+    with pytest.raises(RuntimeError, match="w_out.f32"):
+        hip.check(m._lib.samaudio_finalize(m._ctx, 0))
+    # ... and on a finalized context the option itself is refused
+    m16b = SAMAudio(case["cfg"], precision="bf16", device=str(gpu), f32_classes=0)
+    m16b._register(t)
+    hip.check(m16b._lib.samaudio_finalize(m16b._ctx, 0))
+    with pytest.raises(RuntimeError, match="t_w13.f32"):
+        hip.check(m16b._lib.samaudio_set_option(m16b._ctx, hip.OPT_F32_CLASSES, hip.CLS["time"]))
+
+
+def test_f32_copies_follow_the_classes_in_use(gpu, case):
+    """Only the classes that run in fp32 carry an fp32 operand copy; set_f32_classes adds a class's copies the first time it
+    is switched on, and the result equals that of a model built with the class from the start, bit for bit."""
+    opt = {"method": "midpoint", "options": {"step_size": 0.25}}
+    m = SAMAudio(case["cfg"], precision="bf16", device=str(gpu), f32_classes="out")
+    m.load_state_dict(case["sd"], strict=False)
+    have = {k for k in m.engine_tensors() if k.endswith(".f32")}
+    assert have == {"w_out.f32"}, have
+    m.set_f32_classes("out,time,yemb")
+    have = {k for k in m.engine_tensors() if k.endswith(".f32")}
+    assert have == {"w_out.f32", "t_w13.f32", "t_w2.f32", "tb_w.f32", "y_w13.f32", "y_w2.f32"}, have
     m._prepare(*case["cond"])
-    with pytest.raises(RuntimeError):
-        m.solve(case["noisy"].to(gpu), {"method": "midpoint", "options": {"step_size": 0.5}})
+    got = m.solve(case["noisy"].to(gpu), opt)
+    _, want = _solve(case, gpu, "bf16", f32_classes="out,time,yemb")
+    assert torch.equal(got.cpu(), want)
+    assert SAMAudio(case["cfg"], precision="bf16", device=str(gpu), f32_classes=None).f32_classes == 0
