@@ -945,8 +945,16 @@ template <int N> __device__ __forceinline__ void wait_vm_lit() {   // literal co
   else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
-template <bool PIPE, bool CONV, bool ALT = false, int PROD = -1>
+// PF > 0 (roles with PROD = 0, plain GEMMs): L2 PREFETCH.  In the model - few rows, every launch streaming its own layer's weights
+// from HBM - a launch of <= 256 workgroups is bound by latency x depth: 3 K-tiles (96 KiB, all the LDS ring can hold) in flight
+// per CU behind ~2 us of HBM latency.  The multiplying waves, which wait for no load of their own, therefore TOUCH the lines of K-tile
+// t + 3 + PF while K-tile t + 3 is being requested: one 4-byte load per lane and K-tile, lane -> one 128-byte line (the K-tile's 64
+// elements of one of the row block's 32 A rows / 32 W rows); the data is dropped, the line is in L2 when its DMA asks for it.
+// (Issued by the multiplying waves, not the requesting ones: vmcnt retires in order, so a requesting wave would wait for its own
+// touches - HBM misses - before it could see its younger DMAs complete.)
+template <bool PIPE, bool CONV, bool ALT = false, int PROD = -1, int PF = 0>
 __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const GemmParams p, const int skip256) {
+  static_assert(PF == 0 || (PROD == 0 && !CONV), "the prefetch belongs to the plain-GEMM form whose multiplying waves request nothing");
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 4 : 2;
   constexpr bool ROLES = PROD >= 0;
@@ -1075,6 +1083,27 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
   };
 
   if constexpr (PIPE) {
+    // L2 prefetch (PF > 0): this lane's line of K-tile 0 - A row (lanes 0 - 31) or W row (lanes 32 - 63) of the wave's row block
+    const char* touch_base = nullptr;
+    // The loads' destination: ONE register, defined once by an asm the compiler cannot rematerialise and passed to every touch as an
+    // INPUT - a single-definition value has no copies at control-flow merges (as an in/out operand it had: the tail paths each got
+    // their own copy; an accumulation register instead made the allocator split the file 128 / 128 and spill through it).  A touch may land long after its statement: its register must not be given to anything else
+    // before the s_waitcnt vmcnt(0) that follows the K loop, which the last statement below (a use after that wait) guarantees.
+    unsigned touch_sink = 0;
+    if constexpr (PF > 0) asm volatile("v_mov_b32 %0, 0" : "=v"(touch_sink));
+    if constexpr (PF > 0) {
+      const int row = wave * 32 + (lane & 31);
+      int m = m0 + row, n = n0 + row;
+      m = m < p.M ? m : p.M - 1;
+      n = n < p.N ? n : p.N - 1;
+      touch_base = lane < 32 ? (const char*)(A0 + (long)m * p.lda) : (const char*)(W0 + (long)n * p.K);
+    }
+    auto touch = [&](int kt) {   // branch-free: beyond the last K-tile the last one is touched again (an L2 hit)
+      if constexpr (PF > 0) {
+        const char* line = touch_base + (size_t)(kt < nt ? kt : nt - 1) * (BK * 2);
+        asm volatile("global_load_dword %0, %1, off" ::"v"(touch_sink), "v"(line) : "memory");
+      }
+    };
     bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
     // loads per K-tile of a multiplying wave: all 8 of its row block, or - with requesting waves - PROD of the A tile's
     constexpr int MINE = ROLES ? PROD : 8;
@@ -1099,6 +1128,7 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
       constexpr int OTHER = 1 - decltype(SET)::value;
       // K-tile t+S-1 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
       if (t + S - 1 < nt) stage_mine((t + S - 1) % S, t + S - 1);
+      touch(t + S - 1 + PF);
       if constexpr (decltype(NEXT)::value) {
         // K-tile t+1 has landed; the younger ones (t+2 .. t+S-1, as far as they exist) may be in flight
         if constexpr (MINE > 0) {   // (a multiplying wave that requests nothing has nothing to wait for)
@@ -1124,6 +1154,8 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
     stage_mine(0, 0);
     if (nt > 1) stage_mine(1, 1);
     if (S == 4 && nt > 2) stage_mine(2, 2);
+#pragma unroll
+    for (int d = 0; d < PF; ++d) touch(S - 1 + d);   // the K-tiles the first PF steps will request
     // K-tile 0 has landed; up to S - 2 younger ones stay in flight
     if constexpr (MINE > 0) {
       if (S == 4 && nt > 2) wait_vm_lit<2 * MINE>();
@@ -1142,6 +1174,10 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
       step(t + 1, I1{}, std::false_type{});
     } else {
       step(t, I0{}, std::false_type{});
+    }
+    if constexpr (PF > 0) {   // the touches have returned before their register is given to anything else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" ::"v"(touch_sink));
     }
     if (p.flags & 64) {
       epilogue8_linear<1>(p, acc, b, m0 + wr * 64, n0 + wc * 64, lane);
@@ -1230,13 +1266,21 @@ static GemmParams with_epilogue_choice(const GemmParams& p) {
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
 // alt-format operands (flags bit 10, mixed mode) exist for plain GEMMs only - the DiT's Linears - gemm8_alt_ok()
 #define SA_GEMM8S_ROLES_DEFAULT (-1)   // the shipped form of the pipelined kernel: -1 no roles, 0 / 2 = PROD
+#define SA_GEMM8S_PREFETCH_DEFAULT 0   // ... and its L2 prefetch distance (roles 0 only): 0 none, 4 / 8 K-tiles
 static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 grid, int skip256, hipStream_t st) {
   const dim3 block(256);
   const bool alt = (p.flags & 1024) != 0;
   // wave roles of the pipelined form (see the kernel): debug flag 27 = 1 the form without roles (round 3), 2 / 3 force PROD = 0 / 2
-  const int roles = !pipe || debug_flag(27) == 1 ? -1 : debug_flag(27) == 3 ? 2 : debug_flag(27) == 2 ? 0 : SA_GEMM8S_ROLES_DEFAULT;
+  const int f27 = debug_flag(27);
+  const int roles = !pipe || f27 == 1 ? -1 : f27 == 3 ? 2 : (f27 == 2 || f27 == 4 || f27 == 5) ? 0 : SA_GEMM8S_ROLES_DEFAULT;
+  // ... 4 / 5: PROD = 0 with the L2 prefetch 4 / 8 K-tiles ahead of the request (plain GEMMs; convolutions run without it)
+  const int pf = roles != 0 || conv ? 0 : f27 == 4 ? 4 : f27 == 5 ? 8 : f27 == 0 ? SA_GEMM8S_PREFETCH_DEFAULT : 0;
   if (roles >= 0) {
     const dim3 block8(512);
+    if (pf == 4 && alt) { hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0, 4>), grid, block8, 0, st, p, skip256); return; }
+    if (pf == 4) { hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0, 4>), grid, block8, 0, st, p, skip256); return; }
+    if (pf == 8 && alt) { hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0, 8>), grid, block8, 0, st, p, skip256); return; }
+    if (pf == 8) { hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0, 8>), grid, block8, 0, st, p, skip256); return; }
     if (conv && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 0>), grid, block8, 0, st, p, skip256);
     else if (conv) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 2>), grid, block8, 0, st, p, skip256);
     else if (alt && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0>), grid, block8, 0, st, p, skip256);

@@ -21,7 +21,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            (bitwise-equality tests of the lean forms), 2 / 3 = the register / LDS form for every eligible launch (A/B)
 //   flag 26: 1 = the 8-phase kernel launches one workgroup per tile (shipped: persistent above 256 tiles) - its bitwise test
 //   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
-//            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads
+//            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads,
+//            4 / 5 = as 2 with the multiplying waves touching the lines of the K-tile 4 / 8 requests ahead (L2 prefetch)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library

@@ -198,9 +198,11 @@ def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
     outs = {}
     try:
         # flag 27: the pipelined form's wave roles - 1 = none (4 waves request and multiply), 2 / 3 = 4 requesting waves beside
-        # 4 multiplying ones (the latter issuing 0 / 2 of their loads themselves); 0 = the shipped choice
+        # 4 multiplying ones (the latter issuing 0 / 2 of their loads themselves), 4 / 5 = as 2 with the L2 prefetch 4 / 8 K-tiles
+        # ahead; 0 = the shipped choice
         for name, variant, flag, roles in (("pipelined", 27, 0, 0), ("no roles", 27, 0, 1), ("roles 0", 27, 0, 2),
-                                           ("roles 2", 27, 0, 3), ("plain", 27, 1, 0), ("8phase", 22, 0, 0)):
+                                           ("roles 2", 27, 0, 3), ("roles 0 pf 4", 27, 0, 4), ("roles 0 pf 8", 27, 0, 5),
+                                           ("plain", 27, 1, 0), ("8phase", 22, 0, 0)):
             hip.lib().samaudio_debug_force_gemm_variant(variant)
             hip.lib().samaudio_debug_set_flag(21, flag)
             hip.lib().samaudio_debug_set_flag(27, roles)
@@ -215,7 +217,7 @@ def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
         hip.lib().samaudio_debug_force_gemm_variant(-1)
     want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
     util.report(f"gemm8s pipelined {M}x{N}x{K}", outs["pipelined"][0], want, 5e-4)
-    for other in ("no roles", "roles 0", "roles 2", "plain", "8phase"):
+    for other in ("no roles", "roles 0", "roles 2", "roles 0 pf 4", "roles 0 pf 8", "plain", "8phase"):
         assert torch.equal(outs["pipelined"][0], outs[other][0])
         assert torch.equal(outs["pipelined"][1].view(torch.int16), outs[other][1].view(torch.int16))
 
@@ -240,7 +242,7 @@ def test_gemm8s_wave_roles_are_bitwise_invisible(gpu, kind):
             M, N, K = 300, 768, 448
             A, W = _mk((M, K), 85), _mk((N, K), 86, 1 / math.sqrt(K))
             keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu)]
-        for roles in (1, 2, 3):
+        for roles in (1, 2, 3, 4, 5):
             hip.lib().samaudio_debug_set_flag(27, roles)
             if kind == "conv":
                 out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
@@ -256,7 +258,7 @@ def test_gemm8s_wave_roles_are_bitwise_invisible(gpu, kind):
         hip.lib().samaudio_debug_set_flag(27, 0)
         hip.lib().samaudio_debug_force_gemm_variant(-1)
     assert torch.isfinite(outs[1].float()).all() and float(outs[1].float().abs().max()) > 0
-    for roles in (2, 3):
+    for roles in (2, 3, 4, 5):
         assert torch.equal(outs[1].view(torch.int16), outs[roles].view(torch.int16)), f"flag 27 = {roles}"
     if kind == "plain16":
         util.report("gemm8s roles, 16-bit output", outs[2], util.rounded(A, "bf16") @ util.rounded(W, "bf16").T, 3.2e-2)

@@ -41,8 +41,14 @@ one = model(1)
 print("RUN one", file=sys.stderr, flush=True)
 one.separate(batch, noise=noise, ode_opt=opt); torch.cuda.synchronize()
 ref = one.last_latent.clone()
-two = model(2)
+two = None
+junk = []
 for rep in range(%(reps)d):
+    if two is None or (%(rebuild)d and rep %% %(rebuild)d == 0):
+        # a fresh model: new lanes, new workspaces - on memory that last held finite garbage of another magnitude
+        junk = [torch.full((s,), 200.37 + rep, device=gpu) for s in (1 << 18, 1 << 20, 3 << 20)]
+        del junk
+        two = model(2)
     print(f"RUN two {rep}", file=sys.stderr, flush=True)
     two.separate(batch, noise=noise, ode_opt=opt); torch.cuda.synchronize()
     d = (two.last_latent.float() - ref.float()).abs().flatten(1).max(dim=1).values.tolist()
@@ -89,9 +95,10 @@ def per_clip(run):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--rebuild", type=int, default=0, help="build the two-stream model anew every N repetitions (0: once)")
     args = ap.parse_args()
     env = dict(os.environ, SAMAUDIO_TRACE_HASH="1")
-    p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, reps=args.reps)], env=env, capture_output=True, text=True)
+    p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, reps=args.reps, rebuild=args.rebuild)], env=env, capture_output=True, text=True)
     lines = p.stderr.splitlines()
     runs, results = parse(lines)
     if "one" not in runs:
