@@ -27,6 +27,21 @@ def main(path: str) -> None:
         print(f"| `{short(name)}` | {n} | {tot / 1e6:.3f} | {tot / n / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} |"
               f" {100.0 * tot / total:.2f} |")
     print(f"\ntotal kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    # Is the GPU waiting for the host between launches?  Idle gaps between consecutive dispatches (a gap = the next start minus
+    # the latest end so far; overlapping dispatches of concurrent streams give none), split at 100 us: short gaps are launch
+    # gaps inside a stream of launches, long ones are host phases (model building, H2D copies, the end of a step).
+    iv = db.execute("select start, end from kernels order by start").fetchall()
+    short_gaps, long_gaps, latest = [], [], iv[0][1] if iv else 0
+    for st, en in iv[1:]:
+        if st > latest:
+            (short_gaps if st - latest < 100_000 else long_gaps).append(st - latest)
+        latest = max(latest, en)
+    if short_gaps:
+        sg = sorted(short_gaps)
+        busy = total / (total + sum(sg))
+        print(f"idle gaps < 100 us between dispatches: {len(sg)} totalling {sum(sg) / 1e6:.3f} ms (median {sg[len(sg) // 2] / 1e3:.2f} us, "
+              f"p90 {sg[len(sg) * 9 // 10] / 1e3:.2f} us); gaps >= 100 us: {len(long_gaps)} totalling {sum(long_gaps) / 1e6:.3f} ms; "
+              f"GPU busy inside the launch streams = kernel time / (kernel time + short gaps) = {busy:.3f}")
 
 
 if __name__ == "__main__":
