@@ -23,9 +23,12 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
 //            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads,
 //            4 / 5 = as 2 with the multiplying waves touching the lines of the K-tile 4 / 8 requests ahead (L2 prefetch)
+//   flag 28: measurement aid - every 16-bit GEMM of the DiT's five big classes is preceded by a kernel that reads its weights
+//            (what the launch costs with warm weights; rocprofv3 kernel durations, not end-to-end time)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library
+hipError_t launch_touch(const void* p, size_t bytes, hipStream_t st);   // measurement aid (debug flag 28)
 hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st);
 void* debug_device_alloc(size_t bytes);
 int debug_flag(int flag);
