@@ -57,6 +57,15 @@ __device__ __forceinline__ void dma16v(const void* gsrc, size_t lds_wave_addr) {
   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA8V
 }
+// a plain 16-byte load as inline assembly (scalar base + 32-bit lane offset): the requesting waves of gemm8s' register-staged form keep
+// several K-tiles of such loads in flight across loop iterations and retire them with their own counted s_waitcnt vmcnt - left to the
+// compiler, the loads of the previous iteration were waited for two sets too early.  The result register is "ready" as far as the
+// compiler knows: every use must follow the s_waitcnt that covers the load.
+__device__ __forceinline__ uint4 gload16s(const void* sbase, unsigned voff) {
+  uint4 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");  // SIMT-GLOAD16S
+  return r;
+}
 __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha) {
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_GELU) return gelu_f(v);
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // block's 4 A-tile loads per K-tile a multiplying wave still issues itself (0: none; 2 balances 6 + 2 when the requesting waves are
 // the longer side).  One barrier per K-tile as before; the requesting waves leave at the last barrier.
 template <int N> __device__ __forceinline__ void wait_vm_lit() {   // literal counts: the simulator reads the number from the text
-  static_assert(N == 0 || N == 1 || N == 2 || N == 4 || N == 6 || N == 7 || N == 8 || N == 12 || N == 14 || N == 16, "add the literal");
+  static_assert(N == 0 || N == 1 || N == 2 || N == 4 || N == 6 || N == 7 || N == 8 || N == 12 || N == 14 || N == 16 || N == 24, "add the literal");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -943,18 +952,20 @@ template <int N> __device__ __forceinline__ void wait_vm_lit() {   // literal co
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
 }
-// PF > 0 (roles with PROD = 0, plain GEMMs): L2 PREFETCH.  In the model - few rows, every launch streaming its own layer's weights
-// from HBM - a launch of <= 256 workgroups is bound by latency x depth: 3 K-tiles (96 KiB, all the LDS ring can hold) in flight
-// per CU behind ~2 us of HBM latency.  The multiplying waves, which wait for no load of their own, therefore TOUCH the lines of K-tile
-// t + 3 + PF while K-tile t + 3 is being requested: one 4-byte load per lane and K-tile, lane -> one 128-byte line (the K-tile's 64
-// elements of one of the row block's 32 A rows / 32 W rows); the data is dropped, the line is in L2 when its DMA asks for it.
-// (Issued by the multiplying waves, not the requesting ones: vmcnt retires in order, so a requesting wave would wait for its own
-// touches - HBM misses - before it could see its younger DMAs complete.)
-template <bool PIPE, bool CONV, bool ALT = false, int PROD = -1, int PF = 0>
+// RS (roles with PROD = 0, plain GEMMs): the requesting waves stage through REGISTERS.  In the model - few rows, every launch streaming
+// its layer's weights from HBM, all tiles of a launch asking for K-tile t's lines at the same moment - a launch of <= 256 workgroups is
+// bound by latency x depth: 3 K-tiles (96 KiB - all the LDS ring can hold) in flight per CU behind ~2 us of HBM latency = 0.65 us per
+// K-tile (rocprofv3, 4 clips: 44 us per launch in the model, the form with requesting waves 46.5 us cold against 36.8 us with its
+// weights read just before - profiles/r4_call15/, r4_call16/).  A requesting wave has ~200 registers it does not need: with RS it
+// loads K-tile t+7 into one of 4 register sets (plain 16-byte loads, 8 per K-tile and wave) while it writes K-tile t+3, loaded four steps
+// earlier, into the ring slot K-tile t-1 has left: 7 K-tiles in flight instead of 3, the same LDS image (lane i of a 1 KiB block
+// writes bytes 16 i ..), the same barriers, the multiplying waves untouched: bitwise identical.
+template <bool PIPE, bool CONV, bool ALT = false, int PROD = -1, bool RS = false>
 __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const GemmParams p, const int skip256) {
-  static_assert(PF == 0 || (PROD == 0 && !CONV), "the prefetch belongs to the plain-GEMM form whose multiplying waves request nothing");
+  static_assert(!RS || (PROD == 0 && !CONV), "register staging belongs to the plain-GEMM form whose multiplying waves request nothing");
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 4 : 2;
   constexpr bool ROLES = PROD >= 0;
@@ -1048,7 +1059,99 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
   using Q4 = std::integral_constant<int, 4>;
   auto stage = [&](int buf, int kt) { stage_q(buf, kt, Q0{}, Q4{}, Q4{}); };
 
-  if constexpr (ROLES) {
+  if constexpr (ROLES && RS) {
+    if (wave_id >= 4) {   // a requesting wave, staging through registers: K-tile k lives in register set k % 4, then in ring slot k % 4
+      // (four separately named sets: as one array indexed [set][q] the compiler kept it in scratch memory)
+      uint4 a_0, a_1, a_2, a_3, a_4, a_5, a_6, a_7, b_0, b_1, b_2, b_3, b_4, b_5, b_6, b_7;
+      uint4 c_0, c_1, c_2, c_3, c_4, c_5, c_6, c_7, d_0, d_1, d_2, d_3, d_4, d_5, d_6, d_7;
+      const char* const a0 = (const char*)A0;
+      const char* const w0 = (const char*)W0;
+#define SA_RS_LOAD(x)                                                                                              \
+  {                                                                                                                \
+    const char* ak = a0 + (size_t)kt * (BK * 2);                                                                   \
+    const char* wk = w0 + (size_t)kt * (BK * 2);                                                                   \
+    x##_0 = gload16s(ak, a_off[0]); x##_1 = gload16s(ak, a_off[1]);                                                \
+    x##_2 = gload16s(ak, a_off[2]); x##_3 = gload16s(ak, a_off[3]);                                                \
+    x##_4 = gload16s(wk, w_off[0]); x##_5 = gload16s(wk, w_off[1]);                                                \
+    x##_6 = gload16s(wk, w_off[2]); x##_7 = gload16s(wk, w_off[3]);                                                \
+  }
+#define SA_RS_WRITE(x, s)                                                                                          \
+  {                                                                                                                \
+    char* dst = smem + (s) * (2 * TB) + wave * 4096 + lane * 16;                                                   \
+    *(uint4*)(dst) = x##_0; *(uint4*)(dst + 1024) = x##_1; *(uint4*)(dst + 2048) = x##_2; *(uint4*)(dst + 3072) = x##_3; \
+    *(uint4*)(dst + TB) = x##_4; *(uint4*)(dst + TB + 1024) = x##_5;                                               \
+    *(uint4*)(dst + TB + 2048) = x##_6; *(uint4*)(dst + TB + 3072) = x##_7;                                        \
+  }
+      auto gload = [&](auto SET, int kt) {
+        constexpr int s = decltype(SET)::value;
+        if constexpr (s == 0) SA_RS_LOAD(a) else if constexpr (s == 1) SA_RS_LOAD(b) else if constexpr (s == 2) SA_RS_LOAD(c) else SA_RS_LOAD(d)
+      };
+      auto lwrite = [&](auto SET) {   // set s -> ring slot s, the image a direct-to-LDS load of the same rows leaves
+        constexpr int s = decltype(SET)::value;
+        if constexpr (s == 0) SA_RS_WRITE(a, 0) else if constexpr (s == 1) SA_RS_WRITE(b, 1) else if constexpr (s == 2) SA_RS_WRITE(c, 2) else SA_RS_WRITE(d, 3)
+      };
+      using S0 = std::integral_constant<int, 0>;
+      using S1 = std::integral_constant<int, 1>;
+      using S2 = std::integral_constant<int, 2>;
+      using S3 = std::integral_constant<int, 3>;
+      // K-tile k has arrived when at most 8 x (the younger K-tiles requested so far: k+1 .. min(k+3, nt-1)) loads are outstanding
+      auto arrived = [&](int k) {
+        const int younger = nt - 1 - k;   // uniform
+        if (younger >= 3) wait_vm_lit<24>();
+        else if (younger == 2) wait_vm_lit<16>();
+        else if (younger == 1) wait_vm_lit<8>();
+        else wait_vm_lit<0>();
+      };
+      // K-tiles 0 .. 2 into the ring, 3 .. 6 into the sets (k % 4: set 3, 0, 1, 2)
+      gload(S0{}, 0);
+      if (nt > 1) gload(S1{}, 1);
+      if (nt > 2) gload(S2{}, 2);
+      if (nt > 3) gload(S3{}, 3);
+      arrived(0);
+      lwrite(S0{});
+      if (nt > 4) gload(S0{}, 4);
+      if (nt > 1) { arrived(1); lwrite(S1{}); }
+      if (nt > 5) gload(S1{}, 5);
+      if (nt > 2) { arrived(2); lwrite(S2{}); }
+      if (nt > 6) gload(S2{}, 6);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // step t (the multiplying waves work on K-tile t): K-tile t+3 -> the slot K-tile t-1 has left, K-tile t+7 -> its register set
+      auto step = [&](int t, auto SET, auto GUARD) {   // GUARD: K-tiles t+3 / t+7 may not exist (the last steps)
+        if constexpr (!decltype(GUARD)::value) {
+          wait_vm_lit<24>();   // K-tiles t+4 .. t+6 stay in flight
+          lwrite(SET);
+          gload(SET, t + 7);
+        } else {
+          if (t + 3 < nt) { arrived(t + 3); lwrite(SET); }
+          if (t + 7 < nt) gload(SET, t + 7);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      };
+      int t = 0;
+      for (; t + 10 < nt; t += 4) {   // sets in the order (t + 3) % 4 with t % 4 == 0; branch-free: every K-tile named exists
+        step(t, S3{}, std::false_type{});
+        step(t + 1, S0{}, std::false_type{});
+        step(t + 2, S1{}, std::false_type{});
+        step(t + 3, S2{}, std::false_type{});
+      }
+      for (; t + 4 < nt; t += 4) {
+        step(t, S3{}, std::true_type{});
+        step(t + 1, S0{}, std::true_type{});
+        step(t + 2, S1{}, std::true_type{});
+        step(t + 3, S2{}, std::true_type{});
+      }
+      if (t + 1 < nt) step(t, S3{}, std::true_type{});
+      if (t + 2 < nt) step(t + 1, S0{}, std::true_type{});
+      if (t + 3 < nt) step(t + 2, S1{}, std::true_type{});
+#undef SA_RS_LOAD
+#undef SA_RS_WRITE
+      if (!(p.flags & 64)) __syncthreads();   // the multiplying waves' barrier in front of the LDS-staged epilogues
+      return;
+    }
+  }
+  if constexpr (ROLES && !RS) {
     if (wave_id >= 4) {   // a requesting wave: the ring's producer side, no arithmetic
       using QC = std::integral_constant<int, PROD>;
       constexpr int MINE = 8 - PROD;   // loads per K-tile of this wave
@@ -1083,27 +1186,6 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
   };
 
   if constexpr (PIPE) {
-    // L2 prefetch (PF > 0): this lane's line of K-tile 0 - A row (lanes 0 - 31) or W row (lanes 32 - 63) of the wave's row block
-    const char* touch_base = nullptr;
-    // The loads' destination: ONE register, defined once by an asm the compiler cannot rematerialise and passed to every touch as an
-    // INPUT - a single-definition value has no copies at control-flow merges (as an in/out operand it had: the tail paths each got
-    // their own copy; an accumulation register instead made the allocator split the file 128 / 128 and spill through it).  A touch may land long after its statement: its register must not be given to anything else
-    // before the s_waitcnt vmcnt(0) that follows the K loop, which the last statement below (a use after that wait) guarantees.
-    unsigned touch_sink = 0;
-    if constexpr (PF > 0) asm volatile("v_mov_b32 %0, 0" : "=v"(touch_sink));
-    if constexpr (PF > 0) {
-      const int row = wave * 32 + (lane & 31);
-      int m = m0 + row, n = n0 + row;
-      m = m < p.M ? m : p.M - 1;
-      n = n < p.N ? n : p.N - 1;
-      touch_base = lane < 32 ? (const char*)(A0 + (long)m * p.lda) : (const char*)(W0 + (long)n * p.K);
-    }
-    auto touch = [&](int kt) {   // branch-free: beyond the last K-tile the last one is touched again (an L2 hit)
-      if constexpr (PF > 0) {
-        const char* line = touch_base + (size_t)(kt < nt ? kt : nt - 1) * (BK * 2);
-        asm volatile("global_load_dword %0, %1, off" ::"v"(touch_sink), "v"(line) : "memory");
-      }
-    };
     bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
     // loads per K-tile of a multiplying wave: all 8 of its row block, or - with requesting waves - PROD of the A tile's
     constexpr int MINE = ROLES ? PROD : 8;
@@ -1128,7 +1210,6 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
       constexpr int OTHER = 1 - decltype(SET)::value;
       // K-tile t+S-1 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
       if (t + S - 1 < nt) stage_mine((t + S - 1) % S, t + S - 1);
-      touch(t + S - 1 + PF);
       if constexpr (decltype(NEXT)::value) {
         // K-tile t+1 has landed; the younger ones (t+2 .. t+S-1, as far as they exist) may be in flight
         if constexpr (MINE > 0) {   // (a multiplying wave that requests nothing has nothing to wait for)
@@ -1154,8 +1235,6 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
     stage_mine(0, 0);
     if (nt > 1) stage_mine(1, 1);
     if (S == 4 && nt > 2) stage_mine(2, 2);
-#pragma unroll
-    for (int d = 0; d < PF; ++d) touch(S - 1 + d);   // the K-tiles the first PF steps will request
     // K-tile 0 has landed; up to S - 2 younger ones stay in flight
     if constexpr (MINE > 0) {
       if (S == 4 && nt > 2) wait_vm_lit<2 * MINE>();
@@ -1174,10 +1253,6 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
       step(t + 1, I1{}, std::false_type{});
     } else {
       step(t, I0{}, std::false_type{});
-    }
-    if constexpr (PF > 0) {   // the touches have returned before their register is given to anything else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("" ::"v"(touch_sink));
     }
     if (p.flags & 64) {
       epilogue8_linear<1>(p, acc, b, m0 + wr * 64, n0 + wc * 64, lane);
@@ -1266,21 +1341,19 @@ static GemmParams with_epilogue_choice(const GemmParams& p) {
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
 // alt-format operands (flags bit 10, mixed mode) exist for plain GEMMs only - the DiT's Linears - gemm8_alt_ok()
 #define SA_GEMM8S_ROLES_DEFAULT (-1)   // the shipped form of the pipelined kernel: -1 no roles, 0 / 2 = PROD
-#define SA_GEMM8S_PREFETCH_DEFAULT 0   // ... and its L2 prefetch distance (roles 0 only): 0 none, 4 / 8 K-tiles
+#define SA_GEMM8S_RS_DEFAULT 0          // ... with roles 0: requesting waves stage through registers (7 K-tiles in flight)
 static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 grid, int skip256, hipStream_t st) {
   const dim3 block(256);
   const bool alt = (p.flags & 1024) != 0;
   // wave roles of the pipelined form (see the kernel): debug flag 27 = 1 the form without roles (round 3), 2 / 3 force PROD = 0 / 2
   const int f27 = debug_flag(27);
-  const int roles = !pipe || f27 == 1 ? -1 : f27 == 3 ? 2 : (f27 == 2 || f27 == 4 || f27 == 5) ? 0 : SA_GEMM8S_ROLES_DEFAULT;
-  // ... 4 / 5: PROD = 0 with the L2 prefetch 4 / 8 K-tiles ahead of the request (plain GEMMs; convolutions run without it)
-  const int pf = roles != 0 || conv ? 0 : f27 == 4 ? 4 : f27 == 5 ? 8 : f27 == 0 ? SA_GEMM8S_PREFETCH_DEFAULT : 0;
+  const int roles = !pipe || f27 == 1 ? -1 : f27 == 3 ? 2 : (f27 == 2 || f27 == 6) ? 0 : SA_GEMM8S_ROLES_DEFAULT;
+  // ... 6: PROD = 0 with the requesting waves staging through registers (plain GEMMs; convolutions keep the direct-to-LDS loads)
+  const bool rs = roles == 0 && !conv && (f27 == 6 || (f27 == 0 && SA_GEMM8S_RS_DEFAULT));
   if (roles >= 0) {
     const dim3 block8(512);
-    if (pf == 4 && alt) { hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0, 4>), grid, block8, 0, st, p, skip256); return; }
-    if (pf == 4) { hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0, 4>), grid, block8, 0, st, p, skip256); return; }
-    if (pf == 8 && alt) { hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0, 8>), grid, block8, 0, st, p, skip256); return; }
-    if (pf == 8) { hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0, 8>), grid, block8, 0, st, p, skip256); return; }
+    if (rs && alt) { hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0, true>), grid, block8, 0, st, p, skip256); return; }
+    if (rs) { hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0, true>), grid, block8, 0, st, p, skip256); return; }
     if (conv && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 0>), grid, block8, 0, st, p, skip256);
     else if (conv) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 2>), grid, block8, 0, st, p, skip256);
     else if (alt && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0>), grid, block8, 0, st, p, skip256);

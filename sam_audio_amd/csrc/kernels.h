@@ -22,7 +22,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 26: 1 = the 8-phase kernel launches one workgroup per tile (shipped: persistent above 256 tiles) - its bitwise test
 //   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
 //            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads,
-//            4 / 5 = as 2 with the multiplying waves touching the lines of the K-tile 4 / 8 requests ahead (L2 prefetch)
+//            6 = as 2 with the requesting waves staging through 4 register sets (7 K-tiles in flight instead of 3)
 //   flag 28: measurement aid - every 16-bit GEMM of the DiT's five big classes is preceded by a kernel that reads its weights
 //            (what the launch costs with warm weights; rocprofv3 kernel durations, not end-to-end time)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop

@@ -81,7 +81,7 @@ def test_separate_fp16_error_next_to_bf16(gpu):
     assert errs["fp16"][0] < errs["bf16"][0]
 
 
-@pytest.mark.parametrize("variant,roles", [(22, 0), (27, 0), (27, 1), (27, 2), (27, 3), (27, 4), (27, 5)])
+@pytest.mark.parametrize("variant,roles", [(22, 0), (27, 0), (27, 1), (27, 2), (27, 3), (27, 6)])
 @pytest.mark.parametrize("kind", ["act", "swiglu", "gated"])
 def test_mixed_mode_gemm_reads_and_writes_bfloat16_inside_the_fp16_library(gpu, variant, roles, kind):
     """precision="mixed" (samaudio.h SAMAUDIO_OPT_ALT16_CLASSES): the five big GEMM classes run on bfloat16 operands inside

@@ -186,22 +186,23 @@ def test_8phase_family_tiles_are_bitwise_identical(gpu, M, N, K, swiglu):
     assert torch.equal(a22.view(torch.int16), a27.view(torch.int16))
 
 
-@pytest.mark.parametrize("M,N,K", [(200, 256, 64), (130, 384, 128), (333, 512, 192), (270, 2816, 448), (250, 640, 512)])
+@pytest.mark.parametrize("M,N,K", [(200, 256, 64), (130, 384, 128), (333, 512, 192), (270, 2816, 448), (250, 640, 512),
+                                   (130, 256, 704), (150, 256, 768), (150, 384, 832), (200, 384, 1216), (300, 512, 1408)])
 def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
     """gemm8s runs launches of <= 256 workgroups in its pipelined form (3-stage ring, the fragments of K-tile t+1 read
     underneath the MFMAs of K-tile t; debug flag 21 = the plain double-buffered form).  Same arithmetic: identical bits
-    for 1 .. 8 K-tiles (odd and even counts, shorter than the ring), against the plain form and against the 256x256
-    kernel; gated-residual epilogue, fp32 + bf16 outputs."""
+    for 1 .. 8 K-tiles (odd and even counts, shorter than the ring) and 11 .. 22 (the register-staged form's branch-free loop and
+    each length of its tail), against the plain form and against the 256x256 kernel; gated-residual epilogue, fp32 + bf16 outputs."""
     A, W = _mk((M, K), 51), _mk((N, K), 52, 1 / math.sqrt(K))
     tab, gate, res = _mk((N,), 53), _mk((1, N), 54), _mk((M, N), 55)
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
     outs = {}
     try:
         # flag 27: the pipelined form's wave roles - 1 = none (4 waves request and multiply), 2 / 3 = 4 requesting waves beside
-        # 4 multiplying ones (the latter issuing 0 / 2 of their loads themselves), 4 / 5 = as 2 with the L2 prefetch 4 / 8 K-tiles
-        # ahead; 0 = the shipped choice
+        # 4 multiplying ones (the latter issuing 0 / 2 of their loads themselves), 6 = as 2 with the requesting waves staging through
+        # registers (7 K-tiles in flight); 0 = the shipped choice
         for name, variant, flag, roles in (("pipelined", 27, 0, 0), ("no roles", 27, 0, 1), ("roles 0", 27, 0, 2),
-                                           ("roles 2", 27, 0, 3), ("roles 0 pf 4", 27, 0, 4), ("roles 0 pf 8", 27, 0, 5),
+                                           ("roles 2", 27, 0, 3), ("roles 0 regs", 27, 0, 6),
                                            ("plain", 27, 1, 0), ("8phase", 22, 0, 0)):
             hip.lib().samaudio_debug_force_gemm_variant(variant)
             hip.lib().samaudio_debug_set_flag(21, flag)
@@ -217,7 +218,7 @@ def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
         hip.lib().samaudio_debug_force_gemm_variant(-1)
     want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
     util.report(f"gemm8s pipelined {M}x{N}x{K}", outs["pipelined"][0], want, 5e-4)
-    for other in ("no roles", "roles 0", "roles 2", "roles 0 pf 4", "roles 0 pf 8", "plain", "8phase"):
+    for other in ("no roles", "roles 0", "roles 2", "roles 0 regs", "plain", "8phase"):
         assert torch.equal(outs["pipelined"][0], outs[other][0])
         assert torch.equal(outs["pipelined"][1].view(torch.int16), outs[other][1].view(torch.int16))
 
@@ -242,7 +243,7 @@ def test_gemm8s_wave_roles_are_bitwise_invisible(gpu, kind):
             M, N, K = 300, 768, 448
             A, W = _mk((M, K), 85), _mk((N, K), 86, 1 / math.sqrt(K))
             keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu)]
-        for roles in (1, 2, 3, 4, 5):
+        for roles in (1, 2, 3, 6):
             hip.lib().samaudio_debug_set_flag(27, roles)
             if kind == "conv":
                 out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
@@ -258,7 +259,7 @@ def test_gemm8s_wave_roles_are_bitwise_invisible(gpu, kind):
         hip.lib().samaudio_debug_set_flag(27, 0)
         hip.lib().samaudio_debug_force_gemm_variant(-1)
     assert torch.isfinite(outs[1].float()).all() and float(outs[1].float().abs().max()) > 0
-    for roles in (2, 3, 4, 5):
+    for roles in (2, 3, 6):
         assert torch.equal(outs[1].view(torch.int16), outs[roles].view(torch.int16)), f"flag 27 = {roles}"
     if kind == "plain16":
         util.report("gemm8s roles, 16-bit output", outs[2], util.rounded(A, "bf16") @ util.rounded(W, "bf16").T, 3.2e-2)

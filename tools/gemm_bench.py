@@ -74,8 +74,8 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
     if AB_FLAG[0] is not None:
         cols += [(22, f"8-phase flag {AB_FLAG[0]}={AB_VALUE[0]}", (AB_FLAG[0], AB_VALUE[0])),
                  (-1, f"auto flag {AB_FLAG[0]}={AB_VALUE[0]}", (AB_FLAG[0], AB_VALUE[0]))]
-    if ROLES[0]:   # the pipelined gemm8s form's wave roles (debug flag 27: 1 = none, 2 / 3 = requesting waves, PROD 0 / 2; 4 / 5 = PROD 0 + L2 prefetch 4 / 8 K-tiles ahead)
-        cols = [(27, f"gemm8s flag 27={r}", (27, r)) for r in (1, 2, 3, 4, 5)] + [(22, "8-phase 256x256", None)]
+    if ROLES[0]:   # the pipelined gemm8s form's wave roles (debug flag 27: 1 = none, 2 / 3 = requesting waves, PROD 0 / 2; 6 = PROD 0 with register-staged requests)
+        cols = [(27, f"gemm8s flag 27={r}", (27, r)) for r in (1, 2, 6)] + [(22, "8-phase 256x256", None)]
     for v, vname, flag in cols:
         hip.lib().samaudio_debug_force_gemm_variant(v)
         if flag is not None:
