@@ -433,7 +433,6 @@ hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, co
   return hipSuccess;
 }
 
-hipError_t launch_touch(const void*, size_t, hipStream_t) { return hipSuccess; }
 hipError_t launch_hash_items(const unsigned* x, size_t words, int items, unsigned long long* out, hipStream_t) {
   for (int b = 0; b < items; ++b) {
     unsigned long long h = 0;

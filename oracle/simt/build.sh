@@ -42,9 +42,6 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       grep -q "(void)lds;" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16s asm statement not found"; exit 1; }
       sed -i 's|^.*// SIMT-DMA8V$|  simt::dma_asm = true; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); simt::dma_asm = false; (void)lds; /*v*/|' $OUT/gemm8_simt.hip
       grep -q "(void)lds; /\*v\*/" $OUT/gemm8_simt.hip || { echo "gemm8.hip: dma16v asm statement not found"; exit 1; }
-      # ... and the register-staged form's plain 16-byte load (gload16s) becomes the load it is (complete at issue in the simulation)
-      sed -i 's|^.*// SIMT-GLOAD16S$|  r = *(const uint4*)((const char*)sbase + voff);|' $OUT/gemm8_simt.hip
-      grep -q "r = \*(const uint4\*)((const char\*)sbase + voff);" $OUT/gemm8_simt.hip || { echo "gemm8.hip: gload16s asm statement not found"; exit 1; }
       EXTRA="-I $SRC"
       src=$OUT/gemm8_simt.hip
     fi

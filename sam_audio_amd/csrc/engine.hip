@@ -472,8 +472,6 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
   }
   if (!bf16_ && quant_fmt_ && (quant_classes_ & cls)) p.flags |= (quant_fmt_ << 2) | (quant_fmt_ << 4);
   if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
-  if (debug_flag(28) && bf16_ && (cls & SAMAUDIO_CLS_ALT16_CAPABLE) && p.nbatch == 1)
-    SA_HIP(launch_touch(p.W, (size_t)p.N * p.K * esz_, st));
   if (!prof_on_) {
     SA_HIP(launch_gemm(p, bf16_, st));
     return Status{};

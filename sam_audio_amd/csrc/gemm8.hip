@@ -57,15 +57,6 @@ __device__ __forceinline__ void dma16v(const void* gsrc, size_t lds_wave_addr) {
   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA8V
 }
-// a plain 16-byte load as inline assembly (scalar base + 32-bit lane offset): the requesting waves of gemm8s' register-staged form keep
-// several K-tiles of such loads in flight across loop iterations and retire them with their own counted s_waitcnt vmcnt - left to the
-// compiler, the loads of the previous iteration were waited for two sets too early.  The result register is "ready" as far as the
-// compiler knows: every use must follow the s_waitcnt that covers the load.
-__device__ __forceinline__ uint4 gload16s(const void* sbase, unsigned voff) {
-  uint4 r;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");  // SIMT-GLOAD16S
-  return r;
-}
 __device__ __forceinline__ float act_apply8(float v, int act, float snake_alpha) {
   if (act == ACT_SILU) return silu_f(v);
   if (act == ACT_GELU) return gelu_f(v);
@@ -933,49 +924,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // 3 -> 4 stages: c_wq at 1000 rows 36.9 -> 34.9 us, w2 83.4 -> 79.0; 4 clips per GPU 114.5 -> 119.8 s-audio/s, small* 8 clips
 // 424.0 -> 435.3 (profiles/r3_call9/).  A 5-stage ring (160 KiB, all of the CU's LDS) measured slower again: c_wq 35.9 vs 34.9 us, w2
 // 80.5 vs 76.2, 4 clips 120.7 vs 121.5 (profiles/r3_call28/) - three K-tiles in flight already cover the latency.
-// PROD >= 0 (pipelined form only): WAVE ROLES.  Alone on its CU the pipelined form has one wave per SIMD, and a wave that issues a
-// K-tile's 8 direct-to-LDS loads holds its instruction stream for ~100 cycles each (the issue cost the 4-wave 256 x 256 experiment
-// of round 3 ran into): ~800 cycles of load issue in front of 512 cycles of MFMAs per K-tile, in series - the measured ~1 400 cycles
-// per K-tile (0.58 - 0.61 us: c_wq at 1 000 rows 27 us for 44 K-tiles).  With roles the workgroup has 8 waves: waves 0 - 3 multiply
-// exactly as before (64 x 64 outputs each, same fragments, same MFMA order: bitwise identical), waves 4 - 7 - one per SIMD, beside a
-// multiplying wave - only request K-tiles: their issue time runs underneath the other wave's MFMAs.  PROD = how many of its row
-// block's 4 A-tile loads per K-tile a multiplying wave still issues itself (0: none; 2 balances 6 + 2 when the requesting waves are
-// the longer side).  One barrier per K-tile as before; the requesting waves leave at the last barrier.
-template <int N> __device__ __forceinline__ void wait_vm_lit() {   // literal counts: the simulator reads the number from the text
-  static_assert(N == 0 || N == 1 || N == 2 || N == 4 || N == 6 || N == 7 || N == 8 || N == 12 || N == 14 || N == 16 || N == 24, "add the literal");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-}
-// RS (roles with PROD = 0, plain GEMMs): the requesting waves stage through REGISTERS.  In the model - few rows, every launch streaming
-// its layer's weights from HBM, all tiles of a launch asking for K-tile t's lines at the same moment - a launch of <= 256 workgroups is
-// bound by latency x depth: 3 K-tiles (96 KiB - all the LDS ring can hold) in flight per CU behind ~2 us of HBM latency = 0.65 us per
-// K-tile (rocprofv3, 4 clips: 44 us per launch in the model, the form with requesting waves 46.5 us cold against 36.8 us with its
-// weights read just before - profiles/r4_call15/, r4_call16/).  A requesting wave has ~200 registers it does not need: with RS it
-// loads K-tile t+7 into one of 4 register sets (plain 16-byte loads, 8 per K-tile and wave) while it writes K-tile t+3, loaded four steps
-// earlier, into the ring slot K-tile t-1 has left: 7 K-tiles in flight instead of 3, the same LDS image (lane i of a 1 KiB block
-// writes bytes 16 i ..), the same barriers, the multiplying waves untouched: bitwise identical.
-template <bool PIPE, bool CONV, bool ALT = false, int PROD = -1, bool RS = false>
-__global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const GemmParams p, const int skip256) {
-  static_assert(!RS || (PROD == 0 && !CONV), "register staging belongs to the plain-GEMM form whose multiplying waves request nothing");
+template <bool PIPE, bool CONV, bool ALT = false>
+__global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 4 : 2;
-  constexpr bool ROLES = PROD >= 0;
-  static_assert(!ROLES || PIPE, "wave roles belong to the pipelined form");
   __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wave = wave_id & 3;   // ROLES: waves 4 .. 7 request the row blocks waves 0 .. 3 own
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -1029,21 +986,17 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
   const size_t lds0 = (size_t)(__attribute__((address_space(3))) char*)smem;
   // DMA as inline assembly (dma16s / dma16v, see there): the compiler then counts the fragment reads itself, which is what
   // lets the pipelined form's reads of K-tile t+1 really complete underneath the MFMAs of K-tile t
-  // K-tile kt (CONV: the a_in / a_tap state points at it) -> stage buf: the A-tile loads QA0 <= q < QA1 and the W-tile loads q < QW1
-  // of this wave's row block
-  auto stage_q = [&](int buf, int kt, auto QA0, auto QA1, auto QW1) {
+  auto stage = [&](int buf, int kt) {  // K-tile kt (CONV: the a_in / a_tap state points at it) -> stage buf
     const size_t dst = lds0 + (size_t)(buf * (2 * TB) + wave * 4096);
     const char* a_base = (const char*)A0 + (long)kt * (BK * 2);
     const char* w_base = (const char*)W0 + (long)kt * (BK * 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q < decltype(QA0)::value || q >= decltype(QA1)::value) continue;
       if constexpr (CONV) dma16v(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
       else dma16s(a_base, a_off[q], dst + q * 1024);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if (q >= decltype(QW1)::value) continue;
       if constexpr (CONV) dma16v(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
       else dma16s(w_base, w_off[q], dst + TB + q * 1024);
     }
@@ -1055,126 +1008,6 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
       }
     }
   };
-  using Q0 = std::integral_constant<int, 0>;
-  using Q4 = std::integral_constant<int, 4>;
-  auto stage = [&](int buf, int kt) { stage_q(buf, kt, Q0{}, Q4{}, Q4{}); };
-
-  if constexpr (ROLES && RS) {
-    if (wave_id >= 4) {   // a requesting wave, staging through registers: K-tile k lives in register set k % 4, then in ring slot k % 4
-      // (four separately named sets: as one array indexed [set][q] the compiler kept it in scratch memory)
-      uint4 a_0, a_1, a_2, a_3, a_4, a_5, a_6, a_7, b_0, b_1, b_2, b_3, b_4, b_5, b_6, b_7;
-      uint4 c_0, c_1, c_2, c_3, c_4, c_5, c_6, c_7, d_0, d_1, d_2, d_3, d_4, d_5, d_6, d_7;
-      const char* const a0 = (const char*)A0;
-      const char* const w0 = (const char*)W0;
-#define SA_RS_LOAD(x)                                                                                              \
-  {                                                                                                                \
-    const char* ak = a0 + (size_t)kt * (BK * 2);                                                                   \
-    const char* wk = w0 + (size_t)kt * (BK * 2);                                                                   \
-    x##_0 = gload16s(ak, a_off[0]); x##_1 = gload16s(ak, a_off[1]);                                                \
-    x##_2 = gload16s(ak, a_off[2]); x##_3 = gload16s(ak, a_off[3]);                                                \
-    x##_4 = gload16s(wk, w_off[0]); x##_5 = gload16s(wk, w_off[1]);                                                \
-    x##_6 = gload16s(wk, w_off[2]); x##_7 = gload16s(wk, w_off[3]);                                                \
-  }
-#define SA_RS_WRITE(x, s)                                                                                          \
-  {                                                                                                                \
-    char* dst = smem + (s) * (2 * TB) + wave * 4096 + lane * 16;                                                   \
-    *(uint4*)(dst) = x##_0; *(uint4*)(dst + 1024) = x##_1; *(uint4*)(dst + 2048) = x##_2; *(uint4*)(dst + 3072) = x##_3; \
-    *(uint4*)(dst + TB) = x##_4; *(uint4*)(dst + TB + 1024) = x##_5;                                               \
-    *(uint4*)(dst + TB + 2048) = x##_6; *(uint4*)(dst + TB + 3072) = x##_7;                                        \
-  }
-      auto gload = [&](auto SET, int kt) {
-        constexpr int s = decltype(SET)::value;
-        if constexpr (s == 0) SA_RS_LOAD(a) else if constexpr (s == 1) SA_RS_LOAD(b) else if constexpr (s == 2) SA_RS_LOAD(c) else SA_RS_LOAD(d)
-      };
-      auto lwrite = [&](auto SET) {   // set s -> ring slot s, the image a direct-to-LDS load of the same rows leaves
-        constexpr int s = decltype(SET)::value;
-        if constexpr (s == 0) SA_RS_WRITE(a, 0) else if constexpr (s == 1) SA_RS_WRITE(b, 1) else if constexpr (s == 2) SA_RS_WRITE(c, 2) else SA_RS_WRITE(d, 3)
-      };
-      using S0 = std::integral_constant<int, 0>;
-      using S1 = std::integral_constant<int, 1>;
-      using S2 = std::integral_constant<int, 2>;
-      using S3 = std::integral_constant<int, 3>;
-      // K-tile k has arrived when at most 8 x (the younger K-tiles requested so far: k+1 .. min(k+3, nt-1)) loads are outstanding
-      auto arrived = [&](int k) {
-        const int younger = nt - 1 - k;   // uniform
-        if (younger >= 3) wait_vm_lit<24>();
-        else if (younger == 2) wait_vm_lit<16>();
-        else if (younger == 1) wait_vm_lit<8>();
-        else wait_vm_lit<0>();
-      };
-      // K-tiles 0 .. 2 into the ring, 3 .. 6 into the sets (k % 4: set 3, 0, 1, 2)
-      gload(S0{}, 0);
-      if (nt > 1) gload(S1{}, 1);
-      if (nt > 2) gload(S2{}, 2);
-      if (nt > 3) gload(S3{}, 3);
-      arrived(0);
-      lwrite(S0{});
-      if (nt > 4) gload(S0{}, 4);
-      if (nt > 1) { arrived(1); lwrite(S1{}); }
-      if (nt > 5) gload(S1{}, 5);
-      if (nt > 2) { arrived(2); lwrite(S2{}); }
-      if (nt > 6) gload(S2{}, 6);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      // step t (the multiplying waves work on K-tile t): K-tile t+3 -> the slot K-tile t-1 has left, K-tile t+7 -> its register set
-      auto step = [&](int t, auto SET, auto GUARD) {   // GUARD: K-tiles t+3 / t+7 may not exist (the last steps)
-        if constexpr (!decltype(GUARD)::value) {
-          wait_vm_lit<24>();   // K-tiles t+4 .. t+6 stay in flight
-          lwrite(SET);
-          gload(SET, t + 7);
-        } else {
-          if (t + 3 < nt) { arrived(t + 3); lwrite(SET); }
-          if (t + 7 < nt) gload(SET, t + 7);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      };
-      int t = 0;
-      for (; t + 10 < nt; t += 4) {   // sets in the order (t + 3) % 4 with t % 4 == 0; branch-free: every K-tile named exists
-        step(t, S3{}, std::false_type{});
-        step(t + 1, S0{}, std::false_type{});
-        step(t + 2, S1{}, std::false_type{});
-        step(t + 3, S2{}, std::false_type{});
-      }
-      for (; t + 4 < nt; t += 4) {
-        step(t, S3{}, std::true_type{});
-        step(t + 1, S0{}, std::true_type{});
-        step(t + 2, S1{}, std::true_type{});
-        step(t + 3, S2{}, std::true_type{});
-      }
-      if (t + 1 < nt) step(t, S3{}, std::true_type{});
-      if (t + 2 < nt) step(t + 1, S0{}, std::true_type{});
-      if (t + 3 < nt) step(t + 2, S1{}, std::true_type{});
-#undef SA_RS_LOAD
-#undef SA_RS_WRITE
-      if (!(p.flags & 64)) __syncthreads();   // the multiplying waves' barrier in front of the LDS-staged epilogues
-      return;
-    }
-  }
-  if constexpr (ROLES && !RS) {
-    if (wave_id >= 4) {   // a requesting wave: the ring's producer side, no arithmetic
-      using QC = std::integral_constant<int, PROD>;
-      constexpr int MINE = 8 - PROD;   // loads per K-tile of this wave
-      auto request = [&](int buf, int kt) { stage_q(buf, kt, QC{}, Q4{}, Q4{}); };
-      request(0, 0);
-      if (nt > 1) request(1, 1);
-      if (nt > 2) request(2, 2);
-      if (nt > 2) wait_vm_lit<2 * MINE>();
-      else if (nt > 1) wait_vm_lit<MINE>();
-      else wait_vm_lit<0>();
-      __builtin_amdgcn_s_barrier();
-      for (int t = 0; t + 1 < nt; ++t) {
-        // K-tile t+3 -> the buffer K-tile t-1 was read from: those reads completed before the barrier of step t-1
-        if (t + 3 < nt) request((t + 3) & 3, t + 3);
-        if (t + 3 < nt) wait_vm_lit<2 * MINE>();        // K-tile t+1 has landed; t+2, t+3 may be in flight
-        else if (t + 2 < nt) wait_vm_lit<MINE>();
-        else wait_vm_lit<0>();
-        __builtin_amdgcn_s_barrier();
-      }
-      if (!(p.flags & 64)) __syncthreads();   // the multiplying waves' barrier in front of the LDS-staged epilogues
-      return;
-    }
-  }
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -1187,12 +1020,6 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
 
   if constexpr (PIPE) {
     bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
-    // loads per K-tile of a multiplying wave: all 8 of its row block, or - with requesting waves - PROD of the A tile's
-    constexpr int MINE = ROLES ? PROD : 8;
-    auto stage_mine = [&](int buf, int kt) {
-      if constexpr (!ROLES) stage(buf, kt);
-      else if constexpr (PROD > 0) stage_q(buf, kt, Q0{}, std::integral_constant<int, PROD>{}, Q0{});
-    };
     auto read_frags = [&](int buf, auto SET) {
       const char* At = smem + buf * (2 * TB);
       const char* Wt = At + TB;
@@ -1209,14 +1036,12 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
     auto step = [&](int t, auto SET, auto NEXT) {   // fragments of K-tile t are set SET (reads issued one step earlier)
       constexpr int OTHER = 1 - decltype(SET)::value;
       // K-tile t+S-1 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
-      if (t + S - 1 < nt) stage_mine((t + S - 1) % S, t + S - 1);
+      if (t + S - 1 < nt) stage((t + S - 1) % S, t + S - 1);
       if constexpr (decltype(NEXT)::value) {
         // K-tile t+1 has landed; the younger ones (t+2 .. t+S-1, as far as they exist) may be in flight
-        if constexpr (MINE > 0) {   // (a multiplying wave that requests nothing has nothing to wait for)
-          if (S == 4 && t + 3 < nt) wait_vm_lit<2 * MINE>();
-          else if (t + 2 < nt) wait_vm_lit<MINE>();
-          else wait_vm_lit<0>();
-        }
+        if (S == 4 && t + 3 < nt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();
         read_frags((t + 1) % S, std::integral_constant<int, OTHER>{});      // in flight underneath the MFMAs below
@@ -1232,15 +1057,13 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    stage_mine(0, 0);
-    if (nt > 1) stage_mine(1, 1);
-    if (S == 4 && nt > 2) stage_mine(2, 2);
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (S == 4 && nt > 2) stage(2, 2);
     // K-tile 0 has landed; up to S - 2 younger ones stay in flight
-    if constexpr (MINE > 0) {
-      if (S == 4 && nt > 2) wait_vm_lit<2 * MINE>();
-      else if (nt > 1) wait_vm_lit<MINE>();
-      else wait_vm_lit<0>();
-    }
+    if (S == 4 && nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_frags(0, I0{});
     int t = 0;
@@ -1340,28 +1163,9 @@ static GemmParams with_epilogue_choice(const GemmParams& p) {
 // rows a launch lasts nt x ~0.8 us whatever its workgroup count: it is bound by the depth of the K-tile prefetch (two K-tiles
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
 // alt-format operands (flags bit 10, mixed mode) exist for plain GEMMs only - the DiT's Linears - gemm8_alt_ok()
-#define SA_GEMM8S_ROLES_DEFAULT (-1)   // the shipped form of the pipelined kernel: -1 no roles, 0 / 2 = PROD
-#define SA_GEMM8S_RS_DEFAULT 0          // ... with roles 0: requesting waves stage through registers (7 K-tiles in flight)
 static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 grid, int skip256, hipStream_t st) {
   const dim3 block(256);
   const bool alt = (p.flags & 1024) != 0;
-  // wave roles of the pipelined form (see the kernel): debug flag 27 = 1 the form without roles (round 3), 2 / 3 force PROD = 0 / 2
-  const int f27 = debug_flag(27);
-  const int roles = !pipe || f27 == 1 ? -1 : f27 == 3 ? 2 : (f27 == 2 || f27 == 6) ? 0 : SA_GEMM8S_ROLES_DEFAULT;
-  // ... 6: PROD = 0 with the requesting waves staging through registers (plain GEMMs; convolutions keep the direct-to-LDS loads)
-  const bool rs = roles == 0 && !conv && (f27 == 6 || (f27 == 0 && SA_GEMM8S_RS_DEFAULT));
-  if (roles >= 0) {
-    const dim3 block8(512);
-    if (rs && alt) { hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0, true>), grid, block8, 0, st, p, skip256); return; }
-    if (rs) { hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0, true>), grid, block8, 0, st, p, skip256); return; }
-    if (conv && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 0>), grid, block8, 0, st, p, skip256);
-    else if (conv) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 2>), grid, block8, 0, st, p, skip256);
-    else if (alt && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0>), grid, block8, 0, st, p, skip256);
-    else if (alt) hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 2>), grid, block8, 0, st, p, skip256);
-    else if (roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0>), grid, block8, 0, st, p, skip256);
-    else hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 2>), grid, block8, 0, st, p, skip256);
-    return;
-  }
   if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, skip256);
   else if (pipe && alt) hipLaunchKernelGGL((gemm8s_kernel<true, false, true>), grid, block, 0, st, p, skip256);
   else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, skip256);

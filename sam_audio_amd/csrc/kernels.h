@@ -20,15 +20,9 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            for fp32 output / residual, general contract for everything else), 1 = the general epilogue for every launch
 //            (bitwise-equality tests of the lean forms), 2 / 3 = the register / LDS form for every eligible launch (A/B)
 //   flag 26: 1 = the 8-phase kernel launches one workgroup per tile (shipped: persistent above 256 tiles) - its bitwise test
-//   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
-//            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads,
-//            6 = as 2 with the requesting waves staging through 4 register sets (7 K-tiles in flight instead of 3)
-//   flag 28: measurement aid - every 16-bit GEMM of the DiT's five big classes is preceded by a kernel that reads its weights
-//            (what the launch costs with warm weights; rocprofv3 kernel durations, not end-to-end time)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library
-hipError_t launch_touch(const void* p, size_t bytes, hipStream_t st);   // measurement aid (debug flag 28)
 hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st);
 void* debug_device_alloc(size_t bytes);
 int debug_flag(int flag);

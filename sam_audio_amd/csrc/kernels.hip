@@ -709,22 +709,6 @@ __global__ __launch_bounds__(256) void hash_items_kernel(const unsigned* x, size
   }
   if (threadIdx.x == 0) out[blockIdx.x] = part[0];
 }
-// Measurement aid (debug flag 28, engine.hip Engine::gemm): read a buffer once and drop the data - what a GEMM's weights cost when
-// they are already in the memory-side cache / L2 instead of in HBM.
-__global__ __launch_bounds__(256) void touch_kernel(const uint4* __restrict__ x, size_t n16) {
-  unsigned acc = 0;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
-    const uint4 v = x[i];
-    acc ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  asm volatile("" ::"v"(acc));
-}
-hipError_t launch_touch(const void* p, size_t bytes, hipStream_t st) {
-  if (!p || bytes < 16) return hipSuccess;
-  hipLaunchKernelGGL(touch_kernel, dim3(2048), dim3(256), 0, st, (const uint4*)p, bytes / 16);
-  return hipGetLastError();
-}
-
 hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st) {
   hipLaunchKernelGGL(hash_items_kernel, dim3(items), dim3(256), 0, st, x, words_per_item, out);
   return hipGetLastError();

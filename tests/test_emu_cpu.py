@@ -309,3 +309,10 @@ def test_judge_host_classes_on_the_emulation(emu):
     part of the by-hand dry run)."""
     out = _dryrun(["tests/test_zz_next_rows_gpu.py", "-k", "(judge_forward or dedup) and fp32"], 900)
     assert "2 passed" in out
+
+
+def test_f32_class_copies_and_their_checks_on_the_emulation(emu):
+    """Host logic of the exact-fp32 GEMM classes: fp32 operand copies exist only for the classes in use and are
+    added by set_f32_classes; a class switched on without its copy is refused by finalize / set_option, naming the copy."""
+    out = _dryrun(["tests/test_precision_gpu.py", "-k", "option_validation or f32_copies"], 900)
+    assert "2 passed" in out
