@@ -20,10 +20,13 @@ sys.path.insert(0, ROOT)
 CHILD = r'''
 import sys, os
 sys.path.insert(0, %(root)r)
+if os.environ.get("SAMAUDIO_EMU_DRYRUN"):   # shake-out of this tool on the CPU emulation (tests/conftest.py)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import conftest
 import torch
 from sam_audio_amd import SAMAudio, SAMAudioProcessor, hip, preset_config
 from sam_audio_amd.synthetic import init_state_dict, synthetic_clip, synthetic_noise, synthetic_text_features
-gpu = torch.device("cuda:0")
+gpu = torch.device(os.environ.get("SAMAUDIO_TOOL_DEVICE", "cuda:0"))
 cfg = preset_config("mini")
 sd = init_state_dict(cfg, seed=11)
 hop = cfg.audio_codec.hop_length
@@ -92,38 +95,62 @@ def per_clip(run):
     return out
 
 
+def first_difference(ref, got):
+    first = None
+    for clip in sorted(ref):
+        a, b = ref[clip], got.get(clip, {})
+        for key in sorted(a, key=lambda k: a[k][0]):   # in the order the reference run recorded them
+            if key in b and a[key][1] != b[key][1]:
+                cand = (a[key][0], clip, key)
+                if first is None or cand[0] < first[0]:
+                    first = cand
+                break
+    return first
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--rebuild", type=int, default=0, help="build the two-stream model anew every N repetitions (0: once)")
+    ap.add_argument("--keep", default="", help="directory for the raw checksum lines of every differing repetition (+ the reference)")
     args = ap.parse_args()
     env = dict(os.environ, SAMAUDIO_TRACE_HASH="1")
-    p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, reps=args.reps, rebuild=args.rebuild)], env=env, capture_output=True, text=True)
-    lines = p.stderr.splitlines()
-    runs, results = parse(lines)
-    if "one" not in runs:
-        print(p.stderr[-3000:])
-        sys.exit(1)
-    ref = per_clip(runs["one"])
-    bad = 0
-    for rep in sorted(results):
-        diffs = results[rep]
-        got = per_clip(runs.get(f"two {rep}", {}))
-        first = None
-        for clip in sorted(ref):
-            a, b = ref[clip], got.get(clip, {})
-            for key in sorted(a, key=lambda k: a[k][0]):   # in the order the reference run recorded them
-                if key in b and a[key][1] != b[key][1]:
-                    cand = (a[key][0], clip, key)
-                    if first is None or cand[0] < first[0]:
-                        first = cand
-                    break
-        status = "DIFF" if any(d > 0 for d in diffs) else "same"
-        if status == "DIFF" or first is not None:
+    # the child's stderr is read as it comes and a repetition's records are dropped once it has been compared: thousands of
+    # repetitions (a difference shows up once in several hundred) fit in memory
+    p = subprocess.Popen([sys.executable, "-c", CHILD % dict(root=ROOT, reps=args.reps, rebuild=args.rebuild)], env=env,
+                         stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+    ref, ref_lines, cur_name, cur_lines, n, bad, tail = None, [], None, [], 0, 0, []
+    for ln in p.stderr:
+        ln = ln.rstrip("\n")
+        tail = (tail + [ln])[-30:]
+        if ln.startswith("RUN "):
+            cur_name, cur_lines = ln.split(None, 1)[1].strip(), [ln]
+            continue
+        cur_lines.append(ln)
+        if cur_name == "one" and ln.startswith("[samaudio hash]"):
+            ref_lines.append(ln)
+        if not ln.startswith("RESULT "):
+            continue
+        if ref is None:
+            ref = per_clip(parse(["RUN one"] + ref_lines)[0]["one"])
+        runs, results = parse(cur_lines)
+        (rep, diffs), = results.items()
+        first = first_difference(ref, per_clip(runs.get(cur_name, {})))
+        n += 1
+        if any(d > 0 for d in diffs) or first is not None:
             bad += 1
-            print(f"rep {rep}: latents {status} {diffs}; first differing checksum: {first}")
-    print(f"{len(results)} two-stream repetitions, {bad} with differences; stages per clip in the reference: "
-          f"{len(next(iter(ref.values())))}")
+            status = "DIFF" if any(d > 0 for d in diffs) else "same"
+            print(f"rep {rep}: latents {status} {diffs}; first differing checksum (sequence number, clip, (stage, occurrence)): {first}", flush=True)
+            if args.keep:
+                os.makedirs(args.keep, exist_ok=True)
+                open(os.path.join(args.keep, f"rep{rep}.txt"), "w").write("\n".join(cur_lines) + "\n")
+                open(os.path.join(args.keep, "reference.txt"), "w").write("\n".join(ref_lines) + "\n")
+        cur_lines = []
+    p.wait()
+    if ref is None:
+        print("\n".join(tail))
+        sys.exit(1)
+    print(f"{n} two-stream repetitions, {bad} with differences; stages per clip in the reference: {len(next(iter(ref.values())))}")
 
 
 if __name__ == "__main__":
