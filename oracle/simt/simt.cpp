@@ -125,6 +125,7 @@ void wait_vmcnt_if_visible() {
 // (The one statement whose count is an asm operand, gemm2.hip wait_vmcnt<N>, is rewritten to simt::wait_vmcnt(N) by
 // oracle/simt/build.sh - the preprocessor cannot see an operand's value.)
 void asm_stmt(const char* text) {
+  if (std::strstr(text, "s_nop")) return;   // idle cycles: no meaning here, and legal under divergent control flow (no wave sync)
   const char* v = std::strstr(text, "vmcnt(");
   if (v) {
     if (v[6] < '0' || v[6] > '9') { std::fprintf(stderr, "simt: vmcnt with a non-literal count: %s\n", text); std::abort(); }

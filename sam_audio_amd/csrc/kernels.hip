@@ -421,8 +421,8 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
       float sq = 0.f, sk = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
-      sq = row16_sum(sq);
-      sk = row16_sum(sk);
+      sq = row16_sum_guarded(sq);
+      sk = row16_sum_guarded(sk);
       const float iq = rsqrtf(sq / 128.f + eps), ik = rsqrtf(sk / 128.f + eps);
       const float4 c4 = *(const float4*)(rc + (long)t * 64 + sub * 4), s4 = *(const float4*)(rs + (long)t * 64 + sub * 4);
       const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
