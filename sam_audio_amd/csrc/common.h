@@ -150,26 +150,6 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// The same sum with five idle cycles between the last VALU write of the running value and the DPP instruction that reads it, and
-// nothing for the SLP vectoriser to pair it with (each step starts with an asm statement that "modifies" v).  Round 4, GPU call 18:
-// the per-stage checksum trace caught the run-to-run difference of `separate()` eight times in 4 000 repetitions, and all eight began
-// in qkv_prep's Q output - same qkv input, K and V^T of the same launch identical.  hipcc had packed the q and k reductions into
-// v_pk_add_f32 pairs (q in the low half) followed two to three instructions later by `v_mov_b32_dpp ... row_ror` on the low half
-// first: the compiler's wait states for a VALU write -> DPP read, met exactly for q, exceeded by one for k.  (Round 4's removed q|k|v
-// GEMM epilogue had shown the same thing from the other side: wrong sums in lane 12 of a 16-lane row.)
-__device__ __forceinline__ float row16_sum_guarded(float v) {
-  asm volatile("s_nop 4" : "+v"(v));
-  v += dpp_mov<0x128>(v);
-  asm volatile("s_nop 4" : "+v"(v));
-  v += dpp_mov<0x124>(v);
-  asm volatile("s_nop 4" : "+v"(v));
-  v += dpp_mov<0x122>(v);
-  asm volatile("s_nop 4" : "+v"(v));
-  v += dpp_mov<0x121>(v);
-  asm volatile("s_nop 0" : "+v"(v));
-  return v;
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -374,6 +374,11 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const TA* __restrict__ qk
 
 // bf16 fast path: 16 lanes x 16 bytes per 128-wide head row (4 rows per wave-instruction), so every global access
 // is a 16-byte load / store; the V tile is transposed through LDS as 16-bit words and leaves as 16-byte rows of V^T.
+// VAR (debug flag 29; measurement of round 4's run-to-run difference, which begins in this kernel's Q output - tools/stress_qkv_prep.py):
+// 0 = the 16-bit rounding written out (f2bf: integer add of 0x7fff + lsb; hipcc turns it into SDWA byte-select instructions right
+// behind the packed-fp32 rotation), 1 = the hardware conversion (pack_h16x2: v_cvt_pk_bf16_f32 / v_cvt_f16_f32, the same bits for
+// every finite value), 2 = as 0 with two idle cycles between the rotation and the rounding of every element, 3 = 1 and 2.
+template <int VAR>
 __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ qw,
                                                             const float* __restrict__ kw, const float* __restrict__ rc,
                                                             const float* __restrict__ rs, bf16_t* __restrict__ Q,
@@ -402,9 +407,16 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
       x[2 * e + 1] = h16_hi(w4[e]);
     }
   };
-  auto pack = [](const float (&x)[8]) {
-    return make_uint4((unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16), (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16),
-                      (unsigned)f2bf(x[4]) | ((unsigned)f2bf(x[5]) << 16), (unsigned)f2bf(x[6]) | ((unsigned)f2bf(x[7]) << 16));
+  auto pack = [](float (&x)[8]) {
+    if constexpr (VAR == 2 || VAR == 3) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("s_nop 1" : "+v"(x[e]));
+    }
+    if constexpr (VAR == 1 || VAR == 3)
+      return make_uint4(pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3]), pack_h16x2(x[4], x[5]), pack_h16x2(x[6], x[7]));
+    else
+      return make_uint4((unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16), (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16),
+                        (unsigned)f2bf(x[4]) | ((unsigned)f2bf(x[5]) << 16), (unsigned)f2bf(x[6]) | ((unsigned)f2bf(x[7]) << 16));
   };
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -421,8 +433,8 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
       float sq = 0.f, sk = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
-      sq = row16_sum_guarded(sq);
-      sk = row16_sum_guarded(sk);
+      sq = row16_sum(sq);
+      sk = row16_sum(sk);
       const float iq = rsqrtf(sq / 128.f + eps), ik = rsqrtf(sk / 128.f + eps);
       const float4 c4 = *(const float4*)(rc + (long)t * 64 + sub * 4), s4 = *(const float4*)(rs + (long)t * 64 + sub * 4);
       const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
@@ -461,9 +473,18 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st) {
   dim3 grid(Tp / 64, H, B), block(256);
-  if (bf16)
-    hipLaunchKernelGGL(qkv_prep_bf16_kernel, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin,
-                       (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
+#define SA_QKV_PREP(V)                                                                                                   \
+  hipLaunchKernelGGL(qkv_prep_bf16_kernel<V>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q, \
+                     (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps)
+  if (bf16) {
+    switch (debug_flag(29)) {
+      case 1: SA_QKV_PREP(1); break;
+      case 2: SA_QKV_PREP(2); break;
+      case 3: SA_QKV_PREP(3); break;
+      default: SA_QKV_PREP(0); break;
+    }
+  }
+#undef SA_QKV_PREP
   else
     hipLaunchKernelGGL(qkv_prep_kernel<float>, grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin,
                        (float*)Q, (float*)K, (float*)Vt, T, Tp, H, eps);

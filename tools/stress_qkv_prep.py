@@ -32,89 +32,106 @@ def main():
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--heads", type=int, default=2)
     ap.add_argument("--inject", action="store_true", help="self-test of the report: perturb one element of a reference")
+    ap.add_argument("--variants", type=int, nargs="+", default=[0], help="debug flag 29 (kernels.h): the kernel's 16-bit rounding")
+    ap.add_argument("--operands", default="bf16", choices=["bf16", "fp16"], help="which build of the library (16-bit format)")
     args = ap.parse_args()
     gpu = torch.device(os.environ.get("SAMAUDIO_TOOL_DEVICE", "cuda:0"))
-    lib = hip.lib()
+    lib = hip.lib(args.operands)
+    dt16 = torch.bfloat16 if args.operands == "bf16" else torch.float16
     B, T, H = args.clips, args.frames, args.heads
     Tp, D = (T + 63) // 64 * 64, H * 128
     g = torch.Generator().manual_seed(5)
-    inputs = [torch.randn(B * T, 3 * D, generator=g).to(torch.bfloat16).to(gpu) for _ in range(2)]
+    inputs = [torch.randn(B * T, 3 * D, generator=g).to(dt16).to(gpu) for _ in range(2)]
     qw = (torch.randn(128, generator=g) * 0.1 + 1).to(gpu)
     kw = (torch.randn(128, generator=g) * 0.1 + 1).to(gpu)
     freqs = 1.0 / (20000.0 ** (torch.arange(0, 128, 2).float() / 128))
     ang = torch.outer(torch.arange(128), freqs).float()
     cos, sin = ang.cos().to(gpu).contiguous(), ang.sin().to(gpu).contiguous()
     buf = torch.empty_like(inputs[0])
-    q = torch.empty(B, H, Tp, 128, device=gpu, dtype=torch.bfloat16)
-    k, vt = torch.empty_like(q), torch.empty(B, H, 128, Tp, device=gpu, dtype=torch.bfloat16)
+    q = torch.empty(B, H, Tp, 128, device=gpu, dtype=dt16)
+    k, vt = torch.empty_like(q), torch.empty(B, H, 128, Tp, device=gpu, dtype=dt16)
     P = lambda t: C.c_void_p(t.data_ptr())
 
     def launch():
         hip.check(lib.samaudio_op_qkv_prep(P(buf), P(qw), P(kw), P(cos), P(sin), P(q), P(k), P(vt), hip.BF16, B, T, Tp, H,
                                            C.c_float(1e-5), hip.current_stream_ptr()))
 
-    refs = []
-    for x in inputs:
-        buf.copy_(x)
-        launch()
+    def want_q(x):   # torch fp32 on the device: q-norm + RoPE of the rounded input, [B, H, T, 128]
+        xq = x.float()[:, :D].reshape(B, T, H, 128).permute(0, 2, 1, 3)
+        xq = xq * torch.rsqrt((xq * xq).mean(-1, keepdim=True) + 1e-5) * qw
+        a, b_ = xq[..., 0::2], xq[..., 1::2]
+        c, s_ = cos[None, None, :T, :], sin[None, None, :T, :]
+        return torch.stack([a * c - b_ * s_, a * s_ + b_ * c], -1).reshape(B, H, T, 128)
+
+    for variant in args.variants:
+        lib.samaudio_debug_set_flag(29, variant)
+        print(f"--- variant {variant} (debug flag 29), {args.operands} library")
+        refs = []
+        for x in inputs:
+            buf.copy_(x)
+            launch()
+            if gpu.type == "cuda":
+                torch.cuda.synchronize()
+            refs.append((q.clone(), k.clone(), vt.clone()))
+        if args.inject:
+            refs[0][0][1, 1, 3, 5] += 1.0
+        stop = threading.Event()
+
+        def busy():   # the other row group's stand-in: GEMMs on a second stream
+            s = torch.cuda.Stream()
+            a = torch.randn(2048, 2048, device=gpu, dtype=torch.bfloat16)
+            with torch.cuda.stream(s):
+                while not stop.is_set():
+                    for _ in range(20):
+                        a @ a
+                    s.synchronize()
+
+        th = None
+        if not args.no_second_stream:
+            th = threading.Thread(target=busy)
+            th.start()
+        bad = torch.zeros(3, device=gpu, dtype=torch.int64)       # launches whose Q / K / V^T differed
+        first_q = torch.zeros_like(q)
+        first_i = torch.full((1,), -1, device=gpu, dtype=torch.int64)
+        I16 = torch.int16
+        for i in range(args.iters):
+            w = i & 1
+            buf.copy_(inputs[w])          # the producer rewrites the buffer (as the qkv GEMM does every layer)
+            q.fill_(float("nan"))
+            launch()
+            dq = (q.view(I16) != refs[w][0].view(I16)).any()
+            dk = (k.view(I16) != refs[w][1].view(I16)).any()
+            dv = (vt.view(I16) != refs[w][2].view(I16)).any()
+            bad += torch.stack([dq, dk, dv]).to(torch.int64)
+            take = dq & (first_i < 0)
+            first_q = torch.where(take, q, first_q)
+            first_i = torch.where(take, torch.full_like(first_i, i), first_i)
         if gpu.type == "cuda":
             torch.cuda.synchronize()
-        refs.append((q.clone(), k.clone(), vt.clone()))
-    if args.inject:
-        refs[0][0][1, 1, 3, 5] += 1.0
-    stop = threading.Event()
-
-    def busy():   # the other row group's stand-in: GEMMs on a second stream
-        s = torch.cuda.Stream()
-        a = torch.randn(2048, 2048, device=gpu, dtype=torch.bfloat16)
-        with torch.cuda.stream(s):
-            while not stop.is_set():
-                for _ in range(20):
-                    a @ a
-                s.synchronize()
-
-    th = None
-    if not args.no_second_stream:
-        th = threading.Thread(target=busy)
-        th.start()
-    bad = torch.zeros(3, device=gpu, dtype=torch.int64)       # launches whose Q / K / V^T differed
-    first_q = torch.zeros_like(q)
-    first_i = torch.full((1,), -1, device=gpu, dtype=torch.int64)
-    I16 = torch.int16
-    for i in range(args.iters):
-        w = i & 1
-        buf.copy_(inputs[w])          # the producer rewrites the buffer (as the qkv GEMM does every layer)
-        q.fill_(float("nan"))
-        launch()
-        dq = (q.view(I16) != refs[w][0].view(I16)).any()
-        dk = (k.view(I16) != refs[w][1].view(I16)).any()
-        dv = (vt.view(I16) != refs[w][2].view(I16)).any()
-        bad += torch.stack([dq, dk, dv]).to(torch.int64)
-        take = dq & (first_i < 0)
-        first_q = torch.where(take, q, first_q)
-        first_i = torch.where(take, torch.full_like(first_i, i), first_i)
-    if gpu.type == "cuda":
-        torch.cuda.synchronize()
-    stop.set()
-    if th:
-        th.join()
-    nq, nk, nv = bad.tolist()
-    print(f"{args.iters} launches ({B} clips x {T} frames, {H} heads; second stream {'off' if args.no_second_stream else 'busy'}): "
-          f"Q differed {nq} times, K {nk}, V^T {nv}")
-    if nq:
-        i = int(first_i)
-        w = i & 1
-        want, other = refs[w][0].float(), refs[1 - w][0].float()
-        got = first_q.float()
-        rows = (got != want).any(dim=-1).nonzero().tolist()   # (clip, head, frame)
-        print(f"first at launch {i}: {len(rows)} rows differ (clip, head, frame): {rows[:12]}")
-        for b_, h_, t_ in rows[:6]:
-            g_, w_, o_ = got[b_, h_, t_], want[b_, h_, t_], other[b_, h_, t_]
-            n = int((g_ != w_).sum())
-            print(f"  row {b_, h_, t_}: {n} of 128 elements differ; equal to the other input's row: {bool(torch.equal(g_, o_))}; "
-                  f"max |got - want| {float((g_ - w_).abs().max()):.4g}, ratio got/want of the first differing element "
-                  f"{float(g_[g_ != w_][0] / w_[g_ != w_][0]):.6g}; NaN left: {bool(torch.isnan(g_).any())}; "
-                  f"differing positions {(g_ != w_).nonzero().flatten().tolist()[:16]}")
+        stop.set()
+        if th:
+            th.join()
+        nq, nk, nv = bad.tolist()
+        print(f"{args.iters} launches ({B} clips x {T} frames, {H} heads; second stream {'off' if args.no_second_stream else 'busy'}): "
+              f"Q differed {nq} times, K {nk}, V^T {nv}")
+        if nq:
+            i = int(first_i)
+            w = i & 1
+            want, other = refs[w][0].float(), refs[1 - w][0].float()
+            got = first_q.float()
+            rows = (got != want).any(dim=-1).nonzero().tolist()   # (clip, head, frame)
+            print(f"first at launch {i}: {len(rows)} rows differ (clip, head, frame): {rows[:12]}")
+            for b_, h_, t_ in rows[:6]:
+                g_, w_, o_ = got[b_, h_, t_], want[b_, h_, t_], other[b_, h_, t_]
+                n = int((g_ != w_).sum())
+                print(f"  row {b_, h_, t_}: {n} of 128 elements differ; equal to the other input's row: {bool(torch.equal(g_, o_))}; "
+                      f"max |got - want| {float((g_ - w_).abs().max()):.4g}, ratio got/want of the first differing element "
+                      f"{float(g_[g_ != w_][0] / w_[g_ != w_][0]):.6g}; NaN left: {bool(torch.isnan(g_).any())}; "
+                      f"differing positions {(g_ != w_).nonzero().flatten().tolist()[:16]}")
+        err = max(float((refs[w_][0][:, :, :T].float() - want_q(inputs[w_])).abs().max()) for w_ in range(2))
+        print(f"first launches against torch fp32 on the device: max |Q - want| {err:.3g} (half a 16-bit ulp of values up to ~4 is "
+              f"{'0.016' if args.operands == 'bf16' else '0.002'})")
+    lib.samaudio_debug_set_flag(29, 0)
     return 0
 
 
