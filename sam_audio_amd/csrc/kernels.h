@@ -20,8 +20,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            for fp32 output / residual, general contract for everything else), 1 = the general epilogue for every launch
 //            (bitwise-equality tests of the lean forms), 2 / 3 = the register / LDS form for every eligible launch (A/B)
 //   flag 26: 1 = the 8-phase kernel launches one workgroup per tile (shipped: persistent above 256 tiles) - its bitwise test
-//   flag 29: measurement aid - qkv_prep's 16-bit rounding: 0 written out, 1 hardware conversion, 2 / 3 = 0 / 1 with idle cycles in
-//            front of it (kernels.hip qkv_prep_bf16_kernel, tools/stress_qkv_prep.py)
+//   flag 29: 1 = qkv_prep with its 16-bit rounding written out (the form before round 4: reproducer of the run-to-run difference its
+//            SDWA instruction sequence showed beside another kernel's waves - kernels.hip, tools/stress_qkv_prep.py)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library

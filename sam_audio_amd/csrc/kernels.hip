@@ -374,11 +374,17 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(const TA* __restrict__ qk
 
 // bf16 fast path: 16 lanes x 16 bytes per 128-wide head row (4 rows per wave-instruction), so every global access
 // is a 16-byte load / store; the V tile is transposed through LDS as 16-bit words and leaves as 16-byte rows of V^T.
-// VAR (debug flag 29; measurement of round 4's run-to-run difference, which begins in this kernel's Q output - tools/stress_qkv_prep.py):
-// 0 = the 16-bit rounding written out (f2bf: integer add of 0x7fff + lsb; hipcc turns it into SDWA byte-select instructions right
-// behind the packed-fp32 rotation), 1 = the hardware conversion (pack_h16x2: v_cvt_pk_bf16_f32 / v_cvt_f16_f32, the same bits for
-// every finite value), 2 = as 0 with two idle cycles between the rotation and the rounding of every element, 3 = 1 and 2.
-template <int VAR>
+// SWROUND = false (shipped): the 16-bit rounding of Q / K is the hardware conversion (pack_h16x2: v_cvt_pk_bf16_f32 / v_cvt_f16_f32).
+// SWROUND = true (debug flag 29 = 1) is the form this kernel had until round 4, kept as the reproducer of what it did: written out
+// (f2bf: integer add of 0x7fff + lsb), hipcc turns the bf16 rounding into SDWA word-select instructions (v_and_b32_sdwa ...
+// src0_sel:WORD_1) directly behind the packed-fp32 rotation (v_pk_fma_f32) that produces their operand - and when another kernel's waves
+// share the SIMD, the high half of one dword of Q (element 5 of a lane's 8) comes out wrong in ~0.5 % of the launches: 208 of 40 000
+// with a second stream busy, 0 of 40 000 alone, 0 of 40 000 with the hardware conversion, 0 of 40 000 with two idle cycles between
+// rotation and rounding, never in K or V^T, never in the fp16 build (whose f2bf is the hardware conversion anyway) -
+// tools/stress_qkv_prep.py, profiles/r4_call20/, r4_call21/.  This was the run-to-run difference of SAMAudio(streams=2) that rounds 3
+// and 4 chased: the per-stage checksum trace put all 26 sightings at this kernel's Q output.  Same bits as f2bf
+// for every finite value (the kernel's tests, and 40 000 launches against torch fp32 on the device).
+template <bool SWROUND>
 __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ qw,
                                                             const float* __restrict__ kw, const float* __restrict__ rc,
                                                             const float* __restrict__ rs, bf16_t* __restrict__ Q,
@@ -407,12 +413,8 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
       x[2 * e + 1] = h16_hi(w4[e]);
     }
   };
-  auto pack = [](float (&x)[8]) {
-    if constexpr (VAR == 2 || VAR == 3) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) asm volatile("s_nop 1" : "+v"(x[e]));
-    }
-    if constexpr (VAR == 1 || VAR == 3)
+  auto pack = [](const float (&x)[8]) {
+    if constexpr (!SWROUND)
       return make_uint4(pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3]), pack_h16x2(x[4], x[5]), pack_h16x2(x[6], x[7]));
     else
       return make_uint4((unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16), (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16),
@@ -473,18 +475,12 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st) {
   dim3 grid(Tp / 64, H, B), block(256);
-#define SA_QKV_PREP(V)                                                                                                   \
-  hipLaunchKernelGGL(qkv_prep_bf16_kernel<V>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q, \
-                     (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps)
-  if (bf16) {
-    switch (debug_flag(29)) {
-      case 1: SA_QKV_PREP(1); break;
-      case 2: SA_QKV_PREP(2); break;
-      case 3: SA_QKV_PREP(3); break;
-      default: SA_QKV_PREP(0); break;
-    }
-  }
-#undef SA_QKV_PREP
+  if (bf16 && debug_flag(29) == 1)   // the pre-round-4 rounding: reproducer only (see the kernel)
+    hipLaunchKernelGGL(qkv_prep_bf16_kernel<true>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q,
+                       (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
+  else if (bf16)
+    hipLaunchKernelGGL(qkv_prep_bf16_kernel<false>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q,
+                       (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
   else
     hipLaunchKernelGGL(qkv_prep_kernel<float>, grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin,
                        (float*)Q, (float*)K, (float*)Vt, T, Tp, H, eps);

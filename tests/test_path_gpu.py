@@ -235,7 +235,7 @@ def test_concurrent_streams_are_bitwise_equal_to_one_stream(gpu):
     for rep in range(2):
         res = two.separate(batch, noise=noise, ode_opt=opt)
         torch.cuda.synchronize()
-        if not torch.equal(two.last_latent, ref):   # say where (failed once in round 3, GPU call 11; not reproduced since)
+        if not torch.equal(two.last_latent, ref):   # say where (rounds 3 / 4: ~1 in 500, root cause = qkv_prep's rounding)
             d = (two.last_latent.float() - ref.float()).abs()
             per_clip = d.flatten(1).max(dim=1).values.tolist()
             raise AssertionError(f"two-stream latent differs from the one-stream one in repetition {rep}: max |diff| per clip "

@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--heads", type=int, default=2)
     ap.add_argument("--inject", action="store_true", help="self-test of the report: perturb one element of a reference")
-    ap.add_argument("--variants", type=int, nargs="+", default=[0], help="debug flag 29 (kernels.h): the kernel's 16-bit rounding")
+    ap.add_argument("--variants", type=int, nargs="+", default=[0], help="debug flag 29 (kernels.h): 0 = the shipped kernel (hardware conversion), 1 = the rounding written out (before round 4)")
     ap.add_argument("--operands", default="bf16", choices=["bf16", "fp16"], help="which build of the library (16-bit format)")
     args = ap.parse_args()
     gpu = torch.device(os.environ.get("SAMAUDIO_TOOL_DEVICE", "cuda:0"))
