@@ -19,6 +19,7 @@ SAN=""
 if [ "$1" = "asan" ]; then OUT=../_simt/asan; LIB=libsamaudio_simt_asan.so; SAN="-fsanitize=address -fsanitize-recover=address -fno-omit-frame-pointer -g1 -shared-libsan"; fi
 mkdir -p $OUT
 CXX=/opt/rocm/lib/llvm/bin/clang++
+if [ -n "$SAMAUDIO_BF16_HW_ROUND" ]; then POISON="$POISON -DSA_BF16_HW_ROUND"; OUT=${OUT}_hwround; LIB=${LIB%.so}_hwround.so; mkdir -p $OUT; fi   # experiment build (common.h f2bf); run with SAMAUDIO_SIMT_LIB=oracle/_simt/<that library>
 FLAGS="-x c++ -std=c++17 -O2 -fPIC -fopenmp $POISON $SAN -I stub -Wno-unused-value -Wno-unknown-attributes -Wno-ignored-attributes -Wno-pass-failed -Wno-keyword-macro -Wno-psabi"
 pids=()
 for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 mbert api; do

@@ -5,6 +5,9 @@
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# experiment switch (common.h f2bf): the bf16 build rounds with the hardware conversion; separate object directory
+HW=""; HWDIR=""
+if [ -n "$SAMAUDIO_BF16_HW_ROUND" ]; then HW="-DSA_BF16_HW_ROUND"; HWDIR="_hwround"; fi
 SRCS="gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels engine peav vit t5 mbert api"
 build_one() {  # $1 = object dir, $2 = extra flags, $3 = output
   local dir=$1 extra_all=$2 out=$3 pids=() objs=""
@@ -24,7 +27,7 @@ build_one() {  # $1 = object dir, $2 = extra flags, $3 = output
   hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out
   echo "built $out"
 }
-build_one build "" ../libsamaudio_hip.so &
+build_one build$HWDIR "$HW" ../libsamaudio_hip$HWDIR.so &   # (the experiment build: libsamaudio_hip_hwround.so, loaded with SAMAUDIO_LIB_AB)
 B1=$!
 build_one build_f16 "-DSA_OPERAND_FP16" ../libsamaudio_hip_f16.so &
 B2=$!

@@ -43,6 +43,9 @@ def _enable_emu_dryrun():
     poison = which == "simt" and os.environ.get("SAMAUDIO_SIMT_POISON") == "1"   # LDS poisoned before every workgroup
     asan = which == "simt" and os.environ.get("SAMAUDIO_SIMT_ASAN") == "1"   # AddressSanitizer build (oracle/simt/build.sh)
     emu = os.path.join(ROOT, "oracle", f"_{which}", f"libsamaudio_{which}{'_poison' if poison else '_asan' if asan else ''}.so")
+    if os.environ.get("SAMAUDIO_SIMT_LIB"):   # an experiment build of the simulator library (oracle/simt/build.sh), as is
+        emu = os.path.abspath(os.environ["SAMAUDIO_SIMT_LIB"])
+        os.environ["SAMAUDIO_EMU_NOBUILD"] = "1"
     if not os.environ.get("SAMAUDIO_EMU_NOBUILD"):
         subprocess.check_call(["bash", os.path.join(ROOT, "oracle", which, "build.sh")]
                               + (["poison"] if poison else ["asan"] if asan else []))
