@@ -111,9 +111,9 @@ template <> __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float
 }
 template <typename T> __device__ __forceinline__ void store2(T* p, float a, float b);
 template <> __device__ __forceinline__ void store2<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
-template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) {
-  ushort2 v; v.x = f2bf(a); v.y = f2bf(b); *(ushort2*)p = v;
-}
+// (the pair goes through the hardware conversion, not through f2bf: the same bits for every finite value, and no SDWA word-select
+// instructions behind the arithmetic that produced a / b - DESIGN.md section 8, round 4)
+template <> __device__ __forceinline__ void store2<bf16_t>(bf16_t* p, float a, float b) { *(unsigned*)p = pack_h16x2(a, b); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // nn.GELU() (erf form) and CLIP's x * sigmoid(1.702 x): the vision tower's MLP activations

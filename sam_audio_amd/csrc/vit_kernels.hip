@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void rope2d_split_bf16_kernel(const bf16_t* __
     }
   };
   auto pack = [](const float (&x)[8]) {
-    return make_uint4((unsigned)f2bf(x[0]) | ((unsigned)f2bf(x[1]) << 16), (unsigned)f2bf(x[2]) | ((unsigned)f2bf(x[3]) << 16),
-                      (unsigned)f2bf(x[4]) | ((unsigned)f2bf(x[5]) << 16), (unsigned)f2bf(x[6]) | ((unsigned)f2bf(x[7]) << 16));
+    // hardware conversion, as kernels.hip qkv_prep_bf16_kernel since round 4 (no SDWA rounding behind the packed-fp32 rotation)
+    return make_uint4(pack_h16x2(x[0], x[1]), pack_h16x2(x[2], x[3]), pack_h16x2(x[4], x[5]), pack_h16x2(x[6], x[7]));
   };
 #pragma unroll
   for (int it = 0; it < 64 / RPI; ++it) {
@@ -238,8 +238,12 @@ __global__ __launch_bounds__(256) void pool_attention_kernel(const float* __rest
       for (int e = 0; e < E; ++e) oo[e] += so[w][lane * E + e] * a;
     }
     const float inv = 1.f / ll;
+    if constexpr (E == 2) {   // one pair through store2 (hardware conversion for 16-bit outputs: common.h)
+      store2<TA>(out + (long)f * D + h * HD + lane * E, oo[0] * inv, oo[1] * inv);
+    } else {
 #pragma unroll
-    for (int e = 0; e < E; ++e) Elem<TA>::store(out + (long)f * D + h * HD + lane * E + e, oo[e] * inv);
+      for (int e = 0; e < E; ++e) Elem<TA>::store(out + (long)f * D + h * HD + lane * E + e, oo[e] * inv);
+    }
   }
 }
 

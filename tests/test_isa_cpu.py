@@ -46,13 +46,20 @@ def _sdwa_behind_packed_f32(lines, window=3):
 
 @pytest.fixture(scope="module")
 def kernels_asm(tmp_path_factory):
+    """the bf16 build's code of every file whose kernels round fp32 results to 16 bits outside a GEMM epilogue"""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("isa") / "kernels.s"
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "--cuda-device-only",
-                           "-S", "-o", str(out), os.path.join(CSRC, "kernels.hip")], stderr=subprocess.DEVNULL)
-    return _kernels(out.read_text())
+    tmp, out, procs = tmp_path_factory.mktemp("isa"), {}, []
+    for name in ("kernels", "attention", "vit_kernels", "peav_kernels", "t5_kernels"):
+        dst = tmp / f"{name}.s"
+        procs.append((dst, subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+                                             "--cuda-device-only", "-S", "-o", str(dst), os.path.join(CSRC, f"{name}.hip")],
+                                            stderr=subprocess.DEVNULL)))
+    for dst, p in procs:
+        assert p.wait() == 0, dst
+        out.update(_kernels(dst.read_text()))
+    return out
 
 
 def test_shipped_qkv_prep_has_no_sdwa_rounding(kernels_asm):
@@ -64,11 +71,11 @@ def test_shipped_qkv_prep_has_no_sdwa_rounding(kernels_asm):
     assert _sdwa_behind_packed_f32(old[0]) >= 10, "the reproducer form no longer shows the pattern: is the scan still valid?"
 
 
-def test_sdwa_behind_packed_fp32_stays_where_it_is_known(kernels_asm):
-    """kernels.hip, bf16 build: besides the reproducer, only the two head-norm kernels have such pairs (2 each; never seen to differ -
-    DESIGN.md section 8 lists them with the three of attention.hip / vit_kernels.hip).  A new entry here means a new kernel rounds
-    behind packed-fp32 math with the written-out f2bf: use pack_h16x2 there."""
-    known = ("qkv_prep_bf16_kernelILb1E", "headnorm_kernelINS_6bf16_tE", "headnorm_layers_kernelINS_6bf16_tE")
+def test_no_kernel_rounds_with_sdwa_behind_packed_fp32(kernels_asm):
+    """Round 4 found such pairs in qkv_prep (31: the difference's origin), the two head-norm kernels and the generic cross-attention
+    kernel (2 each), the vision tower's RoPE split (1) and its pooling attention (1); all of them now round through pack_h16x2 /
+    store2 (the hardware conversion).  Only the reproducer keeps the pattern.  A hit here = a kernel that rounds with the written-out
+    f2bf right behind packed-fp32 arithmetic: route it through pack_h16x2."""
     found = {k: _sdwa_behind_packed_f32(v) for k, v in kernels_asm.items()}
-    new = {k: n for k, n in found.items() if n and not any(x in k for x in known)}
+    new = {k: n for k, n in found.items() if n and "qkv_prep_bf16_kernelILb1E" not in k}
     assert not new, new
