@@ -107,6 +107,14 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   the kernels that produce their activation operands (RMSNorm + modulate, self-attention, the wo / w13 epilogues) write that
  *   format.  In libsamaudio_hip.so both formats are bfloat16 and the option changes nothing. */
 #define SAMAUDIO_OPT_ALT16_CLASSES 5
+/*   SAMAUDIO_OPT_PREFETCH_ROWS (16-bit contexts; default 0 = off): in evaluations of at most this many rows (rows = batch x
+ *   frames of one samaudio_forward), every big GEMM of a DiT layer that leaves CUs idle (< 256 workgroups: the few-row launches of
+ *   a batch shard, 4 clips per GPU) uses them to read the NEXT GEMM's weights once, linearly, so that the next launch finds them
+ *   in the memory-side cache instead of fetching them cold.  Scheduling only: results are bitwise unaffected.
+ * Weight layout of the five big GEMM classes of the DiT layers (L<i>.wqkv, wo, c_wq, w13, w2), chosen per tensor by the shape it is
+ * registered with: [N, K] row-major, or [K/64, N, 64] K-TILE-MAJOR - the 64-element K slab of all N rows contiguous (16-bit contexts
+ * only; sam_audio_amd/weights.py ktm_layout).  Same values, same results; a launch of few rows then streams its weights front to back. */
+#define SAMAUDIO_OPT_PREFETCH_ROWS 6
 #define SAMAUDIO_CLS_ALT16_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
 #define SAMAUDIO_CLS_TIME (1 << 0)   /* t_embedder MLP + t_block (transformer.py:236-257,462-467): 1 row per time value */
 #define SAMAUDIO_CLS_OUT (1 << 1)    /* DiT output projection D -> 256 (transformer.py:519): feeds the ODE state */

@@ -183,7 +183,7 @@ enum : int { ACT_NONE = 0, ACT_SNAKE = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_GELU =
 // Rows are clamped to M-1 on load (halo rows make shifted reads legal) and masked on store.
 struct GemmParams {
   const void* A;
-  const void* W;  // [N][K] row-major, K contiguous; same element type as A
+  const void* W;  // [N][K] row-major, K contiguous; same element type as A (flags bit 11: K-tile-major [K/64][N][64])
   long a_off, a_bstride, lda, tap_stride;
   int kc;
   int M, N, K, nbatch;
@@ -216,7 +216,16 @@ struct GemmParams {
                            // caller) never split the launch into whole rounds + tail (gemm.hip gemm_tail_split);
                            // bits 2-3 / 4-5 (fp32 kernel only): round the A / W operand to bf16 (1) or fp16 (2) first;
                            // bit 6 (set by the gemm8.hip launchers): linear epilogue (gemm8_linear_epilogue)
+                           // bits 9 / 10: 16-bit output / operands in the alt format (mixed mode)
+                           // bit 11: W is K-TILE-MAJOR, [K/64][N][64] - the 64-element K slab of ALL N rows contiguous, so a
+                           // launch streams W front to back (8-phase family only, plain operands; weights.py ktm_layout)
   int tag;                 // 1: DAC-VAE launch - same code under its own kernel symbol (rocprofv3 / roofline attribution)
+  // Optional (8-phase family, launches of fewer than 256 workgroups): the workgroups that would otherwise idle touch these bytes
+  // once, line by line - the NEXT launch's weights, so that it finds them in the memory-side cache instead of fetching them
+  // cold.  Results do not depend on it.
+  const void* pf_ptr;
+  long pf_bytes;
 };
+constexpr int GEMM_FLAG_W_KTM = 2048;
 
 }  // namespace sa

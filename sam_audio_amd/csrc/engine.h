@@ -115,6 +115,7 @@ class Engine {
   bool tail_split_ = true;  // SAMAUDIO_OPT_TAIL_SPLIT
   int f32_classes_ = 0;     // SAMAUDIO_OPT_F32_CLASSES (16-bit contexts)
   int alt_classes_ = 0;     // SAMAUDIO_OPT_ALT16_CLASSES (16-bit contexts)
+  int prefetch_rows_ = 0;   // SAMAUDIO_OPT_PREFETCH_ROWS (16-bit contexts)
   int quant_classes_ = 0, quant_fmt_ = 0;  // SAMAUDIO_OPT_QUANT_CLASSES / _FORMAT (fp32 contexts)
   size_t esz_;  // bytes per activation / GEMM-operand element
   int at_dtype_;
@@ -130,7 +131,10 @@ class Engine {
   struct LayerW {
     const float *attn_norm, *ffn_norm, *mod_table, *q_norm, *k_norm, *c_q_norm;
     const void *wqkv, *wo, *c_wq, *c_wo, *w13, *w2;
+    int ktm;   // which of (wqkv, wo, c_wq, w13, w2) - bits 0..4 - are registered K-tile-major [K/64][N][64] (samaudio.h)
   };
+  // a big-five weight: [N, K] row-major or (16-bit contexts) [K/64, N, 64] K-tile-major
+  Status need_w5(const std::string& name, int N, int K, const void** out, int* ktm_bits, int bit);
   std::vector<LayerW> layers_;
   struct {
     const float *final_table, *final_norm, *gn1_w, *gn1_b, *gn2_w, *gn2_b, *pb1, *pb2, *tb_b, *t_freqs, *mem_inv_freq,

@@ -154,6 +154,16 @@ const void* Engine::opt(const std::string& name, std::vector<int64_t> shape) con
   return t && t->dtype == SAMAUDIO_DT_F32 && t->shape == shape ? t->p : nullptr;
 }
 
+Status Engine::need_w5(const std::string& name, int N, int K, const void** out, int* ktm_bits, int bit) {
+  const TensorRef* t = find(name);
+  if (t && bf16_ && t->dtype == at_dtype_ && t->shape == std::vector<int64_t>{K / 64, N, 64} && K % 64 == 0) {
+    *out = t->p;
+    *ktm_bits |= 1 << bit;
+    return Status{};
+  }
+  return need(name, at_dtype_, {N, K}, out);
+}
+
 static int kpad(int k, bool bf16) { return (int)round_up(k, bf16 ? 64 : 32); }
 
 Status Engine::finalize(int what) {
@@ -175,12 +185,12 @@ Status Engine::finalize(int what) {
       NEEDF(w.q_norm, P + "q_norm", 128);
       NEEDF(w.k_norm, P + "k_norm", 128);
       NEEDF(w.c_q_norm, P + "c_q_norm", 128);
-      NEEDW(w.wqkv, P + "wqkv", 3 * D, D);
-      NEEDW(w.wo, P + "wo", D, D);
-      NEEDW(w.c_wq, P + "c_wq", D, D);
+      SA_TRY(need_w5(P + "wqkv", 3 * D, D, &w.wqkv, &w.ktm, 0));
+      SA_TRY(need_w5(P + "wo", D, D, &w.wo, &w.ktm, 1));
+      SA_TRY(need_w5(P + "c_wq", D, D, &w.c_wq, &w.ktm, 2));
       NEEDW(w.c_wo, P + "c_wo", D, D);
-      NEEDW(w.w13, P + "w13", 2 * F, D);
-      NEEDW(w.w2, P + "w2", D, F);
+      SA_TRY(need_w5(P + "w13", 2 * F, D, &w.w13, &w.ktm, 3));
+      SA_TRY(need_w5(P + "w2", D, F, &w.w2, &w.ktm, 4));
     }
     NEEDF(g_.final_table, "final_table", 2, D);
     NEEDF(g_.final_norm, "final_norm", D);
@@ -446,6 +456,12 @@ Status Engine::set_option(int option, int value) {
     alt_classes_ = value;
     return Status{};
   }
+  if (option == SAMAUDIO_OPT_PREFETCH_ROWS) {
+    if (value && !bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_PREFETCH_ROWS applies to 16-bit contexts");
+    if (value < 0) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_PREFETCH_ROWS: a row count (0 = off)");
+    prefetch_rows_ = value;
+    return Status{};
+  }
   if (option == SAMAUDIO_OPT_QUANT_CLASSES || option == SAMAUDIO_OPT_QUANT_FORMAT) {
     if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_QUANT_*: operand-rounding emulation needs an fp32 context");
     if (option == SAMAUDIO_OPT_QUANT_FORMAT && (value < 0 || value > 2))
@@ -461,7 +477,8 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
   p.tag = prof_cls_[0] == 'c' ? 1 : 0;  // codec launches run under their own kernel symbols
   // bit 1: no tail split (gemm.hip gemm_tail_split); bit 9 (from the caller): 16-bit output in the alt format; bit 10: operands
   // in the alt format (SAMAUDIO_OPT_ALT16_CLASSES, mixed mode)
-  p.flags = (p_in.flags & 512) | (tail_split_ ? 0 : 2) | (alt16(cls) && !f32 ? 1024 : 0);
+  // bit 11 (from the caller): W is K-tile-major
+  p.flags = (p_in.flags & (512 | GEMM_FLAG_W_KTM)) | (tail_split_ ? 0 : 2) | (alt16(cls) && !f32 ? 1024 : 0);
   if (p.tag) cls = SAMAUDIO_CLS_CODEC;
   if (f32) {  // a class of SAMAUDIO_OPT_F32_CLASSES: exact-fp32 kernel inside a 16-bit context
     if (!p.W) return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_F32_CLASSES: the class's \"<name>.f32\" weight copy is not registered");
@@ -823,6 +840,12 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
+  // SAMAUDIO_OPT_PREFETCH_ROWS: a launch's idle workgroups read the next big GEMM's weights (gemm8.hip prefetch_lines)
+  const bool pf_on = bf16_ && prefetch_rows_ > 0 && M <= prefetch_rows_;
+  auto prefetch = [&](GemmParams& p, const void* w_next, double elems) {
+    if (pf_on && w_next) { p.pf_ptr = w_next; p.pf_bytes = (long)(elems * esz_); }
+  };
+  auto ktm = [](GemmParams& p, const LayerW& w, int bit) { if (w.ktm & (1 << bit)) p.flags |= GEMM_FLAG_W_KTM; };
   for (int l = 0; l < cfg_.n_layers; ++l) {  // DiTBlock.forward, transformer.py:354-391
     const LayerW& w = layers_[l];
     const float* tab = w.mod_table;
@@ -836,6 +859,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     }));
     {
       GemmParams p = lin(d_.xn, D, w.wqkv, M, 3 * D, D);
+      ktm(p, w, 0);
+      prefetch(p, w.wo, (double)D * D);
       out_act(p, d_.qkv, 3L * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_QKV));
     }
@@ -859,6 +884,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_f32(p, d_.h, D);
       out_act(p, d_.hbf, D);
       if (alt16(SAMAUDIO_CLS_CWQ)) p.flags |= 512;   // hbf is c_wq's operand
+      ktm(p, w, 1);
+      prefetch(p, w.c_wq, (double)D * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
     }
     trace("  h after wo", d_.h, (size_t)M * D, false, st);
@@ -866,6 +893,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     // cross-attention branch: h = h + CA(h, y)   (no norm, no gate: quirk Q4)
     {
       GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
+      ktm(p, w, 2);
+      prefetch(p, w.c_wo, (double)D * D);
       out_act(p, d_.qc, D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWQ));
     }
@@ -889,12 +918,14 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.f32_bstride = (long)T * D;
       trace("  probs", d_.probs, (size_t)M * fold_kp_, bf16_, st);
       trace("  ut", d_.ut, (size_t)rows * D * fold_kp_, bf16_, st);
+      prefetch(p, w.w13, 2.0 * F * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
       SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
+      prefetch(p, w.w13, 2.0 * F * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     }
     trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
@@ -912,6 +943,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.swiglu = 1;
       out_act(p, d_.u, F);
       if (alt16(SAMAUDIO_CLS_W2)) p.flags |= 512;    // u is w2's operand
+      ktm(p, w, 3);
+      prefetch(p, w.w2, (double)D * F);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
       trace("  xn (ffn)", d_.xn, (size_t)M * D, bf16_, st);
       trace("  u", d_.u, (size_t)M * F, bf16_, st);
@@ -919,6 +952,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.gate_tab = tab + 5 * D; p.gate = d_.t0 + 5 * D; p.gate_ld = t6; p.rows_per_gate = T;
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
+      ktm(p, w, 4);
+      if (l + 1 < cfg_.n_layers) prefetch(p, layers_[l + 1].wqkv, 3.0 * D * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W2));
       trace("  h after ffn", d_.h, (size_t)M * D, false, st);
     }

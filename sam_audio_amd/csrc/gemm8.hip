@@ -421,6 +421,40 @@ __device__ __forceinline__ void tile_raster8(const GemmParams& p, const int BM, 
   tile_of(p, BM, BN, xcd_run_pos(total), b, tm, tn);
 }
 
+
+// W addressing (GemmParams.flags bit 11): row-major [N][K] - rows K elements apart, a K-tile 128 bytes further along the row -
+// or K-TILE-MAJOR [K/64][N][64] - rows 64 elements apart inside a slab, a K-tile N * 128 bytes further.  Row-major, a launch of
+// few rows fetches each K-tile of its cold weights as one 128-byte piece out of every one of N DRAM rows 2 K bytes apart, all
+// workgroups at the same K offset at the same time (round 4, profiles/r4_call13 .. 17: that order of requests, not issue time or
+// depth, is what a few-row launch in the model waits for); K-tile-major the same K-tile is ONE contiguous N * 128-byte run and the
+// launch streams W front to back.  Same fragments in LDS either way: the same bits.
+struct WGeom {
+  long ns;      // elements from one W row to the next
+  long kstep;   // bytes from one K-tile to the next
+};
+__device__ __forceinline__ WGeom w_geom(const GemmParams& p) {
+  const bool ktm = (p.flags & GEMM_FLAG_W_KTM) != 0;
+  return WGeom{ktm ? 64L : (long)p.K, ktm ? (long)p.N * 128 : 128L};
+}
+// The workgroups of a launch beyond its tiles (launches of < 256 workgroups are padded to 256 when GemmParams.pf_ptr is set): touch
+// every 128-byte line of [pf_ptr, pf_ptr + pf_bytes) once, eight requests in flight per lane - a linear read that leaves the NEXT
+// launch's weights in the memory-side cache (round 4, the warm-weights measurement: 46.5 -> 36.8 us per few-row launch in the model).
+__device__ __forceinline__ void prefetch_lines(const GemmParams& p, const int wg, const int nwg, const int nthreads) {
+  const long lines = p.pf_bytes >> 7;
+  const char* const base = (const char*)p.pf_ptr;
+  const long stride = (long)nwg * nthreads;
+  for (long i = (long)wg * nthreads + threadIdx.x; i < lines; i += stride * 8) {
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long j = i + u * stride;
+      v[u] = j < lines ? *(const volatile unsigned*)(base + (j << 7)) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+  }
+}
+
 }  // namespace
 
 #ifdef SAMAUDIO_GEMM8_ABL
@@ -694,6 +728,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   // 16-bit epilogue's stores are not waited for: they drain underneath the next tile's prologue loads, which in turn are in
   // flight while the stores are issued.
   const int total = tile_count > 0 ? tile_count : ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  const WGeom wg_ = w_geom(p);
+  if (p.pf_ptr && (int)blockIdx.x >= total) {   // a workgroup beyond the tiles: warm the next launch's weights
+    prefetch_lines(p, (int)blockIdx.x - total, (int)gridDim.x - total, 512);
+    return;
+  }
   for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
   int b, tm, tn;
   tile_of(p, BM, BN, xcd_run_pos_of(total, vb), b, tm, tn);
@@ -722,8 +761,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
         a_off[h][q] = (unsigned)(((long)m * p.lda + chunk[q] * 8) * 2);
         int n = n0 + h * 128 + row;
         n = n < p.N ? n : p.N - 1;
-        w_row[h][q] = W0 + (long)n * p.K + chunk[q] * 8;
-        w_off[h][q] = (unsigned)(((long)n * p.K + chunk[q] * 8) * 2);
+        w_row[h][q] = W0 + (long)n * wg_.ns + chunk[q] * 8;
+        w_off[h][q] = (unsigned)(((long)n * wg_.ns + chunk[q] * 8) * 2);
       }
     }
   }
@@ -757,11 +796,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
     }
   };
   auto stage_w = [&](int h, int buf, int kt) {
-    const char* w_base = (const char*)W0 + (long)kt * (BK * 2);
+    const char* w_base = (const char*)W0 + (long)kt * wg_.kstep;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const size_t dst = lds0 + (size_t)(((2 + h) * 2 + buf) * HT + wave * 2048 + q * 1024);
-      if constexpr (CONV) dma16v(w_row[h][q] + (long)kt * BK, dst);
+      if constexpr (CONV) dma16v((const char*)w_row[h][q] + (long)kt * wg_.kstep, dst);
       else dma16s(w_base, w_off[h][q], dst);
     }
   };
@@ -924,15 +963,39 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // 3 -> 4 stages: c_wq at 1000 rows 36.9 -> 34.9 us, w2 83.4 -> 79.0; 4 clips per GPU 114.5 -> 119.8 s-audio/s, small* 8 clips
 // 424.0 -> 435.3 (profiles/r3_call9/).  A 5-stage ring (160 KiB, all of the CU's LDS) measured slower again: c_wq 35.9 vs 34.9 us, w2
 // 80.5 vs 76.2, 4 clips 120.7 vs 121.5 (profiles/r3_call28/) - three K-tiles in flight already cover the latency.
-template <bool PIPE, bool CONV, bool ALT = false>
-__global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const int skip256) {
+// PROD >= 0 (pipelined form only): WAVE ROLES.  Alone on its CU the pipelined form has one wave per SIMD, and a wave that issues a
+// K-tile's 8 direct-to-LDS loads holds its instruction stream for ~100 cycles each (the issue cost the 4-wave 256 x 256 experiment
+// of round 3 ran into): ~800 cycles of load issue in front of 512 cycles of MFMAs per K-tile, in series - the measured ~1 400 cycles
+// per K-tile (0.58 - 0.61 us: c_wq at 1 000 rows 27 us for 44 K-tiles).  With roles the workgroup has 8 waves: waves 0 - 3 multiply
+// exactly as before (64 x 64 outputs each, same fragments, same MFMA order: bitwise identical), waves 4 - 7 - one per SIMD, beside a
+// multiplying wave - only request K-tiles: their issue time runs underneath the other wave's MFMAs.  PROD = how many of its row
+// block's 4 A-tile loads per K-tile a multiplying wave still issues itself (0: none; 2 balances 6 + 2 when the requesting waves are
+// the longer side).  One barrier per K-tile as before; the requesting waves leave at the last barrier.
+template <int N> __device__ __forceinline__ void wait_vm_lit() {   // literal counts: the simulator reads the number from the text
+  static_assert(N == 0 || N == 1 || N == 2 || N == 4 || N == 6 || N == 7 || N == 8 || N == 12 || N == 14 || N == 16, "add the literal");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+template <bool PIPE, bool CONV, bool ALT = false, int PROD = -1>
+__global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const GemmParams p, const int skip256) {
   constexpr int BM = 128, BN = 128, BK = 64, TB = 128 * 128;  // TB: bytes of one operand tile (128 rows x 128 B)
   constexpr int S = PIPE ? 4 : 2;
+  constexpr bool ROLES = PROD >= 0;
+  static_assert(!ROLES || PIPE, "wave roles belong to the pipelined form");
   __shared__ __attribute__((aligned(16))) char smem[S * 2 * TB];  // [stage][A tile, W tile]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_id & 3;   // ROLES: waves 4 .. 7 request the row blocks waves 0 .. 3 own
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -948,10 +1011,16 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     n0 = tn * 256 + (pos & 1) * 128;
     if (m0 >= p.M || n0 >= p.N) return;  // quadrant outside the problem (uniform for the workgroup)
   } else {
-    tile_raster8(p, BM, BN, b, tm, tn);
+    const int total = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+    if ((int)blockIdx.x >= total) {   // a workgroup beyond the tiles (launch_gemm8s pads to 256): warm the next launch's weights
+      if (p.pf_ptr) prefetch_lines(p, (int)blockIdx.x - total, (int)gridDim.x - total, (int)blockDim.x);
+      return;
+    }
+    tile_of(p, BM, BN, xcd_run_pos(total), b, tm, tn);
     m0 = tm * BM;
     n0 = tn * BN;
   }
+  const WGeom wg_ = w_geom(p);
 
   // staging: wave w moves rows 32w .. 32w+31 of both tiles as 4 + 4 wave instructions of 8 rows (1 KiB each):
   // lane -> row 32w + 8q + (lane>>3), 16-byte slot lane&7, which must hold source chunk slot ^ ((row>>1)&7).
@@ -974,8 +1043,8 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       a_off[q] = (unsigned)(((long)m * p.lda + chunk * 8) * 2);
       int n = n0 + row;
       n = n < p.N ? n : p.N - 1;
-      w_row[q] = W0 + (long)n * p.K + chunk * 8;
-      w_off[q] = (unsigned)(((long)n * p.K + chunk * 8) * 2);
+      w_row[q] = W0 + (long)n * wg_.ns + chunk * 8;
+      w_off[q] = (unsigned)(((long)n * wg_.ns + chunk * 8) * 2);
       a_in[q] = chunk * 8;
       a_tap[q] = 0;
       if constexpr (CONV)
@@ -986,18 +1055,22 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
   const size_t lds0 = (size_t)(__attribute__((address_space(3))) char*)smem;
   // DMA as inline assembly (dma16s / dma16v, see there): the compiler then counts the fragment reads itself, which is what
   // lets the pipelined form's reads of K-tile t+1 really complete underneath the MFMAs of K-tile t
-  auto stage = [&](int buf, int kt) {  // K-tile kt (CONV: the a_in / a_tap state points at it) -> stage buf
+  // K-tile kt (CONV: the a_in / a_tap state points at it) -> stage buf: the A-tile loads QA0 <= q < QA1 and the W-tile loads q < QW1
+  // of this wave's row block
+  auto stage_q = [&](int buf, int kt, auto QA0, auto QA1, auto QW1) {
     const size_t dst = lds0 + (size_t)(buf * (2 * TB) + wave * 4096);
     const char* a_base = (const char*)A0 + (long)kt * (BK * 2);
-    const char* w_base = (const char*)W0 + (long)kt * (BK * 2);
+    const char* w_base = (const char*)W0 + (long)kt * wg_.kstep;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+      if (q < decltype(QA0)::value || q >= decltype(QA1)::value) continue;
       if constexpr (CONV) dma16v(a_row[q] + a_tap[q] + a_in[q], dst + q * 1024);
       else dma16s(a_base, a_off[q], dst + q * 1024);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      if constexpr (CONV) dma16v(w_row[q] + (long)kt * BK, dst + TB + q * 1024);
+      if (q >= decltype(QW1)::value) continue;
+      if constexpr (CONV) dma16v((const char*)w_row[q] + (long)kt * wg_.kstep, dst + TB + q * 1024);
       else dma16s(w_base, w_off[q], dst + TB + q * 1024);
     }
     if constexpr (CONV) {
@@ -1008,6 +1081,34 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
       }
     }
   };
+  using Q0 = std::integral_constant<int, 0>;
+  using Q4 = std::integral_constant<int, 4>;
+  auto stage = [&](int buf, int kt) { stage_q(buf, kt, Q0{}, Q4{}, Q4{}); };
+
+  if constexpr (ROLES) {
+    if (wave_id >= 4) {   // a requesting wave: the ring's producer side, no arithmetic
+      using QC = std::integral_constant<int, PROD>;
+      constexpr int MINE = 8 - PROD;   // loads per K-tile of this wave
+      auto request = [&](int buf, int kt) { stage_q(buf, kt, QC{}, Q4{}, Q4{}); };
+      request(0, 0);
+      if (nt > 1) request(1, 1);
+      if (nt > 2) request(2, 2);
+      if (nt > 2) wait_vm_lit<2 * MINE>();
+      else if (nt > 1) wait_vm_lit<MINE>();
+      else wait_vm_lit<0>();
+      __builtin_amdgcn_s_barrier();
+      for (int t = 0; t + 1 < nt; ++t) {
+        // K-tile t+3 -> the buffer K-tile t-1 was read from: those reads completed before the barrier of step t-1
+        if (t + 3 < nt) request((t + 3) & 3, t + 3);
+        if (t + 3 < nt) wait_vm_lit<2 * MINE>();        // K-tile t+1 has landed; t+2, t+3 may be in flight
+        else if (t + 2 < nt) wait_vm_lit<MINE>();
+        else wait_vm_lit<0>();
+        __builtin_amdgcn_s_barrier();
+      }
+      if (!(p.flags & 64)) __syncthreads();   // the multiplying waves' barrier in front of the LDS-staged epilogues
+      return;
+    }
+  }
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -1020,6 +1121,12 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
 
   if constexpr (PIPE) {
     bf16x8_t af[2][4][2], wf[2][4][2];   // [fragment set][16-row block][k-step]
+    // loads per K-tile of a multiplying wave: all 8 of its row block, or - with requesting waves - PROD of the A tile's
+    constexpr int MINE = ROLES ? PROD : 8;
+    auto stage_mine = [&](int buf, int kt) {
+      if constexpr (!ROLES) stage(buf, kt);
+      else if constexpr (PROD > 0) stage_q(buf, kt, Q0{}, std::integral_constant<int, PROD>{}, Q0{});
+    };
     auto read_frags = [&](int buf, auto SET) {
       const char* At = smem + buf * (2 * TB);
       const char* Wt = At + TB;
@@ -1036,12 +1143,14 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     auto step = [&](int t, auto SET, auto NEXT) {   // fragments of K-tile t are set SET (reads issued one step earlier)
       constexpr int OTHER = 1 - decltype(SET)::value;
       // K-tile t+S-1 -> the buffer K-tile t-1 was read from: those reads COMPLETED before the barrier of step t-1
-      if (t + S - 1 < nt) stage((t + S - 1) % S, t + S - 1);
+      if (t + S - 1 < nt) stage_mine((t + S - 1) % S, t + S - 1);
       if constexpr (decltype(NEXT)::value) {
         // K-tile t+1 has landed; the younger ones (t+2 .. t+S-1, as far as they exist) may be in flight
-        if (S == 4 && t + 3 < nt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MINE > 0) {   // (a multiplying wave that requests nothing has nothing to wait for)
+          if (S == 4 && t + 3 < nt) wait_vm_lit<2 * MINE>();
+          else if (t + 2 < nt) wait_vm_lit<MINE>();
+          else wait_vm_lit<0>();
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's reads of K-tile t are complete
         __builtin_amdgcn_s_barrier();
         read_frags((t + 1) % S, std::integral_constant<int, OTHER>{});      // in flight underneath the MFMAs below
@@ -1057,13 +1166,15 @@ __global__ __launch_bounds__(256) void gemm8s_kernel(const GemmParams p, const i
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    if (S == 4 && nt > 2) stage(2, 2);
+    stage_mine(0, 0);
+    if (nt > 1) stage_mine(1, 1);
+    if (S == 4 && nt > 2) stage_mine(2, 2);
     // K-tile 0 has landed; up to S - 2 younger ones stay in flight
-    if (S == 4 && nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MINE > 0) {
+      if (S == 4 && nt > 2) wait_vm_lit<2 * MINE>();
+      else if (nt > 1) wait_vm_lit<MINE>();
+      else wait_vm_lit<0>();
+    }
     __builtin_amdgcn_s_barrier();
     read_frags(0, I0{});
     int t = 0;
@@ -1163,9 +1274,22 @@ static GemmParams with_epilogue_choice(const GemmParams& p) {
 // rows a launch lasts nt x ~0.8 us whatever its workgroup count: it is bound by the depth of the K-tile prefetch (two K-tiles
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
 // alt-format operands (flags bit 10, mixed mode) exist for plain GEMMs only - the DiT's Linears - gemm8_alt_ok()
+#define SA_GEMM8S_ROLES_DEFAULT (-1)   // the shipped form of the pipelined kernel: -1 no roles, 0 / 2 = PROD
 static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 grid, int skip256, hipStream_t st) {
   const dim3 block(256);
   const bool alt = (p.flags & 1024) != 0;
+  // wave roles of the pipelined form (see the kernel): debug flag 27 = 1 the form without roles (round 3), 2 / 3 force PROD = 0 / 2
+  const int roles = !pipe || debug_flag(27) == 1 ? -1 : debug_flag(27) == 3 ? 2 : debug_flag(27) == 2 ? 0 : SA_GEMM8S_ROLES_DEFAULT;
+  if (roles >= 0) {
+    const dim3 block8(512);
+    if (conv && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 0>), grid, block8, 0, st, p, skip256);
+    else if (conv) hipLaunchKernelGGL((gemm8s_kernel<true, true, false, 2>), grid, block8, 0, st, p, skip256);
+    else if (alt && roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 0>), grid, block8, 0, st, p, skip256);
+    else if (alt) hipLaunchKernelGGL((gemm8s_kernel<true, false, true, 2>), grid, block8, 0, st, p, skip256);
+    else if (roles == 0) hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 0>), grid, block8, 0, st, p, skip256);
+    else hipLaunchKernelGGL((gemm8s_kernel<true, false, false, 2>), grid, block8, 0, st, p, skip256);
+    return;
+  }
   if (pipe && conv) hipLaunchKernelGGL((gemm8s_kernel<true, true>), grid, block, 0, st, p, skip256);
   else if (pipe && alt) hipLaunchKernelGGL((gemm8s_kernel<true, false, true>), grid, block, 0, st, p, skip256);
   else if (pipe) hipLaunchKernelGGL((gemm8s_kernel<true, false>), grid, block, 0, st, p, skip256);
@@ -1186,7 +1310,9 @@ hipError_t launch_gemm8s(const GemmParams& p_in, hipStream_t st) {
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nbatch;
   // flag 21 (A/B): the plain double-buffered form for every launch, as before GPU call 25 of round 2
   const bool pipe = tiles <= 256 && !debug_flag(21), conv = gemm8_wide(p);
-  const dim3 grid((unsigned)tiles);
+  // pf_ptr: the pipelined form holds one workgroup per CU - a launch of fewer than 256 tiles is padded with workgroups that
+  // touch the next launch's weights on the CUs it leaves idle (prefetch_lines)
+  const dim3 grid((unsigned)(p.pf_ptr && p.pf_bytes > 0 && pipe && tiles < 256 ? 256 : tiles));
   launch_gemm8s_grid(p, pipe, conv, grid, -1, st);
   return hipGetLastError();
 }
@@ -1211,6 +1337,7 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   // (+4.7 %, profiles/r4_call7/): a launch now keeps its CUs for its whole duration instead of re-competing for them with
   // the other group's launch after every tile.
   if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
+  if (p.pf_ptr && p.pf_bytes > 0 && tile_count == 0 && grid.x < 256) grid.x = 256;   // idle CUs warm the next launch's weights
   if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (p.flags & 1024) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, tile_count);   // alt-format operands
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);

@@ -51,7 +51,7 @@ def dtype_code(dtype, operands: Optional[str] = None, alt_ok: bool = False) -> i
             raise TypeError(f"{dtype} tensor handed to the {operands}-operand build of libsamaudio_hip")
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
-OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES = 1, 2, 3, 4, 5
+OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES, OPT_PREFETCH_ROWS = 1, 2, 3, 4, 5, 6
 # GEMM classes of the DiT / codec (samaudio.h SAMAUDIO_CLS_*), in bit order
 CLASSES = ("time", "out", "in", "prep", "yemb", "ckv", "patch", "qkv", "wo", "cwq", "cwo", "w13", "w2", "codec")
 CLS = {name: 1 << i for i, name in enumerate(CLASSES)}
@@ -118,6 +118,7 @@ class GemmParams(C.Structure):
         ("act", C.c_int), ("f32_act", C.c_int), ("act_alpha", C.c_void_p),
         ("c_lo", C.c_long), ("c_hi", C.c_long), ("c_ld_rel", C.c_long),
         ("w_bstride", C.c_long), ("raster_gm", C.c_int), ("flags", C.c_int), ("tag", C.c_int),
+        ("pf_ptr", C.c_void_p), ("pf_bytes", C.c_long),
     ]
 
 

@@ -23,6 +23,11 @@ from .processor import Batch
 from .weights import F32_SOURCE_KEYS, convert_codec, convert_dit, convert_dit_f32, split_missing_unexpected
 
 DFLT_ODE_OPT = {"method": "midpoint", "options": {"step_size": 2 / 32}}  # reference model.py:22
+# Layout of the five big DiT weight matrices and the next-weights prefetch of few-row launches (SAMAudio.__init__; DESIGN.md
+# section 7 has the measurements behind the defaults).  Environment overrides (tuning): SAMAUDIO_WEIGHT_LAYOUT,
+# SAMAUDIO_PREFETCH_ROWS.
+DEFAULT_WEIGHT_LAYOUT = "ktm"
+DEFAULT_PREFETCH_ROWS = 2048
 
 
 @dataclass
@@ -79,8 +84,14 @@ class SAMAudio:
     config_cls = SAMAudioConfig
 
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto"):
-        """`f32_classes` (16-bit precisions): the GEMM classes that run on exact-fp32 operands inside the 16-bit engine
+                 text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto",
+                 weight_layout: str = "auto", prefetch_rows: Optional[int] = None):
+        """`weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
+        K-tile-major (weights.ktm_layout; a launch then streams its weights front to back), "rows" keeps them row-major;
+        "auto" = DEFAULT_WEIGHT_LAYOUT.  `prefetch_rows`: evaluations of at most this many rows (batch x frames) let the CUs a
+        GEMM launch leaves idle read the next GEMM's weights (samaudio.h SAMAUDIO_OPT_PREFETCH_ROWS; None =
+        DEFAULT_PREFETCH_ROWS, 0 = off).  Both are scheduling / layout choices: results are bitwise the same.
+        `f32_classes` (16-bit precisions): the GEMM classes that run on exact-fp32 operands inside the 16-bit engine
         (hip.CLASSES names or a mask; "auto" = hip.CLS_F32_DEFAULT: the input and output projections that touch the ODE
         state and the hoisted conditioning, which carry most of a 16-bit mode's error for < 1 % of a step; "time" and
         "yemb" can be added - DESIGN.md section 4)."""
@@ -93,6 +104,14 @@ class SAMAudio:
         self.quant_classes, self.quant_format = 0, 0   # fp32 engines: operand-rounding emulation (error budget)
         # precision="mixed": bf16 operands for the five big GEMM classes inside the fp16 build (hip.CLS_ALT16_MIXED)
         self.alt16_classes = hip.CLS_ALT16_MIXED if precision == "mixed" else 0
+        if weight_layout == "auto":
+            weight_layout = os.environ.get("SAMAUDIO_WEIGHT_LAYOUT", DEFAULT_WEIGHT_LAYOUT)
+        if weight_layout not in ("ktm", "rows"):
+            raise ValueError("weight_layout must be 'auto', 'ktm' or 'rows'")
+        self.weight_layout = "rows" if precision == "fp32" else weight_layout
+        if prefetch_rows is None:
+            prefetch_rows = int(os.environ.get("SAMAUDIO_PREFETCH_ROWS", DEFAULT_PREFETCH_ROWS))
+        self.prefetch_rows = 0 if precision == "fp32" else int(prefetch_rows)
         self.device = torch.device(device) if device is not None else None
         self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])
         # rerankers (reference model.py:94-95): any callable with the reference's Ranker.forward keywords that returns
@@ -226,7 +245,7 @@ class SAMAudio:
             if not dit_missing:
                 alt = [leaf for leaf, c in hip.ALT16_WEIGHTS.items() if self.alt16_classes & hip.CLS[c]]
                 self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device, alt16_leaves=alt,
-                                           f32_classes=self.f32_classes))
+                                           f32_classes=self.f32_classes, ktm=self.weight_layout == "ktm"))
                 # fp32 operand copies exist for the classes that run in fp32 now; set_f32_classes adds a class's later
                 # from these references to the checkpoint entries (no copy is made here)
                 self._f32_have = self.f32_classes
@@ -251,6 +270,7 @@ class SAMAudio:
         if self.precision != "fp32":
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_F32_CLASSES, self.f32_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ALT16_CLASSES, self.alt16_classes))
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_PREFETCH_ROWS, self.prefetch_rows))
         else:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_CLASSES, self.quant_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_FORMAT, self.quant_format))

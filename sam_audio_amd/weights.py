@@ -51,6 +51,22 @@ def _interleave16(w1: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     return torch.stack([w1.reshape(f // 16, 16, k), w3.reshape(f // 16, 16, k)], dim=1).reshape(2 * f, k)
 
 
+def ktm_layout(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] row-major -> [K/64, N, 64] K-TILE-MAJOR (include/samaudio.h): the 64-element K slab of all N rows contiguous,
+    so that a GEMM launch walks the weight matrix front to back - one contiguous N*128-byte run per K-tile instead of a
+    128-byte piece out of each of N rows 2K bytes apart (what a few-row launch waits for with cold weights, DESIGN.md
+    section 7).  The 8-phase GEMM family reads either layout into the same LDS image: same results."""
+    n, k = w.shape
+    assert k % 64 == 0
+    return w.reshape(n, k // 64, 64).permute(1, 0, 2).contiguous()
+
+
+def ktm_to_rows(w: torch.Tensor) -> torch.Tensor:
+    """inverse of ktm_layout: [K/64, N, 64] -> [N, K]"""
+    kt, n, s = w.shape
+    return w.permute(1, 0, 2).reshape(n, kt * s).contiguous()
+
+
 def _pad_k(w: torch.Tensor, slab: int) -> torch.Tensor:
     n, k = w.shape
     kp = (k + slab - 1) // slab * slab
@@ -80,6 +96,7 @@ def expected_keys(cfg: SAMAudioConfig, with_codec: bool = True) -> List[str]:
     return list(init_state_dict(cfg, device="meta", with_codec=with_codec).keys())
 
 
+KTM_LEAVES = ("wqkv", "wo", "c_wq", "w13", "w2")   # per-layer weights that may be stored K-tile-major
 # the GEMM classes a 16-bit engine can run on exact-fp32 operands (hip.CLS_F32_CAPABLE) and the engine weights each reads
 F32_CLASS_WEIGHTS = {"out": ("w_out",), "time": ("t_w13", "t_w2", "tb_w"), "in": ("proj_wy",),
                      "prep": ("proj_wf", "mem_w", "vid_w", "anc_w"), "yemb": ("y_w13", "y_w2")}
@@ -116,8 +133,10 @@ def convert_dit_f32(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, device, cl
 
 
 def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype,
-                device, alt16_leaves=(), f32_classes: Optional[int] = None) -> Dict[str, torch.Tensor]:
-    """`alt16_leaves`: per-layer weight names (of "wqkv", "wo", "c_wq", "w13", "w2") whose GEMM class reads bfloat16
+                device, alt16_leaves=(), f32_classes: Optional[int] = None, ktm: bool = False) -> Dict[str, torch.Tensor]:
+    """`ktm` (16-bit models): the weights of the five big GEMM classes of the layers (wqkv, wo, c_wq, w13, w2) are stored
+    K-tile-major (ktm_layout).
+    `alt16_leaves`: per-layer weight names (of "wqkv", "wo", "c_wq", "w13", "w2") whose GEMM class reads bfloat16
     operands in a mixed-precision model (hip.ALT16_WEIGHTS): converted from fp32 to bfloat16 instead of `act_dtype`.
     `f32_classes` (16-bit models): mask of the F32-capable classes whose weights also get an fp32 copy under
     "<name>.f32" (None = all five, 0.5 GB at large* dims; SAMAudio passes the classes it will run in fp32)."""
@@ -130,9 +149,12 @@ def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: tor
     def f32(x):
         return x.detach().to(device=device, dtype=torch.float32).contiguous()
 
+    ktm = bool(ktm) and act_dtype != torch.float32
+
     def op(x, leaf=None):  # GEMM operand
         dt = torch.bfloat16 if leaf in alt16_leaves else act_dtype
-        return x.detach().to(device=device, dtype=torch.float32).to(dt).contiguous()
+        w = x.detach().to(device=device, dtype=torch.float32).to(dt).contiguous()
+        return ktm_layout(w) if (ktm and leaf in KTM_LEAVES) else w
 
     def op_f32(name, x):
         """GEMM operand of a class that may run in exact fp32 inside a 16-bit engine (samaudio.h SAMAUDIO_OPT_F32_CLASSES):

@@ -30,6 +30,7 @@ def _mk(shape, seed, scale=1.0):
 def _restore_variant():
     yield
     hip.lib("fp16").samaudio_debug_force_gemm_variant(-1)
+    hip.lib("fp16").samaudio_debug_set_flag(27, 0)
 
 
 @pytest.mark.parametrize("variant", [-1, 1, 22, 25, 26, 27])
@@ -80,15 +81,16 @@ def test_separate_fp16_error_next_to_bf16(gpu):
     assert errs["fp16"][0] < errs["bf16"][0]
 
 
-@pytest.mark.parametrize("variant", [22, 27])
+@pytest.mark.parametrize("variant,roles", [(22, 0), (27, 0), (27, 1), (27, 2), (27, 3)])
 @pytest.mark.parametrize("kind", ["act", "swiglu", "gated"])
-def test_mixed_mode_gemm_reads_and_writes_bfloat16_inside_the_fp16_library(gpu, variant, kind):
+def test_mixed_mode_gemm_reads_and_writes_bfloat16_inside_the_fp16_library(gpu, variant, roles, kind):
     """precision="mixed" (samaudio.h SAMAUDIO_OPT_ALT16_CLASSES): the five big GEMM classes run on bfloat16 operands inside
     the fp16 build.  GemmParams.flags bit 10: A and W are bfloat16 (the bf16 MFMA); bit 9: the 16-bit output is written as
     bfloat16 (it feeds another such GEMM).  Against fp32 torch on the bf16-rounded operands; outputs decoded per flag."""
     import ctypes as C
     lib = hip.lib("fp16")
     lib.samaudio_debug_force_gemm_variant(variant)
+    lib.samaudio_debug_set_flag(27, roles)   # gemm8s' pipelined form: without / with requesting waves (gemm8.hip)
     M, N, K = 333, 512, 320
     A, W = _mk((M, K), 31), _mk((N, K), 32, 1 / math.sqrt(K))
     Ab, Wb = A.to(torch.bfloat16).to(gpu), W.to(torch.bfloat16).to(gpu)

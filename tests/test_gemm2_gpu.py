@@ -31,6 +31,7 @@ def _mk(shape, seed, scale=1.0):
 def _restore_variant():
     yield
     hip.lib().samaudio_debug_force_gemm_variant(-1)
+    hip.lib().samaudio_debug_set_flag(27, 0)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -197,9 +198,13 @@ def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
     keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
     outs = {}
     try:
-        for name, variant, flag in (("pipelined", 27, 0), ("plain", 27, 1), ("8phase", 22, 0)):
+        # flag 27: the pipelined form's wave roles - 1 = none (4 waves request and multiply), 2 / 3 = 4 requesting waves beside
+        # 4 multiplying ones (the latter issuing 0 / 2 of their loads themselves); 0 = the shipped choice
+        for name, variant, flag, roles in (("pipelined", 27, 0, 0), ("no roles", 27, 0, 1), ("roles 0", 27, 0, 2),
+                                           ("roles 2", 27, 0, 3), ("plain", 27, 1, 0), ("8phase", 22, 0, 0)):
             hip.lib().samaudio_debug_force_gemm_variant(variant)
             hip.lib().samaudio_debug_set_flag(21, flag)
+            hip.lib().samaudio_debug_set_flag(27, roles)
             out = torch.full((M, N), float("nan"), device=gpu)
             out_act = torch.zeros(M, N, device=gpu, dtype=torch.bfloat16)
             util.gemm("bf16", keep[0], keep[1], M, N, K, gate_tab=keep[2], gate=keep[3], gate_ld=N, rows_per_gate=M,
@@ -207,12 +212,118 @@ def test_gemm8s_pipelined_form_is_bitwise_identical(gpu, M, N, K):
             outs[name] = (out.cpu(), out_act.cpu())
     finally:
         hip.lib().samaudio_debug_set_flag(21, 0)
+        hip.lib().samaudio_debug_set_flag(27, 0)
         hip.lib().samaudio_debug_force_gemm_variant(-1)
     want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
     util.report(f"gemm8s pipelined {M}x{N}x{K}", outs["pipelined"][0], want, 5e-4)
-    for other in ("plain", "8phase"):
+    for other in ("no roles", "roles 0", "roles 2", "plain", "8phase"):
         assert torch.equal(outs["pipelined"][0], outs[other][0])
         assert torch.equal(outs["pipelined"][1].view(torch.int16), outs[other][1].view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K", [(270, 2816, 448), (333, 512, 192), (130, 320, 128), (700, 1024, 704)])
+@pytest.mark.parametrize("kind", ["gated", "swiglu"])
+def test_ktm_weights_and_prefetch_workgroups_are_bitwise_invisible(gpu, M, N, K, kind):
+    """GemmParams.flags bit 11: W stored K-tile-major [K/64][N][64] (weights.ktm_layout) instead of [N][K] - the 8-phase family
+    reads either layout into the same LDS image.  GemmParams.pf_ptr: launches of fewer than 256 workgroups are padded with
+    workgroups that only touch the next launch's weights.  Every form of the family (256x256; 128x128 plain / pipelined without
+    and with requesting waves), both layouts, with and without the prefetch: identical bits; the row-major result is checked
+    against fp32 torch."""
+    from sam_audio_amd.weights import ktm_layout, ktm_to_rows
+    A, W = _mk((M, K), 91), _mk((N, K), 92, 1 / math.sqrt(K))
+    Wb = util.as_act(W, "bf16", gpu)
+    Wk = ktm_layout(Wb)
+    assert Wk.shape == (K // 64, N, 64) and torch.equal(ktm_to_rows(Wk), Wb)
+    nxt = util.as_act(_mk((333, 77), 93), "bf16", gpu)    # "the next launch's weights": 51 282 bytes, not a multiple of 128
+    tab, gate, res = _mk((N,), 94), _mk((1, N), 95), _mk((M, N), 96)
+    keep = [util.as_act(A, "bf16", gpu), tab.to(gpu), gate.to(gpu), res.to(gpu)]
+    n_out = N // 2 if kind == "swiglu" else N
+    outs = {}
+    try:
+        for variant, flag21, roles in ((22, 0, 0), (27, 0, 1), (27, 0, 2), (27, 0, 3), (27, 1, 0)):
+            for layout in ("rows", "ktm"):
+                for pf in (False, True):
+                    hip.lib().samaudio_debug_force_gemm_variant(variant)
+                    hip.lib().samaudio_debug_set_flag(21, flag21)
+                    hip.lib().samaudio_debug_set_flag(27, roles)
+                    out = torch.full((M, n_out), float("nan"), device=gpu)
+                    out_act = torch.zeros(M, n_out, device=gpu, dtype=torch.bfloat16)
+                    kw = dict(out_act=out_act, act_geom=(0, n_out, 0), flags=2048 if layout == "ktm" else 0,
+                              prefetch=nxt if pf else None)
+                    if kind == "swiglu":
+                        kw.update(swiglu=1)
+                    else:
+                        kw.update(gate_tab=keep[1], gate=keep[2], gate_ld=N, rows_per_gate=M, res=keep[3], res_geom=(0, N, 0),
+                                  out_f32=out, f32_geom=(0, N, 0))
+                    util.gemm("bf16", keep[0], Wk if layout == "ktm" else Wb, M, N, K, **kw)
+                    outs[(variant, flag21, roles, layout, pf)] = (out.cpu(), out_act.cpu())
+    finally:
+        hip.lib().samaudio_debug_set_flag(21, 0)
+        hip.lib().samaudio_debug_set_flag(27, 0)
+        hip.lib().samaudio_debug_force_gemm_variant(-1)
+    first = outs[(22, 0, 0, "rows", False)]
+    if kind == "gated":
+        want = (util.rounded(A, "bf16") @ util.rounded(W, "bf16").T) * (tab[None] + gate) + res
+        util.report(f"gemm8 rows {M}x{N}x{K}", first[0], want, 5e-4)
+    else:
+        assert torch.isfinite(first[1].float()).all() and float(first[1].float().abs().max()) > 0
+    for key, (o, a) in outs.items():
+        if kind == "gated":
+            assert torch.equal(first[0], o), key
+        assert torch.equal(first[1].view(torch.int16), a.view(torch.int16)), key
+
+
+def test_ktm_weights_are_refused_outside_the_8phase_family(gpu):
+    """Only gemm8 / gemm8s address K-tile-major weights: any other tile choice (here a forced one) must fail loudly."""
+    from sam_audio_amd.weights import ktm_layout
+    M, N, K = 300, 512, 192
+    A, W = util.as_act(_mk((M, K), 97), "bf16", gpu), ktm_layout(util.as_act(_mk((N, K), 98), "bf16", gpu))
+    out = torch.zeros(M, N, device=gpu)
+    hip.lib().samaudio_debug_force_gemm_variant(25)
+    with pytest.raises(AssertionError, match="K-tile-major"):
+        util.gemm("bf16", A, W, M, N, K, out_f32=out, f32_geom=(0, N, 0), flags=2048)
+
+
+@pytest.mark.parametrize("kind", ["conv", "plain16", "swiglu"])
+def test_gemm8s_wave_roles_are_bitwise_invisible(gpu, kind):
+    """The pipelined form with requesting waves (debug flag 27 = 2 / 3) against the one without (1), on the launches the first
+    test does not reach: an implicit dilated k7 convolution with the Snake epilogue (per-lane source pointers, the tap walk
+    advanced by whichever wave requests a row), a 16-bit-only output (register epilogue: the requesting waves leave without
+    the epilogue barrier) and SwiGLU."""
+    outs = {}
+    try:
+        hip.lib().samaudio_debug_force_gemm_variant(27)
+        if kind == "conv":
+            items, T, C, dil, halo = 2, 300, 256, 3, 40
+            x, w = _mk((items, C, T), 81), _mk((C, C, 7), 82, 1 / math.sqrt(7 * C))
+            bias, alpha = _mk((C,), 83, 0.1), (_mk((C,), 84, 0.2) + 1).clamp(0.3, 2)
+            xb = torch.zeros(items, T + 2 * halo, C)
+            xb[:, halo:halo + T] = x.transpose(1, 2)
+            keep = [util.as_act(xb, "bf16", gpu), util.as_act(w.permute(0, 2, 1).reshape(C, 7 * C), "bf16", gpu), bias.to(gpu), alpha.to(gpu)]
+        else:
+            M, N, K = 300, 768, 448
+            A, W = _mk((M, K), 85), _mk((N, K), 86, 1 / math.sqrt(K))
+            keep = [util.as_act(A, "bf16", gpu), util.as_act(W, "bf16", gpu)]
+        for roles in (1, 2, 3):
+            hip.lib().samaudio_debug_set_flag(27, roles)
+            if kind == "conv":
+                out = torch.zeros(items, T + 2 * halo, C, device=gpu, dtype=torch.bfloat16)
+                util.gemm("bf16", keep[0], keep[1], T, C, 7 * C, nbatch=items, a_off=(halo - 3 * dil) * C,
+                          a_bstride=(T + 2 * halo) * C, lda=C, kc=C, tap_stride=dil * C, bias=keep[2], out_act=out,
+                          act_geom=((T + 2 * halo) * C, C, halo * C), act=hip.ACT_SNAKE, act_alpha=keep[3])
+            else:
+                n_out = N // 2 if kind == "swiglu" else N
+                out = torch.zeros(M, n_out, device=gpu, dtype=torch.bfloat16)
+                util.gemm("bf16", keep[0], keep[1], M, N, K, out_act=out, act_geom=(0, n_out, 0), swiglu=int(kind == "swiglu"))
+            outs[roles] = out.cpu()
+    finally:
+        hip.lib().samaudio_debug_set_flag(27, 0)
+        hip.lib().samaudio_debug_force_gemm_variant(-1)
+    assert torch.isfinite(outs[1].float()).all() and float(outs[1].float().abs().max()) > 0
+    for roles in (2, 3):
+        assert torch.equal(outs[1].view(torch.int16), outs[roles].view(torch.int16)), f"flag 27 = {roles}"
+    if kind == "plain16":
+        util.report("gemm8s roles, 16-bit output", outs[2], util.rounded(A, "bf16") @ util.rounded(W, "bf16").T, 3.2e-2)
 
 
 @pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10)])

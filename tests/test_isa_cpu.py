@@ -79,3 +79,46 @@ def test_no_kernel_rounds_with_sdwa_behind_packed_fp32(kernels_asm):
     found = {k: _sdwa_behind_packed_f32(v) for k, v in kernels_asm.items()}
     new = {k: n for k, n in found.items() if n and "qkv_prep_bf16_kernelILb1E" not in k}
     assert not new, new
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# gemm8.hip: the 8-phase kernels issue their direct-to-LDS loads as inline assembly and order them with hand-counted
+# `s_waitcnt vmcnt(N)` - a count the compiler cannot see.  A register spill is a scratch (vector-memory) operation: inside the
+# K loop it would both slow the loop and sit in the vmcnt queue the manual counts assume to hold DMA loads only.  Today hipcc spills
+# 43 (plain) / 71 (implicit-convolution) VGPRs of gemm8_kernel, all in the per-tile prologue / epilogue; this
+# keeps it that way.
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gemm8_asm(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    dst = tmp_path_factory.mktemp("isa8") / "gemm8.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm",
+                           "-pragma-unroll-threshold=262144", "-Wno-inline-asm", "--cuda-device-only", "-S", "-o", str(dst),
+                           os.path.join(CSRC, "gemm8.hip")], stderr=subprocess.DEVNULL)
+    text = dst.read_text()
+    spills = {}
+    for blk in text.split("- .agpr_count:")[1:]:
+        name, vs = re.search(r"\.name:\s+(\S+)", blk), re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+        if name and vs:
+            spills[name.group(1)] = int(vs.group(1))
+    return _kernels(text), spills
+
+
+def test_gemm8_k_loops_are_free_of_scratch_traffic(gemm8_asm):
+    kernels, spills = gemm8_asm
+    seen = 0
+    for name, lines in kernels.items():
+        if "gemm8_kernel" not in name and "gemm8s_kernel" not in name:
+            continue
+        mfma = [i for i, t in enumerate(lines) if t.startswith("v_mfma")]
+        assert mfma, name
+        seen += 1
+        region = lines[mfma[0]: mfma[-1] + 1]
+        bad = [t for t in region if t.startswith("scratch_") or t.startswith("buffer_load") or t.startswith("buffer_store")]
+        assert not bad, f"{name}: {len(bad)} scratch / buffer operations between the first and the last MFMA, e.g. {bad[:3]}"
+        # the pipelined / plain 128x128 forms must not spill at all; the 256x256 kernel's prologue / epilogue spills are tracked
+        limit = 96 if "gemm8_kernel" in name else 0
+        assert spills.get(name, 0) <= limit, f"{name}: vgpr_spill_count {spills.get(name)} > {limit}"
+    assert seen >= 6

@@ -244,6 +244,33 @@ def test_concurrent_streams_are_bitwise_equal_to_one_stream(gpu):
     assert all(torch.isfinite(w).all() for w in res.target)
 
 
+@pytest.mark.parametrize("prec", ["bf16", "mixed"])
+def test_weight_layout_and_next_weight_prefetch_are_bitwise_invisible(gpu, prec):
+    """SAMAudio(weight_layout="ktm") stores the five big weight matrices of every DiT layer K-tile-major, prefetch_rows lets the
+    CUs a few-row GEMM leaves idle read the next GEMM's weights (samaudio.h): layout and scheduling only - the solve must equal
+    the row-major, no-prefetch model bit for bit (one stream and two row groups)."""
+    cfg = preset_config("mini")
+    sd = init_state_dict(cfg, seed=12)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 12 * hop) for i in range(3)]
+    text, tmask = synthetic_text_features(3, 6, ragged=True)
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["x"] * 3, audios=clips, text_features=text, text_mask=tmask).to(gpu)
+    noise = synthetic_noise(3, 12).to(gpu)
+    opt = {"method": "midpoint", "options": {"step_size": 0.5}}
+    lat = {}
+    for layout, pf, streams in (("rows", 0, 1), ("ktm", 0, 1), ("ktm", 1 << 20, 1), ("rows", 1 << 20, 1), ("ktm", 1 << 20, 2)):
+        m = SAMAudio(cfg, precision=prec, device=str(gpu), weight_layout=layout, prefetch_rows=pf, streams=streams)
+        m.load_state_dict(sd, strict=False)
+        w = m.engine_tensors()["L0.wqkv"]
+        assert w.dim() == (3 if layout == "ktm" else 2)
+        m.separate(batch, noise=noise, ode_opt=opt)
+        lat[(layout, pf, streams)] = m.last_latent.clone()
+    ref = lat[("rows", 0, 1)]
+    assert torch.isfinite(ref).all()
+    for key, v in lat.items():
+        assert torch.equal(ref, v), key
+
+
 def test_load_state_dict_twice_replaces_the_weights(gpu):
     """nn.Module semantics (reference model.py loads checkpoints through load_state_dict): a second load replaces every
     weight - both weight sets are finalized again, stream lanes that borrowed the old tensors are rebuilt - and the model

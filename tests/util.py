@@ -25,7 +25,8 @@ def rounded(x: torch.Tensor, prec: str) -> torch.Tensor:
 def gemm_params(A, W, M, N, K, *, nbatch=1, a_off=0, a_bstride=0, lda=None, kc=None, tap_stride=0,
                 bias=None, chan_mod=0, swiglu=0, gate_tab=None, gate=None, gate_ld=0, rows_per_gate=1, alpha=1.0,
                 res=None, res_geom=(0, 0, 0), out_f32=None, f32_geom=(0, 0, 0), out_act=None, act_geom=(0, 0, 0),
-                act=hip.ACT_NONE, f32_act=0, act_alpha=None, c_lo=0, c_hi=0, c_ld_rel=0, w_bstride=0, raster_gm=0):
+                act=hip.ACT_NONE, f32_act=0, act_alpha=None, c_lo=0, c_hi=0, c_ld_rel=0, w_bstride=0, raster_gm=0, flags=0,
+                prefetch=None):
     p = hip.GemmParams()
     p.A, p.W = A.data_ptr(), W.data_ptr()
     p.a_off, p.a_bstride, p.lda, p.tap_stride = a_off, a_bstride, (K if lda is None else lda), tap_stride
@@ -46,6 +47,9 @@ def gemm_params(A, W, M, N, K, *, nbatch=1, a_off=0, a_bstride=0, lda=None, kc=N
     p.act_alpha = 0 if act_alpha is None else act_alpha.data_ptr()
     p.c_lo, p.c_hi, p.c_ld_rel = c_lo, c_hi, c_ld_rel
     p.w_bstride, p.raster_gm = w_bstride, raster_gm
+    p.flags = flags   # e.g. 2048: W is K-tile-major (common.h GEMM_FLAG_W_KTM)
+    if prefetch is not None:   # bytes the launch's idle workgroups touch (the next launch's weights)
+        p.pf_ptr, p.pf_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     return p
 
 

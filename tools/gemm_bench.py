@@ -26,6 +26,7 @@ BLAS = [False]
 VARIANTS = {-1: "auto policy (tail split)", 22: "8-phase 256x256", 27: "gemm8s 128x128"}
 # A/B of a debug flag on the forced 8-phase kernel: --ab FLAG adds a column "8-phase, flag FLAG = 1"
 AB_FLAG = [None]
+ROLES = [False]
 AB_VALUE = [1]
 
 
@@ -71,11 +72,14 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
     line = f"{name:>22s} M={M} N={N} K={K} {kind:7s} gm={RASTER[0]}"
     cols = [(v, vname, None) for v, vname in VARIANTS.items()]
     if AB_FLAG[0] is not None:
-        cols += [(22, f"8-phase flag {AB_FLAG[0]}={AB_VALUE[0]}", AB_FLAG[0]), (-1, f"auto flag {AB_FLAG[0]}={AB_VALUE[0]}", AB_FLAG[0])]
+        cols += [(22, f"8-phase flag {AB_FLAG[0]}={AB_VALUE[0]}", (AB_FLAG[0], AB_VALUE[0])),
+                 (-1, f"auto flag {AB_FLAG[0]}={AB_VALUE[0]}", (AB_FLAG[0], AB_VALUE[0]))]
+    if ROLES[0]:   # the pipelined gemm8s form's wave roles (debug flag 27: 1 = none, 2 / 3 = requesting waves, PROD 0 / 2)
+        cols = [(27, f"gemm8s flag 27={r}", (27, r)) for r in (1, 2, 3)] + [(22, "8-phase 256x256", None)]
     for v, vname, flag in cols:
         hip.lib().samaudio_debug_force_gemm_variant(v)
         if flag is not None:
-            hip.lib().samaudio_debug_set_flag(flag, AB_VALUE[0])
+            hip.lib().samaudio_debug_set_flag(flag[0], flag[1])
         for _, o, _, _ in outs:
             o.fill_(float("nan"))
         util.gemm("bf16", A, W, M, N, K, **kw)
@@ -95,7 +99,7 @@ def run_case(name, M, N, K, kind, dev, iters, T=250):
         us = e0.elapsed_time(e1) * 1e3 / iters
         line += f" | {vname}: {us:8.1f} us {flops / us / 1e6:7.1f} TF {'ok' if ok else 'WRONG'} ({', '.join(errs)})"
         if flag is not None:
-            hip.lib().samaudio_debug_set_flag(flag, 0)
+            hip.lib().samaudio_debug_set_flag(flag[0], 0)
     hip.lib().samaudio_debug_force_gemm_variant(-1)
     if BLAS[0]:   # yardstick: hipBLASLt through torch.matmul on the same operands (plain product, 16-bit output, no epilogue)
         for _ in range(2):
@@ -121,12 +125,14 @@ def main():
     ap.add_argument("--raster", action="store_true", help="sweep the tile-raster group size of the 8-phase kernel")
     ap.add_argument("--ab", type=int, default=None, help="debug flag to A/B on the forced 8-phase kernel and the policy")
     ap.add_argument("--ab-value", type=int, default=1)
+    ap.add_argument("--roles", action="store_true", help="columns: gemm8s under debug flag 27 = 1 / 2 / 3 (wave roles of the pipelined form)")
     ap.add_argument("--vit", action="store_true", help="the PE-Core-L14-336 tower's GEMM shapes (250 frames x 577 tokens)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     BLAS[0] = not args.no_blas
     AB_FLAG[0] = args.ab
     AB_VALUE[0] = args.ab_value
+    ROLES[0] = args.roles
     if args.vit:
         Mv = 250 * 577
         run_case("vit qkv (bias)", Mv, 3072, 1024, "plain", dev, 5)
