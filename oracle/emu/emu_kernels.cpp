@@ -85,10 +85,14 @@ static void gemm_t(const GemmParams& p) {
       std::vector<float> arow((size_t)p.K), acc((size_t)p.N);
       const T* Ar = A0 + p.a_off + (long)b * p.a_bstride + (long)m * p.lda;
       for (int k = 0; k < p.K; ++k) arow[k] = HE<T>::ld(Ar + (long)(k / p.kc) * p.tap_stride + (k % p.kc));
+      const bool ktm = (p.flags & GEMM_FLAG_W_KTM) != 0;   // W stored [K/64][N][64] (common.h) instead of [N][K]
       for (int n = 0; n < p.N; ++n) {
         const T* w = W + (long)n * p.K;
         float s = 0.f;
-        for (int k = 0; k < p.K; ++k) s += arow[k] * HE<T>::ld(w + k);
+        if (ktm)
+          for (int k = 0; k < p.K; ++k) s += arow[k] * HE<T>::ld(W + ((long)(k / 64) * p.N + n) * 64 + k % 64);
+        else
+          for (int k = 0; k < p.K; ++k) s += arow[k] * HE<T>::ld(w + k);
         acc[n] = s;
       }
       const int n_out = p.swiglu ? p.N / 2 : p.N;
@@ -442,6 +446,7 @@ hipError_t launch_hash_items(const unsigned* x, size_t words, int items, unsigne
   return hipSuccess;
 }
 void* debug_device_alloc(size_t bytes) { return std::malloc(bytes); }
+void debug_device_free(void* p) { std::free(p); }
 
 hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_col0, void* out, long out_bstride,
                          bool bf16, int B, long T, int C_in, int C_out, int halo, hipStream_t) {

@@ -33,6 +33,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::m
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
 inline hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }

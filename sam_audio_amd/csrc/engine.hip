@@ -40,6 +40,13 @@ struct HashTrace {
   size_t used = 0, seq = 0;
   std::vector<Rec> recs;
   static constexpr size_t CAP = 1 << 20;
+  bool full_warned = false;
+};
+// eval_field sets the running context's recorder for the duration of ONE evaluation: cleared on every way out, so that a later
+// trace() on this thread (the codec, another context) cannot append to this context's recorder
+struct HashScope {
+  explicit HashScope(HashTrace* h, int items);
+  ~HashScope();
 };
 static bool hash_on() {
   static const bool on = std::getenv("SAMAUDIO_TRACE_HASH") != nullptr;
@@ -47,13 +54,19 @@ static bool hash_on() {
 }
 static thread_local HashTrace* g_hash = nullptr;   // the running context's recorder (set by eval_field)
 static thread_local int g_hash_items = 1;
+HashScope::HashScope(HashTrace* h, int items) { g_hash = h; g_hash_items = items; }
+HashScope::~HashScope() { g_hash = nullptr; g_hash_items = 1; }
 static void hash_stage(const char* name, const void* dev, size_t bytes, hipStream_t st) {
   HashTrace* h = g_hash;
   if (!h || !dev || bytes < 4) return;
   if (!h->dev && !(h->dev = (unsigned long long*)debug_device_alloc(HashTrace::CAP * 8))) return;
   int items = g_hash_items;
   if (items <= 0 || (bytes / 4) % (size_t)items) items = 1;
-  if (h->used + items > HashTrace::CAP) return;
+  if (h->used + items > HashTrace::CAP) {
+    if (!h->full_warned) std::fprintf(stderr, "[samaudio hash] recorder full (%zu words): later stages are NOT recorded\n", HashTrace::CAP);
+    h->full_warned = true;
+    return;
+  }
   (void)launch_hash_items((const unsigned*)dev, bytes / 4 / items, items, h->dev + h->used, st);
   h->recs.push_back({name, items, h->used});
   h->used += items;
@@ -453,6 +466,11 @@ Status Engine::set_option(int option, int value) {
     if (value && !bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_ALT16_CLASSES applies to 16-bit contexts");
     if (value & ~SAMAUDIO_CLS_ALT16_CAPABLE)
       return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_ALT16_CLASSES: only the five big GEMM classes of the DiT layers (qkv, wo, cwq, w13, w2)");
+    // (what eval_field needs for these classes: the pre-combined RMSNorm operands - checked here, not at the first evaluation)
+    if (value && !(2 * cfg_.n_layers <= kMaxModNorms && cfg_.n_layers > 0 && cfg_.dim <= 256 * 12))
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_ALT16_CLASSES (precision 'mixed') supports 1 .. " + std::to_string(kMaxModNorms / 2) +
+                                        " layers and dim <= 3072: this config has " + std::to_string(cfg_.n_layers) + " layers, dim " +
+                                        std::to_string(cfg_.dim) + " - use precision 'fp16' or 'bf16'");
     alt_classes_ = value;
     return Status{};
   }
@@ -505,6 +523,11 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
     const int variant = gemm_variant(p, bf16_);
     const char* conv = (variant == 22 || variant == 27) && p.kc < p.K ? "_conv" : "";
     r.key = std::string(prof_cls_) + "/" + (part ? "gemm8s_bf16_128x128_tail" : gemm_variant_name(variant, bf16_)) + conv;
+    if (static const bool by_class = std::getenv("SAMAUDIO_PROF_BY_CLASS") != nullptr; by_class) {   // diagnosis: one record per GEMM class
+      int bit = 0;
+      while (bit < SAMAUDIO_CLS_COUNT && !(cls & (1 << bit))) ++bit;
+      r.key += "#" + std::to_string(bit);
+    }
     r.flops = flops * share;
     r.bytes = bytes * share;
     SA_TRY(prof_event(&r.e0));
@@ -612,6 +635,11 @@ Status Engine::profile_end(std::vector<KernelStat>& out) {
 
 Engine::~Engine() {
   for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
+  if (hash_) {   // SAMAUDIO_TRACE_HASH recorder: the library's only device allocation
+    HashTrace* h = (HashTrace*)hash_;
+    debug_device_free(h->dev);
+    delete h;
+  }
 }
 
 static GemmParams lin(const void* A, long lda, const void* W, long M, int N, int K) {
@@ -726,12 +754,9 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   const long t6 = nt == 1 ? 0 : 6L * D, t1 = nt == 1 ? 0 : (long)D;
   prof_cls_ = "dit";
   const double MD = (double)M * D;
-  if (hash_on()) {
-    if (!hash_) hash_ = new HashTrace();
-    g_hash = (HashTrace*)hash_;
-    g_hash_items = rows;
-    hash_stage("noisy", noisy, (size_t)M * C2 * 4, st);
-  }
+  if (hash_on() && !hash_) hash_ = new HashTrace();
+  const HashScope hash_scope(hash_on() ? (HashTrace*)hash_ : nullptr, rows);
+  hash_stage("noisy", noisy, (size_t)M * C2 * 4, st);
 
   // aligned = noisy @ Wy^T + cond                                   (model.py:116-125, columns 0..255)
   {
@@ -840,7 +865,10 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
-  // SAMAUDIO_OPT_PREFETCH_ROWS: a launch's idle workgroups read the next big GEMM's weights (gemm8.hip prefetch_lines)
+  // SAMAUDIO_OPT_PREFETCH_ROWS: a launch's idle workgroups read the next big GEMM's weights (gemm8.hip prefetch_lines).  Chain per
+  // layer: qkv -> wo -> c_wq -> c_wo (read by the fold kernel); w13 -> w2 -> the next layer's qkv.  Nobody prefetches w13: the only
+  // launch in front of it with idle CUs is the folded cross-attention GEMM (K = 192: 15 us), which the 85 MB read stretched to 27 us,
+  // and w13 itself (236 tiles of 256 x 256) measured the same warm or cold (round 5, profiles/r5_call2/).
   const bool pf_on = bf16_ && prefetch_rows_ > 0 && M <= prefetch_rows_;
   auto prefetch = [&](GemmParams& p, const void* w_next, double elems) {
     if (pf_on && w_next) { p.pf_ptr = w_next; p.pf_bytes = (long)(elems * esz_); }
@@ -918,14 +946,12 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       p.f32_bstride = (long)T * D;
       trace("  probs", d_.probs, (size_t)M * fold_kp_, bf16_, st);
       trace("  ut", d_.ut, (size_t)rows * D * fold_kp_, bf16_, st);
-      prefetch(p, w.w13, 2.0 * F * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
       SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
-      prefetch(p, w.w13, 2.0 * F * D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     }
     trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
@@ -971,10 +997,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     out_f32(p, out, C2);
     SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_OUT, f));
   }
-  if (hash_on()) {
-    hash_stage("field out", out, (size_t)M * C2 * 4, st);
-    g_hash = nullptr;
-  }
+  hash_stage("field out", out, (size_t)M * C2 * 4, st);
   return Status{};
 }
 

@@ -329,7 +329,8 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
       // timed configuration - the other row group's HBM-bound kernels run on them.  profiles/r3_call2/.)
       const long t256 = rows256 * ((p.N + 255) / 256);
       if (p.N < 1024 && p.N % 256) return 27;
-      return t256 >= 128 ? 22 : 27;
+      const long min256 = debug_flag(30) > 0 ? debug_flag(30) : 128;   // flag 30 (A/B): the tile count from which gemm8 is used
+      return t256 >= min256 ? 22 : 27;
     }
     // 96 <= N < 256 with few rows: 128- / 64-row tiles of the 32x32x16 family
     return rows128 * ((p.N + 127) / 128) >= 192 ? 25 : 26;

@@ -1274,7 +1274,7 @@ static GemmParams with_epilogue_choice(const GemmParams& p) {
 // rows a launch lasts nt x ~0.8 us whatever its workgroup count: it is bound by the depth of the K-tile prefetch (two K-tiles
 // of L2 latency in flight), not by how many CUs hold a tile.  Removed; profiles/r3_call8/.)
 // alt-format operands (flags bit 10, mixed mode) exist for plain GEMMs only - the DiT's Linears - gemm8_alt_ok()
-#define SA_GEMM8S_ROLES_DEFAULT (-1)   // the shipped form of the pipelined kernel: -1 no roles, 0 / 2 = PROD
+#define SA_GEMM8S_ROLES_DEFAULT 2   // the shipped form of the pipelined kernel: -1 no roles, 0 / 2 = PROD
 static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 grid, int skip256, hipStream_t st) {
   const dim3 block(256);
   const bool alt = (p.flags & 1024) != 0;

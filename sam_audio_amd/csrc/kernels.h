@@ -22,11 +22,15 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 26: 1 = the 8-phase kernel launches one workgroup per tile (shipped: persistent above 256 tiles) - its bitwise test
 //   flag 29: 1 = qkv_prep with its 16-bit rounding written out (the form before round 4: reproducer of the run-to-run difference its
 //            SDWA instruction sequence showed beside another kernel's waves - kernels.hip, tools/stress_qkv_prep.py)
+//   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
+//            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads
+//   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library
 hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st);
 void* debug_device_alloc(size_t bytes);
+void debug_device_free(void* p);
 int debug_flag(int flag);
 
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
@@ -46,8 +50,6 @@ hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // gemm8.hip: GemmParams.flags bits 9 / 10 (mixed mode: out_act written / operands read in the alt 16-bit format) are well-formed;
 // only the 8-phase family (variants 22 / 27) implements them
 bool gemm8_alt_ok(const GemmParams& p);
-// gemm8.hip: GemmParams.flags bit 8 (q|k|v epilogue) is well-formed; only the 8-phase family (variants 22 / 27) implements it
-bool gemm8_qkv_ok(const GemmParams& p);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
 // LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
 bool conv7h_ok(const GemmParams& p);

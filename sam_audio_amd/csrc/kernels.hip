@@ -734,5 +734,6 @@ void* debug_device_alloc(size_t bytes) {   // debugging aids only: the product p
   void* p = nullptr;
   return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr;
 }
+void debug_device_free(void* p) { if (p) (void)hipFree(p); }
 
 }  // namespace sa

@@ -6,9 +6,9 @@ What runs where
     engine context (`samaudio_finalize(ctx, 2)`).
   * both PE-AV transformers, the Judge's projections / LayerNorm / pooled head, the PE-A-Frame heads and frame logits:
     hand-written HIP behind `samaudio_judge_*` / `samaudio_frame_*` (include/samaudio.h).
-  * the ModernBERT text tower: on the HIP library too (sam_audio_amd/mbert_encoder.py, `samaudio_mbert_*`; `text_backend=
-    "torch"` keeps the `transformers` module on PyTorch-ROCm as an explicit option); the tokenizer is Hugging Face's (a once-per-call cost on a
-    handful of tokens).
+  * the ModernBERT text tower: on the HIP library too (sam_audio_amd/mbert_encoder.py, `samaudio_mbert_*`); the `transformers`
+    module only carries the weights.  The tokenizer is Hugging Face's (a once-per-call cost on a handful of tokens,
+    SURVEY.md section 8 f1).
 The reference repeats the mixture once per reranking candidate (ranking/judge.py:31-33).  Every op of the Judge is
 per-row, so `score_candidates` evaluates the mixture branch once per clip: identical results, about half the DAC
 encodes and transformer rows (pinned on the CPU by tests/test_judge_oracle.py::test_judge_rows_are_independent...).
@@ -184,28 +184,19 @@ class _CodecEncoder:
 
 
 class _TextTower:
-    """The ModernBERT text tower of a Judge / PE-A-Frame model.  `module` (a `transformers.ModernBertModel`) stays the
-    container of the weights - `state_dict()` / `load_state_dict()` keep their reference semantics - while the forward runs
-    on the HIP library (`backend="hip"`, sam_audio_amd/mbert_encoder.py; fp32: a handful of tokens once per call) once the
-    model sits on a GPU.  `backend="torch"` runs the module itself on PyTorch-ROCm; it is chosen explicitly (constructor
-    argument `text_backend`), never as a silent fallback - an injected non-ModernBERT module must ask for it."""
+    """The ModernBERT text tower of a Judge / PE-A-Frame model.  `module` (a `transformers.ModernBertModel`) is the CONTAINER
+    of the weights - `state_dict()` / `load_state_dict()` keep their reference semantics - and is never executed: the forward
+    runs on the HIP library (sam_audio_amd/mbert_encoder.py; fp32: a handful of tokens once per call) once the model sits on
+    a GPU.  (The tests' checker runs the module itself: tests/torch_text.py.)"""
 
-    default_backend = "hip"   # tests/conftest.py's launcher emulation (no text-tower kernels) switches it to "torch"
-
-    def __init__(self, module, backend: Optional[str] = None):
-        backend = backend or self.default_backend
-        if backend not in ("hip", "torch"):
-            raise ValueError("text_backend must be 'hip' or 'torch'")
-        self.module, self.backend = module, backend
+    def __init__(self, module):
+        self.module = module
         self._hip = None
         self._device = None
 
     def place(self, device) -> None:
         """(re)build the device copy after the weights changed or the model moved"""
         self._device = torch.device(device)
-        if self.backend == "torch":
-            self.module = self.module.to(self._device).eval()
-            return
         from .mbert_encoder import ModernBertHIP
         self._hip = ModernBertHIP.from_module(self.module, self._device, precision="fp32")
 
@@ -214,26 +205,10 @@ class _TextTower:
         """transformers' `hidden_states[nth]` ([B, Lt, hidden]); nth None = last_hidden_state.  nth == num_hidden_layers is
         version-dependent in transformers (SAMAudioJudgeConfig.last_text_layer_prenorm): `last_prenorm` True = the 4.x
         meaning (output of the last layer, before final_norm), False = the 5.x meaning (last_hidden_state) - independent of
-        the transformers version that happens to be installed, on both backends."""
-        if self.backend == "hip":
-            if self._hip is None:
-                raise hip.SamAudioHipError("text tower: load the model's weights on a ROCm GPU first (no CPU fallback)")
-            return self._hip(input_ids, attention_mask, nth, last_prenorm=last_prenorm)
-        layers = self.module.config.num_hidden_layers
-        grabbed = []
-        hook = None
-        if nth == layers and last_prenorm:   # the input of final_norm IS the 4.x hidden_states[layers]
-            hook = self.module.final_norm.register_forward_pre_hook(lambda mod, args: grabbed.append(args[0]))
-        try:
-            out = self.module(input_ids=input_ids.to(self._device),
-                              attention_mask=None if attention_mask is None else attention_mask.to(self._device),
-                              output_hidden_states=nth is not None and nth != layers)
-        finally:
-            if hook is not None:
-                hook.remove()
-        if nth is None or (nth == layers and not last_prenorm):
-            return out.last_hidden_state
-        return grabbed[0] if nth == layers else out.hidden_states[nth]
+        the transformers version that happens to be installed."""
+        if self._hip is None:
+            raise hip.SamAudioHipError("text tower: load the model's weights on a ROCm GPU first (no CPU fallback)")
+        return self._hip(input_ids, attention_mask, nth, last_prenorm=last_prenorm)
 
 
 def _text_tower(text_cfg: Dict[str, Any]):
@@ -248,14 +223,14 @@ class SAMAudioJudgeModel:
     config_cls = SAMAudioJudgeConfig
 
     def __init__(self, config: SAMAudioJudgeConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_model=None, text_backend: Optional[str] = None):
+                 text_model=None):
         config.check_supported()
         hip.check_precision(precision)
         self.config = config
         self.precision = precision
         self.device = torch.device(device) if device is not None else None
         self.text_model = text_model if text_model is not None else _text_tower(config.text_model)  # judge.py:48
-        self._text = _TextTower(self.text_model, text_backend)
+        self._text = _TextTower(self.text_model)
         self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
@@ -477,13 +452,13 @@ class PEAudioFrame:
     `predictor(input_features=[B, T, 128], padding_mask=[B, T], return_spans=True, input_ids=..., attention_mask=...)`."""
 
     def __init__(self, config: PEAudioFrameConfig, precision: str = "bf16", device: Optional[str] = None,
-                 text_model=None, hop_length: int = 1920, sample_rate: int = 48_000, text_backend: Optional[str] = None):
+                 text_model=None, hop_length: int = 1920, sample_rate: int = 48_000):
         config.check_supported()
         self.config, self.precision = config, precision
         self.device = torch.device(device) if device is not None else None
         self.hop_length, self.sample_rate = hop_length, sample_rate
         self.text_model = text_model if text_model is not None else _text_tower(config.text_model)
-        self._text = _TextTower(self.text_model, text_backend)
+        self._text = _TextTower(self.text_model)
         self._lib = hip.lib(hip.operands_for(precision))
         self._h = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}

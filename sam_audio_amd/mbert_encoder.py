@@ -73,7 +73,7 @@ class MBertDims:
     def check_supported(self) -> None:
         if self.norm_bias or self.attention_bias or self.mlp_bias or self.hidden_activation != "gelu":
             raise NotImplementedError("ModernBERT with biases / an activation other than gelu is not built on the HIP "
-                                      "library; use text_backend='torch'")
+                                      "library")
 
 
 def rope_tables(dims: MBertDims):

@@ -284,7 +284,12 @@ class SAMAudio:
                 self._register(convert_dit_f32(self._f32_sd, self.cfg, self.device, need))
                 self._f32_have |= need
                 self._lanes = []   # stream lanes borrow the registered tensors: rebuilt on demand
-                hip.check(self._lib.samaudio_finalize(self._ctx, 0))   # binds the new names
+                # binds the new names.  Registering a name the engine already holds (the copies of an earlier checkpoint that
+                # a later load_state_dict left behind) marks EVERY weight set as not finalized: each set the model has is
+                # finalized again (the codec set was not, and the next separate() failed in the codec)
+                hip.check(self._lib.samaudio_finalize(self._ctx, 0))
+                if self._has_codec:
+                    hip.check(self._lib.samaudio_finalize(self._ctx, 1))
         for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
             self._set_precision_options(ctx)
 

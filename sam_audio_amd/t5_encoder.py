@@ -70,7 +70,7 @@ class T5Dims:
         if self.is_gated_act or self.dense_act_fn not in ACTS:
             raise NotImplementedError(
                 f"T5 feed-forward '{'gated-' if self.is_gated_act else ''}{self.dense_act_fn}' is not built on the HIP "
-                "library (t5-base, the reference's text encoder, is non-gated ReLU); use T5TextEncoder(backend='torch')")
+                "library (t5-base, the reference's text encoder, is non-gated ReLU)")
 
 
 def relative_position_bucket(relative_position: torch.Tensor, num_buckets: int, max_distance: int) -> torch.Tensor:

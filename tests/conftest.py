@@ -98,7 +98,8 @@ def _enable_emu_dryrun():
     if which == "emu":
         os.environ["SAMAUDIO_NO_FOLD"] = "1"  # the folded cross-attention projection's kernels are not emulated
         from sam_audio_amd import judge
-        judge._TextTower.default_backend = "torch"   # nor is the ModernBERT text tower (the SIMT simulator build carries it)
+        from tests.torch_text import TorchTextTower
+        judge._TextTower = TorchTextTower   # nor is the ModernBERT text tower (the SIMT simulator build carries it)
 
 
 if EMU_DRYRUN:

@@ -212,8 +212,11 @@ def test_product_span_rule_equals_the_oracle_rule():
         assert spans_from_logits(logits, pad, 1920, 48000, th) == J.spans_from_logits(logits, pad, 1920, 48000, th)
 
 
-def test_t5_text_encoder_wrapper_matches_the_hf_module():
+def test_t5_text_encoder_wrapper_has_no_cpu_execution_path():
+    """The wrapper validates its container on the CPU, but only the HIP stack ever runs it (tests/test_t5_gpu.py compares that
+    stack with the transformers module)."""
     transformers = pytest.importorskip("transformers")
+    from sam_audio_amd import hip
     from sam_audio_amd.text_encoder import T5TextEncoder
     torch.manual_seed(0)
     t5 = transformers.T5EncoderModel(transformers.T5Config(d_model=64, d_kv=16, d_ff=128, num_layers=2, num_heads=4,
@@ -224,12 +227,11 @@ def test_t5_text_encoder_wrapper_matches_the_hf_module():
             return _Tok()(texts)
 
     enc = T5TextEncoder(T5EncoderConfig(name="unused", dim=64), model=t5, tokenizer=Tok())
-    feats, mask = enc(["dog barking", "rain"])
-    assert feats.shape[0] == 2 and feats.shape[2] == 64 and mask.dtype == torch.bool and mask.shape == feats.shape[:2]
-    tok = _Tok()(["dog barking", "rain"])
-    with torch.inference_mode():
-        ref = t5(input_ids=tok["input_ids"], attention_mask=tok["attention_mask"]).last_hidden_state
-    assert torch.equal(feats, ref)
+    assert enc.backend == "hip" and enc.device is None
+    with pytest.raises(hip.SamAudioHipError, match="no CPU fallback"):
+        enc(["dog barking", "rain"])
+    with pytest.raises(hip.SamAudioHipError, match="no CPU fallback"):
+        enc.to("cpu")
     with pytest.raises(ValueError):
         T5TextEncoder(T5EncoderConfig(name="unused", dim=768), model=t5, tokenizer=Tok())
     with pytest.raises(FileNotFoundError):
@@ -282,15 +284,15 @@ def test_last_text_hidden_state_semantics_do_not_depend_on_the_installed_transfo
     """hidden_states[num_hidden_layers] is the last layer's output BEFORE final_norm in transformers
     4.48 - 4.5x (what the reference pins and the Judge was trained with) and the normalised tensor in 5.x; the reference's
     default nth_text_layer = 22 selects exactly that entry.  `last_text_layer_prenorm` (default True = 4.x) decides, on the
-    torch backend too (the HIP backend: tests/test_mbert_gpu.py)."""
-    from sam_audio_amd.judge import _TextTower
+    checker's tower (tests/torch_text.py) as on the HIP one (tests/test_mbert_gpu.py)."""
+    from tests.torch_text import TorchTextTower
     tm = G.make_text_model(SAMAudioJudgeConfig(text_model=G.TINY_TEXT), seed=5) if hasattr(G, "make_text_model") else None
     if tm is None:
         import transformers
         torch.manual_seed(5)
         tm = transformers.ModernBertModel(transformers.ModernBertConfig(**G.TINY_TEXT)).eval()
     L = tm.config.num_hidden_layers
-    tower = _TextTower(tm, backend="torch")
+    tower = TorchTextTower(tm)
     tower.place("cpu")
     ids = torch.randint(3, 128, (2, 7), generator=torch.Generator().manual_seed(1))
     mask = torch.ones(2, 7, dtype=torch.long)

@@ -295,3 +295,29 @@ def test_load_state_dict_twice_replaces_the_weights(gpu):
     assert torch.equal(twice.last_latent, want_lat)
     assert all(torch.equal(a, b) for a, b in zip(got.target, want.target))
     assert all(torch.isfinite(w).all() for w in first.target)
+
+
+def test_f32_class_changes_across_two_loads_keep_the_codec_usable(gpu):
+    """load(A), set_f32_classes('all' of the capable ones), set('out'), load(B), set(all) re-registers "<name>.f32"
+    tensors the engine still holds from checkpoint A - which marks every weight set as not finalized.  set_f32_classes must
+    finalize the codec set again too: separate() then works and equals a fresh model built with those classes."""
+    cfg = preset_config("tiny")
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 4 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 4)
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["x"] * 2, audios=clips, text_features=text, text_mask=tmask).to(gpu)
+    noise = synthetic_noise(2, 4).to(gpu)
+    sd_a, sd_b = init_state_dict(cfg, seed=31), init_state_dict(cfg, seed=32)
+    every = "time,out,in,prep,yemb"
+    m = SAMAudio(cfg, precision="bf16", device=str(gpu), f32_classes="out")
+    m.load_state_dict(sd_a, strict=False)
+    m.set_f32_classes(every)
+    m.set_f32_classes("out")
+    m.load_state_dict(sd_b, strict=False)
+    m.set_f32_classes(every)
+    got = m.separate(batch, noise=noise)
+    fresh = SAMAudio(cfg, precision="bf16", device=str(gpu), f32_classes=every)
+    fresh.load_state_dict(sd_b, strict=False)
+    want = fresh.separate(batch, noise=noise)
+    assert torch.equal(m.last_latent, fresh.last_latent)
+    assert all(torch.equal(a, b) for a, b in zip(got.target, want.target))

@@ -147,7 +147,7 @@ def test_text_encoder_wrapper_runs_the_hip_stack(gpu):
                 att[i, : len(r)] = 1
             return {"input_ids": ids, "attention_mask": att}
 
-    enc = T5TextEncoder(T5EncoderConfig(name="unused", dim=64), model=m, tokenizer=Tok(), device=gpu, backend="hip")
+    enc = T5TextEncoder(T5EncoderConfig(name="unused", dim=64), model=m, tokenizer=Tok(), device=gpu)
     assert enc.backend == "hip" and enc._hip is not None
     texts = ["a dog barking loudly", "rain", "two words"]
     feats, mask = enc(texts)
@@ -157,6 +157,6 @@ def test_text_encoder_wrapper_runs_the_hip_stack(gpu):
     assert mask.dtype == torch.bool and mask.tolist() == tok["attention_mask"].bool().tolist()
     assert feats.shape == want.shape and feats.dtype == torch.float32
     assert (feats.cpu() - want).abs().max().item() / want.abs().max().item() < 2e-5
-    cpu_enc = T5TextEncoder(T5EncoderConfig(name="unused", dim=64), model=m, tokenizer=Tok(), backend="hip")
+    cpu_enc = T5TextEncoder(T5EncoderConfig(name="unused", dim=64), model=m, tokenizer=Tok())
     with pytest.raises(hip.SamAudioHipError, match="no CPU fallback"):
         cpu_enc(texts)
