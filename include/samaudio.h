@@ -115,6 +115,13 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  * registered with: [N, K] row-major, or [K/64, N, 64] K-TILE-MAJOR - the 64-element K slab of all N rows contiguous (16-bit contexts
  * only; sam_audio_amd/weights.py ktm_layout).  Same values, same results; a launch of few rows then streams its weights front to back. */
 #define SAMAUDIO_OPT_PREFETCH_ROWS 6
+/*   SAMAUDIO_OPT_SENTINEL (default 0; validation aid, never on in timed runs): value 1 makes the context scan every 16-bit tensor a
+ *   GEMM of the hot path writes (and the RMSNorm / attention outputs that feed GEMMs) for its largest magnitude and for
+ *   non-finite values, per GEMM class, on the launch stream - an IEEE-fp16 operand that overflowed (|x| > 65504 -> inf) is then
+ *   REPORTED by samaudio_sentinel_read with the class it came from instead of propagating silently.  Allocates 4 KiB of device
+ *   memory on first use (the only allocation of the library besides the checksum trace). */
+#define SAMAUDIO_OPT_SENTINEL 7
+#define SAMAUDIO_SENTINEL_SLOTS 16   /* SAMAUDIO_CLS_COUNT GEMM classes (bit order) + slot 14: RMSNorm outputs, 15: attention outputs */
 #define SAMAUDIO_CLS_ALT16_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
 #define SAMAUDIO_CLS_TIME (1 << 0)   /* t_embedder MLP + t_block (transformer.py:236-257,462-467): 1 row per time value */
 #define SAMAUDIO_CLS_OUT (1 << 1)    /* DiT output projection D -> 256 (transformer.py:519): feeds the ODE state */
@@ -348,6 +355,9 @@ typedef struct {
   double ms;
 } samaudio_kernel_stat;
 int samaudio_profile_begin(samaudio_ctx* ctx);
+/* SAMAUDIO_OPT_SENTINEL: synchronises `stream`, copies out absmax[SAMAUDIO_SENTINEL_SLOTS] / nonfinite[SAMAUDIO_SENTINEL_SLOTS]
+ * (counts as doubles) accumulated since the last read, and resets them. */
+int samaudio_sentinel_read(samaudio_ctx* ctx, float* absmax, double* nonfinite, samaudio_stream stream);
 /* Test hook: force the GEMM kernel variant (-1 automatic; 0..2 the 128-row tiles of gemm.hip; 22 = gemm8 256x256 8-phase,
  * 27 = gemm8s 128x128, 25 / 26 / 28 / 29 / 32 / 33 / 34 = the 32x32x16-family tiles, 35 = conv7h; csrc/gemm.hip
  * gemm_variant_name).  A launch the forced kernel does not cover falls back to gemm.hip's tiles. */

@@ -393,6 +393,11 @@ hipError_t launch_cross_attn_fold(const void*, const void*, long, void*, int, in
   return hipErrorNotSupported;
 }
 
+hipError_t launch_sentinel(const void*, int, long, int, long, float*, float*, hipStream_t) { return hipSuccess; }   // not emulated
+hipError_t launch_set_floats(float* dst, const float* host_values, int n, hipStream_t) {
+  for (int i = 0; i < n; ++i) dst[i] = host_values[i];
+  return hipSuccess;
+}
 hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,
                                 void* temb, float* tsin, bool bf16, hipStream_t) {
   const int hf = fdim / 2, hd = D / 2;

@@ -133,6 +133,11 @@ int samaudio_profile_begin(samaudio_ctx* ctx) {
   return ret(ctx->engine->profile_begin());
 }
 
+int samaudio_sentinel_read(samaudio_ctx* ctx, float* absmax, double* nonfinite, samaudio_stream stream) {
+  if (!ctx || !absmax || !nonfinite) return bad("samaudio_sentinel_read: null argument");
+  return ret(ctx->engine->sentinel_read(absmax, nonfinite, (hipStream_t)stream));
+}
+
 int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capacity, int* count) {
   if (!ctx || !count || (capacity > 0 && !out)) return bad("samaudio_profile_end: null argument");
   std::vector<sa::Engine::KernelStat> st;

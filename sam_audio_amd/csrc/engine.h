@@ -71,6 +71,7 @@ class Engine {
     long launches = 0;
     double flops = 0, bytes = 0, ms = 0;
   };
+  Status sentinel_read(float* absmax, double* nonfinite, hipStream_t st);   // SAMAUDIO_OPT_SENTINEL
   Status profile_begin();
   Status profile_end(std::vector<KernelStat>& out);
   ~Engine();
@@ -116,6 +117,10 @@ class Engine {
   int f32_classes_ = 0;     // SAMAUDIO_OPT_F32_CLASSES (16-bit contexts)
   int alt_classes_ = 0;     // SAMAUDIO_OPT_ALT16_CLASSES (16-bit contexts)
   int prefetch_rows_ = 0;   // SAMAUDIO_OPT_PREFETCH_ROWS (16-bit contexts)
+  bool sentinel_on_ = false;   // SAMAUDIO_OPT_SENTINEL
+  float* sentinel_dev_ = nullptr;   // [SAMAUDIO_SENTINEL_SLOTS][2] slots + [kSentinelPartials][2] partials (debug_device_alloc)
+  // fold the scan of a tensor into `slot` (no-op unless the sentinel is on); fmt as launch_sentinel
+  Status sentinel(int slot, const void* x, int fmt, long rows, int cols, long ld, hipStream_t st);
   int quant_classes_ = 0, quant_fmt_ = 0;  // SAMAUDIO_OPT_QUANT_CLASSES / _FORMAT (fp32 contexts)
   size_t esz_;  // bytes per activation / GEMM-operand element
   int at_dtype_;

@@ -480,6 +480,10 @@ Status Engine::set_option(int option, int value) {
     prefetch_rows_ = value;
     return Status{};
   }
+  if (option == SAMAUDIO_OPT_SENTINEL) {
+    sentinel_on_ = value != 0;
+    return Status{};
+  }
   if (option == SAMAUDIO_OPT_QUANT_CLASSES || option == SAMAUDIO_OPT_QUANT_FORMAT) {
     if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_QUANT_*: operand-rounding emulation needs an fp32 context");
     if (option == SAMAUDIO_OPT_QUANT_FORMAT && (value < 0 || value > 2))
@@ -490,7 +494,53 @@ Status Engine::set_option(int option, int value) {
   return fail(SAMAUDIO_ERR_ARG, "samaudio_set_option: unknown option " + std::to_string(option));
 }
 
+Status Engine::sentinel(int slot, const void* x, int fmt, long rows, int cols, long ld, hipStream_t st) {
+  if (!sentinel_on_ || !x) return Status{};
+  constexpr size_t kFloats = 2 * (SAMAUDIO_SENTINEL_SLOTS + kSentinelPartials);
+  if (!sentinel_dev_) {
+    sentinel_dev_ = (float*)debug_device_alloc(kFloats * 4);
+    if (!sentinel_dev_) return fail(SAMAUDIO_ERR_HIP, "sentinel: device allocation failed");
+    SA_HIP(hipMemsetAsync(sentinel_dev_, 0, kFloats * 4, st));
+  }
+  SA_HIP(launch_sentinel(x, fmt, rows, cols, ld, sentinel_dev_ + 2 * SAMAUDIO_SENTINEL_SLOTS, sentinel_dev_ + 2 * slot, st));
+  return Status{};
+}
+
+Status Engine::sentinel_read(float* absmax, double* nonfinite, hipStream_t st) {
+  for (int i = 0; i < SAMAUDIO_SENTINEL_SLOTS; ++i) { absmax[i] = 0.f; nonfinite[i] = 0.0; }
+  if (!sentinel_dev_) return Status{};
+  float host[2 * SAMAUDIO_SENTINEL_SLOTS];
+  SA_HIP(hipStreamSynchronize(st));
+  SA_HIP(hipMemcpy(host, sentinel_dev_, sizeof(host), hipMemcpyDeviceToHost));
+  SA_HIP(hipMemsetAsync(sentinel_dev_, 0, sizeof(host), st));
+  for (int i = 0; i < SAMAUDIO_SENTINEL_SLOTS; ++i) { absmax[i] = host[2 * i]; nonfinite[i] = host[2 * i + 1]; }
+  return Status{};
+}
+
+// the 16-bit output of a GEMM launch, scanned into its class's slot (outputs with a window mask - transposed convolutions - have
+// rows the launch does not write: skipped)
+static int cls_slot(int cls) {
+  int bit = 0;
+  while (bit < SAMAUDIO_CLS_COUNT - 1 && !(cls & (1 << bit))) ++bit;
+  return bit;
+}
+
 Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, bool f32) {
+  if (sentinel_on_ && p_in.out_act && !p_in.c_ld_rel) {
+    sentinel_on_ = false;   // (the launch itself, without recursion)
+    const Status s = gemm(p_in, st, alg_flops, cls, f32);
+    sentinel_on_ = true;
+    if (!s.ok()) return s;
+    const int c = prof_cls_[0] == 'c' ? SAMAUDIO_CLS_CODEC : cls;
+    const int fmt = (f32 || !bf16_) ? 0 : ((p_in.flags & 512) ? 2 : 1);
+    const int n_out = p_in.swiglu ? p_in.N / 2 : p_in.N;
+    for (int b = 0; b < p_in.nbatch; ++b) {
+      const size_t esz = fmt == 0 ? 4 : 2;
+      const char* base = (const char*)p_in.out_act + ((size_t)p_in.act_off + (size_t)b * p_in.act_bstride) * esz;
+      SA_TRY(sentinel(cls_slot(c), base, fmt, p_in.M, n_out, p_in.act_ld, st));
+    }
+    return Status{};
+  }
   GemmParams p = p_in;
   p.tag = prof_cls_[0] == 'c' ? 1 : 0;  // codec launches run under their own kernel symbols
   // bit 1: no tail split (gemm.hip gemm_tail_split); bit 9 (from the caller): 16-bit output in the alt format; bit 10: operands
@@ -568,6 +618,10 @@ Status Engine::res_unit(GemmParams p, GemmParams q, void*& cur, void*& alt, doub
   const double inter = (double)p.M * p.N * p.nbatch * esz_;   // the intermediate: neither written nor read
   SA_TRY(op("resunit_bf16", gemm_alg_bytes(fp, esz_) + gemm_alg_bytes(fq, esz_) - 2 * inter, flops7 + flops1, st,
             [&] { return launch_resunit(fp, fq, st); }));
+  if (sentinel_on_)   // the fused unit's 16-bit output (halo layout: the rows the launch writes)
+    for (int b = 0; b < fq.nbatch; ++b)
+      SA_TRY(sentinel(cls_slot(SAMAUDIO_CLS_CODEC), (const char*)fq.out_act + ((size_t)fq.act_off + (size_t)b * fq.act_bstride) * esz_,
+                      bf16_ ? 1 : 0, fq.M, fq.N, fq.act_ld, st));
   std::swap(cur, alt);
   return Status{};
 }
@@ -635,7 +689,8 @@ Status Engine::profile_end(std::vector<KernelStat>& out) {
 
 Engine::~Engine() {
   for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
-  if (hash_) {   // SAMAUDIO_TRACE_HASH recorder: the library's only device allocation
+  debug_device_free(sentinel_dev_);
+  if (hash_) {   // SAMAUDIO_TRACE_HASH recorder
     HashTrace* h = (HashTrace*)hash_;
     debug_device_free(h->dev);
     delete h;
@@ -885,6 +940,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       return launch_rmsnorm_mod(d_.h, w.attn_norm, tab + 0 * D, tab + 1 * D, d_.t0, t6, 0 * D, 1 * D, d_.xn, bf16_, (int)M, D,
                                 T, eps, st);
     }));
+    SA_TRY(sentinel(14, d_.xn, !bf16_ ? 0 : (alt16(SAMAUDIO_CLS_QKV) ? 2 : 1), M, D, D, st));
     {
       GemmParams p = lin(d_.xn, D, w.wqkv, M, 3 * D, D);
       ktm(p, w, 0);
@@ -905,6 +961,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       return launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st, alt16(SAMAUDIO_CLS_WO));
     }));
     trace("  attn", d_.attn, (size_t)M * D, bf16_, st);
+    SA_TRY(sentinel(15, d_.attn, !bf16_ ? 0 : (alt16(SAMAUDIO_CLS_WO) ? 2 : 1), M, D, D, st));
     {
       GemmParams p = lin(d_.attn, D, w.wo, M, D, D);  // h = x + gate_msa * attn
       p.gate_tab = tab + 2 * D; p.gate = d_.t0 + 2 * D; p.gate_ld = t6; p.rows_per_gate = T;
@@ -964,6 +1021,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       return launch_rmsnorm_mod(d_.h, w.ffn_norm, tab + 3 * D, tab + 4 * D, d_.t0, t6, 3 * D, 4 * D, d_.xn, bf16_, (int)M, D,
                                 T, eps, st);
     }));
+    SA_TRY(sentinel(14, d_.xn, !bf16_ ? 0 : (alt16(SAMAUDIO_CLS_W13) ? 2 : 1), M, D, D, st));
     {
       GemmParams p = lin(d_.xn, D, w.w13, M, 2 * F, D);
       p.swiglu = 1;
@@ -1019,8 +1077,7 @@ Status Engine::ode_solve(float* y, int method, const float* grid, int n_grid, hi
     ev[2 * k] = grid[k];
     ev[2 * k + 1] = (float)((double)grid[k] + 0.5 * ((double)grid[k + 1] - (double)grid[k]));
   }
-  SA_HIP(hipMemcpyAsync(d_.times, ev.data(), ev.size() * 4, hipMemcpyHostToDevice, st));
-  SA_HIP(hipStreamSynchronize(st));  // `ev` is pageable host memory owned by this frame
+  SA_HIP(launch_set_floats(d_.times, ev.data(), (int)ev.size(), st));   // as kernel arguments: no host synchronisation
   for (int k = 0; k + 1 < n_grid; ++k) {
     const float dt = (float)((double)grid[k + 1] - (double)grid[k]);
     if (method == SAMAUDIO_ODE_EULER) {

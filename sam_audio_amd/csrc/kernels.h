@@ -29,6 +29,9 @@ hipError_t launch_poison_lds(hipStream_t st);
 void set_debug_flag(int flag, int value);
 // SAMAUDIO_TRACE_HASH debugging aid (engine.hip): per-item checksums of a buffer; the only device allocation of the library
 hipError_t launch_hash_items(const unsigned* x, size_t words_per_item, int items, unsigned long long* out, hipStream_t st);
+// SAMAUDIO_OPT_SENTINEL: absmax / non-finite scan of a tensor folded into slot[0..1] (kernels.hip)
+constexpr int kSentinelPartials = 256;
+hipError_t launch_sentinel(const void* x, int fmt, long rows, int cols, long ld, float* partial, float* slot, hipStream_t st);
 void* debug_device_alloc(size_t bytes);
 void debug_device_free(void* p);
 int debug_flag(int flag);
@@ -130,6 +133,13 @@ hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, i
 // timestep features: temb [nt, fdim] (AT) = cat(cos, sin)(t*freqs);  tsin [nt, D] fp32 likewise with inv_freq
 hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,
                                 void* temb, float* tsin, bool bf16, hipStream_t st);
+
+// dst[0 .. n) = host_values, passed as kernel arguments (no host buffer has to outlive the call, no synchronisation)
+struct FloatPack {
+  static constexpr int N = 64;
+  float v[N];
+};
+hipError_t launch_set_floats(float* dst, const float* host_values, int n, hipStream_t st);
 
 // out[r,:] = AT(x[r,:] + vec[(r / rows_per_b) * vec_ld + :])
 hipError_t launch_add_rowvec(const float* x, const float* vec, long vec_ld, void* out, bool bf16, int rows, int D,

@@ -586,6 +586,23 @@ __global__ void time_features_kernel(const float* __restrict__ t, const float* _
   }
 }
 
+// dst[0 .. n) = the values, handed over as KERNEL ARGUMENTS: a host -> device copy of a few floats that needs neither pinned host
+// memory nor a stream synchronisation to keep a pageable source alive (ode_solve's evaluation times: before, a hipMemcpyAsync +
+// hipStreamSynchronize sat between the DAC encode and the first DiT evaluation of every separate())
+__global__ void set_floats_kernel(float* __restrict__ dst, const FloatPack v, const int n) {
+  const int i = threadIdx.x;
+  if (i < n) dst[i] = v.v[i];
+}
+hipError_t launch_set_floats(float* dst, const float* host_values, int n, hipStream_t st) {
+  for (int off = 0; off < n; off += FloatPack::N) {
+    FloatPack v;
+    const int m = n - off < FloatPack::N ? n - off : FloatPack::N;
+    for (int i = 0; i < FloatPack::N; ++i) v.v[i] = i < m ? host_values[off + i] : 0.f;
+    hipLaunchKernelGGL(set_floats_kernel, dim3(1), dim3(FloatPack::N), 0, st, dst + off, v, m);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,
                                 void* temb, float* tsin, bool bf16, hipStream_t st) {
   if (bf16)
@@ -709,6 +726,62 @@ hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo
     hipLaunchKernelGGL(zero_halo_kernel<bf16_t>, dim3(gx, B), dim3(256), 0, st, (bf16_t*)buf, T, C, halo);
   else
     hipLaunchKernelGGL(zero_halo_kernel<float>, dim3(gx, B), dim3(256), 0, st, (float*)buf, T, C, halo);
+  return hipGetLastError();
+}
+
+// SAMAUDIO_OPT_SENTINEL (engine.hip): largest magnitude and number of non-finite values of a 16-bit (or fp32) tensor [rows, cols]
+// with row pitch ld, folded into a per-class slot {float absmax, float nonfinite count} - two launches on the launch stream, no
+// atomics (partials per workgroup, then one workgroup folds them into the slot; launches of a stream are ordered).  A debugging /
+// validation aid: an fp16 operand that overflowed is REPORTED with its class, not propagated silently.
+template <typename T> struct SentinelLoad;
+template <> struct SentinelLoad<float> { static __device__ float ld(const float* p) { return *p; } };
+template <> struct SentinelLoad<bf16_t> { static __device__ float ld(const bf16_t* p) { return bf2f(p->v); } };
+template <> struct SentinelLoad<alt16_t> { static __device__ float ld(const alt16_t* p) { return __uint_as_float(((unsigned)p->v) << 16); } };
+template <typename T>
+__global__ __launch_bounds__(256) void sentinel_scan_kernel(const T* __restrict__ x, long rows, int cols, long ld, float* __restrict__ partial) {
+  float mx = 0.f, bad = 0.f;
+  const long total = rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float v = SentinelLoad<T>::ld(x + (i / cols) * ld + (i % cols));
+    if (v != v || fabsf(v) > 3.0e38f) bad += 1.f;
+    else mx = fmaxf(mx, fabsf(v));
+  }
+  __shared__ float smx[256], sbad[256];
+  smx[threadIdx.x] = mx;
+  sbad[threadIdx.x] = bad;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + o]);
+      sbad[threadIdx.x] += sbad[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = smx[0];
+    partial[2 * blockIdx.x + 1] = sbad[0];
+  }
+}
+__global__ void sentinel_fold_kernel(const float* __restrict__ partial, int n, float* __restrict__ slot) {
+  if (threadIdx.x != 0) return;
+  float mx = slot[0], bad = slot[1];
+  for (int i = 0; i < n; ++i) {
+    mx = fmaxf(mx, partial[2 * i]);
+    bad += partial[2 * i + 1];
+  }
+  slot[0] = mx;
+  slot[1] = bad;
+}
+// fmt: 0 = fp32, 1 = the library's 16-bit operand format, 2 = the alt 16-bit format (bfloat16)
+hipError_t launch_sentinel(const void* x, int fmt, long rows, int cols, long ld, float* partial, float* slot, hipStream_t st) {
+  if (!x || rows <= 0 || cols <= 0) return hipSuccess;
+  const long total = rows * cols;
+  int grid = (int)((total + 256 * 16 - 1) / (256 * 16));
+  grid = grid < 1 ? 1 : (grid > kSentinelPartials ? kSentinelPartials : grid);
+  if (fmt == 0) hipLaunchKernelGGL(sentinel_scan_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, rows, cols, ld, partial);
+  else if (fmt == 1) hipLaunchKernelGGL(sentinel_scan_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, rows, cols, ld, partial);
+  else hipLaunchKernelGGL(sentinel_scan_kernel<alt16_t>, dim3(grid), dim3(256), 0, st, (const alt16_t*)x, rows, cols, ld, partial);
+  hipLaunchKernelGGL(sentinel_fold_kernel, dim3(1), dim3(64), 0, st, partial, grid, slot);
   return hipGetLastError();
 }
 

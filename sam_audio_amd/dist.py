@@ -64,6 +64,9 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Batch:
     out.anchor_ids = pick(batch.anchor_ids)
     out.anchor_alignment = pick(batch.anchor_alignment)[:, :frames]
     out.anchors = None if batch.anchors is None else [batch.anchors[i] for i in rows]
+    host = getattr(batch, "sizes_host", None)
+    out.sizes_host = [host[i] for i in rows] if host is not None else [int(v) for v in sizes.tolist()]
+    out.anchors_validated = bool(getattr(batch, "anchors_validated", False))   # rows of tensors that were checked on the host
     return out
 
 

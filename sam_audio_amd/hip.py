@@ -51,7 +51,8 @@ def dtype_code(dtype, operands: Optional[str] = None, alt_ok: bool = False) -> i
             raise TypeError(f"{dtype} tensor handed to the {operands}-operand build of libsamaudio_hip")
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
-OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES, OPT_PREFETCH_ROWS = 1, 2, 3, 4, 5, 6
+OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES, OPT_PREFETCH_ROWS, OPT_SENTINEL = 1, 2, 3, 4, 5, 6, 7
+SENTINEL_SLOTS = 16
 # GEMM classes of the DiT / codec (samaudio.h SAMAUDIO_CLS_*), in bit order
 CLASSES = ("time", "out", "in", "prep", "yemb", "ckv", "patch", "qkv", "wo", "cwq", "cwo", "w13", "w2", "codec")
 CLS = {name: 1 << i for i, name in enumerate(CLASSES)}
@@ -66,6 +67,7 @@ CLS_F32_DEFAULT = CLS["out"] | CLS["in"] | CLS["prep"]
 CLS_ALT16_MIXED = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["w13"] | CLS["w2"]
 ALT16_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "w13": "w13", "w2": "w2"}   # engine tensor L<i>.<name> -> class
 QUANT_FORMATS = {"bf16": 1, "fp16": 2}
+SENTINEL_NAMES = CLASSES + ("norm", "attn")
 
 
 def class_mask(classes) -> int:
@@ -209,6 +211,7 @@ _PROTOS = {
     "samaudio_codec_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "samaudio_codec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "samaudio_profile_begin": (C.c_int, [C.c_void_p]),
+    "samaudio_sentinel_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p]),
     "samaudio_debug_force_gemm_variant": (None, [C.c_int]),
     "samaudio_debug_set_flag": (None, [C.c_int, C.c_int]),
     "samaudio_debug_poison_lds": (C.c_int, [C.c_void_p]),

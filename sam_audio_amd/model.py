@@ -143,6 +143,7 @@ class SAMAudio:
         self._f32_have = 0                    # F32-capable classes whose fp32 operand copies are registered
         self._f32_sd: Dict[str, torch.Tensor] = {}
         self._profiling = self._serial_groups = False
+        self._sentinel = False
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
             precision=hip.precision_code(precision), dim=t.dim, n_heads=t.n_heads,
@@ -271,6 +272,7 @@ class SAMAudio:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_F32_CLASSES, self.f32_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ALT16_CLASSES, self.alt16_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_PREFETCH_ROWS, self.prefetch_rows))
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_SENTINEL, int(getattr(self, "_sentinel", False))))
         else:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_CLASSES, self.quant_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_FORMAT, self.quant_format))
@@ -318,6 +320,28 @@ class SAMAudio:
 
     def engine_tensors(self) -> Dict[str, torch.Tensor]:
         return self._tensors
+
+    # ------------------------------------------------------------------ validation aid
+    def sentinel(self, on: bool = True) -> None:
+        """samaudio.h SAMAUDIO_OPT_SENTINEL: every 16-bit tensor a GEMM of the hot path writes (and the RMSNorm / attention
+        outputs that feed GEMMs) is scanned for its largest magnitude and for non-finite values; sentinel_report() reads and
+        resets the figures.  An fp16 overflow is then reported with its GEMM class instead of propagating."""
+        self._sentinel = bool(on)
+        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_SENTINEL, int(self._sentinel)))
+
+    def sentinel_report(self) -> Dict[str, Dict[str, float]]:
+        """{class: {"absmax": ..., "nonfinite": ...}} over every engine context since the last report (synchronises)."""
+        out = {n: {"absmax": 0.0, "nonfinite": 0.0} for n in hip.SENTINEL_NAMES}
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+                mx, bad = (C.c_float * hip.SENTINEL_SLOTS)(), (C.c_double * hip.SENTINEL_SLOTS)()
+                hip.check(self._lib.samaudio_sentinel_read(ctx, mx, bad, hip.current_stream_ptr()))
+                for i, n in enumerate(hip.SENTINEL_NAMES):
+                    out[n]["absmax"] = max(out[n]["absmax"], float(mx[i]))
+                    out[n]["nonfinite"] += float(bad[i])
+        return out
 
     # ------------------------------------------------------------------ measurement (bench.py)
     def profile_begin(self, serial_groups: bool = True) -> None:
@@ -418,7 +442,7 @@ class SAMAudio:
 
     # ------------------------------------------------------------------ DiT
     def _prepare(self, audio_features, text_features, text_mask, masked_video_features, anchor_ids,
-                 anchor_alignment, audio_pad_mask, lane: Optional[_Lane] = None) -> None:
+                 anchor_alignment, audio_pad_mask, lane: Optional[_Lane] = None, anchors_validated: bool = False) -> None:
         dev = self.device
         own = lane if lane is not None else self
         feats = audio_features.to(dev, torch.float32).contiguous()
@@ -439,13 +463,16 @@ class SAMAudio:
             ids = anchor_ids.to(dev, torch.long).contiguous()
             align = anchor_alignment.to(dev, torch.long).contiguous()
             n_ids = ids.size(1)
-            # the reference's gather / nn.Embedding raise on out-of-range indices (model.py:61); one host sync per separate()
-            lo, hi = int(align.min()), int(align.max())
-            if lo < 0 or hi >= n_ids:
-                raise IndexError(f"anchor_alignment values must be in [0, {n_ids}): found [{lo}, {hi}]")
-            lo, hi = int(ids.min()), int(ids.max())
-            if lo < 0 or hi > self.cfg.num_anchors:
-                raise IndexError(f"anchor_ids must be in [0, {self.cfg.num_anchors}]: found [{lo}, {hi}]")
+            # the reference's gather / nn.Embedding raise on out-of-range indices (model.py:61).  Tensors a Batch built on the
+            # host are in range by construction (processor.Batch.process_anchors checks them there); anything else - forward()
+            # called with hand-made tensors - is checked here, at the price of blocking device -> host reads
+            if not anchors_validated:
+                lo, hi = int(align.min()), int(align.max())
+                if lo < 0 or hi >= n_ids:
+                    raise IndexError(f"anchor_alignment values must be in [0, {n_ids}): found [{lo}, {hi}]")
+                lo, hi = int(ids.min()), int(ids.max())
+                if lo < 0 or hi > self.cfg.num_anchors:
+                    raise IndexError(f"anchor_ids must be in [0, {self.cfg.num_anchors}]: found [{lo}, {hi}]")
         if audio_pad_mask is not None:
             pad = audio_pad_mask.to(dev).to(torch.uint8).contiguous()
         own._live = (feats, text, tmask, video, ids, align, pad)
@@ -490,7 +517,7 @@ class SAMAudio:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_TAIL_SPLIT, split))
 
     def _solve_concurrent(self, noise: torch.Tensor, ode_opt: Dict[str, Any], cond: List[Optional[torch.Tensor]],
-                          groups: int, decode: bool = False):
+                          groups: int, decode: bool = False, anchors_validated: bool = False):
         """prepare + ODE solve (+ DAC-VAE decode of target and residual when `decode`) of `groups` contiguous row groups,
         each on its own engine context and HIP stream, driven by one host thread per group (the C calls release the GIL).
         Rows are independent, so the result equals the single-stream one bit for bit.  Returns the
@@ -526,7 +553,7 @@ class SAMAudio:
                         if t is not None and t.is_cuda:
                             t.record_stream(stream)
                 with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(stream):
-                    self._prepare(*part, lane=lane)
+                    self._prepare(*part, lane=lane, anchors_validated=anchors_validated)
                     ctx = self._ctx if lane is None else lane._ctx
                     hip.check(self._lib.samaudio_ode_solve(ctx, hip.ptr(state[sl]), method, g, len(grid),
                                                            hip.current_stream_ptr()))
@@ -599,6 +626,7 @@ class SAMAudio:
             # process_anchors rebinds new tensors, so in the reference snapshot predicted spans never reach the ODE
             # (quirk Q13).  fix_span_order=True opts into the evidently intended order.
             anchor_ids, anchor_alignment = batch.anchor_ids, batch.anchor_alignment
+            validated = bool(getattr(batch, "anchors_validated", False))   # host-built anchors: no device-side range check
             if predict_spans and batch.anchors is None:
                 if self.span_predictor is None:
                     warnings.warn("predict_spans=True ignored: no span predictor attached (model.span_predictor)")
@@ -619,10 +647,10 @@ class SAMAudio:
                 cond = [None if c is None else c.to(self.device) for c in cond]
                 # each group also decodes its own rows on its stream: the codec's HBM-bound convolutions of one group run
                 # beside the other group's kernels instead of after both solves
-                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True)
+                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True, anchors_validated=validated)
             else:
                 self._apply_options(1)
-                self._prepare(*cond)
+                self._prepare(*cond, anchors_validated=validated)
                 latent = self.solve(noise, ode_opt)                              # states[-1], [Bc, T, 256]
             self.last_latent = latent
             # [Bc, T, 2C] -> rows (2b, 2b+1) = (target, residual) latents, channels-last (model.py:291-295)
@@ -630,16 +658,20 @@ class SAMAudio:
             if wavs is None:
                 lat = latent.reshape(Bc, T, 2, half).permute(0, 2, 1, 3).reshape(2 * Bc, T, half).contiguous()
                 wavs = self.decode_audio(lat).view(Bc, 2, -1)
-            sizes = (batch.sizes.to(self.device) * self.cfg.audio_codec.hop_length).int()  # codec.py:91-97
+            # codec.py:91-97, from the batch's host copy of the frame counts: slicing by device scalars would block on the GPU
+            hop = self.cfg.audio_codec.hop_length
+            sizes = [n * hop for n in (getattr(batch, "sizes_host", None) or [int(v) for v in batch.sizes.tolist()])]
             target = self.unbatch(wavs[:, 0].view(B, cand, -1), sizes)
             residual = self.unbatch(wavs[:, 1].view(B, cand, -1), sizes)
+            if cand == 1:   # nothing to pick: views, no index kernels, no device -> host reads
+                return SeparationResult(target=[w[0] for w in target], residual=[w[0] for w in residual], noise=noise)
             idxs = self._rerank(batch, target, sizes, cand)                      # model.py:306-330
             return SeparationResult(
                 target=[w[i] for w, i in zip(target, idxs)],
                 residual=[w[i] for w, i in zip(residual, idxs)],
                 noise=noise)
 
-    def _rerank(self, batch: Batch, target_wavs: List[torch.Tensor], sizes: torch.Tensor, cand: int) -> torch.Tensor:
+    def _rerank(self, batch: Batch, target_wavs: List[torch.Tensor], sizes: List[int], cand: int) -> torch.Tensor:
         """Candidate selection, reference model.py:306-330: visual ranker if a masked video came with the batch, else
         the text ranker, else candidate 0; `idxs = scores.argmax(dim=1)`."""
         B = len(target_wavs)
@@ -689,6 +721,6 @@ class SAMAudio:
             except NotImplementedError as exc:  # CLAP / ImageBind / ... wrap third-party models this build does not ship
                 warnings.warn(f"{name} not attached: {exc}")
 
-    def unbatch(self, wavs: torch.Tensor, sizes: torch.Tensor, time_dim: int = -1):
+    def unbatch(self, wavs: torch.Tensor, sizes, time_dim: int = -1):
         """reference model.py:340-344"""
         return [row.narrow(dim=time_dim, start=0, length=int(size)) for row, size in zip(wavs, sizes)]

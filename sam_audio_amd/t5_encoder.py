@@ -171,16 +171,20 @@ class T5EncoderHIP:
         return missing, unexpected
 
     @torch.inference_mode()
-    def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+    def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, ids_checked: bool = False) -> torch.Tensor:
+        """`ids_checked`: the caller has validated the token ids on the host (T5TextEncoder does, on the tokenizer's CPU output).
+        Ids that arrive on the CPU are checked here for free; ids that arrive on the GPU unchecked cost a blocking device -> host
+        read (it waits for everything queued on the stream - inside separate() that is the DAC encode)."""
         if not self._loaded:
             raise hip.SamAudioHipError("T5EncoderHIP: no weights loaded")
         assert input_ids.dim() == 2 and attention_mask.shape == input_ids.shape, "input_ids / attention_mask must be [B, Lt]"
         rows, tokens = input_ids.shape
         if tokens > self.dims.max_len:
             raise ValueError(f"{tokens} tokens exceed the encoder's max_len {self.dims.max_len}")
-        ids_host = input_ids.detach().to("cpu", torch.int64)
-        if rows and tokens and (int(ids_host.min()) < 0 or int(ids_host.max()) >= self.dims.vocab_size):
-            raise IndexError(f"token id outside [0, {self.dims.vocab_size})")   # nn.Embedding raises IndexError too
+        if rows and tokens and not (ids_checked and input_ids.device.type != "cpu"):
+            ids_host = input_ids.detach().to("cpu", torch.int64)
+            if int(ids_host.min()) < 0 or int(ids_host.max()) >= self.dims.vocab_size:
+                raise IndexError(f"token id outside [0, {self.dims.vocab_size})")   # nn.Embedding raises IndexError too
         with torch.cuda.device(self.device):
             ids = input_ids.to(self.device, torch.int64).contiguous()
             mask = (attention_mask.to(self.device) != 0).to(torch.uint8).contiguous()

@@ -88,8 +88,15 @@ class T5TextEncoder:
             raise hip.SamAudioHipError("T5TextEncoder needs a ROCm GPU: call .to('cuda') first; there is no CPU fallback")
         encoded = self.tokenizer(texts, truncation=True, max_length=self.max_length, padding=self.pad_mode,
                                  return_tensors="pt")
-        input_ids = encoded["input_ids"].to(self._device)
-        attention_mask = encoded["attention_mask"].to(self._device)
-        return self._hip(input_ids, attention_mask), attention_mask.bool()
+        ids_cpu = encoded["input_ids"]
+        if ids_cpu.numel() and (int(ids_cpu.min()) < 0 or int(ids_cpu.max()) >= self._hip.dims.vocab_size):
+            raise IndexError(f"token id outside [0, {self._hip.dims.vocab_size})")   # nn.Embedding raises IndexError too
+        # the host -> device copies are issued from pinned staging tensors and do not wait for the GPU: inside separate() the DAC
+        # encode is still running on the stream while the prompt is tokenised and the T5 stack is queued behind it
+        def up(t):
+            return t.pin_memory().to(self._device, non_blocking=True) if self._device.type == "cuda" else t.to(self._device)
+
+        input_ids, attention_mask = up(ids_cpu), up(encoded["attention_mask"])
+        return self._hip.encode(input_ids, attention_mask, ids_checked=True), attention_mask.bool()
 
     __call__ = forward
