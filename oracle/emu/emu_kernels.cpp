@@ -278,8 +278,8 @@ static void qkv_prep_t(const TA* qkv, const float* qw, const float* kw, const fl
 }
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
-                           float eps, hipStream_t) {
-  if (Tp % 64 || Tp < T) return hipErrorInvalidValue;
+                           float eps, hipStream_t, int head_dim) {
+  if (Tp % 64 || Tp < T || head_dim != 128) return hipErrorInvalidValue;   // the launcher emulation covers head_dim 128 only
   if (bf16) qkv_prep_t<bf16_t>((const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)Vt, B, T, Tp, H, eps);
   else qkv_prep_t<float>((const float*)qkv, qw, kw, rope_cos, rope_sin, (float*)Q, (float*)K, (float*)Vt, B, T, Tp, H, eps);
   return hipSuccess;
@@ -312,6 +312,11 @@ static void self_attn_t(const TA* Q, const TA* K, const TA* Vt, const unsigned c
       }
     }
 }
+hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask, void* out,
+                                    bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st, bool alt) {
+  if (head_dim != 128) return hipErrorInvalidValue;
+  return launch_self_attention(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st, alt);
+}
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask, void* out,
                                  bool bf16, int B, int T, int Tp, int H, hipStream_t, bool) {
   if (bf16) self_attn_t<bf16_t>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, key_mask, (bf16_t*)out, B, T, Tp, H);
@@ -331,16 +336,18 @@ static void headnorm_t(TA* x, const float* w, long rows, long ld, int col0, int 
     }
 }
 hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
-                           hipStream_t) {
+                           hipStream_t, int head_dim) {
+  if (head_dim != 128) return hipErrorInvalidValue;
   if (bf16) headnorm_t<bf16_t>((bf16_t*)x, w, rows, ld, col0, H, eps);
   else headnorm_t<float>((float*)x, w, rows, ld, col0, H, eps);
   return hipSuccess;
 }
 hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,
-                                  hipStream_t st) {
+                                  hipStream_t st, int head_dim) {
+  if (head_dim != 128) return hipErrorInvalidValue;
   const long D2 = 2L * H * 128;
   for (int l = 0; l < L; ++l) {
-    hipError_t e = launch_headnorm(kv_all, w_all + l * 128, bf16, rows, D2 * L, (int)(l * D2), H, eps, st);
+    hipError_t e = launch_headnorm(kv_all, w_all + l * 128, bf16, rows, D2 * L, (int)(l * D2), H, eps, st, 128);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
@@ -377,7 +384,8 @@ static void cross_attn_t(const TA* q, const float* qw, const TA* kv, long kv_ld,
     }
 }
 hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
-                                  void* out, bool bf16, int B, int T, int Lt, int H, float eps, hipStream_t) {
+                                  void* out, bool bf16, int B, int T, int Lt, int H, float eps, hipStream_t, int head_dim) {
+  if (head_dim != 128) return hipErrorInvalidValue;
   if (bf16) cross_attn_t<bf16_t>((const bf16_t*)q, qw, (const bf16_t*)kv, kv_ld, mask, (bf16_t*)out, (long)B * T, T, Lt, H, eps);
   else cross_attn_t<float>((const float*)q, qw, (const float*)kv, kv_ld, mask, (float*)out, (long)B * T, T, Lt, H, eps);
   return hipSuccess;

@@ -156,8 +156,8 @@ class TransformerConfig:
     def check_supported(self) -> None:
         """The HIP path implements the configuration family the reference ships."""
         problems = []
-        if self.head_dim != 128:
-            problems.append(f"head_dim must be 128 (got {self.head_dim})")
+        if self.head_dim not in (64, 128):   # 128: every kernel tuned for it; 64: the general kernel forms (csrc/engine.hip finalize)
+            problems.append(f"head_dim (dim / n_heads) must be 128 or 64 (got {self.head_dim})")
         if self.dim % self.n_heads:
             problems.append("dim must be divisible by n_heads")
         if not self.qk_norm:

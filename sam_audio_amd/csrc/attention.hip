@@ -266,11 +266,11 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
 template <int HD>
 static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                           void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st, bool out_alt = false) {
-  if (bf16 && out_alt && HD == 128 && Tp % 128 == 0)
-    hipLaunchKernelGGL((self_attn_bf16_kernel<8, 128, true>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
+  if (bf16 && out_alt && Tp % 128 == 0)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<8, HD, true>), dim3(Tp / 128, H, B), dim3(512), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
-  else if (bf16 && out_alt && HD == 128)
-    hipLaunchKernelGGL((self_attn_bf16_kernel<4, 128, true>), dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
+  else if (bf16 && out_alt)
+    hipLaunchKernelGGL((self_attn_bf16_kernel<4, HD, true>), dim3(Tp / 64, H, B), dim3(256), 0, st, (const bf16_t*)Q, (const bf16_t*)K,
                        (const bf16_t*)Vt, key_mask, (bf16_t*)out, T, Tp, H);
   else if (out_alt)
     return hipErrorInvalidValue;
@@ -291,9 +291,9 @@ hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, c
   return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st, out_alt);
 }
 hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
-                                    void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st) {
-  if (head_dim == 64) return launch_self_attention_t<64>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st);
-  if (head_dim == 128) return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st);
+                                    void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st, bool out_alt) {
+  if (head_dim == 64) return launch_self_attention_t<64>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st, out_alt);
+  if (head_dim == 128) return launch_self_attention_t<128>(Q, K, Vt, key_mask, out, bf16, B, T, Tp, H, st, out_alt);
   return hipErrorInvalidValue;
 }
 
@@ -301,7 +301,7 @@ hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt
 // cross-attention onto the text memory (reference transformer.py:382-388 via :128-161: qk-norm on, no RoPE,
 // no gate).  One wave per (row, head); lane holds elements (2*lane, 2*lane+1) of the 128-wide head.
 // ---------------------------------------------------------------------------------------------------
-template <typename TA>
+template <typename TA, int HD>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ q, const float* __restrict__ qw,
                                                          const TA* __restrict__ kv, long kv_ld,
                                                          const unsigned char* __restrict__ mask, TA* __restrict__ out,
@@ -309,23 +309,26 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ 
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= M * H) return;
   const int lane = threadIdx.x & 63;
+  const bool on = lane < HD / 2;   // HD = 64: half the wave sits out (zeros in the reductions)
   const long m = item / H;
   const int h = (int)(item % H);
   const long b = m / T;
-  const int D = H * 128;
-  float q0, q1;
-  load2<TA>(q + m * D + h * 128 + 2 * lane, q0, q1);
-  const float inv = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / 128.f + eps);
-  q0 *= inv * qw[2 * lane];
-  q1 *= inv * qw[2 * lane + 1];
-  const float scale = 0.08838834764831845f;
+  const int D = H * HD;
+  float q0 = 0.f, q1 = 0.f;
+  if (on) load2<TA>(q + m * D + h * HD + 2 * lane, q0, q1);
+  const float inv = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / (float)HD + eps);
+  q0 *= inv * (on ? qw[2 * lane] : 0.f);
+  q1 *= inv * (on ? qw[2 * lane + 1] : 0.f);
+  const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;   // head_dim^-0.5
   float mx = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
   for (int j = 0; j < Lt; ++j) {
     if (!mask[b * Lt + j]) continue;  // wave-uniform
-    const TA* krow = kv + (b * Lt + j) * kv_ld + h * 128 + 2 * lane;
-    float k0, k1, v0, v1;
-    load2<TA>(krow, k0, k1);
-    load2<TA>(krow + D, v0, v1);
+    const TA* krow = kv + (b * Lt + j) * kv_ld + h * HD + 2 * lane;
+    float k0 = 0.f, k1 = 0.f, v0 = 0.f, v1 = 0.f;
+    if (on) {
+      load2<TA>(krow, k0, k1);
+      load2<TA>(krow + D, v0, v1);
+    }
     const float s = wave_sum(q0 * k0 + q1 * k1) * scale;
     const float m_new = fmaxf(mx, s);
     const float a = expf(mx - m_new), p = expf(s - m_new);
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const TA* __restrict__ 
     mx = m_new;
   }
   const float il = 1.f / l;
-  store2<TA>(out + m * D + h * 128 + 2 * lane, o0 * il, o1 * il);
+  if (on) store2<TA>(out + m * D + h * HD + 2 * lane, o0 * il, o1 * il);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -690,19 +693,26 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
 
 hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,
                                   const unsigned char* mask, void* out, bool bf16, int B, int T, int Lt, int H,
-                                  float eps, hipStream_t st) {
+                                  float eps, hipStream_t st, int head_dim) {
   const long M = (long)B * T;
-  if (bf16 && Lt <= 16) {
+  if (head_dim != 64 && head_dim != 128) return hipErrorInvalidValue;
+  if (bf16 && Lt <= 16 && head_dim == 128) {
     hipLaunchKernelGGL(cross_attn_mfma_kernel, dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const bf16_t*)q, qw,
                        (const bf16_t*)kv, kv_ld, mask, (bf16_t*)out, T, Lt, H, eps);
     return hipGetLastError();
   }
   dim3 grid((unsigned)((M * H + 3) / 4)), block(256);
-  if (bf16)
-    hipLaunchKernelGGL(cross_attn_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)q, qw, (const bf16_t*)kv, kv_ld,
+  if (bf16 && head_dim == 128)
+    hipLaunchKernelGGL((cross_attn_kernel<bf16_t, 128>), grid, block, 0, st, (const bf16_t*)q, qw, (const bf16_t*)kv, kv_ld,
                        mask, (bf16_t*)out, M, T, Lt, H, eps);
+  else if (bf16)
+    hipLaunchKernelGGL((cross_attn_kernel<bf16_t, 64>), grid, block, 0, st, (const bf16_t*)q, qw, (const bf16_t*)kv, kv_ld,
+                       mask, (bf16_t*)out, M, T, Lt, H, eps);
+  else if (head_dim == 128)
+    hipLaunchKernelGGL((cross_attn_kernel<float, 128>), grid, block, 0, st, (const float*)q, qw, (const float*)kv, kv_ld, mask,
+                       (float*)out, M, T, Lt, H, eps);
   else
-    hipLaunchKernelGGL(cross_attn_kernel<float>, grid, block, 0, st, (const float*)q, qw, (const float*)kv, kv_ld, mask,
+    hipLaunchKernelGGL((cross_attn_kernel<float, 64>), grid, block, 0, st, (const float*)q, qw, (const float*)kv, kv_ld, mask,
                        (float*)out, M, T, Lt, H, eps);
   return hipGetLastError();
 }

@@ -185,7 +185,11 @@ Status Engine::finalize(int what) {
 #define NEEDF(field, name, ...) SA_TRY(need(name, F32, {__VA_ARGS__}, (const void**)&(field)))
 #define NEEDW(field, name, ...) SA_TRY(need(name, AT, {__VA_ARGS__}, (const void**)&(field)))
   if (what == 0) {
-    if (D % 256 || cfg_.n_heads * 128 != D) return fail(SAMAUDIO_ERR_ARG, "dim must be n_heads*128 and a multiple of 256");
+    // head_dim = dim / n_heads: 128 (every kernel tuned for it) or 64 (general forms of qkv_prep / the norms / cross-attention,
+    // the self-attention kernel's 64-wide instantiation, no folded cross-attention projection)
+    if (D % 256 || cfg_.n_heads <= 0 || D % cfg_.n_heads || (D / cfg_.n_heads != 128 && D / cfg_.n_heads != 64))
+      return fail(SAMAUDIO_ERR_ARG, "dim must be a multiple of 256 and dim / n_heads (the head width) 128 or 64");
+    const int hd = D / cfg_.n_heads;
     if (F % 64 || C2 % 64 || cfg_.text_dim % 64 || cfg_.video_dim % 64 || cfg_.freq_dim % 64 || cfg_.anchor_dim % 64)
       return fail(SAMAUDIO_ERR_ARG, "channel widths must be multiples of 64");
     layers_.assign(L, LayerW{});
@@ -195,9 +199,9 @@ Status Engine::finalize(int what) {
       NEEDF(w.attn_norm, P + "attn_norm", D);
       NEEDF(w.ffn_norm, P + "ffn_norm", D);
       NEEDF(w.mod_table, P + "mod_table", 6, D);
-      NEEDF(w.q_norm, P + "q_norm", 128);
-      NEEDF(w.k_norm, P + "k_norm", 128);
-      NEEDF(w.c_q_norm, P + "c_q_norm", 128);
+      NEEDF(w.q_norm, P + "q_norm", hd);
+      NEEDF(w.k_norm, P + "k_norm", hd);
+      NEEDF(w.c_q_norm, P + "c_q_norm", hd);
       SA_TRY(need_w5(P + "wqkv", 3 * D, D, &w.wqkv, &w.ktm, 0));
       SA_TRY(need_w5(P + "wo", D, D, &w.wo, &w.ktm, 1));
       SA_TRY(need_w5(P + "c_wq", D, D, &w.c_wq, &w.ktm, 2));
@@ -224,8 +228,8 @@ Status Engine::finalize(int what) {
     NEEDF(g_.tb_b, "tb_b", 6 * D);
     NEEDF(g_.t_freqs, "t_freqs", cfg_.freq_dim / 2);
     NEEDF(g_.mem_inv_freq, "mem_inv_freq", D / 2);
-    NEEDF(g_.rope_cos, "rope_cos", cfg_.max_positions, 64);
-    NEEDF(g_.rope_sin, "rope_sin", cfg_.max_positions, 64);
+    NEEDF(g_.rope_cos, "rope_cos", cfg_.max_positions, hd / 2);
+    NEEDF(g_.rope_sin, "rope_sin", cfg_.max_positions, hd / 2);
     NEEDW(g_.proj_wy, "proj_wy", D, C2);
     NEEDW(g_.proj_wf, "proj_wf", D, C2);
     NEEDF(g_.proj_b, "proj_b", D);
@@ -241,7 +245,7 @@ Status Engine::finalize(int what) {
     // cross-attention K|V projections of ALL layers as one operand: the text memory changes with t only through
     // the y-embedder, so one GEMM per evaluation serves the 22 layers (reference transformer.py:382-388, :102-114)
     NEEDW(g_.c_wkv_all, "c_wkv_all", (int64_t)L * 2 * D, D);
-    NEEDF(g_.c_k_norm_all, "c_k_norm_all", L, 128);
+    NEEDF(g_.c_k_norm_all, "c_k_norm_all", L, hd);
     if (bf16_) {  // fp32 copies for SAMAUDIO_OPT_F32_CLASSES: optional, checked when a class is switched on / used
 #define OPTF(field, name, ...) g32_.field = (const float*)opt(name ".f32", {__VA_ARGS__})
       OPTF(w_out, "w_out", C2, D);
@@ -339,8 +343,8 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   float* tsin = f32(nt * D); float* vtmp = f32(M * D); float* times = f32(4096);
   float* modgs = f32(2L * cfg_.n_layers * nt * 2 * D);   // pre-combined RMSNorm + modulate operands of an evaluation
   void* ybf = act(M * C2); void* xn = act(M * D); void* qkv = act(M * 3 * D);
-  void* Q = act((long)rows * H * Tp * 128); void* K = act((long)rows * H * Tp * 128);
-  void* Vt = act((long)rows * H * 128 * Tp);
+  void* Q = act((long)rows * Tp * D); void* K = act((long)rows * Tp * D);   // [rows, H, Tp, head_dim]
+  void* Vt = act((long)rows * D * Tp);
   void* attn = act(M * D); void* hbf = act(M * D); void* qc = act(M * D); void* ca = act(M * D); void* u = act(M * F);
   void* gnbuf = act((long)rows * (T + 2) * D); void* mem = act(Mt * D); void* yu = act(Mt * D); void* yemb = act(Mt * D);
   void* kvc = act(Mt * 2 * D * cfg_.n_layers); void* temb = act(nt * cfg_.freq_dim); void* tu = act(nt * D); void* tsilu = act(nt * D);
@@ -763,7 +767,7 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   // cond += tanh(g_a) * proj(Emb[ids.gather(alignment)])            (model.py:54-65; tanh folded into anc_w)
   // folded cross-attention output projection: zero the probability buffer once (its K padding columns stay zero)
   fold_ltp_ = fold_kp_ = 0;
-  if (bf16_ && Lt <= 16 && !std::getenv("SAMAUDIO_NO_FOLD")) {
+  if (bf16_ && Lt <= 16 && D / cfg_.n_heads == 128 && !std::getenv("SAMAUDIO_NO_FOLD")) {
     fold_ltp_ = Lt <= 8 ? 8 : 16;
     fold_kp_ = (int)round_up((long)cfg_.n_heads * fold_ltp_, 64);
     SA_HIP(hipMemsetAsync(d_.probs, 0, (size_t)M * fold_kp_ * esz_, st));
@@ -806,6 +810,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
             Lt = text_len_, Tp = frames_pad_, rows = rows_;
   const long M = (long)rows * T, Mt = (long)rows * Lt;
   const float eps = cfg_.norm_eps;
+  const int hd = D / H;   // 128 | 64 (finalize)
   const long t6 = nt == 1 ? 0 : 6L * D, t1 = nt == 1 ? 0 : (long)D;
   prof_cls_ = "dit";
   const double MD = (double)M * D;
@@ -917,7 +922,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     GemmParams p = lin(d_.yemb, D, g_.c_wkv_all, Mt, (int)kv_ld, D);
     out_act(p, d_.kvc, kv_ld);
     SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CKV));
-    SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st));
+    SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st, hd));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
   // SAMAUDIO_OPT_PREFETCH_ROWS: a launch's idle workgroups read the next big GEMM's weights (gemm8.hip prefetch_lines).  Chain per
@@ -950,15 +955,15 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     }
     SA_TRY(op("qkv_prep", 2 * 3 * MD * esz_, 0, st, [&] {
       return launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp, H,
-                             eps, st);
+                             eps, st, hd);
     }));
     trace("  xn", d_.xn, (size_t)M * D, bf16_, st);
     trace("  qkv", d_.qkv, (size_t)M * 3 * D, bf16_, st);
-    trace("  Q", d_.Q, (size_t)rows * H * Tp * 128, bf16_, st);
-    trace("  K", d_.K, (size_t)rows * H * Tp * 128, bf16_, st);
-    trace("  Vt", d_.Vt, (size_t)rows * H * Tp * 128, bf16_, st);
-    SA_TRY(op("self_attention", 4 * MD * esz_, 4.0 * T * T * 128 * H * rows, st, [&] {
-      return launch_self_attention(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, st, alt16(SAMAUDIO_CLS_WO));
+    trace("  Q", d_.Q, (size_t)rows * Tp * D, bf16_, st);
+    trace("  K", d_.K, (size_t)rows * Tp * D, bf16_, st);
+    trace("  Vt", d_.Vt, (size_t)rows * Tp * D, bf16_, st);
+    SA_TRY(op("self_attention", 4 * MD * esz_, 4.0 * T * T * D * rows, st, [&] {
+      return launch_self_attention_hd(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, hd, st, alt16(SAMAUDIO_CLS_WO));
     }));
     trace("  attn", d_.attn, (size_t)M * D, bf16_, st);
     SA_TRY(sentinel(15, d_.attn, !bf16_ ? 0 : (alt16(SAMAUDIO_CLS_WO) ? 2 : 1), M, D, D, st));
@@ -1005,7 +1010,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       trace("  ut", d_.ut, (size_t)rows * D * fold_kp_, bf16_, st);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
-      SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st));
+      SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st, hd));
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);

@@ -100,7 +100,7 @@ hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* 
                              float eps, hipStream_t st, bool out_alt = false);   // out_alt: 16-bit output in the alt format (mixed mode)
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
-                           float eps, hipStream_t st);
+                           float eps, hipStream_t st, int head_dim = 128);   // head_dim 64 | 128 (rope tables [T, head_dim / 2])
 
 // self-attention over the padded layout above; key_mask [B,T] bytes (1 = attend); out [B*T, H*128]
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
@@ -108,17 +108,18 @@ hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, c
 
 // the same with head_dim 64 or 128 (Q, K [B,H,Tp,hd], Vt [B,H,hd,Tp], out [B*T, H*hd]; scale hd^-0.5)
 hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
-                                    void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st);
+                                    void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st,
+                                    bool out_alt = false);
 
 // in-place per-(row, head) RMSNorm of x[rows, ld] columns [col0, col0 + H*128)
 hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
-                           hipStream_t st);
+                           hipStream_t st, int head_dim = 128);
 
 // cross attention: q [M, D] (raw, q-norm applied here), kv rows b*Lt + j with row stride kv_ld elements holding
 // (k already normalised | v) in columns [0, 2D); mask [B, Lt] bytes; out [M, D]
 hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,
                                   const unsigned char* mask, void* out, bool bf16, int B, int T, int Lt, int H,
-                                  float eps, hipStream_t st);
+                                  float eps, hipStream_t st, int head_dim = 128);
 // folded cross-attention output projection (bf16, Lt <= 16; see attention.hip): P [M, ldp] = softmax probabilities
 // at column h*LtP + token; UT [B][D][KP] = per-batch weight operand of the GEMM h += P . U
 hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
@@ -128,7 +129,7 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
 // per-(row, layer, head) RMSNorm of the K halves of kv_all [rows, L*2D] (all layers' cross-attention keys at
 // once); w_all [L, 128]
 hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,
-                                  hipStream_t st);
+                                  hipStream_t st, int head_dim = 128);
 
 // timestep features: temb [nt, fdim] (AT) = cat(cos, sin)(t*freqs);  tsin [nt, D] fp32 likewise with inv_freq
 hipError_t launch_time_features(const float* t, int nt, const float* freqs, int fdim, const float* inv_freq, int D,

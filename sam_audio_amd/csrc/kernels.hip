@@ -329,46 +329,54 @@ hipError_t launch_groupnorm_silu(const float* x, const float* w, const float* b,
 // The QKV GEMM already produces head-major columns (weights permuted at load, quirk Q1).
 // grid (Tp/64, H, B), 256 threads.
 // ------------------------------------------------------------------------------------------------
-template <typename TA>
+// HD = head_dim (128: every lane of the wave holds one adjacent pair of the head row; 64: lanes 32 .. 63 sit out - the general
+// form for DiT configurations whose dim / n_heads is 64, reference transformer.py:100-119; the 16-byte fast path below is 128 only)
+template <typename TA, int HD>
 __global__ __launch_bounds__(256) void qkv_prep_kernel(const TA* __restrict__ qkv, const float* __restrict__ qw,
                                                        const float* __restrict__ kw, const float* __restrict__ rc,
                                                        const float* __restrict__ rs, TA* __restrict__ Q,
                                                        TA* __restrict__ K, TA* __restrict__ Vt, int T, int Tp, int H,
                                                        float eps) {
   const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int D = H * 128;
+  const int D = H * HD;
   const long ld = 3L * D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool on = lane < HD / 2;
   const long bh = (long)b * H + h;
-  const float w0q = qw[2 * lane], w1q = qw[2 * lane + 1], w0k = kw[2 * lane], w1k = kw[2 * lane + 1];
+  const float w0q = on ? qw[2 * lane] : 0.f, w1q = on ? qw[2 * lane + 1] : 0.f;
+  const float w0k = on ? kw[2 * lane] : 0.f, w1k = on ? kw[2 * lane + 1] : 0.f;
   for (int i = 0; i < 16; ++i) {
     const int t = t0 + wave * 16 + i;
     float q0 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f;
     if (t < T) {
-      const TA* row = qkv + ((long)b * T + t) * ld + h * 128 + 2 * lane;
-      load2<TA>(row, q0, q1);
-      load2<TA>(row + D, k0, k1);
-      const float iq = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / 128.f + eps);
-      const float ik = rsqrtf(wave_sum(k0 * k0 + k1 * k1) / 128.f + eps);
+      if (on) {
+        const TA* row = qkv + ((long)b * T + t) * ld + h * HD + 2 * lane;
+        load2<TA>(row, q0, q1);
+        load2<TA>(row + D, k0, k1);
+      }
+      const float iq = rsqrtf(wave_sum(q0 * q0 + q1 * q1) / (float)HD + eps);
+      const float ik = rsqrtf(wave_sum(k0 * k0 + k1 * k1) / (float)HD + eps);
       q0 *= iq * w0q; q1 *= iq * w1q; k0 *= ik * w0k; k1 *= ik * w1k;
-      const float c = rc[(long)t * 64 + lane], s = rs[(long)t * 64 + lane];
+      const float c = on ? rc[(long)t * (HD / 2) + lane] : 1.f, s = on ? rs[(long)t * (HD / 2) + lane] : 0.f;
       const float a0 = q0 * c - q1 * s, a1 = q0 * s + q1 * c;
       const float b0 = k0 * c - k1 * s, b1 = k0 * s + k1 * c;
       q0 = a0; q1 = a1; k0 = b0; k1 = b1;
     }
-    store2<TA>(Q + (bh * Tp + t) * 128 + 2 * lane, q0, q1);
-    store2<TA>(K + (bh * Tp + t) * 128 + 2 * lane, k0, k1);
+    if (on) {
+      store2<TA>(Q + (bh * Tp + t) * HD + 2 * lane, q0, q1);
+      store2<TA>(K + (bh * Tp + t) * HD + 2 * lane, k0, k1);
+    }
   }
-  __shared__ float tile[64][129];
-  for (int idx = threadIdx.x; idx < 64 * 128; idx += 256) {
-    const int tt = idx >> 7, d = idx & 127;
+  __shared__ float tile[64][HD + 1];
+  for (int idx = threadIdx.x; idx < 64 * HD; idx += 256) {
+    const int tt = idx / HD, d = idx % HD;
     const int t = t0 + tt;
-    tile[tt][d] = t < T ? Elem<TA>::load(qkv + ((long)b * T + t) * ld + 2L * D + h * 128 + d) : 0.f;
+    tile[tt][d] = t < T ? Elem<TA>::load(qkv + ((long)b * T + t) * ld + 2L * D + h * HD + d) : 0.f;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 64 * 128; idx += 256) {
+  for (int idx = threadIdx.x; idx < 64 * HD; idx += 256) {
     const int d = idx >> 6, tt = idx & 63;
-    Elem<TA>::store(Vt + (bh * 128 + d) * Tp + t0 + tt, tile[tt][d]);
+    Elem<TA>::store(Vt + (bh * HD + d) * Tp + t0 + tt, tile[tt][d]);
   }
 }
 
@@ -473,8 +481,18 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
 
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
-                           float eps, hipStream_t st) {
+                           float eps, hipStream_t st, int head_dim) {
   dim3 grid(Tp / 64, H, B), block(256);
+  if (head_dim == 64) {   // the general form (no 16-byte fast path for 64-wide heads)
+    if (bf16)
+      hipLaunchKernelGGL((qkv_prep_kernel<bf16_t, 64>), grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q,
+                         (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
+    else
+      hipLaunchKernelGGL((qkv_prep_kernel<float, 64>), grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin, (float*)Q,
+                         (float*)K, (float*)Vt, T, Tp, H, eps);
+    return hipGetLastError();
+  }
+  if (head_dim != 128) return hipErrorInvalidValue;
   if (bf16 && debug_flag(29) == 1)   // the pre-round-4 rounding: reproducer only (see the kernel)
     hipLaunchKernelGGL(qkv_prep_bf16_kernel<true>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q,
                        (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
@@ -482,7 +500,7 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
     hipLaunchKernelGGL(qkv_prep_bf16_kernel<false>, grid, block, 0, st, (const bf16_t*)qkv, qw, kw, rope_cos, rope_sin, (bf16_t*)Q,
                        (bf16_t*)K, (bf16_t*)Vt, T, Tp, H, eps);
   else
-    hipLaunchKernelGGL(qkv_prep_kernel<float>, grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin,
+    hipLaunchKernelGGL((qkv_prep_kernel<float, 128>), grid, block, 0, st, (const float*)qkv, qw, kw, rope_cos, rope_sin,
                        (float*)Q, (float*)K, (float*)Vt, T, Tp, H, eps);
   return hipGetLastError();
 }
@@ -490,60 +508,72 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
 // ------------------------------------------------------------------------------------------------
 // in-place per-(row, head) RMSNorm (cross-attention k_norm, transformer.py:143-144); wave per (row, head)
 // ------------------------------------------------------------------------------------------------
-template <typename TA>
+template <typename TA, int HD>
 __global__ __launch_bounds__(256) void headnorm_kernel(TA* __restrict__ x, const float* __restrict__ w, long rows,
                                                        long ld, int col0, int H, float eps) {
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= rows * H) return;
   const int lane = threadIdx.x & 63;
+  const bool on = lane < HD / 2;   // HD = 64: half the wave sits out
   const long r = item / H;
   const int h = (int)(item % H);
-  TA* p = x + r * ld + col0 + h * 128 + 2 * lane;
-  float a, c;
-  load2<TA>(p, a, c);
-  const float inv = rsqrtf(wave_sum(a * a + c * c) / 128.f + eps);
-  store2<TA>(p, a * inv * w[2 * lane], c * inv * w[2 * lane + 1]);
+  TA* p = x + r * ld + col0 + h * HD + 2 * lane;
+  float a = 0.f, c = 0.f;
+  if (on) load2<TA>(p, a, c);
+  const float inv = rsqrtf(wave_sum(a * a + c * c) / (float)HD + eps);
+  if (on) store2<TA>(p, a * inv * w[2 * lane], c * inv * w[2 * lane + 1]);
 }
 
 hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,
-                           hipStream_t st) {
+                           hipStream_t st, int head_dim) {
   const long items = (long)rows * H;
   dim3 grid((unsigned)((items + 3) / 4)), block(256);
-  if (bf16)
-    hipLaunchKernelGGL(headnorm_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)x, w, (long)rows, ld, col0, H, eps);
+  if (head_dim != 64 && head_dim != 128) return hipErrorInvalidValue;
+  if (bf16 && head_dim == 128)
+    hipLaunchKernelGGL((headnorm_kernel<bf16_t, 128>), grid, block, 0, st, (bf16_t*)x, w, (long)rows, ld, col0, H, eps);
+  else if (bf16)
+    hipLaunchKernelGGL((headnorm_kernel<bf16_t, 64>), grid, block, 0, st, (bf16_t*)x, w, (long)rows, ld, col0, H, eps);
+  else if (head_dim == 128)
+    hipLaunchKernelGGL((headnorm_kernel<float, 128>), grid, block, 0, st, (float*)x, w, (long)rows, ld, col0, H, eps);
   else
-    hipLaunchKernelGGL(headnorm_kernel<float>, grid, block, 0, st, (float*)x, w, (long)rows, ld, col0, H, eps);
+    hipLaunchKernelGGL((headnorm_kernel<float, 64>), grid, block, 0, st, (float*)x, w, (long)rows, ld, col0, H, eps);
   return hipGetLastError();
 }
 
 // K halves of all layers' cross-attention key/value projections in one launch: kv_all [rows, L*2D], item =
 // (row, layer, head); weight w_all[layer][128]
-template <typename TA>
+template <typename TA, int HD>
 __global__ __launch_bounds__(256) void headnorm_layers_kernel(TA* __restrict__ x, const float* __restrict__ w_all,
                                                               long rows, int L, int H, float eps) {
   const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (item >= rows * L * H) return;
   const int lane = threadIdx.x & 63;
+  const bool on = lane < HD / 2;
   const int h = (int)(item % H);
   const int l = (int)((item / H) % L);
   const long r = item / ((long)H * L);
-  const long D2 = 2L * H * 128;
-  TA* p = x + r * (D2 * L) + l * D2 + h * 128 + 2 * lane;
-  const float* w = w_all + l * 128;
-  float a, c;
-  load2<TA>(p, a, c);
-  const float inv = rsqrtf(wave_sum(a * a + c * c) / 128.f + eps);
-  store2<TA>(p, a * inv * w[2 * lane], c * inv * w[2 * lane + 1]);
+  const long D2 = 2L * H * HD;
+  TA* p = x + r * (D2 * L) + l * D2 + h * HD + 2 * lane;
+  const float* w = w_all + l * HD;
+  float a = 0.f, c = 0.f;
+  if (on) load2<TA>(p, a, c);
+  const float inv = rsqrtf(wave_sum(a * a + c * c) / (float)HD + eps);
+  if (on) store2<TA>(p, a * inv * w[2 * lane], c * inv * w[2 * lane + 1]);
 }
 
 hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,
-                                  hipStream_t st) {
+                                  hipStream_t st, int head_dim) {
   const long items = (long)rows * L * H;
   dim3 grid((unsigned)((items + 3) / 4)), block(256);
-  if (bf16)
-    hipLaunchKernelGGL(headnorm_layers_kernel<bf16_t>, grid, block, 0, st, (bf16_t*)kv_all, w_all, (long)rows, L, H, eps);
+  if (head_dim != 64 && head_dim != 128) return hipErrorInvalidValue;
+  if (bf16 && head_dim == 128)
+    hipLaunchKernelGGL((headnorm_layers_kernel<bf16_t, 128>), grid, block, 0, st, (bf16_t*)kv_all, w_all, (long)rows, L, H, eps);
+  else if (bf16)
+    hipLaunchKernelGGL((headnorm_layers_kernel<bf16_t, 64>), grid, block, 0, st, (bf16_t*)kv_all, w_all, (long)rows, L, H, eps);
+  else if (head_dim == 128)
+    hipLaunchKernelGGL((headnorm_layers_kernel<float, 128>), grid, block, 0, st, (float*)kv_all, w_all, (long)rows, L, H, eps);
   else
-    hipLaunchKernelGGL(headnorm_layers_kernel<float>, grid, block, 0, st, (float*)kv_all, w_all, (long)rows, L, H, eps);
+    hipLaunchKernelGGL((headnorm_layers_kernel<float, 64>), grid, block, 0, st, (float*)kv_all, w_all, (long)rows, L, H, eps);
   return hipGetLastError();
 }
 

@@ -321,3 +321,44 @@ def test_f32_class_changes_across_two_loads_keep_the_codec_usable(gpu):
     want = fresh.separate(batch, noise=noise)
     assert torch.equal(m.last_latent, fresh.last_latent)
     assert all(torch.equal(a, b) for a, b in zip(got.target, want.target))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "mixed"])
+def test_head_dim_64_configuration(gpu, prec):
+    """The reference is parametric in dim / n_heads (transformer.py:100-119, config.py:86-135) and the real config.json files are not
+    reachable offline: besides head_dim 128 (every benchmarked stand-in) the engine builds head_dim 64 - general forms of qkv_prep,
+    the head norms and cross-attention, the self-attention kernel's 64-wide instantiation, the cross-attention output projection
+    unfolded.  One evaluation with ragged masks and anchors + a short solve, D = 1024 / H = 16 on hardware, against the oracle."""
+    small = gpu.type != "cuda"
+    D = 512 if small else 1024
+    cfg = preset_config("tiny", transformer=dict(dim=D, context_dim=D, n_heads=D // 64, n_layers=2))
+    assert cfg.transformer.head_dim == 64
+    if prec == "mixed" and small:
+        pytest.skip("the dry run binds one library: the mixed mode needs the fp16 build")
+    sd = init_state_dict(cfg, seed=15, with_codec=False)
+    B, T, Lt = 2, 40, 5
+    g = torch.Generator().manual_seed(2)
+    noisy, z = torch.randn(B, T, 256, generator=g), torch.randn(B, T, 128, generator=g)
+    feats, text = torch.cat([z, z], 2), torch.randn(B, Lt, 768, generator=g)
+    tmask = torch.ones(B, Lt, dtype=torch.bool)
+    tmask[1, 3:] = False
+    pad = torch.ones(B, T, dtype=torch.bool)
+    pad[1, 33:] = False
+    ids, align = O.anchors_to_ids([[("+", 0.2, 0.9)], []], pad, 1920, 48000)
+    time = torch.tensor([0.4375, 0.4375])
+    with torch.inference_mode():
+        want = O.samaudio_forward(sd, cfg, noisy, feats, text, time, video=torch.zeros(B, 1024, T), text_mask=tmask,
+                                  anchor_ids=ids, anchor_alignment=align, pad_mask=pad)
+
+        def field(t, y):
+            return O.samaudio_forward(sd, cfg, y, feats, text, t.expand(B), video=torch.zeros(B, 1024, T), text_mask=tmask,
+                                      anchor_ids=ids, anchor_alignment=align, pad_mask=pad)
+
+        want_ode = O.ode_fixed_grid(field, noisy, method="midpoint", step_size=0.5)
+    model = _model(cfg, sd, prec, gpu)
+    out = model.forward(noisy, feats, text, time[:1], text_mask=tmask, anchor_ids=ids, anchor_alignment=align, audio_pad_mask=pad)
+    tol = {"fp32": 1e-3, "bf16": 2e-2, "mixed": 4e-3}[prec]
+    util.report(f"head_dim 64 forward {prec}", out, want, tol)
+    model._prepare(feats, text, tmask, None, ids, align, pad)
+    lat = model.solve(noisy.to(gpu), {"method": "midpoint", "options": {"step_size": 0.5}})
+    util.report(f"head_dim 64 two-step solve {prec}", lat, want_ode, tol)

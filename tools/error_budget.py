@@ -35,10 +35,16 @@ def main():
     ap.add_argument("--steps", type=int, default=16, help="midpoint steps of the solve (16 = the reference's default)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "error_budget.json"))
     ap.add_argument("--formats", default="bf16,fp16")
+    ap.add_argument("--hostile", action="store_true",
+                    help="trained-like statistics (synthetic.make_hostile: residual-stream outlier channels, O(3) adaLN tables, Snake "
+                         "alphas over two decades, gains on the DAC convolutions) instead of the benign seeded init")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = preset_config(args.size)
     sd = init_state_dict(cfg, seed=0, device=dev)
+    if args.hostile:
+        from sam_audio_amd.synthetic import make_hostile
+        sd = make_hostile(sd, cfg, seed=0)
     R = args.clips
     n_samples = 10 * cfg.audio_codec.sample_rate
     clips = [synthetic_clip(i, n_samples) for i in range(R)]
@@ -62,7 +68,7 @@ def main():
         d = (a - b).float()
         return float(d.abs().max()), float(d.pow(2).mean().sqrt())
 
-    out = {"size": args.size, "clips": R, "midpoint_steps": args.steps, "rows": []}
+    out = {"size": args.size, "clips": R, "midpoint_steps": args.steps, "hostile": bool(args.hostile), "rows": []}
     m32 = SAMAudio(cfg, precision="fp32", device=str(dev))
     m32.load_state_dict(sd, strict=False)
     lat0, wav0, dt = run(m32)
