@@ -37,8 +37,11 @@ The JSON line also carries
                    timed on this box's host cores on a bounded sample (2 clips, the whole path; rank 0, N=1 only);
   parity_check   - the same sample (2 clips, fixed noise, the full 16-step solve) run through the HIP path in the benchmarked
                    precision and compared with the oracle's result: encode latent, ODE latent and waveform max-abs error;
-  bf16_mode      - the same steps timed with bfloat16 operands everywhere (BASELINE's nominal dtype), with its own parity_check
-                   (outside the 1e-3 bound; the headline mode `mixed` keeps bf16 where the flops are and is inside it);
+  mixed_mode     - the same steps timed in precision "mixed" (bfloat16 - BASELINE's nominal dtype - on the five big GEMM classes
+                   of the DiT layers = 96 % of the flops, fp16 elsewhere), with its own parity_check.  On the benign seeded weights
+                   of this bench both modes are inside the 1e-3 bound and mixed is ~3 % faster; on trained-like ("hostile") weights
+                   (tests/test_hostile_gpu.py) fp16 is ten times closer to the fp32 reference than any mode
+                   with bfloat16 operands - which is why fp16 is the headline;
   other_configs  - short lines of BASELINE configs[1], [3], [4] and of one GPU's share of configs[2] under strong scaling, each
                    a sub-process after the main measurement, with its own roofline and its OWN parity_check: configs[4] compares
                    the PE-Core tower's features and the visually conditioned solve, configs[3] the candidate solve, the Judge's
@@ -75,18 +78,19 @@ def parse(argv=None):
     ap.add_argument("--no-other-scaling", "--no-strong", dest="no_other", action="store_true",
                     help="N > 1: skip the extra measurement of the other scaling mode")
     ap.add_argument("--text-len", type=int, default=8)
-    ap.add_argument("--precision", default="mixed", choices=["bf16", "fp16", "mixed", "fp32"],
-                    help="GEMM-operand format of the timed model: mixed (default) = bfloat16 on the five big GEMM classes of the DiT "
-                         "layers (qkv, wo, c_wq, w13, w2: 96 %% of the flops), IEEE fp16 on the classes that carry the error - the "
-                         "full solve stays inside the 1e-3 parity bound at bf16's speed | fp16 everywhere (inside the bound, 3 %% "
-                         "slower) | bf16 everywhere (outside the bound) | fp32 (exact-fp32 parity mode).  The pure bf16 mode is timed "
-                         "side by side (--no-parity-mode skips it)")
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "mixed", "fp32"],
+                    help="GEMM-operand format of the timed model: fp16 (default) = IEEE half operands everywhere (16 bits like "
+                         "BASELINE's nominal bf16, the same MFMA rate, 10 mantissa bits instead of 7): inside the 1e-3 parity bound "
+                         "on the benign weights and the 16-bit mode that stays closest to fp32 on trained-like ones | mixed = "
+                         "bfloat16 on the five big GEMM classes of the DiT layers (96 %% of the flops), fp16 elsewhere: inside the "
+                         "bound on benign weights, ~3 %% faster, 10x further off on hostile ones | bf16 everywhere (outside the "
+                         "bound) | fp32 (exact-fp32 parity mode).  The mixed mode is timed side by side (--no-parity-mode skips it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip parity_check (it shares the oracle run with cpu_baseline)")
     ap.add_argument("--no-parity-mode", action="store_true",
-                    help="bf16 runs also time the SAME step in the parity mode (--precision fp16: IEEE fp16 operands, the mode "
-                         "that meets the 1e-3 bound on the full solve) and report it under \"parity_mode\"; this skips it")
+                    help="skip the side-by-side timing of the other 16-bit mode (fp16 runs: \"mixed_mode\"; mixed / bf16 runs: "
+                         "\"fp16_mode\")")
     ap.add_argument("--verify", action="store_true", help="run parity_check even with --no-cpu-baseline")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--streams", type=int, default=0,
@@ -689,7 +693,7 @@ def run(args):
 
     model = SAMAudio(cfg, precision=args.precision, device=str(dev), streams=max(args.streams, 2))
     model.load_state_dict(sd, strict=False)
-    side = {"fp16": "bf16", "bf16": "fp16", "mixed": "bf16"}.get(args.precision)   # another 16-bit mode, timed side by side
+    side = {"fp16": "mixed", "bf16": "fp16", "mixed": "fp16"}.get(args.precision)   # another 16-bit mode, timed side by side
     want_parity_mode = (side is not None and not args.no_parity_mode and not args.visual and args.candidates == 1
                         and not args.predict_spans)
     sd_keep = sd if want_parity_mode else None   # the parity-mode model is built from the same weights after the timed run
@@ -938,9 +942,10 @@ def run(args):
             t = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             p_elapsed = float(t.item())
-        pmode = {"precision": side, "what": f"the same workload and streams with {side} GEMM operands (same kernels, same MFMA "
-                 "rate; fp16 = the mode whose full-solve latent and waveform stay inside the 1e-3 bound, bf16 does not: "
-                 "tests/test_large_gpu.py::test_full_solve_and_decode, DESIGN.md section 4)",
+        pmode = {"precision": side, "what": f"the same workload and streams in precision {side!r} (same kernels, same MFMA rate): on the "
+                 "benign seeded weights fp16 and mixed are inside the 1e-3 bound and bf16 is not (tests/test_large_gpu.py::"
+                 "test_full_solve_and_decode); on trained-like weights fp16 is 10x closer to fp32 than mixed / bf16 "
+                 "(tests/test_hostile_gpu.py, DESIGN.md section 4)",
                  "value": round(clips_total * CLIP_SECONDS * p_steps / p_elapsed, 3), "unit": "s-audio/s", "steps": p_steps,
                  "ms_per_step": round(1e3 * p_elapsed / p_steps, 2), "parity_check": None}
         log(f"side by side ({side}): {p_steps} steps in {p_elapsed:.3f} s -> {pmode['value']:.2f} s-audio/s")
@@ -995,8 +1000,9 @@ def run(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": ("bf16 (five big GEMM classes of the DiT layers = 96 % of the flops) + fp16 (other GEMMs), fp32 accumulation"
-                      if args.precision == "mixed" else args.precision),
+            "dtype": {"mixed": "bf16 (five big GEMM classes of the DiT layers = 96 % of the flops) + fp16 (other GEMMs), fp32 accumulation",
+                      "fp16": "fp16 (IEEE half GEMM operands: 16 bits as BASELINE's nominal bf16, the same MFMA rate), fp32 accumulation"
+                      }.get(args.precision, args.precision),
             "data": ("synthetic (seeded random weights, synthetic 10 s/48 kHz clips, "
                      + ("prompts through a random-init t5-base-shaped encoder inside the step)" if args.t5
                         else "resident synthetic T5-shaped text features)")),
@@ -1018,7 +1024,7 @@ def run(args):
             },
             "vision_tower": vision,
             "roofline": roof["roofline"], "roofline_hbm": roof["roofline_hbm"], "cpu_baseline": cpu,
-            "parity_check": parity, ("parity_mode" if side == "fp16" else "bf16_mode"): pmode, "other_scaling": strong, "rerank_breakdown": breakdown,
+            "parity_check": parity, (f"{side}_mode" if side else "side_mode"): pmode, "other_scaling": strong, "rerank_breakdown": breakdown,
             "kernels": roof.get("kernels"),
         }
         if default_workload(args) and world == 1 and not args.no_other_configs:

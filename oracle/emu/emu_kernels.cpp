@@ -397,6 +397,9 @@ hipError_t launch_cross_attn_probs(const void*, const float*, const void*, long,
 // the fused residual-unit kernel is not emulated: the engine then issues the two launches
 bool resunit_ok(const GemmParams&, const GemmParams&) { return false; }
 hipError_t launch_resunit(const GemmParams&, const GemmParams&, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_cross_attn_fold_layers(const void* const*, int, const void*, long, void*, int, int, int, int, int, hipStream_t) {
+  return hipErrorNotSupported;   // (the emulation runs with SAMAUDIO_NO_FOLD=1)
+}
 hipError_t launch_cross_attn_fold(const void*, const void*, long, void*, int, int, int, int, int, hipStream_t) {
   return hipErrorNotSupported;
 }

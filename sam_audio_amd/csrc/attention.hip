@@ -609,13 +609,25 @@ __global__ __launch_bounds__(256) void cross_attn_probs_kernel(const bf16_t* __r
 // grid (D/64, ceil(KP / (8 LtP)), batch splits).  Heads >= H of the last group write the zeros the K padding of U holds.
 // MFMA orientation: rows = tokens (A = V), columns = n (B = Wo^T) -> a lane owns 4 consecutive tokens of one n; the sum
 // over d runs through the same four MFMAs in the same order as before: bitwise the round-2 result.
-__global__ __launch_bounds__(512) void cross_attn_fold_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ kv,
-                                                              long kv_ld, bf16_t* __restrict__ UT, int KP, int B, int Lt,
+// Round 5: ALL LAYERS OF AN EVALUATION IN ONE LAUNCH.  U depends on the layer's Wo and on the text memory only - not on the
+// residual stream - so the 22 folds of an evaluation need not sit between the layers' GEMMs as 22 launches of 132 workgroups (12 us
+// each at 4 clips, mostly latency): gridDim.z = layers x batch splits, layer l reads Wo_l (pointer table), the K | V columns
+// [l * 2 D, (l + 1) * 2 D) of the stacked cross-attention projections and writes its own [B][D][KP] slice.  Same arithmetic per
+// (layer, item): bitwise the per-layer launches.
+struct FoldLayers {
+  const bf16_t* wo[kMaxFoldLayers];
+};
+__global__ __launch_bounds__(512) void cross_attn_fold_kernel(const FoldLayers layers, const int zsplits, const bf16_t* __restrict__ kv_all,
+                                                              long kv_ld, bf16_t* __restrict__ UT_all, int KP, int B, int Lt,
                                                               int LtP, int H) {
   __shared__ __attribute__((aligned(16))) unsigned short stage[4 * 64 * 8 * 16];  // [item][n][head][token <= 16]: 64 KiB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int D = H * 128;
+  const int layer = (int)blockIdx.z / zsplits, zsplit = (int)blockIdx.z % zsplits;
+  const bf16_t* __restrict__ wo = layers.wo[layer];
+  const bf16_t* __restrict__ kv = kv_all + (long)layer * 2 * D;
+  bf16_t* __restrict__ UT = UT_all + (long)layer * B * D * KP;
   const int h = blockIdx.y * 8 + wave;
   const bool head_ok = h < H;
   const int hc = head_ok ? h : H - 1;
@@ -629,9 +641,9 @@ __global__ __launch_bounds__(512) void cross_attn_fold_kernel(const bf16_t* __re
   const int run = 8 * LtP;                        // elements of one (item, channel) run: this workgroup's heads
   const int k0 = blockIdx.y * run;                // first column of the run inside a U^T row
   const int segs = run / 8;                       // 16-byte segments per run
-  const int bz = (((B + (int)gridDim.z - 1) / (int)gridDim.z) + 3) & ~3;
-  const int b_end = (int)(blockIdx.z + 1) * bz < B ? (int)(blockIdx.z + 1) * bz : B;
-  for (int b0 = blockIdx.z * bz; b0 < b_end; b0 += 4) {
+  const int bz = (((B + zsplits - 1) / zsplits) + 3) & ~3;
+  const int b_end = (zsplit + 1) * bz < B ? (zsplit + 1) * bz : B;
+  for (int b0 = zsplit * bz; b0 < b_end; b0 += 4) {
     uint4 v[4][4];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
@@ -674,9 +686,12 @@ hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* k
   return hipGetLastError();
 }
 
-hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
-                                  int H, hipStream_t st) {
-  if ((H * 128) % 64 || (LtP != 8 && LtP != 16) || KP % 8 || KP < H * LtP) return hipErrorInvalidValue;
+// wo[l]: the output projection of layer l; kv_all [B * Lt, kv_ld] with layer l's (k | v) in columns [l * 2 D, (l + 1) * 2 D);
+// UT_all [n_layers][B][D][KP]
+hipError_t launch_cross_attn_fold_layers(const void* const* wo, int n_layers, const void* kv_all, long kv_ld, void* UT_all, int KP,
+                                         int B, int Lt, int LtP, int H, hipStream_t st) {
+  if ((H * 128) % 64 || (LtP != 8 && LtP != 16) || KP % 8 || KP < H * LtP || n_layers < 1 || n_layers > kMaxFoldLayers)
+    return hipErrorInvalidValue;
   const int groups = (KP + 8 * LtP - 1) / (8 * LtP);   // 8-head groups covering the padded row
   // batch splits, at least 4 items each (a trip handles 4).  Every split re-reads Wo, and the kernel is bound by the sum of its
   // L2 traffic, not by how many CUs hold a workgroup: up to 16 items no split at all (132 workgroups walking 4 trips: 23.3 vs
@@ -686,9 +701,15 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
   int zs = (target + (H * 128 / 64) * groups - 1) / ((H * 128 / 64) * groups);
   const int zmax = (B + 3) / 4;
   zs = zs < 1 ? 1 : zs > zmax ? zmax : zs;
-  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, groups, zs), dim3(512), 0, st, (const bf16_t*)wo,
-                     (const bf16_t*)kv, kv_ld, (bf16_t*)UT, KP, B, Lt, LtP, H);
+  FoldLayers layers;
+  for (int l = 0; l < kMaxFoldLayers; ++l) layers.wo[l] = (const bf16_t*)wo[l < n_layers ? l : 0];
+  hipLaunchKernelGGL(cross_attn_fold_kernel, dim3(H * 128 / 64, groups, zs * n_layers), dim3(512), 0, st, layers, zs,
+                     (const bf16_t*)kv_all, kv_ld, (bf16_t*)UT_all, KP, B, Lt, LtP, H);
   return hipGetLastError();
+}
+hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
+                                  int H, hipStream_t st) {
+  return launch_cross_attn_fold_layers(&wo, 1, kv, kv_ld, UT, KP, B, Lt, LtP, H, st);
 }
 
 hipError_t launch_cross_attention(const void* q, const float* qw, const void* kv, long kv_ld,

@@ -361,7 +361,9 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   // folded cross-attention (bf16, Lt <= 16): probabilities [M, KP] and the per-batch operand U^T [rows][D][KP]
   const long ltp = Lt <= 8 ? 8 : 16, kp = round_up(H * ltp, 64);
   void* probs = (bf16_ && Lt <= 16) ? act(M * kp) : nullptr;
-  void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp) : nullptr;
+  // (one slice per layer: the folds of an evaluation run as one launch in front of the layer loop)
+  const bool fold_all = cfg_.n_layers <= kMaxFoldLayers;
+  void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp * (fold_all ? cfg_.n_layers : 1)) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
@@ -771,7 +773,8 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
     fold_ltp_ = Lt <= 8 ? 8 : 16;
     fold_kp_ = (int)round_up((long)cfg_.n_heads * fold_ltp_, 64);
     SA_HIP(hipMemsetAsync(d_.probs, 0, (size_t)M * fold_kp_ * esz_, st));
-    SA_HIP(hipMemsetAsync(d_.ut, 0, (size_t)rows * D * fold_kp_ * esz_, st));  // 0 * (K padding of U) must stay 0
+    // 0 * (K padding of U) must stay 0
+    SA_HIP(hipMemsetAsync(d_.ut, 0, (size_t)rows * D * fold_kp_ * esz_ * (cfg_.n_layers <= kMaxFoldLayers ? cfg_.n_layers : 1), st));
   }
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
@@ -925,6 +928,16 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st, hd));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
+  // folded cross-attention: U_l = Wo_l V_l of EVERY layer in one launch (it depends on the text memory only, not on h)
+  const bool fold_all = fold_ltp_ && cfg_.n_layers <= kMaxFoldLayers && !debug_flag(31);   // flag 31: one launch per layer (A/B, tests)
+  const size_t ut_layer = (size_t)rows * D * fold_kp_ * esz_;
+  if (fold_all) {
+    const void* wos[kMaxFoldLayers];
+    for (int l = 0; l < cfg_.n_layers; ++l) wos[l] = layers_[l].c_wo;
+    SA_TRY(op("cross_attn_fold", ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_ * cfg_.n_layers, 0, st, [&] {
+      return launch_cross_attn_fold_layers(wos, cfg_.n_layers, d_.kvc, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st);
+    }));
+  }
   // SAMAUDIO_OPT_PREFETCH_ROWS: a launch's idle workgroups read the next big GEMM's weights (gemm8.hip prefetch_lines).  Chain per
   // layer: qkv -> wo -> c_wq -> c_wo (read by the fold kernel); w13 -> w2 -> the next layer's qkv.  Nobody prefetches w13: the only
   // launch in front of it with idle CUs is the folded cross-attention GEMM (K = 192: 15 us), which the 85 MB read stretched to 27 us,
@@ -984,7 +997,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     {
       GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
       ktm(p, w, 2);
-      prefetch(p, w.c_wo, (double)D * D);
+      if (!fold_all) prefetch(p, w.c_wo, (double)D * D);   // (read by the per-layer fold kernel)
       out_act(p, d_.qc, D);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWQ));
     }
@@ -995,10 +1008,12 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
         return launch_cross_attn_probs(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.probs, fold_kp_, rows, T, Lt,
                                        fold_ltp_, H, eps, st);
       }));
-      SA_TRY(op("cross_attn_fold", ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_, 0, st, [&] {
-        return launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st);
-      }));
-      GemmParams p = lin(d_.probs, fold_kp_, d_.ut, T, D, fold_kp_);
+      const void* ut_l = fold_all ? (const void*)((const char*)d_.ut + (size_t)l * ut_layer) : d_.ut;
+      if (!fold_all)
+        SA_TRY(op("cross_attn_fold", ((double)D * D + (double)rows * D * fold_kp_ + (double)Mt * D) * esz_, 0, st, [&] {
+          return launch_cross_attn_fold(w.c_wo, kv_l, kv_ld, d_.ut, fold_kp_, rows, Lt, fold_ltp_, H, st);
+        }));
+      GemmParams p = lin(d_.probs, fold_kp_, ut_l, T, D, fold_kp_);
       p.nbatch = rows;
       p.a_bstride = (long)T * fold_kp_;
       p.w_bstride = (long)D * fold_kp_;
@@ -1007,7 +1022,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_f32(p, d_.h, D);
       p.f32_bstride = (long)T * D;
       trace("  probs", d_.probs, (size_t)M * fold_kp_, bf16_, st);
-      trace("  ut", d_.ut, (size_t)rows * D * fold_kp_, bf16_, st);
+      trace("  ut", ut_l, (size_t)rows * D * fold_kp_, bf16_, st);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
       SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st, hd));

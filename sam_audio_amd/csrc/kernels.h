@@ -24,6 +24,8 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            SDWA instruction sequence showed beside another kernel's waves - kernels.hip, tools/stress_qkv_prep.py)
 //   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
 //            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads
+//   flag 31: 1 = the folded cross-attention operand U = Wo V of every layer in its own launch (shipped: all layers of an evaluation in
+//            one launch in front of the layer loop) - its bitwise test
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
@@ -126,6 +128,11 @@ hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* k
                                    void* P, int ldp, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st);
 hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, void* UT, int KP, int B, int Lt, int LtP,
                                   int H, hipStream_t st);
+// every layer of an evaluation in one launch: wo[l] = layer l's output projection, kv_all [B * Lt, kv_ld] with layer l's (k | v) in
+// columns [l * 2 D, (l + 1) * 2 D), UT_all [n_layers][B][D][KP]; bitwise the per-layer launches
+constexpr int kMaxFoldLayers = 48;
+hipError_t launch_cross_attn_fold_layers(const void* const* wo, int n_layers, const void* kv_all, long kv_ld, void* UT_all, int KP,
+                                         int B, int Lt, int LtP, int H, hipStream_t st);
 // per-(row, layer, head) RMSNorm of the K halves of kv_all [rows, L*2D] (all layers' cross-attention keys at
 // once); w_all [L, 128]
 hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,

@@ -362,3 +362,29 @@ def test_head_dim_64_configuration(gpu, prec):
     model._prepare(feats, text, tmask, None, ids, align, pad)
     lat = model.solve(noisy.to(gpu), {"method": "midpoint", "options": {"step_size": 0.5}})
     util.report(f"head_dim 64 two-step solve {prec}", lat, want_ode, tol)
+
+
+def test_fold_of_all_layers_in_one_launch_is_bitwise_the_per_layer_launches(gpu):
+    """The folded cross-attention operand U_l = Wo_l V_l depends on the text memory only: the engine computes every layer's in ONE
+    launch in front of the layer loop (debug flag 31 = 1: one launch per layer, between the layers' GEMMs, as before round 5)."""
+    from sam_audio_amd import hip
+    cfg = preset_config("mini")
+    sd = init_state_dict(cfg, seed=16, with_codec=False)
+    B, T, Lt = 3, 40, 5
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(B, T, 128, generator=g)
+    feats, text = torch.cat([z, z], 2), torch.randn(B, Lt, 768, generator=g)
+    tmask = torch.ones(B, Lt, dtype=torch.bool)
+    tmask[2, 2:] = False
+    noise = synthetic_noise(B, T).to(gpu)
+    opt = {"method": "midpoint", "options": {"step_size": 0.5}}
+    model = _model(cfg, sd, "bf16", gpu)
+    lat = {}
+    try:
+        for flag in (0, 1):
+            hip.lib().samaudio_debug_set_flag(31, flag)
+            model._prepare(feats, text, tmask, None, None, None, None)
+            lat[flag] = model.solve(noise, opt).clone()
+    finally:
+        hip.lib().samaudio_debug_set_flag(31, 0)
+    assert torch.isfinite(lat[0]).all() and torch.equal(lat[0], lat[1])
