@@ -547,7 +547,7 @@ def traffic_of(kernel: str, split: bool = False):
     """HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/r2_final.sh -> tools/pmc_traffic.py); they
     cannot be collected inside a timed run.  r2_traffic.json: launches not split into whole rounds + tail (what two
     concurrent row groups run); r2_traffic_split.json: the single-group form."""
-    for fname in ("r4_traffic.json", "r3_traffic.json") + (("r2_traffic_split.json",) if split else ()) + ("r2_traffic.json", "r1_traffic.json"):
+    for fname in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json") + (("r2_traffic_split.json",) if split else ()) + ("r2_traffic.json", "r1_traffic.json"):
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", fname)))["kernels"]
         except (OSError, KeyError, ValueError):

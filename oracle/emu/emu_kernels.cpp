@@ -42,15 +42,15 @@ inline float snake_h(float x, float a) {
   const float s = std::sin(a * x);
   return x + s * s / (a + 1e-9f);
 }
-int g_flags[8] = {0};
+int g_flags[64] = {0};
 int g_force = -1;
 }  // namespace
 
 hipError_t launch_poison_lds(hipStream_t) { return hipSuccess; }
 void set_debug_flag(int flag, int value) {
-  if (flag >= 0 && flag < 8) g_flags[flag] = value;
+  if (flag >= 0 && flag < 64) g_flags[flag] = value;
 }
-int debug_flag(int flag) { return flag >= 0 && flag < 8 ? g_flags[flag] : 0; }
+int debug_flag(int flag) { return flag >= 0 && flag < 64 ? g_flags[flag] : 0; }
 void gemm_force_variant(int v) { g_force = v; }
 int gemm_variant(const GemmParams&, bool) { return 0; }
 const char* gemm_variant_name(int v, bool) { return v == 0 ? "emu_gemm" : ""; }

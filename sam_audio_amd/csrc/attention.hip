@@ -178,6 +178,12 @@ __global__ __launch_bounds__(NW * 64, 4) void self_attn_bf16_kernel(const bf16_t
   }
 }
 
+// (Round 5, GPU calls 9 - 11: a form of this kernel that reads the qkv GEMM's output rows directly - q/k RMSNorm + RoPE applied on load,
+// V transposed on its way into LDS, no qkv_prep pass - was built, passed its parity tests on the simulator and on hardware, and was
+// REMOVED: 38 us per launch at 4 clips against 18.5 + 12.5 for the two kernels (138.7 vs 95.3 ms per 32-clip step), 152.1 vs 156.7
+// s-audio/s end to end at 4 clips, 231.3 vs 236.4 at 32; and a row's result depended on the batch it was evaluated in
+// (tests/test_configs_gpu.py::test_sixty_four_rows_at_large_star, both of its V-transposition forms), which the two kernels do not
+// show.  profiles/r5_call9/ ... r5_call11/; the code is in the history (commit "self-attention from the qkv rows").)
 // ---------------------------------------------------------------------------------------------------
 // fp32 self-attention (parity path).  grid (ceil(T/32), H, B), 256 threads: thread = (query qi, lane-in-8 sub).
 // ---------------------------------------------------------------------------------------------------

@@ -5,11 +5,11 @@
 
 namespace sa {
 
-static int g_debug_flags[32] = {0};
+static int g_debug_flags[64] = {0};
 void set_debug_flag(int flag, int value) {
-  if (flag >= 0 && flag < 32) g_debug_flags[flag] = value;
+  if (flag >= 0 && flag < 64) g_debug_flags[flag] = value;
 }
-int debug_flag(int flag) { return flag >= 0 && flag < 32 ? g_debug_flags[flag] : 0; }
+int debug_flag(int flag) { return flag >= 0 && flag < 64 ? g_debug_flags[flag] : 0; }
 
 // ------------------------------------------------------------------------------------------------
 // RMSNorm (+ adaLN modulate).  Reference transformer.py:36-47 (fp32 inside, eps in the rsqrt),

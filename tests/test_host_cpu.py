@@ -35,8 +35,9 @@ def test_config_defaults_match_reference_rule():
     assert preset_config("large*").transformer.ffn_hidden == 7552
     assert preset_config("small*").transformer.ffn_hidden == 4096
     assert SAMAudioConfig().audio_codec.hop_length == 1920
+    SAMAudioConfig(transformer=dict(dim=2048, n_heads=32)).check_supported()   # head_dim 64: built since round 5
     with pytest.raises(NotImplementedError):
-        SAMAudioConfig(transformer=dict(dim=2048, n_heads=32)).check_supported()
+        SAMAudioConfig(transformer=dict(dim=2048, n_heads=64)).check_supported()   # head_dim 32 is not
     with pytest.raises(TypeError):
         SAMAudioConfig(transformer=dict(bogus=1))
 
