@@ -183,7 +183,8 @@ __global__ __launch_bounds__(NW * 64, 4) void self_attn_bf16_kernel(const bf16_t
 // REMOVED: 38 us per launch at 4 clips against 18.5 + 12.5 for the two kernels (138.7 vs 95.3 ms per 32-clip step), 152.1 vs 156.7
 // s-audio/s end to end at 4 clips, 231.3 vs 236.4 at 32; and a row's result depended on the batch it was evaluated in
 // (tests/test_configs_gpu.py::test_sixty_four_rows_at_large_star, both of its V-transposition forms), which the two kernels do not
-// show.  profiles/r5_call9/ ... r5_call11/; the code is in the history (commit "self-attention from the qkv rows").)
+// show.  Not root-caused (the first suspect - 2-byte LDS scatter stores of V, 16-way bank conflicts - was replaced by a staging tile
+// + column reads: same result).  Logs: profiles/r5_call9/ ... r5_call11/.)
 // ---------------------------------------------------------------------------------------------------
 // fp32 self-attention (parity path).  grid (ceil(T/32), H, B), 256 threads: thread = (query qi, lane-in-8 sub).
 // ---------------------------------------------------------------------------------------------------
