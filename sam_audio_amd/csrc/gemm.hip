@@ -381,9 +381,10 @@ int gemm_tail_split(const GemmParams& p, bool is_bf16) {
   // 557 -> 500 with the split; profiles/r2_call15/)
   // (round 4: with the lean epilogues a last round that is half full is cheaper as it stands - w13 at 4000 rows, 944 tiles = 3 x 256
   // + 176: 249 us in one launch, 268 split; qkv, 528 = 2 x 256 + 16: 179 vs 160 split; profiles/r4_call5/gemm_bench_f3.log)
-  // (round 5: the floor of the tail is a debug flag for the A/B - qkv at 8 clips per GPU is 264 tiles = one round + 8, i.e. a second
-  //  round of 8 tiles as long as the first; flag 33 = minimum tail, 0 = the shipped 16)
-  const long min_tail = debug_flag(33) > 0 ? debug_flag(33) : 16;
+  // (round 5: the floor of the tail went from 16 to 8 tiles - qkv at 8 clips per GPU, the 4-GPU share of the 32-clip batch, is 264
+  //  tiles = one round + 8, i.e. a second round of 8 tiles as long as the first: 164.8 / 165.3 -> 170.0 s-audio/s at 8 clips, nothing
+  //  at 4 clips or small* (profiles/r5_call12/); flag 33 = another floor for the A/B)
+  const long min_tail = debug_flag(33) > 0 ? debug_flag(33) : 8;
   return full >= 256 && full <= 1024 && rem >= min_tail && rem <= 128 ? (int)full : 0;
 }
 hipError_t launch_gemm_part(const GemmParams& p, bool is_bf16, int part, hipStream_t st) {

@@ -24,6 +24,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            SDWA instruction sequence showed beside another kernel's waves - kernels.hip, tools/stress_qkv_prep.py)
 //   flag 27: wave roles of gemm8s' pipelined form (gemm8.hip): 0 = shipped choice, 1 = none (4 waves request and multiply, round 3),
 //            2 = 4 requesting waves beside 4 multiplying ones, 3 = the same with the multiplying waves issuing 2 of their 8 loads
+//   flag 33: (A/B) smallest last round, in 256x256 tiles, that is split off as a 128x128-tile tail launch (0 = shipped: 8)
 //   flag 31: 1 = the folded cross-attention operand U = Wo V of every layer in its own launch (shipped: all layers of an evaluation in
 //            one launch in front of the layer loop) - its bitwise test
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)

@@ -326,10 +326,11 @@ def test_gemm8s_wave_roles_are_bitwise_invisible(gpu, kind):
         util.report("gemm8s roles, 16-bit output", outs[2], util.rounded(A, "bf16") @ util.rounded(W, "bf16").T, 3.2e-2)
 
 
-@pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10)])
+@pytest.mark.parametrize("M,N,K,nbatch", [(4352, 4096, 128, 1), (300, 3500, 192, 10), (2000, 8448, 128, 1)])
 def test_tail_split_is_bitwise_invisible(gpu, M, N, K, nbatch):
     """8-phase launches whose last round of 256x256 tiles is mostly empty run as two kernels (gemm.hip gemm_tail_split:
-    whole rounds on gemm8, the rest as 128x128 quadrants on gemm8s).  272 / 280 tiles here -> 256 + 16 / 24; ragged M and N
+    whole rounds on gemm8, the rest as 128x128 quadrants on gemm8s).  272 / 280 / 264 tiles here -> 256 + 16 / 24 / 8 (the last
+    = the qkv GEMM of 8 clips per GPU: the smallest tail that is split off since round 5); ragged M and N
     put quadrants partly and wholly outside the problem.  The automatic (split) result must equal the forced single-kernel
     one bit for bit - gated residual epilogue, fp32 + bf16 outputs, per-batch strides."""
     A, W = _mk((nbatch, M, K), 41), _mk((N, K), 42, 1 / math.sqrt(K))
