@@ -1015,6 +1015,7 @@ def run(args):
                                                                          if args.share_gpu and world > 1 else ""),
                 "streams_per_gpu": n_streams, "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
+                "ode_graph_replays": model.graph_replays(),   # SAMAudio(ode_graph=...) / SAMAUDIO_ODE_GRAPH: 0 = eager launches
                 "text_encoder_in_step": ("t5-base dims (12 layers, d_model 768), random init, hash tokenizer, T5 stack on the HIP "
                                          "library (fp32), run on the descriptions inside every timed step") if args.t5 else None,
                 "visual_prompt": (f"{cfg.vision_encoder.name} tower, 250 frames x 336x336 per clip, encoded inside the step"

@@ -121,6 +121,12 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   REPORTED by samaudio_sentinel_read with the class it came from instead of propagating silently.  Allocates 4 KiB of device
  *   memory on first use (the only allocation of the library besides the checksum trace). */
 #define SAMAUDIO_OPT_SENTINEL 7
+/*   SAMAUDIO_OPT_ODE_GRAPH (default 0): value 1 lets samaudio_ode_solve replay the launches of a solve as a HIP graph (SURVEY.md
+ *   section 7 step 6).  The first solve of a shape runs eagerly, the second is captured (stream capture, thread-local mode: the row
+ *   groups of two contexts capture independently) and instantiated, later ones with the same context state - workspace, shapes, grid,
+ *   method, options, weights - replay it; anything else falls back to eager launches.  The state tensor travels through a buffer
+ *   of the workspace so that the captured pointers stay valid.  Scheduling only: the same kernels with the same arguments. */
+#define SAMAUDIO_OPT_ODE_GRAPH 8
 #define SAMAUDIO_SENTINEL_SLOTS 16   /* SAMAUDIO_CLS_COUNT GEMM classes (bit order) + slot 14: RMSNorm outputs, 15: attention outputs */
 #define SAMAUDIO_CLS_ALT16_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
 #define SAMAUDIO_CLS_TIME (1 << 0)   /* t_embedder MLP + t_block (transformer.py:236-257,462-467): 1 row per time value */
@@ -358,6 +364,8 @@ int samaudio_profile_begin(samaudio_ctx* ctx);
 /* SAMAUDIO_OPT_SENTINEL: synchronises `stream`, copies out absmax[SAMAUDIO_SENTINEL_SLOTS] / nonfinite[SAMAUDIO_SENTINEL_SLOTS]
  * (counts as doubles) accumulated since the last read, and resets them. */
 int samaudio_sentinel_read(samaudio_ctx* ctx, float* absmax, double* nonfinite, samaudio_stream stream);
+/* SAMAUDIO_OPT_ODE_GRAPH: how many solves of this context ran as a graph launch so far (0 = every solve was launched eagerly). */
+long samaudio_graph_replays(samaudio_ctx* ctx);
 /* Test hook: force the GEMM kernel variant (-1 automatic; 0..2 the 128-row tiles of gemm.hip; 22 = gemm8 256x256 8-phase,
  * 27 = gemm8s 128x128, 25 / 26 / 28 / 29 / 32 / 33 / 34 = the 32x32x16-family tiles, 35 = conv7h; csrc/gemm.hip
  * gemm_variant_name).  A launch the forced kernel does not cover falls back to gemm.hip's tiles. */

@@ -9,7 +9,7 @@ OUT=../_emu
 mkdir -p $OUT
 REN=""
 for f in hipMemsetAsync hipMemcpyAsync hipMemcpy hipStreamSynchronize hipEventCreate hipEventDestroy hipEventRecord \
-         hipEventSynchronize hipEventElapsedTime; do
+         hipEventSynchronize hipEventElapsedTime hipStreamBeginCapture hipStreamCreateWithFlags; do
   REN="$REN -D$f=emu_$f"
 done
 FLAGS="--offload-host-only --offload-arch=gfx950 -O2 -std=c++17 -fPIC -fopenmp -Wno-unused-result $REN"

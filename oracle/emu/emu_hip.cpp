@@ -21,6 +21,9 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
   return hipSuccess;
 }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// SAMAUDIO_OPT_ODE_GRAPH: no capture here - the engine falls back to its eager launches
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned) { return hipErrorNotSupported; }
 hipError_t hipEventCreate(hipEvent_t* e) {
   *e = (hipEvent_t)std::malloc(8);
   return hipSuccess;

@@ -44,7 +44,11 @@ inline float snake_h(float x, float a) {
 }
 int g_flags[64] = {0};
 int g_force = -1;
+unsigned long long g_epoch = 0;
 }  // namespace
+
+void debug_touch() { ++g_epoch; }
+unsigned long long debug_epoch() { return g_epoch; }
 
 hipError_t launch_poison_lds(hipStream_t) { return hipSuccess; }
 void set_debug_flag(int flag, int value) {

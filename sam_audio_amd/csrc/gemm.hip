@@ -275,7 +275,7 @@ static hipError_t launch_cfg(const GemmParams& p, hipStream_t st) {
 }
 
 static int g_force = -1;
-void gemm_force_variant(int v) { g_force = v; }
+void gemm_force_variant(int v) { g_force = v; debug_touch(); }
 
 // tile variant of gemm.hip: 0 = 128x128, 1 = 128x64, 2 = 128x32.  Narrow outputs (codec stages with 1 / 64 /
 // 96 / 192 channels) use narrower N tiles.

@@ -38,6 +38,8 @@ hipError_t launch_sentinel(const void* x, int fmt, long rows, int cols, long ld,
 void* debug_device_alloc(size_t bytes);
 void debug_device_free(void* p);
 int debug_flag(int flag);
+void debug_touch();   // a process-wide debugging switch changed
+unsigned long long debug_epoch();
 
 hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);

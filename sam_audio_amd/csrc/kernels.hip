@@ -6,8 +6,12 @@
 namespace sa {
 
 static int g_debug_flags[64] = {0};
+static unsigned long long g_debug_epoch = 0;   // counts changes of the process-wide debugging switches (captured solves check it)
+void debug_touch() { ++g_debug_epoch; }
+unsigned long long debug_epoch() { return g_debug_epoch; }
 void set_debug_flag(int flag, int value) {
   if (flag >= 0 && flag < 64) g_debug_flags[flag] = value;
+  debug_touch();
 }
 int debug_flag(int flag) { return flag >= 0 && flag < 64 ? g_debug_flags[flag] : 0; }
 
