@@ -78,7 +78,7 @@ def parse(argv=None):
     ap.add_argument("--no-other-scaling", "--no-strong", dest="no_other", action="store_true",
                     help="N > 1: skip the extra measurement of the other scaling mode")
     ap.add_argument("--text-len", type=int, default=8)
-    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "mixed", "fp32"],
+    ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "mixed", "fp32", "fp16x3", "bf16x3"],
                     help="GEMM-operand format of the timed model: fp16 (default) = IEEE half operands everywhere (16 bits like "
                          "BASELINE's nominal bf16, the same MFMA rate, 10 mantissa bits instead of 7): inside the 1e-3 parity bound "
                          "on the benign weights and the 16-bit mode that stays closest to fp32 on trained-like ones | mixed = "
@@ -576,6 +576,11 @@ def reference_flops(cfg, clips, text_len):
     return clips * (32.0 * per_eval + 0.487e12 + 2 * 1.096e12)   # codec figures: SURVEY.md section 8(a2, a15), default codec dims
 
 
+def tower_precision(precision):
+    """the towers beside the DiT (Judge, span predictor, vision tower) have no compensated mode: fp32 storage = fp32"""
+    return "fp32" if precision.endswith("x3") else precision
+
+
 def rooflines(stats):
     """stats: [{name 'class/kernel', launches, flops, bytes, ms}] of ONE instrumented step."""
     rows = []
@@ -740,7 +745,7 @@ def run(args):
         from sam_audio_amd.synthetic import init_vision_state_dict
         from sam_audio_amd.vision_encoder import PerceptionEncoder
         pe_cfg = PE_VISION_CONFIGS[cfg.vision_encoder.name]
-        model.vision_encoder = PerceptionEncoder(cfg.vision_encoder, device=dev, precision=args.precision)
+        model.vision_encoder = PerceptionEncoder(cfg.vision_encoder, device=dev, precision=tower_precision(args.precision))
         vsd = init_vision_state_dict(pe_cfg, seed=5, device=dev)
         if want_verify:
             vsd_cpu = {k: v.float().cpu() for k, v in vsd.items()}
@@ -750,12 +755,12 @@ def run(args):
             f"{pe_cfg.tokens} tokens per frame)")
 
     if args.candidates > 1:
-        model.text_ranker, judge_sd = build_judge_ranker(cfg, args.precision, dev)
+        model.text_ranker, judge_sd = build_judge_ranker(cfg, tower_precision(args.precision), dev)
         if want_verify:
             judge_sd_cpu = {k: v.float().cpu() for k, v in judge_sd.items()}
         del judge_sd
     if args.predict_spans:
-        model.span_predictor, model.span_predictor_transform = build_span_predictor(cfg, args.precision, dev)
+        model.span_predictor, model.span_predictor_transform = build_span_predictor(cfg, tower_precision(args.precision), dev)
 
     def fence():
         torch.cuda.synchronize()

@@ -127,6 +127,18 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   method, options, weights - replay it; anything else falls back to eager launches.  The state tensor travels through a buffer
  *   of the workspace so that the captured pointers stay valid.  Scheduling only: the same kernels with the same arguments. */
 #define SAMAUDIO_OPT_ODE_GRAPH 8
+/*   SAMAUDIO_OPT_X3_CLASSES (fp32 contexts; value = mask of SAMAUDIO_CLS_X3_CAPABLE bits, default 0): COMPENSATED 16-bit operands -
+ *   precision "fp16x3" of the host classes.  The reference computes in fp32 (README.md:48); no plain 16-bit operand format holds
+ *   the 1e-3 parity bound on trained-like weight statistics.  A GEMM of a named class keeps its fp32
+ *   activation operand and fp32 outputs, but multiplies on the 16-bit MFMA: each operand is split into hi = rn16(x) and
+ *   lo = rn16(x - hi), the activation row becomes [lo | hi | hi] (3K elements, written by a streaming kernel on the launch stream)
+ *   and the weight row [W_hi | W_lo | W_hi], so that ONE launch of the library's 16-bit GEMM over K' = 3K accumulates
+ *   x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32 - the fp32 product to ~2^-21 relative for three times the MFMA work.  Needs the
+ *   class's weights registered in that split form under "<name>.x3" - 16-bit, [N, 3K] row-major or [3K/64, N, 64] K-tile-major
+ *   (sam_audio_amd/weights.py x3_weight) - for L<i>.wqkv, wo, c_wq, c_wo, w13, w2; checked like the ".f32" copies above.
+ *   Everything else of the context (norms, attention, the small GEMM classes, the codec) stays exact fp32.  In
+ *   libsamaudio_hip_f16.so the halves are IEEE fp16 (22 mantissa bits per operand); in libsamaudio_hip.so bfloat16 (16 bits). */
+#define SAMAUDIO_OPT_X3_CLASSES 9
 #define SAMAUDIO_SENTINEL_SLOTS 16   /* SAMAUDIO_CLS_COUNT GEMM classes (bit order) + slot 14: RMSNorm outputs, 15: attention outputs */
 #define SAMAUDIO_CLS_ALT16_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
 #define SAMAUDIO_CLS_TIME (1 << 0)   /* t_embedder MLP + t_block (transformer.py:236-257,462-467): 1 row per time value */
@@ -144,6 +156,7 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
 #define SAMAUDIO_CLS_W2 (1 << 12)
 #define SAMAUDIO_CLS_CODEC (1 << 13) /* every DAC-VAE convolution */
 #define SAMAUDIO_CLS_COUNT 14
+#define SAMAUDIO_CLS_X3_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_CWO | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
 #define SAMAUDIO_CLS_F32_CAPABLE (SAMAUDIO_CLS_TIME | SAMAUDIO_CLS_OUT | SAMAUDIO_CLS_IN | SAMAUDIO_CLS_PREP | SAMAUDIO_CLS_YEMB)
 int samaudio_set_option(samaudio_ctx* ctx, int option, int value);
 
@@ -420,6 +433,9 @@ int samaudio_op_masked_groupnorm_silu(const float* x, const float* w, const floa
                                       int channels, int halo, float eps, samaudio_stream stream);
 int samaudio_op_layernorm_rows(const float* x, int64_t x_ld, const float* w, const float* b, float* out_f32,
                                void* out_act, int precision, int64_t rows, int dim, float eps, samaudio_stream stream);
+/* SAMAUDIO_OPT_X3_CLASSES: the activation operand of a compensated GEMM - x [rows, k] f32 (row stride x_ld) -> out [rows, 3k]
+ * in the library's 16-bit format = [lo | hi | hi] per row, hi = rn16(x) (clamped to the largest finite value), lo = rn16(x - hi) */
+int samaudio_op_split3(const float* x, int64_t x_ld, void* out, int64_t rows, int k, samaudio_stream stream);
 
 #ifdef __cplusplus
 }

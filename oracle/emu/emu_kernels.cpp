@@ -482,6 +482,20 @@ hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_co
   return hipSuccess;
 }
 
+hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hipStream_t) {   // [lo | hi | hi], kernels.hip split3_kernel
+  bf16_t* o = (bf16_t*)out;
+  for (long m = 0; m < M; ++m)
+    for (int k = 0; k < K; ++k) {
+      const float v = x[m * ldx + k];
+      bf16_t hi;
+      HE<bf16_t>::st(&hi, v);
+      HE<bf16_t>::st(o + m * 3L * K + k, v - HE<bf16_t>::ld(&hi));
+      o[m * 3L * K + K + k] = hi;
+      o[m * 3L * K + 2L * K + k] = hi;
+    }
+  return hipSuccess;
+}
+
 hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t) {
   const size_t e = bf16 ? 2 : 4;
   for (int b = 0; b < B; ++b) {

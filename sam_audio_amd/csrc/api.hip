@@ -257,6 +257,11 @@ int samaudio_op_layernorm_rows(const float* x, int64_t x_ld, const float* w, con
                                            (hipStream_t)stream), "layernorm_rows");
 }
 
+int samaudio_op_split3(const float* x, int64_t x_ld, void* out, int64_t rows, int k, samaudio_stream stream) {
+  if (!x || !out || rows <= 0 || k <= 0 || k % 8 || x_ld % 4) return bad("split3: k % 8, x_ld % 4");
+  return hip_ret(sa::launch_split3(x, x_ld, out, rows, k, (hipStream_t)stream), "split3");
+}
+
 // ---- Judge reranker ----------------------------------------------------------------------------------
 int samaudio_judge_create(const samaudio_judge_config* cfg, samaudio_judge** out) {
   if (!cfg || !out) return bad("samaudio_judge_create: null argument");

@@ -89,7 +89,13 @@ class Engine {
   // alg_flops < 0: 2*M*N*K*nbatch (exact unless K carries zero padding, then the caller passes the true count).
   // cls: SAMAUDIO_CLS_* bit of the launch (0: codec launches are classed by prof_cls_); f32: exact-fp32 operands inside a
   // 16-bit context (SAMAUDIO_OPT_F32_CLASSES - the caller hands fp32 A / W / out_act pointers)
-  Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0, int cls = 0, bool f32 = false);
+  // mode 2: a SAMAUDIO_OPT_X3_CLASSES launch inside an fp32 context (16-bit A / W over K' = 3K, fp32 outputs; gemm_x3 builds it)
+  Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0, int cls = 0, int mode = 0);
+  // SAMAUDIO_OPT_X3_CLASSES: `p` = the fp32 context's plain launch (fp32 A rows, fp32-typed outputs) of a class that is switched
+  // on; `w3` = its "<name>.x3" weight.  Splits A into the scratch operand [lo | hi | hi] and runs ONE 16-bit GEMM over K' = 3K.
+  Status gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls);
+  bool x3(int cls) const { return !bf16_ && (x3_classes_ & cls) != 0; }
+  Status check_x3_weights(int classes) const;
   bool f32c(int cls) const { return bf16_ && (f32_classes_ & cls) != 0; }
   bool alt16(int cls) const { return bf16_ && (alt_classes_ & cls) != 0; }   // SAMAUDIO_OPT_ALT16_CLASSES (mixed mode)
   const void* opt(const std::string& name, std::vector<int64_t> shape) const;  // optional fp32 tensor, null if absent / mis-shaped
@@ -118,6 +124,7 @@ class Engine {
   int f32_classes_ = 0;     // SAMAUDIO_OPT_F32_CLASSES (16-bit contexts)
   int alt_classes_ = 0;     // SAMAUDIO_OPT_ALT16_CLASSES (16-bit contexts)
   int prefetch_rows_ = 0;   // SAMAUDIO_OPT_PREFETCH_ROWS (16-bit contexts)
+  int x3_classes_ = 0;      // SAMAUDIO_OPT_X3_CLASSES (fp32 contexts)
   // SAMAUDIO_OPT_ODE_GRAPH: the launches of one solve as a HIP graph, replayed while `graph_key_` describes the context's state
   bool graphs_ = false;
   unsigned long long gen_ = 0;   // bumped by everything that can change what a solve launches (weights, workspace, options)
@@ -157,6 +164,9 @@ class Engine {
     const float *attn_norm, *ffn_norm, *mod_table, *q_norm, *k_norm, *c_q_norm;
     const void *wqkv, *wo, *c_wq, *c_wo, *w13, *w2;
     int ktm;   // which of (wqkv, wo, c_wq, w13, w2) - bits 0..4 - are registered K-tile-major [K/64][N][64] (samaudio.h)
+    // SAMAUDIO_OPT_X3_CLASSES (fp32 contexts): the "<name>.x3" split weights [W_hi | W_lo | W_hi], 16-bit; null = not registered
+    const void *wqkv3, *wo3, *c_wq3, *c_wo3, *w13_3, *w2_3;
+    int ktm3;  // which of them - bits 0..5 in that order - are K-tile-major [3K/64][N][64]
   };
   // a big-five weight: [N, K] row-major or (16-bit contexts) [K/64, N, 64] K-tile-major
   Status need_w5(const std::string& name, int N, int K, const void** out, int* ktm_bits, int bit);
@@ -191,7 +201,7 @@ class Engine {
   struct {
     float *ystate, *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
-        *feats, *text, *video, *anch, *probs, *ut;
+        *feats, *text, *video, *anch, *probs, *ut, *x3a;
     float *temb32, *tu32, *tsilu32, *xn32, *prep32, *mem32, *yu32, *yemb32;  // fp32 operands of the f32 classes (16-bit contexts)
     unsigned char *pad_mask, *text_mask;
     double* gn_part;

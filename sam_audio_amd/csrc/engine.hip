@@ -211,6 +211,19 @@ Status Engine::finalize(int what) {
       NEEDW(w.c_wo, P + "c_wo", D, D);
       SA_TRY(need_w5(P + "w13", 2 * F, D, &w.w13, &w.ktm, 3));
       SA_TRY(need_w5(P + "w2", D, F, &w.w2, &w.ktm, 4));
+      if (!bf16_) {   // SAMAUDIO_OPT_X3_CLASSES: optional split copies, checked when a class is switched on / at the end of finalize
+        const struct { const char* leaf; int N, K; const void** out; } x3w[6] = {
+            {"wqkv", 3 * D, D, &w.wqkv3}, {"wo", D, D, &w.wo3}, {"c_wq", D, D, &w.c_wq3},
+            {"c_wo", D, D, &w.c_wo3},     {"w13", 2 * F, D, &w.w13_3}, {"w2", D, F, &w.w2_3}};
+        for (int j = 0; j < 6; ++j) {
+          const TensorRef* t = find(P + x3w[j].leaf + ".x3");
+          *x3w[j].out = nullptr;
+          if (!t || t->dtype != SAMAUDIO_DT_BF16) continue;
+          const int64_t N = x3w[j].N, K3 = 3L * x3w[j].K;
+          if (t->shape == std::vector<int64_t>{K3 / 64, N, 64}) { *x3w[j].out = t->p; w.ktm3 |= 1 << j; }
+          else if (t->shape == std::vector<int64_t>{N, K3}) *x3w[j].out = t->p;
+        }
+      }
     }
     NEEDF(g_.final_table, "final_table", 2, D);
     NEEDF(g_.final_norm, "final_norm", D);
@@ -265,7 +278,8 @@ Status Engine::finalize(int what) {
 #undef OPTF
       SA_TRY(check_f32_weights(f32_classes_));
     }
-    dit_ready_ = true;
+    dit_ready_ = true;   // (check_x3_weights looks at the resolved layers)
+    if (const Status s3 = check_x3_weights(x3_classes_); !s3.ok()) { dit_ready_ = false; return s3; }
   } else {
     const int CD = cfg_.codec_dim, CL = cfg_.codec_latent;
     auto res_units = [&](const std::string& P, StageW& s, int C) -> Status {
@@ -368,6 +382,8 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   // (one slice per layer: the folds of an evaluation run as one launch in front of the layer loop)
   const bool fold_all = cfg_.n_layers <= kMaxFoldLayers;
   void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp * (fold_all ? cfg_.n_layers : 1)) : nullptr;
+  // SAMAUDIO_OPT_X3_CLASSES: the split activation operand [lo | hi | hi] of the widest GEMM input (16-bit, 3 K elements per row)
+  void* x3a = (!bf16_ && x3_classes_) ? b.take((size_t)M * 3 * (size_t)(F > D ? F : D) * 2) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
@@ -377,7 +393,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
     d.video = video; d.anch = anch; d.temb32 = temb32; d.tu32 = tu32; d.tsilu32 = tsilu32; d.xn32 = xn32; d.prep32 = prep32;
-    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
+    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.x3a = x3a; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
   }
   return Status{};
 }
@@ -460,9 +476,25 @@ Status Engine::check_f32_weights(int classes) const {
   return Status{};
 }
 
+Status Engine::check_x3_weights(int classes) const {
+  if (!classes) return Status{};
+  for (size_t i = 0; i < layers_.size(); ++i) {
+    const LayerW& w = layers_[i];
+    const struct { int cls; const void* p; const char* leaf; } need[6] = {
+        {SAMAUDIO_CLS_QKV, w.wqkv3, "wqkv"}, {SAMAUDIO_CLS_WO, w.wo3, "wo"},     {SAMAUDIO_CLS_CWQ, w.c_wq3, "c_wq"},
+        {SAMAUDIO_CLS_CWO, w.c_wo3, "c_wo"}, {SAMAUDIO_CLS_W13, w.w13_3, "w13"}, {SAMAUDIO_CLS_W2, w.w2_3, "w2"}};
+    for (const auto& n : need)
+      if ((classes & n.cls) && !n.p)
+        return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_X3_CLASSES: the split weight 'L" + std::to_string(i) + "." + n.leaf +
+                                             ".x3' (16-bit, [N, 3K] or [3K/64, N, 64]) of a class that is switched on is not registered");
+  }
+  return Status{};
+}
+
 Status Engine::set_option(int option, int value) {
   const auto sig = [this] {
-    return std::make_tuple(tail_split_, f32_classes_, alt_classes_, prefetch_rows_, sentinel_on_, quant_classes_, quant_fmt_, graphs_);
+    return std::make_tuple(tail_split_, f32_classes_, alt_classes_, prefetch_rows_, sentinel_on_, quant_classes_, quant_fmt_, graphs_,
+                           x3_classes_);
   };
   const auto before = sig();
   const Status s = set_option_value(option, value);
@@ -504,6 +536,15 @@ Status Engine::set_option_value(int option, int value) {
     if (value && !bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_PREFETCH_ROWS applies to 16-bit contexts");
     if (value < 0) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_PREFETCH_ROWS: a row count (0 = off)");
     prefetch_rows_ = value;
+    return Status{};
+  }
+  if (option == SAMAUDIO_OPT_X3_CLASSES) {
+    if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES applies to fp32 contexts (compensated 16-bit operands under fp32 storage)");
+    if (value & ~SAMAUDIO_CLS_X3_CAPABLE)
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: only the six big GEMM classes of the DiT layers (qkv, wo, cwq, cwo, w13, w2)");
+    if (dit_ready_) SA_TRY(check_x3_weights(value));   // (before finalize(0): checked there)
+    if ((value != 0) != (x3_classes_ != 0)) prepared_ = false;   // the scratch operand is part of the workspace plan
+    x3_classes_ = value;
     return Status{};
   }
   if (option == SAMAUDIO_OPT_SENTINEL) {
@@ -551,10 +592,12 @@ static int cls_slot(int cls) {
   return bit;
 }
 
-Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, bool f32) {
+Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, int mode) {
+  const bool f32 = mode == 1, x3m = mode == 2;
+  const bool is16 = bf16_ || x3m;   // the launch's operand format (an X3 launch: 16-bit operands inside an fp32 context)
   if (sentinel_on_ && p_in.out_act && !p_in.c_ld_rel) {
     sentinel_on_ = false;   // (the launch itself, without recursion)
-    const Status s = gemm(p_in, st, alg_flops, cls, f32);
+    const Status s = gemm(p_in, st, alg_flops, cls, mode);
     sentinel_on_ = true;
     if (!s.ok()) return s;
     const int c = prof_cls_[0] == 'c' ? SAMAUDIO_CLS_CODEC : cls;
@@ -581,24 +624,24 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
     return op(gemm_variant_name(gemm_variant(p, false), false), gemm_alg_bytes(p, 4), flops, st,
               [&] { return launch_gemm(p, false, st); });
   }
-  if (!bf16_ && quant_fmt_ && (quant_classes_ & cls)) p.flags |= (quant_fmt_ << 2) | (quant_fmt_ << 4);
-  if (const char* why = gemm_check(p, bf16_)) return fail(SAMAUDIO_ERR_ARG, why);
+  if (!is16 && quant_fmt_ && (quant_classes_ & cls)) p.flags |= (quant_fmt_ << 2) | (quant_fmt_ << 4);
+  if (const char* why = gemm_check(p, is16)) return fail(SAMAUDIO_ERR_ARG, why);
   if (!prof_on_) {
-    SA_HIP(launch_gemm(p, bf16_, st));
+    SA_HIP(launch_gemm(p, is16, st));
     return Status{};
   }
   const double flops = alg_flops >= 0 ? alg_flops : 2.0 * p.M * (double)p.N * p.K * p.nbatch;
-  const double bytes = gemm_alg_bytes(p, esz_);
-  const int full = gemm_tail_split(p, bf16_);
+  const double bytes = gemm_alg_bytes(p, is16 ? 2 : 4);
+  const int full = gemm_tail_split(p, is16);
   const long tiles = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.nbatch;
   for (int part = 0; part < (full ? 2 : 1); ++part) {
     // a split launch (gemm.hip gemm_tail_split) is two kernels: each gets its own record, flops / bytes by tile share
     const double share = !full ? 1.0 : (part == 0 ? (double)full / tiles : 1.0 - (double)full / tiles);
     ProfRec r;
     // implicit convolutions (kc < K) run the 8-phase kernels under their own instantiation (gemm8_kernel<true>): own record
-    const int variant = gemm_variant(p, bf16_);
+    const int variant = gemm_variant(p, is16);
     const char* conv = (variant == 22 || variant == 27) && p.kc < p.K ? "_conv" : "";
-    r.key = std::string(prof_cls_) + "/" + (part ? "gemm8s_bf16_128x128_tail" : gemm_variant_name(variant, bf16_)) + conv;
+    r.key = std::string(prof_cls_) + "/" + (part ? "gemm8s_bf16_128x128_tail" : gemm_variant_name(variant, is16)) + conv + (x3m ? "_x3" : "");
     if (static const bool by_class = std::getenv("SAMAUDIO_PROF_BY_CLASS") != nullptr; by_class) {   // diagnosis: one record per GEMM class
       int bit = 0;
       while (bit < SAMAUDIO_CLS_COUNT && !(cls & (1 << bit))) ++bit;
@@ -609,12 +652,29 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
     SA_TRY(prof_event(&r.e0));
     SA_TRY(prof_event(&r.e1));
     SA_HIP(hipEventRecord(r.e0, st));
-    if (full) SA_HIP(launch_gemm_part(p, bf16_, part, st));
-    else SA_HIP(launch_gemm(p, bf16_, st));
+    if (full) SA_HIP(launch_gemm_part(p, is16, part, st));
+    else SA_HIP(launch_gemm(p, is16, st));
     SA_HIP(hipEventRecord(r.e1, st));
     prof_.push_back(r);
   }
   return Status{};
+}
+
+Status Engine::gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls) {
+  if (!w3 || !d_.x3a) return fail(SAMAUDIO_ERR_STATE, "SAMAUDIO_OPT_X3_CLASSES: split weight or scratch operand missing (set the option before samaudio_prepare)");
+  if (p.nbatch != 1 || p.kc != p.K || p.a_off || p.tap_stride || (p.out_act && p.out_f32))
+    return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: plain single-batch launches with one output only");
+  const int K = p.K;
+  // algorithmic bytes of the split: the fp32 row in, three 16-bit copies out
+  SA_TRY(op("split3", (double)p.M * K * (4 + 6), 0, st, [&] { return launch_split3((const float*)p.A, p.lda, d_.x3a, p.M, K, st); }));
+  p.A = d_.x3a; p.lda = 3L * K; p.K = 3 * K; p.kc = 3 * K; p.W = w3;
+  if (p.out_act) {   // an fp32 context's "activation" outputs are fp32 tensors: the 16-bit kernel writes them as its fp32 output
+    p.out_f32 = (float*)p.out_act; p.f32_ld = p.act_ld; p.f32_bstride = p.act_bstride; p.f32_off = p.act_off;
+    p.f32_act = p.act != ACT_NONE;
+    p.out_act = nullptr; p.act_ld = p.act_bstride = p.act_off = 0;
+  }
+  if (ktm) p.flags |= GEMM_FLAG_W_KTM;
+  return gemm(p, st, 2.0 * p.M * (double)p.N * K, cls, 2);   // flops as the reference counts them: one product over K
 }
 
 // One DAC residual unit: k7 convolution `p` (Snake'd bf16 intermediate) followed by the k1 convolution `q` on it
@@ -986,7 +1046,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       ktm(p, w, 0);
       prefetch(p, w.wo, (double)D * D);
       out_act(p, d_.qkv, 3L * D);
-      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_QKV));
+      if (x3(SAMAUDIO_CLS_QKV)) SA_TRY(gemm_x3(p, w.wqkv3, w.ktm3 & 1, st, SAMAUDIO_CLS_QKV));
+      else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_QKV));
     }
     SA_TRY(op("qkv_prep", 2 * 3 * MD * esz_, 0, st, [&] {
       return launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp, H,
@@ -1011,17 +1072,22 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       if (alt16(SAMAUDIO_CLS_CWQ)) p.flags |= 512;   // hbf is c_wq's operand
       ktm(p, w, 1);
       prefetch(p, w.c_wq, (double)D * D);
-      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
+      if (x3(SAMAUDIO_CLS_WO)) {   // (fp32 outputs only: c_wq then reads h itself)
+        p.out_act = nullptr; p.act_ld = 0;
+        SA_TRY(gemm_x3(p, w.wo3, w.ktm3 & 2, st, SAMAUDIO_CLS_WO));
+      } else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
     }
     trace("  h after wo", d_.h, (size_t)M * D, false, st);
     trace("  hbf", d_.hbf, (size_t)M * D, bf16_, st);
     // cross-attention branch: h = h + CA(h, y)   (no norm, no gate: quirk Q4)
     {
-      GemmParams p = lin(d_.hbf, D, w.c_wq, M, D, D);
+      // (an fp32 context whose wo ran on compensated operands has no second copy of h)
+      GemmParams p = lin(x3(SAMAUDIO_CLS_WO) ? (const void*)d_.h : d_.hbf, D, w.c_wq, M, D, D);
       ktm(p, w, 2);
       if (!fold_all) prefetch(p, w.c_wo, (double)D * D);   // (read by the per-layer fold kernel)
       out_act(p, d_.qc, D);
-      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWQ));
+      if (x3(SAMAUDIO_CLS_CWQ)) SA_TRY(gemm_x3(p, w.c_wq3, w.ktm3 & 4, st, SAMAUDIO_CLS_CWQ));
+      else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWQ));
     }
     const void* kv_l = (const char*)d_.kvc + (size_t)l * 2 * D * esz_;
     if (fold_ltp_) {
@@ -1051,7 +1117,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);
-      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
+      if (x3(SAMAUDIO_CLS_CWO)) SA_TRY(gemm_x3(p, w.c_wo3, w.ktm3 & 8, st, SAMAUDIO_CLS_CWO));
+      else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     }
     trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
     trace("  h after cross", d_.h, (size_t)M * D, false, st);
@@ -1071,7 +1138,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       if (alt16(SAMAUDIO_CLS_W2)) p.flags |= 512;    // u is w2's operand
       ktm(p, w, 3);
       prefetch(p, w.w2, (double)D * F);
-      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
+      if (x3(SAMAUDIO_CLS_W13)) SA_TRY(gemm_x3(p, w.w13_3, w.ktm3 & 16, st, SAMAUDIO_CLS_W13));
+      else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
       trace("  xn (ffn)", d_.xn, (size_t)M * D, bf16_, st);
       trace("  u", d_.u, (size_t)M * F, bf16_, st);
       p = lin(d_.u, F, w.w2, M, D, F);  // out = h + gate_mlp * ff
@@ -1080,7 +1148,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_f32(p, d_.h, D);
       ktm(p, w, 4);
       if (l + 1 < cfg_.n_layers) prefetch(p, layers_[l + 1].wqkv, 3.0 * D * D);
-      SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W2));
+      if (x3(SAMAUDIO_CLS_W2)) SA_TRY(gemm_x3(p, w.w2_3, w.ktm3 & 32, st, SAMAUDIO_CLS_W2));
+      else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W2));
       trace("  h after ffn", d_.h, (size_t)M * D, false, st);
     }
   }

@@ -165,6 +165,10 @@ hipError_t launch_anchor_gather(const float* emb, const long* ids, int n_ids, co
 hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_col0, void* out, long out_bstride,
                          bool bf16, int B, long T, int C_in, int C_out, int halo, hipStream_t st);
 
+// compensated 16-bit GEMM operand (SAMAUDIO_OPT_X3_CLASSES): x fp32 [M, K] (row stride ldx) -> out [M, 3K] in the library's 16-bit
+// format = [lo | hi | hi] per row, hi = rn16(x), lo = rn16(x - hi); K % 8 == 0
+hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hipStream_t st);
+
 // zero the halo rows of a [B][halo + T + halo][C] buffer
 hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t st);
 

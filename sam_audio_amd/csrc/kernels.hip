@@ -741,6 +741,52 @@ hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_co
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compensated 16-bit GEMM operands (SAMAUDIO_OPT_X3_CLASSES): an fp32 activation row x[K] becomes the
+// 16-bit row [lo | hi | hi] of 3K elements with hi = rn16(x), lo = rn16(x - hi), i.e. x = hi + lo to ~2^-22 relative.  Against a
+// weight row laid out [W_hi | W_lo | W_hi] one plain 16-bit GEMM over K' = 3K then accumulates, in fp32 and small terms first,
+// x_lo W_hi + x_hi W_lo + x_hi W_hi = x W - x_lo W_lo: the product of the fp32 operands to ~2^-21.  hi is clamped to the format's
+// largest finite value (IEEE half: 65504), so a value up to twice that still splits exactly instead of becoming inf - inf.
+// One thread = 8 consecutive elements: two 16-byte loads, three 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+#ifdef SA_OPERAND_FP16
+constexpr float kH16Max = 65504.f;
+#else
+constexpr float kH16Max = 3.3895313892515355e38f;
+#endif
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out,
+                                                     long chunks, int cpr, int K) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long)gridDim.x * 256) {
+    const long m = i / cpr;
+    const int c = (int)(i - m * cpr) * 8;
+    const float* src = x + m * ldx + c;
+    const float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v0 = v[2 * e], v1 = v[2 * e + 1];
+      hi[e] = pack_h16x2(fminf(fmaxf(v0, -kH16Max), kH16Max), fminf(fmaxf(v1, -kH16Max), kH16Max));
+      lo[e] = pack_h16x2(v0 - h16_lo(hi[e]), v1 - h16_hi(hi[e]));
+    }
+    bf16_t* dst = out + m * (3L * K) + c;
+    *(uint4*)dst = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    *(uint4*)(dst + K) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *(uint4*)(dst + 2L * K) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  }
+}
+
+hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hipStream_t st) {
+  if (K % 8 || ldx % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return hipErrorInvalidValue;
+  const int cpr = K / 8;
+  const long chunks = M * cpr;
+  long gx = (chunks + 255) / 256;
+  if (gx > 8192) gx = 8192;
+  hipLaunchKernelGGL(split3_kernel, dim3((unsigned)gx), dim3(256), 0, st, x, ldx, (bf16_t*)out, chunks, cpr, K);
+  return hipGetLastError();
+}
+
 template <typename TA>
 __global__ void zero_halo_kernel(TA* __restrict__ buf, long T, int C, int halo) {
   const int b = blockIdx.y;

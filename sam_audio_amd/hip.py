@@ -19,25 +19,46 @@ LIB_PATHS = {"bf16": LIB_PATH, "fp16": os.path.join(_HERE, "libsamaudio_hip_f16.
 F32, BF16 = 0, 1             # precision codes of the C ABI: fp32 parity mode | 16-bit GEMM operands (bf16 or fp16 by library)
 DT_F32, DT_BF16, DT_I64, DT_U8 = 0, 1, 2, 3   # DT_BF16 = "the library's 16-bit operand format"
 PRECISIONS = ("bf16", "fp16", "mixed", "fp32")
+# COMPENSATED 16-bit operands under fp32 storage (SAMAudio only; samaudio.h SAMAUDIO_OPT_X3_CLASSES): an fp32 engine context whose six
+# big GEMM classes multiply hi/lo-split operands on the 16-bit MFMA - "fp16x3" in libsamaudio_hip_f16.so (22 mantissa bits per
+# operand: the mode that holds the 1e-3 parity bound on trained-like weights), "bf16x3" the same mechanism on
+# bfloat16 halves in libsamaudio_hip.so (16 bits; what the CPU simulator build exercises).
+X3_PRECISIONS = ("fp16x3", "bf16x3")
 
 
-def check_precision(precision: str) -> None:
-    if precision not in PRECISIONS:
-        raise ValueError("precision must be 'bf16', 'fp16', 'mixed' or 'fp32'")
+def check_precision(precision: str, x3_ok: bool = False) -> None:
+    if precision not in PRECISIONS + (X3_PRECISIONS if x3_ok else ()):
+        raise ValueError("precision must be 'bf16', 'fp16', 'mixed' or 'fp32'" + (", 'fp16x3' or 'bf16x3'" if x3_ok else ""))
+
+
+def is_x3(precision: str) -> bool:
+    return precision in X3_PRECISIONS
+
+
+def storage_precision(precision: str) -> str:
+    """The precision of everything that is not a compensated GEMM (and of the towers beside the DiT): fp32 for the x3 modes."""
+    return "fp32" if is_x3(precision) else precision
 
 
 def precision_code(precision: str) -> int:
-    return F32 if precision == "fp32" else BF16
+    return F32 if storage_precision(precision) == "fp32" else BF16
 
 
 def operands_for(precision: str) -> str:
     """Which build of the library a host object of this precision talks to (fp32 mode lives in both; use the default)."""
-    return "fp16" if precision in ("fp16", "mixed") else "bf16"
+    return "fp16" if precision in ("fp16", "mixed", "fp16x3") else "bf16"
 
 
 def act_dtype(precision: str):
     import torch
-    return {"bf16": torch.bfloat16, "fp16": torch.float16, "mixed": torch.float16, "fp32": torch.float32}[precision]
+    return {"bf16": torch.bfloat16, "fp16": torch.float16, "mixed": torch.float16, "fp32": torch.float32,
+            "fp16x3": torch.float32, "bf16x3": torch.float32}[precision]
+
+
+def half_dtype(precision: str):
+    """the 16-bit format of the hi / lo halves of an x3 precision"""
+    import torch
+    return torch.float16 if operands_for(precision) == "fp16" else torch.bfloat16
 
 
 def dtype_code(dtype, operands: Optional[str] = None, alt_ok: bool = False) -> int:
@@ -53,6 +74,7 @@ def dtype_code(dtype, operands: Optional[str] = None, alt_ok: bool = False) -> i
 ODE_EULER, ODE_MIDPOINT = 0, 1
 OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES, OPT_PREFETCH_ROWS, OPT_SENTINEL = 1, 2, 3, 4, 5, 6, 7
 OPT_ODE_GRAPH = 8
+OPT_X3_CLASSES = 9
 SENTINEL_SLOTS = 16
 # GEMM classes of the DiT / codec (samaudio.h SAMAUDIO_CLS_*), in bit order
 CLASSES = ("time", "out", "in", "prep", "yemb", "ckv", "patch", "qkv", "wo", "cwq", "cwo", "w13", "w2", "codec")
@@ -67,6 +89,9 @@ CLS_F32_DEFAULT = CLS["out"] | CLS["in"] | CLS["prep"]
 # read bfloat16 operands inside the fp16 build; everything else stays fp16 (samaudio.h SAMAUDIO_OPT_ALT16_CLASSES)
 CLS_ALT16_MIXED = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["w13"] | CLS["w2"]
 ALT16_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "w13": "w13", "w2": "w2"}   # engine tensor L<i>.<name> -> class
+# the six big GEMM classes of the DiT layers (97 % of the flops) and the engine weight each reads
+CLS_X3_DEFAULT = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["cwo"] | CLS["w13"] | CLS["w2"]
+X3_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "c_wo": "cwo", "w13": "w13", "w2": "w2"}
 QUANT_FORMATS = {"bf16": 1, "fp16": 2}
 SENTINEL_NAMES = CLASSES + ("norm", "attn")
 
@@ -231,6 +256,7 @@ _PROTOS = {
     "samaudio_op_masked_groupnorm_silu": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     "samaudio_op_layernorm_rows": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 4 + [C.c_int, C.c_int64, C.c_int,
                                                                                           C.c_float, C.c_void_p]),
+    "samaudio_op_split3": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "samaudio_judge_create": (C.c_int, [C.POINTER(JudgeConfig), C.POINTER(C.c_void_p)]),
     "samaudio_judge_destroy": (None, [C.c_void_p]),
     "samaudio_judge_set_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64)]),

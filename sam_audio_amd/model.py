@@ -20,7 +20,7 @@ import torch
 from . import hip
 from .config import SAMAudioConfig
 from .processor import Batch
-from .weights import F32_SOURCE_KEYS, convert_codec, convert_dit, convert_dit_f32, split_missing_unexpected
+from .weights import F32_SOURCE_KEYS, convert_codec, convert_dit, convert_dit_f32, convert_dit_x3, split_missing_unexpected
 
 DFLT_ODE_OPT = {"method": "midpoint", "options": {"step_size": 2 / 32}}  # reference model.py:22
 # Layout of the five big DiT weight matrices and the next-weights prefetch of few-row launches (SAMAudio.__init__; DESIGN.md
@@ -85,7 +85,8 @@ class SAMAudio:
 
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
                  text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto",
-                 weight_layout: str = "auto", prefetch_rows: Optional[int] = None, ode_graph: Optional[bool] = None):
+                 weight_layout: str = "auto", prefetch_rows: Optional[int] = None, ode_graph: Optional[bool] = None,
+                 x3_classes="auto"):
         """`ode_graph`: replay the launches of a solve as a HIP graph from the third solve of a shape on (samaudio.h
         SAMAUDIO_OPT_ODE_GRAPH; None = environment SAMAUDIO_ODE_GRAPH, default off).  Scheduling only.
         `weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
@@ -98,9 +99,14 @@ class SAMAudio:
         state and the hoisted conditioning, which carry most of a 16-bit mode's error for < 1 % of a step; "time" and
         "yemb" can be added - DESIGN.md section 4)."""
         cfg.check_supported()
-        hip.check_precision(precision)
+        hip.check_precision(precision, x3_ok=True)
         self.cfg = cfg
         self.precision = precision
+        # precision "fp16x3" (and "bf16x3"): fp32 storage and fp32 small classes, the six big GEMM classes of the layers on
+        # compensated 16-bit operands (samaudio.h SAMAUDIO_OPT_X3_CLASSES; `x3_classes`: names or a mask, "auto" = all six)
+        self.x3_classes = 0 if not hip.is_x3(precision) else (
+            hip.CLS_X3_DEFAULT if x3_classes == "auto" else hip.class_mask(x3_classes))
+        precision = hip.storage_precision(precision)   # what everything below means by "fp32"
         self.f32_classes = 0 if precision == "fp32" else (
             hip.CLS_F32_DEFAULT if f32_classes == "auto" else hip.class_mask(f32_classes))
         self.quant_classes, self.quant_format = 0, 0   # fp32 engines: operand-rounding emulation (error budget)
@@ -128,7 +134,7 @@ class SAMAudio:
         self.span_predictor_transform = None
         self.vision_encoder = None            # callable: list of [T,3,H,W] videos -> [B, T, vision_encoder.dim]
         self.fix_span_order = False           # quirk Q13, see separate()
-        self._lib = hip.lib(hip.operands_for(precision))   # raises if the HIP library is not built
+        self._lib = hip.lib(hip.operands_for(self.precision))   # raises if the HIP library is not built
         self._ctx = C.c_void_p()
         self._tensors: Dict[str, torch.Tensor] = {}
         self._workspace: Optional[torch.Tensor] = None
@@ -149,7 +155,7 @@ class SAMAudio:
         self._sentinel = False
         t, c = cfg.transformer, cfg.audio_codec
         hc = hip.Config(
-            precision=hip.precision_code(precision), dim=t.dim, n_heads=t.n_heads,
+            precision=hip.precision_code(self.precision), dim=t.dim, n_heads=t.n_heads,
             n_layers=t.n_layers, ffn_hidden=t.ffn_hidden, latent_channels=t.out_channels,
             text_dim=cfg.text_encoder.dim, video_dim=cfg.vision_encoder.dim, freq_dim=t.frequency_embedding_dim,
             anchor_dim=cfg.anchor_embedding_dim, anchor_vocab=cfg.num_anchors + 1, max_positions=t.max_positions,
@@ -211,7 +217,7 @@ class SAMAudio:
         except FileNotFoundError as exc:
             warnings.warn(f"text encoder not attached ({exc}); pass text_features / text_mask to the processor or set "
                           "model.text_encoder")
-        model.attach_rankers(precision=precision)
+        model.attach_rankers(precision=hip.storage_precision(precision))
         return model
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
@@ -230,7 +236,8 @@ class SAMAudio:
             # reference model.py:83: SAMAudio owns `PerceptionEncoder(cfg.vision_encoder)`; build it when the checkpoint
             # really carries the PE-Core tower (a text-only deployment pays nothing for it)
             from .vision_encoder import PerceptionEncoder
-            self.vision_encoder = PerceptionEncoder(self.cfg.vision_encoder, device=self.device, precision=self.precision)
+            self.vision_encoder = PerceptionEncoder(self.cfg.vision_encoder, device=self.device,
+                                                    precision=hip.storage_precision(self.precision))
         if vis and hasattr(self.vision_encoder, "load_state_dict"):
             # The tower's key list is restated from the published PE-Core architecture (perception_models is not
             # importable offline), so it is validated for what the engine NEEDS, not for what a genuine checkpoint may carry
@@ -248,8 +255,12 @@ class SAMAudio:
             # weight sets as not finalized, so each set the model has is finalized again afterwards
             if not dit_missing:
                 alt = [leaf for leaf, c in hip.ALT16_WEIGHTS.items() if self.alt16_classes & hip.CLS[c]]
-                self._register(convert_dit(state_dict, self.cfg, self.act_dtype, self.device, alt16_leaves=alt,
-                                           f32_classes=self.f32_classes, ktm=self.weight_layout == "ktm"))
+                dit = convert_dit(state_dict, self.cfg, self.act_dtype, self.device, alt16_leaves=alt,
+                                  f32_classes=self.f32_classes, ktm=self.weight_layout == "ktm")
+                self._register(dit)
+                if self.x3_classes:
+                    self._register(convert_dit_x3(dit, self.cfg.transformer.n_layers, hip.half_dtype(self.precision),
+                                                  self.x3_classes))
                 # fp32 operand copies exist for the classes that run in fp32 now; set_f32_classes adds a class's later
                 # from these references to the checkpoint entries (no copy is made here)
                 self._f32_have = self.f32_classes
@@ -272,7 +283,7 @@ class SAMAudio:
 
     def _set_precision_options(self, ctx) -> None:
         hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ODE_GRAPH, int(self.ode_graph)))
-        if self.precision != "fp32":
+        if hip.storage_precision(self.precision) != "fp32":
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_F32_CLASSES, self.f32_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ALT16_CLASSES, self.alt16_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_PREFETCH_ROWS, self.prefetch_rows))
@@ -280,10 +291,11 @@ class SAMAudio:
         else:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_CLASSES, self.quant_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_QUANT_FORMAT, self.quant_format))
+            hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_X3_CLASSES, self.x3_classes))
 
     def set_f32_classes(self, classes) -> None:
         """Switch the exact-fp32 GEMM classes of a 16-bit model (see __init__); takes effect from the next call."""
-        self.f32_classes = 0 if self.precision == "fp32" else hip.class_mask(classes)
+        self.f32_classes = 0 if hip.storage_precision(self.precision) == "fp32" else hip.class_mask(classes)
         need = self.f32_classes & ~self._f32_have
         if need and self._has_dit:   # the classes switched on for the first time: their "<name>.f32" operand copies
             with torch.cuda.device(self.device):
@@ -302,7 +314,7 @@ class SAMAudio:
     def set_quantised_classes(self, classes, fmt: str = "bf16") -> None:
         """fp32 models only - measurement aid: the GEMMs of `classes` round both operands to `fmt` ("bf16" | "fp16")
         before multiplying, everything else stays exact (samaudio.h SAMAUDIO_OPT_QUANT_CLASSES)."""
-        if self.precision != "fp32":
+        if hip.storage_precision(self.precision) != "fp32":
             raise ValueError("operand-rounding emulation needs precision='fp32'")
         self.quant_classes, self.quant_format = hip.class_mask(classes), hip.QUANT_FORMATS[fmt]
         for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:

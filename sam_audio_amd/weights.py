@@ -67,6 +67,20 @@ def ktm_to_rows(w: torch.Tensor) -> torch.Tensor:
     return w.permute(1, 0, 2).reshape(n, kt * s).contiguous()
 
 
+def x3_weight(w: torch.Tensor, half: torch.dtype, ktm: bool = True) -> torch.Tensor:
+    """fp32 [N, K] -> the split operand [W_hi | W_lo | W_hi] of a compensated 16-bit GEMM (include/samaudio.h
+    SAMAUDIO_OPT_X3_CLASSES): W_hi = rn16(W), W_lo = rn16(W - W_hi), so W = W_hi + W_lo to ~2^-22 (IEEE half) and the activation
+    row [x_lo | x_hi | x_hi] gives x_lo W_hi + x_hi W_lo + x_hi W_hi in one pass over K' = 3K.  [N, 3K] row-major, or K-tile-major
+    [3K/64, N, 64] (`ktm`, as ktm_layout)."""
+    w = w.float()
+    hi = w.to(half)
+    if half == torch.float16:   # a weight beyond the format's range would split into inf - inf
+        hi = w.clamp(-65504.0, 65504.0).to(half)
+    lo = (w - hi.float()).to(half)
+    w3 = torch.cat([hi, lo, hi], dim=1).contiguous()
+    return ktm_layout(w3) if ktm else w3
+
+
 def _pad_k(w: torch.Tensor, slab: int) -> torch.Tensor:
     n, k = w.shape
     kp = (k + slab - 1) // slab * slab
@@ -130,6 +144,19 @@ def convert_dit_f32(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, device, cl
     from . import hip
     return {name + ".f32": make().contiguous() for name, make in _f32_capable_sources(sd, cfg, device).items()
             if classes & hip.CLS[_F32_WEIGHT_CLASS[name]]}
+
+
+def convert_dit_x3(tensors: Dict[str, torch.Tensor], n_layers: int, half: torch.dtype, classes: int,
+                   ktm: bool = True) -> Dict[str, torch.Tensor]:
+    """The "<name>.x3" split weights of the classes in the mask `classes` (hip.CLS bits of hip.X3_WEIGHTS), made from the fp32
+    engine tensors `tensors` (convert_dit's output for act_dtype float32: the row permutations and interleaves are already in)."""
+    from . import hip
+    out: Dict[str, torch.Tensor] = {}
+    for i in range(n_layers):
+        for leaf, cls in hip.X3_WEIGHTS.items():
+            if classes & hip.CLS[cls]:
+                out[f"L{i}.{leaf}.x3"] = x3_weight(tensors[f"L{i}.{leaf}"], half, ktm)
+    return out
 
 
 def convert_dit(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: torch.dtype,

@@ -1,0 +1,170 @@
+"""Compensated 16-bit GEMM operands: precision "fp16x3" / "bf16x3" (include/samaudio.h SAMAUDIO_OPT_X3_CLASSES).
+
+The reference computes separate() in fp32 (README.md:48).  No plain 16-bit operand format holds the north_star's 1e-3 max-abs on
+trained-like weight statistics (tests/test_hostile_gpu.py); the x3 modes keep fp32 storage and run the six big GEMM classes of
+the DiT layers (reference transformer.py:121-161,195-206,354-391) on hi/lo-split operands: one 16-bit MFMA GEMM over K' = 3K.
+Here: the split kernel, the GEMM identity through the C ABI (incl. halves that are SUBNORMAL in IEEE half: the MFMA must not flush
+them), and the full path against the CPU oracle.  On the CPU simulator (SAMAUDIO_EMU_DRYRUN=simt: bfloat16 library only) the
+bf16x3 form exercises the same kernels, layouts and engine plumbing.
+"""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from oracle import samaudio_oracle as O
+from sam_audio_amd import SAMAudio, SAMAudioProcessor, hip, preset_config
+from sam_audio_amd.synthetic import init_state_dict, make_hostile, synthetic_clip, synthetic_noise, synthetic_text_features
+from sam_audio_amd.weights import ktm_to_rows, x3_weight
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SIM = os.environ.get("SAMAUDIO_EMU_DRYRUN", "") != ""
+X3 = ["bf16x3"] if SIM else ["fp16x3", "bf16x3"]
+HALF = {"fp16x3": torch.float16, "bf16x3": torch.bfloat16}
+PLAIN = {"fp16x3": "fp16", "bf16x3": "bf16"}   # the plain 16-bit mode of the same library
+
+
+def _split3(x, prec, gpu):
+    M, K = x.shape
+    out = torch.empty(M, 3 * K, dtype=HALF[prec], device=gpu)
+    xd = x.to(gpu).contiguous()
+    hip.check(hip.lib(hip.operands_for(prec)).samaudio_op_split3(hip.ptr(xd), K, hip.ptr(out), M, K, util.stream()))
+    return out
+
+
+@pytest.mark.parametrize("prec", X3)
+def test_split3_writes_lo_hi_hi(gpu, prec):
+    g = torch.Generator().manual_seed(1)
+    M, K = 37, 192
+    x = torch.randn(M, K, generator=g) * torch.logspace(-6, 3, K)[None, :]   # 1e-6 .. 1e3: lo halves from subnormal to large
+    x[0, :8] = torch.tensor([0.0, -0.0, 65504.0, 7e4, -1.2e5, 6e-8, 1.0, -3.3333333])
+    half = HALF[prec]
+    out = _split3(x, prec, gpu).cpu()
+    hi_ref = (x.clamp(-65504.0, 65504.0) if half == torch.float16 else x).to(half)
+    lo_ref = (x - hi_ref.float()).to(half)
+    assert torch.equal(out[:, K:2 * K], hi_ref) and torch.equal(out[:, 2 * K:], hi_ref), "hi halves"
+    assert torch.equal(out[:, :K], lo_ref), "lo half"
+    # what the pair represents: x to ~2^-22 (IEEE half; coarser only where lo itself is subnormal) / 2^-17 (bfloat16)
+    rel = ((out[:, :K].float() + out[:, K:2 * K].float() - x).abs() / x.abs().clamp_min(1e-3)).max().item()
+    print(f"split3 {prec}: max relative |hi + lo - x| = {rel:.3e}")
+    assert rel < (2.0 ** -21 if half == torch.float16 else 2.0 ** -15)
+
+
+@pytest.mark.parametrize("prec", X3)
+@pytest.mark.parametrize("shape", [(300, 256, 128), (130, 512, 448)])
+def test_x3_gemm_is_the_fp32_product(gpu, prec, shape):
+    """[x_lo | x_hi | x_hi] . [W_hi | W_lo | W_hi]^T through the library's 16-bit GEMM, both weight layouts, against the fp64 product
+    of the fp32 operands - and against what the plain 16-bit operands give.  Column scales put many lo halves into IEEE half's
+    SUBNORMAL range (|lo| < 6.1e-5): a matrix core that flushed them would lose the compensation."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-2, 1, K)[None, :]
+    w = torch.randn(N, K, generator=g) * 0.05
+    ref = (x.double() @ w.double().T).float()
+    half = HALF[prec]
+    plain = (x.to(half).double() @ w.to(half).double().T).float()
+    a3 = _split3(x, prec, gpu)
+    errs = {}
+    for ktm in (False, True):
+        w3 = x3_weight(w, half, ktm=ktm).to(gpu)
+        if ktm:
+            assert torch.equal(ktm_to_rows(w3.cpu()), x3_weight(w, half, ktm=False))
+        out = torch.full((M, N), float("nan"), device=gpu)
+        util.gemm(PLAIN[prec], a3, w3, M, N, 3 * K, out_f32=out, f32_geom=(0, N, 0), flags=2048 if ktm else 0)
+        errs[ktm] = (out.cpu() - ref).abs().max().item()
+    e_plain = (plain - ref).abs().max().item()
+    print(f"x3 GEMM {prec} {shape}: max-abs err rows {errs[False]:.3e} / ktm {errs[True]:.3e}; plain 16-bit operands {e_plain:.3e}; "
+          f"|ref| <= {ref.abs().max():.2f}")
+    assert errs[False] == errs[True], "the two weight layouts accumulate in the same order"
+    assert errs[True] < e_plain / (200 if half == torch.float16 else 20)
+    assert errs[True] < 2e-5 * ref.abs().max().item() if half == torch.float16 else True
+
+
+@pytest.mark.parametrize("prec", X3)
+def test_separate_x3_matches_oracle(gpu, prec):
+    """Full path at 'mini' dims (ragged text mask, anchors): the x3 mode must sit with the fp32 mode, far inside 1e-3, where the
+    plain 16-bit mode of the same library does not."""
+    cfg = preset_config("mini")
+    sd = init_state_dict(cfg, seed=8)
+    hop = cfg.audio_codec.hop_length
+    T = 12 if SIM else 25
+    clips = [synthetic_clip(i, T * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 8, ragged=True)
+    anchors = [[("+", 0.04, 0.12)], [("-", 0.0, 0.08), ("+", 0.08, 0.16)]]
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["x", "y"], audios=clips, anchors=anchors, text_features=text,
+                                               text_mask=tmask)
+    noise = synthetic_noise(2, T)
+    steps = 2 if SIM else 16
+    opt = {"method": "midpoint", "options": {"step_size": 1.0 / steps}}
+    with torch.inference_mode():
+        t_ref, r_ref, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise, anchors=anchors,
+                                           step_size=1.0 / steps)
+    errs = {}
+    for p in (prec, PLAIN[prec]):
+        model = SAMAudio(cfg, precision=p, device=str(gpu))
+        model.load_state_dict(sd, strict=False)
+        res = model.separate(batch.to(gpu), noise=noise.to(gpu), ode_opt=opt)
+        lat = (model.last_latent.cpu() - lat_ref).abs().max().item()
+        wav = max((a.cpu() - b).abs().max().item() for a, b in zip(res.target + res.residual, t_ref + r_ref))
+        errs[p] = (lat, wav)
+    print(f"separate 'mini' {steps} midpoint steps: {prec} latent {errs[prec][0]:.3e} wave {errs[prec][1]:.3e}; "
+          f"{PLAIN[prec]} latent {errs[PLAIN[prec]][0]:.3e} wave {errs[PLAIN[prec]][1]:.3e} (|latent| <= {lat_ref.abs().max():.2f})")
+    tol = 1e-3 if prec == "fp16x3" else 2e-3   # bfloat16 halves: 16 mantissa bits per operand
+    assert errs[prec][0] < tol and errs[prec][1] < tol
+    assert errs[prec][0] < errs[PLAIN[prec]][0] / 4
+
+
+@pytest.mark.parametrize("prec", X3)
+def test_x3_classes_can_be_switched_per_class_and_need_their_weights(gpu, prec):
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=3)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 6 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, 4)
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["a", "b"], audios=clips, text_features=text, text_mask=tmask)
+    noise = synthetic_noise(2, 6)
+    opt = {"method": "euler", "options": {"step_size": 0.5}}
+    with torch.inference_mode():
+        _, _, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise, method="euler", step_size=0.5,
+                                   decode=False)
+    lats = {}
+    for classes in ("auto", "w13,w2", "qkv,wo,cwq,cwo"):
+        model = SAMAudio(cfg, precision=prec, device=str(gpu), x3_classes=classes)
+        model.load_state_dict(sd, strict=False)
+        model.separate(batch.to(gpu), noise=noise.to(gpu), ode_opt=opt)
+        lats[classes] = model.last_latent.cpu()
+        assert (lats[classes] - lat_ref).abs().max().item() < 1e-3
+    assert not torch.equal(lats["auto"], lats["w13,w2"])   # the masks really select different kernels
+    # a class without its split weights is refused with the tensor's name (RuntimeError = SAMAUDIO_ERR_WEIGHT)
+    model = SAMAudio(cfg, precision=prec, device=str(gpu), x3_classes="w2")
+    model.load_state_dict(sd, strict=False)
+    model.x3_classes = hip.CLS_X3_DEFAULT
+    with pytest.raises(RuntimeError, match=r"\.x3"):
+        model._set_precision_options(model._ctx)
+
+
+@pytest.mark.skipif(SIM, reason="10 s clips at small* dims: hardware only")
+def test_x3_holds_the_bound_on_hostile_weights_where_fp16_does_not(gpu):
+    """tests/test_hostile_gpu.py's configuration (trained-like statistics, separate() as timed) - the parity gate of the headline mode."""
+    size = os.environ.get("SAMAUDIO_HOSTILE_SIZE", "small*")
+    cfg = preset_config(size)
+    sd = make_hostile(init_state_dict(cfg, seed=0, device=gpu), cfg, seed=0)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    R = 2
+    n = 10 * cfg.audio_codec.sample_rate // cfg.audio_codec.hop_length * cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, n) for i in range(R)]
+    text, tmask = synthetic_text_features(R, 8, seed=7)
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["sound"] * R, audios=clips, text_features=text, text_mask=tmask)
+    noise = synthetic_noise(R, n // cfg.audio_codec.hop_length)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    with torch.inference_mode():
+        t_ref, r_ref, lat_ref = O.separate(sd_cpu, cfg, batch.audios, batch.sizes.long(), text, tmask, noise)
+    model = SAMAudio(cfg, precision="fp16x3", device=str(gpu))
+    model.load_state_dict(sd, strict=False)
+    res = model.separate(batch.to(gpu), noise=noise.to(gpu))
+    lat = (model.last_latent.cpu() - lat_ref).abs().max().item()
+    wav = max((a.cpu() - b).abs().max().item() for a, b in zip(res.target + res.residual, t_ref + r_ref))
+    print(f"hostile {size} fp16x3: latent max-abs err {lat:.3e} (|ref| <= {lat_ref.abs().max():.2f}), waveform {wav:.3e}")
+    assert lat <= 1e-3 and wav <= 1e-3
