@@ -135,8 +135,11 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   and the weight row [W_hi | W_lo | W_hi], so that ONE launch of the library's 16-bit GEMM over K' = 3K accumulates
  *   x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32 - the fp32 product to ~2^-21 relative for three times the MFMA work.  Needs the
  *   class's weights registered in that split form under "<name>.x3" - 16-bit, [N, 3K] row-major or [3K/64, N, 64] K-tile-major
- *   (sam_audio_amd/weights.py x3_weight) - for L<i>.wqkv, wo, c_wq, c_wo, w13, w2; checked like the ".f32" copies above.
- *   Everything else of the context (norms, attention, the small GEMM classes, the codec) stays exact fp32.  In
+ *   (sam_audio_amd/weights.py x3_weight) - for L<i>.wqkv, wo, c_wq, c_wo, w13, w2; checked like the ".f32" copies above.  Classes
+ *   PATCH (the patcher's k3 convolutions: "patch1.w.x3" / "patch2.w.x3", [D, 9D] with EACH tap's D columns split into 3D) and CKV
+ *   ("c_wkv_all.x3") can be switched on as well.
+ *   Bit SAMAUDIO_X3_ATTENTION does the same for the two contractions of the self-attention.  Everything else of the context
+ *   (norms, softmax, the small GEMM classes, the codec) stays exact fp32.  In
  *   libsamaudio_hip_f16.so the halves are IEEE fp16 (22 mantissa bits per operand); in libsamaudio_hip.so bfloat16 (16 bits). */
 #define SAMAUDIO_OPT_X3_CLASSES 9
 #define SAMAUDIO_SENTINEL_SLOTS 16   /* SAMAUDIO_CLS_COUNT GEMM classes (bit order) + slot 14: RMSNorm outputs, 15: attention outputs */
@@ -156,7 +159,12 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
 #define SAMAUDIO_CLS_W2 (1 << 12)
 #define SAMAUDIO_CLS_CODEC (1 << 13) /* every DAC-VAE convolution */
 #define SAMAUDIO_CLS_COUNT 14
-#define SAMAUDIO_CLS_X3_CAPABLE (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_CWO | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2)
+/* SAMAUDIO_OPT_X3_CLASSES only (not a GEMM class): the self-attention of an fp32 context on hi/lo-split operands on the 16-bit MFMA
+ * (S = Ql Kh + Qh Kl + Qh Kh, O likewise) instead of the fp32 vector-ALU kernel; fp32 tensors in and out */
+#define SAMAUDIO_X3_ATTENTION (1 << 14)
+#define SAMAUDIO_CLS_X3_CAPABLE \
+  (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_CWO | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2 | SAMAUDIO_CLS_PATCH | \
+   SAMAUDIO_CLS_CKV | SAMAUDIO_X3_ATTENTION)
 #define SAMAUDIO_CLS_F32_CAPABLE (SAMAUDIO_CLS_TIME | SAMAUDIO_CLS_OUT | SAMAUDIO_CLS_IN | SAMAUDIO_CLS_PREP | SAMAUDIO_CLS_YEMB)
 int samaudio_set_option(samaudio_ctx* ctx, int option, int value);
 

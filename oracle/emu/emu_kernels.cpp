@@ -121,6 +121,14 @@ static void gemm_t(const GemmParams& p) {
         else if (p.act == ACT_TANH) a = std::tanh(v);
         else if (p.act == ACT_SILU) a = silu_h(v);
         if (p.out_f32) p.out_f32[p.f32_off + (long)b * p.f32_bstride + (long)m * p.f32_ld + n] = p.f32_act ? a : v;
+        if (p.out_act && (p.flags & GEMM_FLAG_OUT_SPLIT3)) {   // [lo | hi | hi] rows of 3 n_out elements (common.h)
+          T* row = (T*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)m * p.act_ld;
+          T hi;
+          HE<T>::st(&hi, a);
+          HE<T>::st(row + n, a - HE<T>::ld(&hi));
+          row[n_out + n] = hi;
+          row[2 * n_out + n] = hi;
+        } else
         if (p.out_act) HE<T>::st((T*)p.out_act + p.act_off + (long)b * p.act_bstride + (long)m * p.act_ld + n, a);
       }
     }
@@ -165,6 +173,14 @@ hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec,
       }
     }
   return hipSuccess;
+}
+hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
+                             float eps, hipStream_t, bool);
+hipError_t launch_rmsnorm_gs_split3(const float* x, const float* gs, long gs_ld, void* out, int M, int D, int rows_per_b, float eps,
+                                    hipStream_t st) {
+  std::vector<float> tmp((size_t)M * D);
+  launch_rmsnorm_gs(x, gs, gs_ld, tmp.data(), false, M, D, rows_per_b, eps, st, false);
+  return launch_split3(tmp.data(), D, out, M, D, st);
 }
 hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
                              float eps, hipStream_t, bool) {
@@ -315,6 +331,18 @@ static void self_attn_t(const TA* Q, const TA* K, const TA* Vt, const unsigned c
         }
       }
     }
+}
+hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hipStream_t);
+hipError_t launch_self_attention_x3(const float* Q, const float* K, const float* Vt, const unsigned char* key_mask, float* out, int B,
+                                    int T, int Tp, int H, int head_dim, hipStream_t st, void* out3) {   // fp32 tensors: the emulation is the fp32 product
+  if (head_dim != 128) return hipErrorInvalidValue;
+  if (!out3) {
+    self_attn_t<float>(Q, K, Vt, key_mask, out, B, T, Tp, H);
+    return hipSuccess;
+  }
+  std::vector<float> tmp((size_t)B * T * H * 128);
+  self_attn_t<float>(Q, K, Vt, key_mask, tmp.data(), B, T, Tp, H);
+  return launch_split3(tmp.data(), (long)H * 128, out3, (long)B * T, H * 128, st);
 }
 hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask, void* out,
                                     bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st, bool alt) {

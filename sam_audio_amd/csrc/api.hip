@@ -213,6 +213,9 @@ int samaudio_op_self_attention(const void* q, const void* k, const void* vt, con
                                int precision, int batch, int frames, int frames_padded, int heads,
                                samaudio_stream stream) {
   if (frames_padded % 64 || frames_padded < frames) return bad("self_attention: frames_padded");
+  if (precision == 2)   // fp32 tensors, both contractions on hi/lo-split operands (SAMAUDIO_X3_ATTENTION)
+    return hip_ret(sa::launch_self_attention_x3((const float*)q, (const float*)k, (const float*)vt, key_mask, (float*)out, batch, frames,
+                                                frames_padded, heads, 128, (hipStream_t)stream), "self_attention_x3");
   return hip_ret(sa::launch_self_attention(q, k, vt, key_mask, out, precision == SAMAUDIO_BF16, batch, frames,
                                            frames_padded, heads, (hipStream_t)stream), "self_attention");
 }

@@ -270,6 +270,217 @@ __global__ __launch_bounds__(256) void self_attn_f32_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Compensated MFMA self-attention of an fp32 context (SAMAUDIO_OPT_X3_CLASSES bit SAMAUDIO_X3_ATTENTION; reference
+// transformer.py:153-160).  fp32 Q, K [B,H,Tp,HD] and V^T [B,H,HD,Tp] in, fp32 context rows out, as self_attn_f32_kernel - but
+// both contractions run on the 16-bit MFMA over hi/lo-split operands (x = rn16(x) + rn16(x - rn16(x)), split on the way into
+// LDS / registers):  S = Ql Kh + Qh Kl + Qh Kh,  O = Pl Vh + Ph Vl + Ph Vh  - each the fp32 product to ~2^-21 (IEEE half), small
+// terms first, fp32 accumulation; softmax statistics in fp32 as in the 16-bit kernel.  The VALU kernel it replaces ran at 18 TF/s
+// (810 ms of a 5.7 s step at 32 clips, profiles/r6_call1/).  Tiling = self_attn_bf16_kernel: NW waves x 16 query rows, keys in tiles
+// of 64; LDS = hi + lo images of the K tile and of the V^T tile (4 x 16 KiB at HD 128) + per-wave P tiles.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
+#pragma clang fp contract(off)
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = pack_h16x2(v[2 * e], v[2 * e + 1]);
+    l[e] = pack_h16x2(v[2 * e] - h16_lo(h[e]), v[2 * e + 1] - h16_hi(h[e]));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// OUT3: the context rows leave as the NEXT GEMM's compensated operand, out3 [B*T, 3 D] 16-bit = [lo | hi | hi] (wo on split operands),
+// instead of fp32 rows
+template <int NW, int HD, bool OUT3 = false>
+__global__ __launch_bounds__(NW * 64) void self_attn_x3_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                               const float* __restrict__ Vt,
+                                                               const unsigned char* __restrict__ key_mask,
+                                                               float* __restrict__ out, bf16_t* __restrict__ out3, int T, int Tp, int H) {
+  constexpr int CH = HD / 8;       // 8-element chunks per K row
+  constexpr int KS = HD / 32;      // k-steps of S = Q K^T
+  constexpr int NF = HD / 16;      // output fragments
+  constexpr int KB = 64 * HD * 2;  // bytes of one K-tile image; a V^T-tile image is HD * 128 = the same
+  __shared__ __attribute__((aligned(16))) char Ks[2 * KB];            // [hi | lo][key][HD d], chunk ^= key & (CH - 1)
+  __shared__ __attribute__((aligned(16))) char Vs[2 * KB];            // [hi | lo][d][64 keys], chunk ^= (d >> 1) & 7
+  __shared__ __attribute__((aligned(16))) char Ps[2 * NW * 16 * 128];  // [hi | lo] per wave [16 q][64 keys]
+  constexpr int MAXT = 2048;
+  __shared__ unsigned char Ms[MAXT];
+  const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qb * (16 * NW);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const long bh = (long)b * H + h;
+  const float scale = HD == 128 ? 0.08838834764831845f : 0.125f;
+
+  bf16x8_t qh[KS], ql[KS];
+  {
+    int qr = q0 + wave * 16 + lr;
+    qr = qr < Tp ? qr : Tp - 1;
+    const float* qrow = Q + (bh * Tp + qr) * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* src = qrow + (ks * 4 + lg) * 8;
+      uint4 hi, lo;
+      split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+      qh[ks] = __builtin_bit_cast(bf16x8_t, hi);
+      ql[ks] = __builtin_bit_cast(bf16x8_t, lo);
+    }
+  }
+  const bool mask_in_lds = Tp <= MAXT;   // uniform
+  if (mask_in_lds)
+    for (int i = tid; i < Tp; i += NW * 64) Ms[i] = (i < T && key_mask[(long)b * T + (i < T ? i : 0)] != 0) ? 1 : 0;
+  float m_i[4], l_i[4];
+  f32x4_t o[NF];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { m_i[r] = -INFINITY; l_i[r] = 0.f; }
+#pragma unroll
+  for (int n = 0; n < NF; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  char* Pw = Ps + wave * 2048;
+  constexpr int PL = NW * 2048;   // offset of the lo image of P
+
+  for (int kt = 0; kt < Tp; kt += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < HD / (8 * NW); ++it) {
+      const int idx = tid + 64 * NW * it;
+      {
+        const int row = idx / CH, c = idx % CH;
+        const float* src = K + (bh * Tp + kt + row) * HD + c * 8;
+        uint4 hi, lo;
+        split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+        const int off = row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4);
+        *(uint4*)(Ks + off) = hi;
+        *(uint4*)(Ks + KB + off) = lo;
+      }
+      {
+        const int d = idx >> 3, c = idx & 7;
+        const float* src = Vt + (bh * HD + d) * Tp + kt + c * 8;
+        uint4 hi, lo;
+        split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+        const int off = d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+        *(uint4*)(Vs + off) = hi;
+        *(uint4*)(Vs + KB + off) = lo;
+      }
+    }
+    __syncthreads();
+    f32x4_t s[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      s[nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const int row = nb * 16 + lr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4);
+        const bf16x8_t kh = *(const bf16x8_t*)(Ks + off), kl = *(const bf16x8_t*)(Ks + KB + off);
+        s[nb] = SA_MFMA_16x16x32(ql[ks], kh, s[nb]);
+        s[nb] = SA_MFMA_16x16x32(qh[ks], kl, s[nb]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = row * (HD * 2) + (((ks * 4 + lg) ^ (row & (CH - 1))) << 4);
+        s[nb] = SA_MFMA_16x16x32(qh[ks], *(const bf16x8_t*)(Ks + off), s[nb]);
+      }
+    }
+    bool valid[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int key = kt + nb * 16 + lr;
+      valid[nb] = mask_in_lds ? Ms[key] != 0 : (key < T && key_mask[(long)b * T + key] != 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        s[nb][r] = valid[nb] ? s[nb][r] * scale : -INFINITY;
+        mx = fmaxf(mx, s[nb][r]);
+      }
+      mx = row16_max(mx);
+      const float m_new = fmaxf(m_i[r], mx);
+      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+      const float alpha = expf(m_i[r] - m_safe);
+      float rs = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const float pv = expf(s[nb][r] - m_safe);
+        s[nb][r] = pv;
+        rs += pv;
+      }
+      rs = row16_sum(rs);
+      l_i[r] = l_i[r] * alpha + rs;
+      m_i[r] = m_new;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) o[n][r] *= alpha;
+      const int q = lg * 4 + r;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int c = nb * 2 + (lr >> 3);
+        const int off = q * 128 + ((c ^ ((q >> 1) & 7)) << 4) + (lr & 7) * 2;
+        const unsigned short ph = f2bf(s[nb][r]);
+        *(unsigned short*)(Pw + off) = ph;
+        *(unsigned short*)(Pw + PL + off) = f2bf(s[nb][r] - bf2f(ph));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ks * 4 + lg;
+      const int poff = lr * 128 + ((c ^ ((lr >> 1) & 7)) << 4);
+      const bf16x8_t ph = *(const bf16x8_t*)(Pw + poff), pl = *(const bf16x8_t*)(Pw + PL + poff);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const int d = n * 16 + lr;
+        const int voff = d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+        const bf16x8_t vh = *(const bf16x8_t*)(Vs + voff), vl = *(const bf16x8_t*)(Vs + KB + voff);
+        o[n] = SA_MFMA_16x16x32(pl, vh, o[n]);
+        o[n] = SA_MFMA_16x16x32(ph, vl, o[n]);
+        o[n] = SA_MFMA_16x16x32(ph, vh, o[n]);
+      }
+    }
+  }
+  // fp32 context rows through LDS (a wave-private 16 x HD fp32 slice of the K / V^T staging areas): 16-byte stores, whole lines
+  const int D = H * HD;
+  __syncthreads();   // every wave is through with Ks / Vs
+  constexpr int SLICE = 16 * HD * 4;
+  static_assert(4 * SLICE <= 2 * KB && NW <= 8, "output staging fits the K / V^T staging areas");
+  char* mine = wave < 4 ? Ks + wave * SLICE : Vs + (wave - 4) * SLICE;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float inv = 1.f / l_i[r];
+    const int q = lg * 4 + r;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) *(float*)(mine + q * (HD * 4) + (n * 16 + lr) * 4) = o[n][r] * inv;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private: only wave-level ordering is needed
+  if constexpr (OUT3) {
+    constexpr int CPR8 = HD / 8;   // 8-element chunks per output row: two 16-byte LDS reads, three 16-byte stores
+#pragma unroll
+    for (int u = lane; u < 16 * CPR8; u += 64) {
+      const int row = u / CPR8, c = u % CPR8;
+      const int q = q0 + wave * 16 + row;
+      const float* src = (const float*)(mine + row * (HD * 4) + c * 32);
+      uint4 hi, lo;
+      split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+      if (q < T) {
+        bf16_t* dst = out3 + ((long)b * T + q) * (3L * D) + h * HD + c * 8;
+        *(uint4*)dst = lo;
+        *(uint4*)(dst + D) = hi;
+        *(uint4*)(dst + 2L * D) = hi;
+      }
+    }
+    return;
+  }
+  constexpr int CPRO = HD / 4;   // 16-byte chunks per output row
+#pragma unroll
+  for (int u = lane; u < 16 * CPRO; u += 64) {
+    const int row = u / CPRO, c = u % CPRO;
+    const int q = q0 + wave * 16 + row;
+    if (q < T) *(uint4*)(out + ((long)b * T + q) * D + h * HD + c * 4) = *(const uint4*)(mine + row * (HD * 4) + c * 16);
+  }
+}
+
 template <int HD>
 static hipError_t launch_self_attention_t(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                           void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st, bool out_alt = false) {
@@ -290,6 +501,26 @@ static hipError_t launch_self_attention_t(const void* Q, const void* K, const vo
   else
     hipLaunchKernelGGL(self_attn_f32_kernel<HD>, dim3((T + 31) / 32, H, B), dim3(256), 0, st, (const float*)Q,
                        (const float*)K, (const float*)Vt, key_mask, (float*)out, T, Tp, H);
+  return hipGetLastError();
+}
+
+template <int NW, int HD>
+static void launch_self_attention_x3_t(const float* Q, const float* K, const float* Vt, const unsigned char* key_mask, float* out,
+                                       void* out3, dim3 grid, int T, int Tp, int H, hipStream_t st) {
+  if (out3)
+    hipLaunchKernelGGL((self_attn_x3_kernel<NW, HD, true>), grid, dim3(NW * 64), 0, st, Q, K, Vt, key_mask, out, (bf16_t*)out3, T, Tp, H);
+  else
+    hipLaunchKernelGGL((self_attn_x3_kernel<NW, HD, false>), grid, dim3(NW * 64), 0, st, Q, K, Vt, key_mask, out, (bf16_t*)nullptr, T, Tp, H);
+}
+hipError_t launch_self_attention_x3(const float* Q, const float* K, const float* Vt, const unsigned char* key_mask, float* out,
+                                    int B, int T, int Tp, int H, int head_dim, hipStream_t st, void* out3) {
+  if (Tp % 64 || (head_dim != 64 && head_dim != 128) || (!out && !out3)) return hipErrorInvalidValue;
+  const bool wide = Tp % 128 == 0;
+  const dim3 grid(wide ? Tp / 128 : Tp / 64, H, B);
+  if (head_dim == 128 && wide) launch_self_attention_x3_t<8, 128>(Q, K, Vt, key_mask, out, out3, grid, T, Tp, H, st);
+  else if (head_dim == 128) launch_self_attention_x3_t<4, 128>(Q, K, Vt, key_mask, out, out3, grid, T, Tp, H, st);
+  else if (wide) launch_self_attention_x3_t<8, 64>(Q, K, Vt, key_mask, out, out3, grid, T, Tp, H, st);
+  else launch_self_attention_x3_t<4, 64>(Q, K, Vt, key_mask, out, out3, grid, T, Tp, H, st);
   return hipGetLastError();
 }
 

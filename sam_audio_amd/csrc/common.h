@@ -62,6 +62,13 @@ __device__ __forceinline__ unsigned pack_h16x2(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2_t));
 }
 
+// the largest finite value of the library's 16-bit operand format
+#ifdef SA_OPERAND_FP16
+constexpr float kH16Max = 65504.f;
+#else
+constexpr float kH16Max = 3.3895313892515355e38f;
+#endif
+
 // ---- the OTHER 16-bit format (mixed mode) ------------------------------------------------------------------------------
 // precision = "mixed" runs on the fp16 build of the library with the five big GEMM classes of the DiT (qkv, wo, c_wq, w13, w2:
 // 96 % of the flops, 2e-4 of the error each in bf16 - DESIGN.md section 4) on bfloat16 operands, i.e. BASELINE's dtype where
@@ -227,5 +234,9 @@ struct GemmParams {
   long pf_bytes;
 };
 constexpr int GEMM_FLAG_W_KTM = 2048;
+// flags bit 12 (8-phase family, SwiGLU launches with a 16-bit output only): out_act receives the COMPENSATED-operand form of the
+// result - row stride act_ld = 3 * (N / 2), [lo | hi | hi] with hi = rn16(v), lo = rn16(v - hi) - i.e. the next GEMM's split
+// activation operand straight from the fp32 accumulators (SAMAUDIO_OPT_X3_CLASSES; kernels.hip split3_kernel is the stand-alone form)
+constexpr int GEMM_FLAG_OUT_SPLIT3 = 4096;
 
 }  // namespace sa

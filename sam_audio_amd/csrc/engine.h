@@ -93,7 +93,8 @@ class Engine {
   Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0, int cls = 0, int mode = 0);
   // SAMAUDIO_OPT_X3_CLASSES: `p` = the fp32 context's plain launch (fp32 A rows, fp32-typed outputs) of a class that is switched
   // on; `w3` = its "<name>.x3" weight.  Splits A into the scratch operand [lo | hi | hi] and runs ONE 16-bit GEMM over K' = 3K.
-  Status gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls);
+  // `presplit`: the activation operand is already in its split form at that address (written by the kernel that produced it)
+  Status gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls, const void* presplit = nullptr);
   bool x3(int cls) const { return !bf16_ && (x3_classes_ & cls) != 0; }
   Status check_x3_weights(int classes) const;
   bool f32c(int cls) const { return bf16_ && (f32_classes_ & cls) != 0; }
@@ -177,6 +178,10 @@ class Engine {
     const void *w_out, *pw1, *pw2, *y_w13, *y_w2, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w,
         *c_wkv_all;
   } g_;
+  struct {  // SAMAUDIO_OPT_X3_CLASSES, classes PATCH and CKV: "patch1.w.x3", "patch2.w.x3" (per tap [W_hi | W_lo | W_hi]), "c_wkv_all.x3"
+    const void *pw1, *pw2, *c_wkv_all;
+    int ktm;   // bits 0..2 in that order: K-tile-major
+  } g3_;
   struct {  // optional fp32 copies ("<name>.f32") of the weights of the SAMAUDIO_CLS_F32_CAPABLE classes
     const float *w_out, *t_w13, *t_w2, *tb_w, *proj_wy, *proj_wf, *mem_w, *vid_w, *anc_w, *y_w13, *y_w2;
   } g32_;
@@ -201,7 +206,7 @@ class Engine {
   struct {
     float *ystate, *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
-        *feats, *text, *video, *anch, *probs, *ut, *x3a;
+        *feats, *text, *video, *anch, *probs, *ut, *x3a, *x3u;
     float *temb32, *tu32, *tsilu32, *xn32, *prep32, *mem32, *yu32, *yemb32;  // fp32 operands of the f32 classes (16-bit contexts)
     unsigned char *pad_mask, *text_mask;
     double* gn_part;

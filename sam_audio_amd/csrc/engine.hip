@@ -123,6 +123,7 @@ Engine::Engine(const samaudio_config& c) : cfg_(c) {
   at_dtype_ = bf16_ ? SAMAUDIO_DT_BF16 : SAMAUDIO_DT_F32;
   std::memset(&g_, 0, sizeof(g_));
   std::memset(&g32_, 0, sizeof(g32_));
+  std::memset(&g3_, 0, sizeof(g3_));
   std::memset(&enc_, 0, sizeof(enc_));
   std::memset(&dec_, 0, sizeof(dec_));
   std::memset(&d_, 0, sizeof(d_));
@@ -278,6 +279,17 @@ Status Engine::finalize(int what) {
 #undef OPTF
       SA_TRY(check_f32_weights(f32_classes_));
     }
+    if (!bf16_) {   // SAMAUDIO_OPT_X3_CLASSES, classes PATCH / CKV: optional split copies
+      std::memset(&g3_, 0, sizeof(g3_));
+      const struct { const char* name; int64_t N, K3; const void** out; } x3g[3] = {
+          {"patch1.w.x3", D, 9L * D, &g3_.pw1}, {"patch2.w.x3", D, 9L * D, &g3_.pw2}, {"c_wkv_all.x3", (int64_t)L * 2 * D, 3L * D, &g3_.c_wkv_all}};
+      for (int j = 0; j < 3; ++j) {
+        const TensorRef* t = find(x3g[j].name);
+        if (!t || t->dtype != SAMAUDIO_DT_BF16) continue;
+        if (t->shape == std::vector<int64_t>{x3g[j].K3 / 64, x3g[j].N, 64}) { *x3g[j].out = t->p; g3_.ktm |= 1 << j; }
+        else if (t->shape == std::vector<int64_t>{x3g[j].N, x3g[j].K3}) *x3g[j].out = t->p;
+      }
+    }
     dit_ready_ = true;   // (check_x3_weights looks at the resolved layers)
     if (const Status s3 = check_x3_weights(x3_classes_); !s3.ok()) { dit_ready_ = false; return s3; }
   } else {
@@ -383,7 +395,10 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   const bool fold_all = cfg_.n_layers <= kMaxFoldLayers;
   void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp * (fold_all ? cfg_.n_layers : 1)) : nullptr;
   // SAMAUDIO_OPT_X3_CLASSES: the split activation operand [lo | hi | hi] of the widest GEMM input (16-bit, 3 K elements per row)
-  void* x3a = (!bf16_ && x3_classes_) ? b.take((size_t)M * 3 * (size_t)(F > D ? F : D) * 2) : nullptr;
+  // (x3a: D-wide operands and the patcher's halo-padded rows; x3u: the SwiGLU hidden, written by the w13 launch while it reads x3a)
+  const bool x3g = !bf16_ && (x3_classes_ & ~SAMAUDIO_X3_ATTENTION);
+  void* x3a = x3g ? b.take((size_t)rows * (T + 2) * 3 * (size_t)D * 2) : nullptr;
+  void* x3u = x3g ? b.take((size_t)M * 3 * (size_t)F * 2) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
@@ -393,7 +408,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
     d.video = video; d.anch = anch; d.temb32 = temb32; d.tu32 = tu32; d.tsilu32 = tsilu32; d.xn32 = xn32; d.prep32 = prep32;
-    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.x3a = x3a; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
+    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.x3a = x3a; d.x3u = x3u; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
   }
   return Status{};
 }
@@ -478,6 +493,10 @@ Status Engine::check_f32_weights(int classes) const {
 
 Status Engine::check_x3_weights(int classes) const {
   if (!classes) return Status{};
+  if ((classes & SAMAUDIO_CLS_PATCH) && !(g3_.pw1 && g3_.pw2))
+    return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_X3_CLASSES: the split weights 'patch1.w.x3' / 'patch2.w.x3' (16-bit, [D, 9D] or [9D/64, D, 64]) are not registered");
+  if ((classes & SAMAUDIO_CLS_CKV) && !g3_.c_wkv_all)
+    return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_X3_CLASSES: the split weight 'c_wkv_all.x3' (16-bit, [L*2D, 3D] or [3D/64, L*2D, 64]) is not registered");
   for (size_t i = 0; i < layers_.size(); ++i) {
     const LayerW& w = layers_[i];
     const struct { int cls; const void* p; const char* leaf; } need[6] = {
@@ -541,9 +560,9 @@ Status Engine::set_option_value(int option, int value) {
   if (option == SAMAUDIO_OPT_X3_CLASSES) {
     if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES applies to fp32 contexts (compensated 16-bit operands under fp32 storage)");
     if (value & ~SAMAUDIO_CLS_X3_CAPABLE)
-      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: only the six big GEMM classes of the DiT layers (qkv, wo, cwq, cwo, w13, w2)");
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: only the six big GEMM classes of the DiT layers (qkv, wo, cwq, cwo, w13, w2), patch, ckv and SAMAUDIO_X3_ATTENTION");
     if (dit_ready_) SA_TRY(check_x3_weights(value));   // (before finalize(0): checked there)
-    if ((value != 0) != (x3_classes_ != 0)) prepared_ = false;   // the scratch operand is part of the workspace plan
+    if (((value & ~SAMAUDIO_X3_ATTENTION) != 0) != ((x3_classes_ & ~SAMAUDIO_X3_ATTENTION) != 0)) prepared_ = false;   // the scratch operand is part of the workspace plan
     x3_classes_ = value;
     return Status{};
   }
@@ -595,7 +614,7 @@ static int cls_slot(int cls) {
 Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, int mode) {
   const bool f32 = mode == 1, x3m = mode == 2;
   const bool is16 = bf16_ || x3m;   // the launch's operand format (an X3 launch: 16-bit operands inside an fp32 context)
-  if (sentinel_on_ && p_in.out_act && !p_in.c_ld_rel) {
+  if (sentinel_on_ && p_in.out_act && !p_in.c_ld_rel && !x3m) {
     sentinel_on_ = false;   // (the launch itself, without recursion)
     const Status s = gemm(p_in, st, alg_flops, cls, mode);
     sentinel_on_ = true;
@@ -615,7 +634,7 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
   // bit 1: no tail split (gemm.hip gemm_tail_split); bit 9 (from the caller): 16-bit output in the alt format; bit 10: operands
   // in the alt format (SAMAUDIO_OPT_ALT16_CLASSES, mixed mode)
   // bit 11 (from the caller): W is K-tile-major
-  p.flags = (p_in.flags & (512 | GEMM_FLAG_W_KTM)) | (tail_split_ ? 0 : 2) | (alt16(cls) && !f32 ? 1024 : 0);
+  p.flags = (p_in.flags & (512 | GEMM_FLAG_W_KTM | GEMM_FLAG_OUT_SPLIT3)) | (tail_split_ ? 0 : 2) | (alt16(cls) && !f32 ? 1024 : 0);
   if (p.tag) cls = SAMAUDIO_CLS_CODEC;
   if (f32) {  // a class of SAMAUDIO_OPT_F32_CLASSES: exact-fp32 kernel inside a 16-bit context
     if (!p.W) return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_F32_CLASSES: the class's \"<name>.f32\" weight copy is not registered");
@@ -660,20 +679,25 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
   return Status{};
 }
 
-Status Engine::gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls) {
+Status Engine::gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls, const void* presplit) {
   if (!w3 || !d_.x3a) return fail(SAMAUDIO_ERR_STATE, "SAMAUDIO_OPT_X3_CLASSES: split weight or scratch operand missing (set the option before samaudio_prepare)");
   if (p.nbatch != 1 || p.kc != p.K || p.a_off || p.tap_stride || (p.out_act && p.out_f32))
     return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: plain single-batch launches with one output only");
   const int K = p.K;
   // algorithmic bytes of the split: the fp32 row in, three 16-bit copies out
-  SA_TRY(op("split3", (double)p.M * K * (4 + 6), 0, st, [&] { return launch_split3((const float*)p.A, p.lda, d_.x3a, p.M, K, st); }));
-  p.A = d_.x3a; p.lda = 3L * K; p.K = 3 * K; p.kc = 3 * K; p.W = w3;
+  if (!presplit)
+    SA_TRY(op("split3", (double)p.M * K * (4 + 6), 0, st, [&] { return launch_split3((const float*)p.A, p.lda, d_.x3a, p.M, K, st); }));
+  p.A = presplit ? presplit : d_.x3a; p.lda = 3L * K; p.K = 3 * K; p.kc = 3 * K; p.W = w3;
   if (p.out_act) {   // an fp32 context's "activation" outputs are fp32 tensors: the 16-bit kernel writes them as its fp32 output
     p.out_f32 = (float*)p.out_act; p.f32_ld = p.act_ld; p.f32_bstride = p.act_bstride; p.f32_off = p.act_off;
     p.f32_act = p.act != ACT_NONE;
     p.out_act = nullptr; p.act_ld = p.act_bstride = p.act_off = 0;
   }
   if (ktm) p.flags |= GEMM_FLAG_W_KTM;
+  if ((p.flags & GEMM_FLAG_OUT_SPLIT3) && p.out_f32) {   // the result leaves as the next GEMM's split operand (16-bit, 3 x n_out per row)
+    p.out_act = p.out_f32; p.act_ld = 3L * (p.swiglu ? p.N / 2 : p.N); p.act_bstride = p.act_off = 0;
+    p.out_f32 = nullptr; p.f32_ld = p.f32_bstride = p.f32_off = 0; p.f32_act = 0;
+  }
   return gemm(p, st, 2.0 * p.M * (double)p.N * K, cls, 2);   // flops as the reference counts them: one product over K
 }
 
@@ -913,25 +937,33 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_IN, f));
   }
   // patcher: (GroupNorm(1) -> SiLU -> conv k3) x 2 + skip           (patcher.py:138-141)
-  auto patch_conv = [&](const void* W, const float* bias, const float* skip, float* dst) -> Status {
+  auto patch_conv = [&](const void* W, const void* W3, bool ktm3, const float* bias, const float* skip, float* dst) -> Status {
     GemmParams p = lin(d_.gnbuf, D, W, T, D, 3 * D);
     p.kc = D; p.tap_stride = D; p.a_off = 0; p.a_bstride = (long)(T + 2) * D; p.nbatch = rows;
     p.bias = bias;
     if (skip) { with_res(p, skip, D); p.res_bstride = (long)T * D; }
     out_f32(p, dst, D);
     p.f32_bstride = (long)T * D;
-    return gemm(p, st, -1.0, SAMAUDIO_CLS_PATCH);
+    if (!x3(SAMAUDIO_CLS_PATCH)) return gemm(p, st, -1.0, SAMAUDIO_CLS_PATCH);
+    // compensated operands: every row of the halo-padded GroupNorm output (halo rows are zeros: they split into zeros) becomes
+    // [lo | hi | hi], a tap of the convolution then is 3 D contiguous elements against that tap's [W_hi | W_lo | W_hi]
+    if (!W3 || !d_.x3a) return fail(SAMAUDIO_ERR_STATE, "SAMAUDIO_OPT_X3_CLASSES: patcher split weight or scratch operand missing");
+    const long prow = (long)rows * (T + 2);
+    SA_TRY(op("split3", (double)prow * D * (4 + 6), 0, st, [&] { return launch_split3((const float*)d_.gnbuf, D, d_.x3a, prow, D, st); }));
+    p.A = d_.x3a; p.W = W3; p.lda = 3L * D; p.kc = 3 * D; p.tap_stride = 3L * D; p.a_bstride = (long)(T + 2) * 3 * D; p.K = 9 * D;
+    if (ktm3) p.flags |= GEMM_FLAG_W_KTM;
+    return gemm(p, st, 2.0 * T * (double)D * 3 * D * rows, SAMAUDIO_CLS_PATCH, 2);
   };
   trace("cond", d_.cond, (size_t)M * D, false, st);
   trace("aligned", d_.aligned, (size_t)M * D, false, st);
   SA_TRY(op("groupnorm_silu", MD * (4 + esz_), 0, st, [&] {
     return launch_groupnorm_silu(d_.aligned, g_.gn1_w, g_.gn1_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st);
   }));
-  SA_TRY(patch_conv(g_.pw1, g_.pb1, nullptr, d_.hp1));
+  SA_TRY(patch_conv(g_.pw1, g3_.pw1, g3_.ktm & 1, g_.pb1, nullptr, d_.hp1));
   SA_TRY(op("groupnorm_silu", MD * (4 + esz_), 0, st, [&] {
     return launch_groupnorm_silu(d_.hp1, g_.gn2_w, g_.gn2_b, d_.gn_part, d_.gnbuf, bf16_, rows, T, D, 1, 1e-5f, st);
   }));
-  SA_TRY(patch_conv(g_.pw2, g_.pb2, d_.aligned, d_.h));
+  SA_TRY(patch_conv(g_.pw2, g3_.pw2, g3_.ktm & 2, g_.pb2, d_.aligned, d_.h));
 
   // timestep embeddings                                             (transformer.py:490-493, model.py:170)
   {
@@ -1006,7 +1038,8 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   if (cfg_.n_layers > 0) {  // cross-attention keys / values of every layer (k-normed), [Mt, L*2D]
     GemmParams p = lin(d_.yemb, D, g_.c_wkv_all, Mt, (int)kv_ld, D);
     out_act(p, d_.kvc, kv_ld);
-    SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CKV));
+    if (x3(SAMAUDIO_CLS_CKV)) SA_TRY(gemm_x3(p, g3_.c_wkv_all, g3_.ktm & 4, st, SAMAUDIO_CLS_CKV));
+    else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CKV));
     SA_HIP(launch_headnorm_layers(d_.kvc, g_.c_k_norm_all, bf16_, (int)Mt, cfg_.n_layers, H, eps, st, hd));
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
@@ -1033,7 +1066,13 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     const LayerW& w = layers_[l];
     const float* tab = w.mod_table;
     // self-attention branch
-    SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
+    // compensated operands (fp32 contexts): the producers write the split form [lo | hi | hi] themselves where they can
+    const bool qkv_pre = x3(SAMAUDIO_CLS_QKV) && mod_gs, w13_pre = x3(SAMAUDIO_CLS_W13) && mod_gs;
+    const bool wo_pre = x3(SAMAUDIO_CLS_WO) && x3(SAMAUDIO_X3_ATTENTION);
+    const bool w2_pre = x3(SAMAUDIO_CLS_W2) && x3(SAMAUDIO_CLS_W13) && F % 16 == 0;
+    SA_TRY(op("rmsnorm_mod", MD * (4 + (qkv_pre ? 6 : esz_)), 0, st, [&] {
+      if (qkv_pre)
+        return launch_rmsnorm_gs_split3(d_.h, d_.modgs + (2L * l) * nt * 2 * D, gs_ld, d_.x3a, (int)M, D, T, eps, st);
       if (mod_gs)
         return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st,
                                  alt16(SAMAUDIO_CLS_QKV));
@@ -1046,7 +1085,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       ktm(p, w, 0);
       prefetch(p, w.wo, (double)D * D);
       out_act(p, d_.qkv, 3L * D);
-      if (x3(SAMAUDIO_CLS_QKV)) SA_TRY(gemm_x3(p, w.wqkv3, w.ktm3 & 1, st, SAMAUDIO_CLS_QKV));
+      if (x3(SAMAUDIO_CLS_QKV)) SA_TRY(gemm_x3(p, w.wqkv3, w.ktm3 & 1, st, SAMAUDIO_CLS_QKV, qkv_pre ? d_.x3a : nullptr));
       else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_QKV));
     }
     SA_TRY(op("qkv_prep", 2 * 3 * MD * esz_, 0, st, [&] {
@@ -1058,6 +1097,12 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     trace("  Q", d_.Q, (size_t)rows * Tp * D, bf16_, st);
     trace("  K", d_.K, (size_t)rows * Tp * D, bf16_, st);
     trace("  Vt", d_.Vt, (size_t)rows * Tp * D, bf16_, st);
+    if (x3(SAMAUDIO_X3_ATTENTION))
+      SA_TRY(op("self_attention_x3", 4 * MD * 4, 4.0 * T * T * D * rows, st, [&] {
+        return launch_self_attention_x3((const float*)d_.Q, (const float*)d_.K, (const float*)d_.Vt, d_.pad_mask, (float*)d_.attn, rows,
+                                        T, Tp, H, hd, st, wo_pre ? d_.x3a : nullptr);
+      }));
+    else
     SA_TRY(op("self_attention", 4 * MD * esz_, 4.0 * T * T * D * rows, st, [&] {
       return launch_self_attention_hd(d_.Q, d_.K, d_.Vt, d_.pad_mask, d_.attn, bf16_, rows, T, Tp, H, hd, st, alt16(SAMAUDIO_CLS_WO));
     }));
@@ -1074,7 +1119,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       prefetch(p, w.c_wq, (double)D * D);
       if (x3(SAMAUDIO_CLS_WO)) {   // (fp32 outputs only: c_wq then reads h itself)
         p.out_act = nullptr; p.act_ld = 0;
-        SA_TRY(gemm_x3(p, w.wo3, w.ktm3 & 2, st, SAMAUDIO_CLS_WO));
+        SA_TRY(gemm_x3(p, w.wo3, w.ktm3 & 2, st, SAMAUDIO_CLS_WO, wo_pre ? d_.x3a : nullptr));
       } else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_WO));
     }
     trace("  h after wo", d_.h, (size_t)M * D, false, st);
@@ -1123,7 +1168,9 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     trace("  qc", d_.qc, (size_t)M * D, bf16_, st);
     trace("  h after cross", d_.h, (size_t)M * D, false, st);
     // feed-forward branch
-    SA_TRY(op("rmsnorm_mod", MD * (4 + esz_), 0, st, [&] {
+    SA_TRY(op("rmsnorm_mod", MD * (4 + (w13_pre ? 6 : esz_)), 0, st, [&] {
+      if (w13_pre)
+        return launch_rmsnorm_gs_split3(d_.h, d_.modgs + (2L * l + 1) * nt * 2 * D, gs_ld, d_.x3a, (int)M, D, T, eps, st);
       if (mod_gs)
         return launch_rmsnorm_gs(d_.h, d_.modgs + (2L * l + 1) * nt * 2 * D, gs_ld, d_.xn, bf16_, (int)M, D, T, eps, st,
                                  alt16(SAMAUDIO_CLS_W13));
@@ -1138,7 +1185,10 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       if (alt16(SAMAUDIO_CLS_W2)) p.flags |= 512;    // u is w2's operand
       ktm(p, w, 3);
       prefetch(p, w.w2, (double)D * F);
-      if (x3(SAMAUDIO_CLS_W13)) SA_TRY(gemm_x3(p, w.w13_3, w.ktm3 & 16, st, SAMAUDIO_CLS_W13));
+      if (x3(SAMAUDIO_CLS_W13)) {
+        if (w2_pre) { p.out_act = d_.x3u; p.flags |= GEMM_FLAG_OUT_SPLIT3; }   // the SwiGLU epilogue writes w2's split operand itself
+        SA_TRY(gemm_x3(p, w.w13_3, w.ktm3 & 16, st, SAMAUDIO_CLS_W13, w13_pre ? d_.x3a : nullptr));
+      }
       else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W13));
       trace("  xn (ffn)", d_.xn, (size_t)M * D, bf16_, st);
       trace("  u", d_.u, (size_t)M * F, bf16_, st);
@@ -1148,7 +1198,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       out_f32(p, d_.h, D);
       ktm(p, w, 4);
       if (l + 1 < cfg_.n_layers) prefetch(p, layers_[l + 1].wqkv, 3.0 * D * D);
-      if (x3(SAMAUDIO_CLS_W2)) SA_TRY(gemm_x3(p, w.w2_3, w.ktm3 & 32, st, SAMAUDIO_CLS_W2));
+      if (x3(SAMAUDIO_CLS_W2)) SA_TRY(gemm_x3(p, w.w2_3, w.ktm3 & 32, st, SAMAUDIO_CLS_W2, w2_pre ? d_.x3u : nullptr));
       else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_W2));
       trace("  h after ffn", d_.h, (size_t)M * D, false, st);
     }

@@ -416,6 +416,11 @@ const char* gemm_check(const GemmParams& p, bool is_bf16) {
     const int v = gemm_variant(p, is_bf16);
     if (v != 22 && v != 27) return "gemm: alt 16-bit format: the tile policy did not pick the 8-phase family for this launch";
   }
+  if (p.flags & GEMM_FLAG_OUT_SPLIT3) {   // compensated-operand output: the register epilogue of the 8-phase family, SwiGLU launches
+    if (!is_bf16 || !gemm2_ok(p) || !gemm8_split3_ok(p)) return "gemm: split3 output: 16-bit SwiGLU launches with a lean epilogue only";
+    const int v = gemm_variant(p, is_bf16);
+    if (v != 22 && v != 27) return "gemm: split3 output: the tile policy did not pick the 8-phase family for this launch";
+  }
   if (p.flags & GEMM_FLAG_W_KTM) {   // K-tile-major weights: only the 8-phase family addresses them
     if (!is_bf16 || !gemm2_ok(p) || p.w_bstride) return "gemm: K-tile-major W: plain 16-bit launches with one weight matrix only";
     const int v = gemm_variant(p, is_bf16);

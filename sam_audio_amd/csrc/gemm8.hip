@@ -218,19 +218,38 @@ __device__ __forceinline__ void epilogue8_linear(const GemmParams& p, f32x4_t (&
     const int c_own = (n_wave0 >> 1) + lg * 4;                              // + 16 jp: the lane's own 4 outputs
     const int c_st = (n_wave0 >> 1) + (lg & 1) * 16 + (lg >> 1) * 8;        // after the swap: 8 consecutive outputs
     (void)c_own;
+    const bool split3 = (p.flags & GEMM_FLAG_OUT_SPLIT3) != 0;   // [lo | hi | hi] rows of 3 * (N / 2) elements (common.h)
+    const int n_out = p.N >> 1;
 #pragma unroll
     for (int I = 0; I < NI; ++I) {
       const int m = m_wave0 + I * 16 + lr;
-      unsigned lo[2], hi[2];
+      unsigned lo[2], hi[2], rlo[2], rhi[2];
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
         const f32x4_t a = acc[I][2 * jp], g = acc[I][2 * jp + 1];
-        lo[jp] = pack(silu_f(a[0]) * g[0], silu_f(a[1]) * g[1]);
-        hi[jp] = pack(silu_f(a[2]) * g[2], silu_f(a[3]) * g[3]);
+        const float v0 = silu_f(a[0]) * g[0], v1 = silu_f(a[1]) * g[1], v2 = silu_f(a[2]) * g[2], v3 = silu_f(a[3]) * g[3];
+        lo[jp] = pack(v0, v1);
+        hi[jp] = pack(v2, v3);
+        if (split3) {   // the residuals of the 16-bit rounding, rounded themselves: v = h16 + r16 to ~2^-22
+          rlo[jp] = pack_h16x2(v0 - h16_lo(lo[jp]), v1 - h16_hi(lo[jp]));
+          rhi[jp] = pack_h16x2(v2 - h16_lo(hi[jp]), v3 - h16_hi(hi[jp]));
+        }
       }
       const auto s0 = __builtin_amdgcn_permlane16_swap(lo[0], lo[1], false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(hi[0], hi[1], false, false);
-      if (m <= m_last) *(uint4*)(act0 + (long)m * p.act_ld + c_st) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      if (!split3) {
+        if (m <= m_last) *(uint4*)(act0 + (long)m * p.act_ld + c_st) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        continue;
+      }
+      const auto t0 = __builtin_amdgcn_permlane16_swap(rlo[0], rlo[1], false, false);
+      const auto t1 = __builtin_amdgcn_permlane16_swap(rhi[0], rhi[1], false, false);
+      if (m <= m_last) {
+        bf16_t* row = act0 + (long)m * p.act_ld + c_st;
+        const uint4 h4 = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        *(uint4*)row = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+        *(uint4*)(row + n_out) = h4;
+        *(uint4*)(row + 2 * n_out) = h4;
+      }
     }
     return;
   }
@@ -1251,6 +1270,7 @@ static int gemm8_linear_epilogue(const GemmParams& p) {
   if (p.act != ACT_NONE || p.chan_mod || p.c_ld_rel || (p.flags & 1) || p.N % 64 || p.alpha != 1.f) return 0;
   if (!p.out_act && !p.out_f32) return 0;
   if (p.swiglu && (!p.out_act || p.out_f32 || p.bias || p.gate || p.res)) return 0;
+  if ((p.flags & GEMM_FLAG_OUT_SPLIT3) && (!p.swiglu || (p.flags & 512) || (p.N / 2) % 8)) return 0;   // (gemm8_split3_ok)
   if (p.bias && (p.gate || p.gate_tab)) return 0;
   if (p.gate_tab && !p.gate) return 0;
   auto al = [](long v, long a) { return v % a == 0; };
@@ -1296,6 +1316,10 @@ static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 g
   else if (conv) hipLaunchKernelGGL((gemm8s_kernel<false, true>), grid, block, 0, st, p, skip256);
   else if (alt) hipLaunchKernelGGL((gemm8s_kernel<false, false, true>), grid, block, 0, st, p, skip256);
   else hipLaunchKernelGGL((gemm8s_kernel<false, false>), grid, block, 0, st, p, skip256);
+}
+// flags bit 12 is well-formed: only the register epilogue of a SwiGLU launch writes the split form
+bool gemm8_split3_ok(const GemmParams& p) {
+  return !(p.flags & GEMM_FLAG_OUT_SPLIT3) || (p.swiglu && p.out_act && gemm8_linear_epilogue(p) == 64);
 }
 // flags bits 9 / 10 are well-formed for this launch: plain operands within 32-bit offsets, a lean epilogue for an alt-format output
 bool gemm8_alt_ok(const GemmParams& p) {

@@ -58,6 +58,9 @@ hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // gemm8.hip: GemmParams.flags bits 9 / 10 (mixed mode: out_act written / operands read in the alt 16-bit format) are well-formed;
 // only the 8-phase family (variants 22 / 27) implements them
 bool gemm8_alt_ok(const GemmParams& p);
+// gemm8.hip: GemmParams.flags bit 12 (out_act in the compensated-operand form [lo | hi | hi]) is well-formed: SwiGLU launches of the
+// 8-phase family with a 16-bit output only
+bool gemm8_split3_ok(const GemmParams& p);
 // gemm2.hip: dilated k = 7 'same' convolution C -> C (C = 64 / 96 / 128 / 192) with the activation halo tile resident in
 // LDS; bitwise equal to the implicit GEMM of the 32x32x16 family
 bool conv7h_ok(const GemmParams& p);
@@ -103,6 +106,9 @@ hipError_t launch_mod_tables(const ModTables& t, int n_norms, const float* tvec,
                              hipStream_t st);
 hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
                              float eps, hipStream_t st, bool out_alt = false);   // out_alt: 16-bit output in the alt format (mixed mode)
+// the same with the result in the compensated-operand form: out [M, 3D] 16-bit = [lo | hi | hi] (SAMAUDIO_OPT_X3_CLASSES)
+hipError_t launch_rmsnorm_gs_split3(const float* x, const float* gs, long gs_ld, void* out, int M, int D, int rows_per_b, float eps,
+                                    hipStream_t st);
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st, int head_dim = 128);   // head_dim 64 | 128 (rope tables [T, head_dim / 2])
@@ -115,6 +121,12 @@ hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, c
 hipError_t launch_self_attention_hd(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                     void* out, bool bf16, int B, int T, int Tp, int H, int head_dim, hipStream_t st,
                                     bool out_alt = false);
+
+// fp32 contexts, SAMAUDIO_OPT_X3_CLASSES bit SAMAUDIO_X3_ATTENTION: the same contract on fp32 tensors with both contractions on the
+// 16-bit MFMA over hi/lo-split operands (attention.hip self_attn_x3_kernel); Tp % 64 == 0
+// out3 != nullptr: the context rows leave in the compensated-operand form instead, out3 [B*T, 3*H*hd] 16-bit = [lo | hi | hi]
+hipError_t launch_self_attention_x3(const float* Q, const float* K, const float* Vt, const unsigned char* key_mask, float* out,
+                                    int B, int T, int Tp, int H, int head_dim, hipStream_t st, void* out3 = nullptr);
 
 // in-place per-(row, head) RMSNorm of x[rows, ld] columns [col0, col0 + H*128)
 hipError_t launch_headnorm(void* x, const float* w, bool bf16, int rows, long ld, int col0, int H, float eps,

@@ -163,6 +163,51 @@ __global__ __launch_bounds__(256) void rmsnorm_gs_reg_kernel(const float* __rest
   }
 }
 
+// the same row arithmetic with the result written as a compensated GEMM operand (split3_kernel's form): out [M, 3D] = [lo | hi | hi]
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_gs_split3_kernel(const float* __restrict__ x, const float* __restrict__ gs, long gs_ld,
+                                                                bf16_t* __restrict__ out, int M, int D, int rows_per_b, float eps) {
+#pragma clang fp contract(off)
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float4* xr = (const float4*)(x + (long)row * D);
+  const int n4 = D >> 2;
+  float4 v[MAXV];
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    v[k] = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+  }
+  ss = wave_sum(ss);
+  const float inv = rsqrtf(ss / (float)D + eps);
+  const float4* g = (const float4*)(gs + (long)(row / rows_per_b) * gs_ld);
+  const float4* s = g + n4;
+  bf16_t* orow = out + (long)row * 3 * D;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int i = lane + 64 * k;
+    if (i >= n4) continue;
+    const float4 gg = g[i], sv = s[i];
+    const float o0 = v[k].x * inv * gg.x + sv.x, o1 = v[k].y * inv * gg.y + sv.y, o2 = v[k].z * inv * gg.z + sv.z,
+                o3 = v[k].w * inv * gg.w + sv.w;
+    const unsigned h0 = pack_h16x2(fminf(fmaxf(o0, -kH16Max), kH16Max), fminf(fmaxf(o1, -kH16Max), kH16Max));
+    const unsigned h1 = pack_h16x2(fminf(fmaxf(o2, -kH16Max), kH16Max), fminf(fmaxf(o3, -kH16Max), kH16Max));
+    const unsigned l0 = pack_h16x2(o0 - h16_lo(h0), o1 - h16_hi(h0)), l1 = pack_h16x2(o2 - h16_lo(h1), o3 - h16_hi(h1));
+    *(uint2*)(orow + 4 * i) = make_uint2(l0, l1);
+    *(uint2*)(orow + D + 4 * i) = make_uint2(h0, h1);
+    *(uint2*)(orow + 2 * D + 4 * i) = make_uint2(h0, h1);
+  }
+}
+hipError_t launch_rmsnorm_gs_split3(const float* x, const float* gs, long gs_ld, void* out, int M, int D, int rows_per_b, float eps,
+                                    hipStream_t st) {
+  if (D > 256 * 12 || D % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((rmsnorm_gs_split3_kernel<12>), dim3((M + 3) / 4), dim3(256), 0, st, x, gs, gs_ld, (bf16_t*)out, M, D, rows_per_b, eps);
+  return hipGetLastError();
+}
+
 // gs = [g | s] of this norm for time value 0, gs_ld = floats between the time values (0: one time value for every row)
 hipError_t launch_rmsnorm_gs(const float* x, const float* gs, long gs_ld, void* out, bool bf16, int M, int D, int rows_per_b,
                              float eps, hipStream_t st, bool out_alt) {
@@ -749,11 +794,6 @@ hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_co
 // largest finite value (IEEE half: 65504), so a value up to twice that still splits exactly instead of becoming inf - inf.
 // One thread = 8 consecutive elements: two 16-byte loads, three 16-byte stores.
 // ------------------------------------------------------------------------------------------------
-#ifdef SA_OPERAND_FP16
-constexpr float kH16Max = 65504.f;
-#else
-constexpr float kH16Max = 3.3895313892515355e38f;
-#endif
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out,
                                                      long chunks, int cpr, int K) {
 #pragma clang fp contract(off)

@@ -90,7 +90,9 @@ CLS_F32_DEFAULT = CLS["out"] | CLS["in"] | CLS["prep"]
 CLS_ALT16_MIXED = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["w13"] | CLS["w2"]
 ALT16_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "w13": "w13", "w2": "w2"}   # engine tensor L<i>.<name> -> class
 # the six big GEMM classes of the DiT layers (97 % of the flops) and the engine weight each reads
-CLS_X3_DEFAULT = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["cwo"] | CLS["w13"] | CLS["w2"]
+X3_ATTENTION = 1 << 14   # samaudio.h SAMAUDIO_X3_ATTENTION: the self-attention's contractions on split operands as well
+CLS_X3_GEMMS = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["cwo"] | CLS["w13"] | CLS["w2"]
+CLS_X3_DEFAULT = CLS_X3_GEMMS | CLS["patch"] | CLS["ckv"] | X3_ATTENTION
 X3_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "c_wo": "cwo", "w13": "w13", "w2": "w2"}
 QUANT_FORMATS = {"bf16": 1, "fp16": 2}
 SENTINEL_NAMES = CLASSES + ("norm", "attn")
@@ -106,7 +108,7 @@ def class_mask(classes) -> int:
         classes = [c for c in classes.split(",") if c]
     mask = 0
     for c in classes:
-        mask |= (1 << len(CLASSES)) - 1 if c == "all" else CLS[c]
+        mask |= (1 << len(CLASSES)) - 1 if c == "all" else (X3_ATTENTION if c == "attn" else CLS[c])
     return mask
 
 

@@ -53,6 +53,28 @@ def ode_grid(ode_opt: Dict[str, Any], t0: float = 0.0, t1: float = 1.0):
     return (hip.ODE_MIDPOINT if method == "midpoint" else hip.ODE_EULER), grid
 
 
+class _Codec16:
+    """A codec-only engine context on plain 16-bit operands beside an fp32-storage model (precision "fp16x3", `codec_decode="16"`):
+    SAMAudio.decode_audio runs on it.  It borrows the model's 16-bit copies of the codec weights and whatever workspace its owner
+    (the model or a stream lane) holds at the time of the call."""
+
+    def __init__(self, model: "SAMAudio"):
+        self.lib = model._lib
+        self._ctx = C.c_void_p()
+        hc = hip.Config.from_buffer_copy(model._hc)
+        hc.precision = hip.BF16   # "the library's 16-bit operand format"
+        hip.check(self.lib.samaudio_create(C.byref(hc), C.byref(self._ctx)))
+        for name, t in model._codec16_tensors.items():
+            dt = hip.dtype_code(t.dtype, hip.operands_for(model.precision))
+            hip.check(self.lib.samaudio_set_tensor(self._ctx, name.encode(), hip.ptr(t), dt, t.dim(), hip.shape_array(t.shape)))
+        hip.check(self.lib.samaudio_finalize(self._ctx, 1))
+
+    def __del__(self):
+        if getattr(self, "_ctx", None):
+            self.lib.samaudio_destroy(self._ctx)
+            self._ctx = None
+
+
 class _Lane:
     """An extra engine context bound to its own HIP stream.  It borrows the model's weight tensors (no copy) and
     owns only a workspace; `SAMAudio(streams=S)` solves S contiguous row groups of a batch concurrently so that one
@@ -72,6 +94,7 @@ class _Lane:
             hip.check(self.lib.samaudio_finalize(self._ctx, 1))
         self._workspace: Optional[torch.Tensor] = None
         self._live = None
+        self._codec16: Optional[_Codec16] = None
         self.stream = torch.cuda.Stream(device=model.device)
 
     def __del__(self):
@@ -86,7 +109,7 @@ class SAMAudio:
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
                  text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto",
                  weight_layout: str = "auto", prefetch_rows: Optional[int] = None, ode_graph: Optional[bool] = None,
-                 x3_classes="auto"):
+                 x3_classes="auto", codec_decode: str = "auto"):
         """`ode_graph`: replay the launches of a solve as a HIP graph from the third solve of a shape on (samaudio.h
         SAMAUDIO_OPT_ODE_GRAPH; None = environment SAMAUDIO_ODE_GRAPH, default off).  Scheduling only.
         `weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
@@ -106,6 +129,17 @@ class SAMAudio:
         # compensated 16-bit operands (samaudio.h SAMAUDIO_OPT_X3_CLASSES; `x3_classes`: names or a mask, "auto" = all six)
         self.x3_classes = 0 if not hip.is_x3(precision) else (
             hip.CLS_X3_DEFAULT if x3_classes == "auto" else hip.class_mask(x3_classes))
+        # x3 precisions: the DAC-VAE DECODER on plain 16-bit operands ("16": a codec-only context of the same library beside the
+        # fp32 one; the encoder, whose error reaches the ODE as conditioning, stays fp32) or in fp32 like everything else ("32").
+        # Measured on the hostile weights: decoder alone 16-bit leaves the waveform inside 1e-3 for a
+        # sixth of the fp32 decoder's time.  "auto" = environment SAMAUDIO_X3_DECODE, default "16".
+        if codec_decode == "auto":
+            codec_decode = os.environ.get("SAMAUDIO_X3_DECODE", "16")
+        if codec_decode not in ("16", "32"):
+            raise ValueError("codec_decode must be 'auto', '16' or '32'")
+        self.codec_decode = codec_decode if hip.is_x3(precision) else "native"
+        self._codec16_tensors: Dict[str, torch.Tensor] = {}
+        self._codec16: Optional[_Codec16] = None
         precision = hip.storage_precision(precision)   # what everything below means by "fp32"
         self.f32_classes = 0 if precision == "fp32" else (
             hip.CLS_F32_DEFAULT if f32_classes == "auto" else hip.class_mask(f32_classes))
@@ -269,6 +303,11 @@ class SAMAudio:
             if not codec_missing:
                 self._register(convert_codec(state_dict, self.cfg, self.act_dtype, self.device))
                 self._has_codec = True
+                if self.codec_decode == "16":
+                    self._codec16_tensors = convert_codec(state_dict, self.cfg, hip.half_dtype(self.precision), self.device)
+                    self._codec16 = None
+                    for lane in self._lanes:
+                        lane._codec16 = None
             if self._has_dit and not (dit_missing and codec_missing):
                 hip.check(self._lib.samaudio_finalize(self._ctx, 0))
             if self._has_codec and not (dit_missing and codec_missing):
@@ -370,15 +409,24 @@ class SAMAudio:
         groups run ONE AFTER THE OTHER on the caller's stream, so that an event pair times a kernel that has the GPU to
         itself - the launches (shapes, tile policy, options) are exactly those of the concurrent run."""
         self._profiling, self._serial_groups = True, bool(serial_groups)
-        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+        for ctx in self._profiled_ctxs():
             hip.check(self._lib.samaudio_profile_begin(ctx))
+
+    def _profiled_ctxs(self):
+        """every engine context that launches kernels of a step: the model's, its stream lanes', and their 16-bit codec contexts"""
+        owners = [self] + list(self._lanes)
+        if self.codec_decode == "16" and self._has_codec:
+            for own in owners:
+                if own._codec16 is None:
+                    own._codec16 = _Codec16(self)
+        return [o._ctx for o in owners] + [o._codec16._ctx for o in owners if o._codec16 is not None]
 
     def profile_end(self) -> List[Dict[str, Any]]:
         """[{name, launches, flops, bytes, ms}] per (class, kernel) since profile_begin() (synchronises), summed over the
         contexts.  name = "dit/<kernel>" | "codec/<kernel>" | "prep/<kernel>"; flops / bytes are algorithmic (see
         include/samaudio.h)."""
         merged: Dict[str, Dict[str, Any]] = {}
-        for ctx in [self._ctx] + [lane._ctx for lane in self._lanes]:
+        for ctx in self._profiled_ctxs():
             buf = (hip.KernelStat * 64)()
             n = C.c_int(0)
             hip.check(self._lib.samaudio_profile_end(ctx, buf, 64, C.byref(n)))
@@ -456,6 +504,18 @@ class SAMAudio:
         with torch.cuda.device(self.device):
             self._ensure_workspace(0, 0, 0, self._codec_chunk(items), samples, lane=lane)
             ctx = self._ctx if lane is None else lane._ctx
+            if self.codec_decode == "16":
+                # the 16-bit codec context of this owner, on the owner's workspace (sized for the fp32 context's codec pass, which
+                # needs more; stream order keeps the two contexts' uses of it apart)
+                own = lane if lane is not None else self
+                if own._codec16 is None:
+                    own._codec16 = _Codec16(self)
+                ctx = own._codec16._ctx
+                base = own._workspace.data_ptr()
+                aligned = (base + 255) // 256 * 256
+                need = self._lib.samaudio_workspace_bytes(ctx, 0, 0, 1, self._codec_chunk(items), samples)
+                assert own._workspace.numel() - (aligned - base) >= need
+                hip.check(self._lib.samaudio_set_workspace(ctx, C.c_void_p(aligned), own._workspace.numel() - (aligned - base)))
             hip.check(self._lib.samaudio_codec_decode(ctx, hip.ptr(lat), items, frames, hip.ptr(wav),
                                                       hip.current_stream_ptr()))
         return wav
@@ -554,6 +614,9 @@ class SAMAudio:
             self._lanes.append(_Lane(self))
             if self._profiling:
                 hip.check(self._lib.samaudio_profile_begin(self._lanes[-1]._ctx))
+                if self.codec_decode == "16":
+                    self._lanes[-1]._codec16 = _Codec16(self)
+                    hip.check(self._lib.samaudio_profile_begin(self._lanes[-1]._codec16._ctx))
         self._apply_options(groups)
         main = torch.cuda.current_stream(self.device)
         errors: List[BaseException] = []

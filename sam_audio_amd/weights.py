@@ -156,6 +156,14 @@ def convert_dit_x3(tensors: Dict[str, torch.Tensor], n_layers: int, half: torch.
         for leaf, cls in hip.X3_WEIGHTS.items():
             if classes & hip.CLS[cls]:
                 out[f"L{i}.{leaf}.x3"] = x3_weight(tensors[f"L{i}.{leaf}"], half, ktm)
+    if classes & hip.CLS["patch"]:   # [D, 3 taps x D] -> each tap's D columns split: [D, 3 taps x 3D]
+        for n in (1, 2):
+            w = tensors[f"patch{n}.w"]
+            d = w.shape[0]
+            w3 = torch.cat([x3_weight(w[:, j * d:(j + 1) * d], half, ktm=False) for j in range(3)], dim=1).contiguous()
+            out[f"patch{n}.w.x3"] = ktm_layout(w3) if ktm else w3
+    if classes & hip.CLS["ckv"]:
+        out["c_wkv_all.x3"] = x3_weight(tensors["c_wkv_all"], half, ktm)
     return out
 
 
