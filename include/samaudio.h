@@ -137,7 +137,8 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   class's weights registered in that split form under "<name>.x3" - 16-bit, [N, 3K] row-major or [3K/64, N, 64] K-tile-major
  *   (sam_audio_amd/weights.py x3_weight) - for L<i>.wqkv, wo, c_wq, c_wo, w13, w2; checked like the ".f32" copies above.  Classes
  *   PATCH (the patcher's k3 convolutions: "patch1.w.x3" / "patch2.w.x3", [D, 9D] with EACH tap's D columns split into 3D) and CKV
- *   ("c_wkv_all.x3") can be switched on as well.
+ *   ("c_wkv_all.x3") can be switched on as well.  Class CODEC needs no second copy of anything: the fp32 convolution kernel splits the
+ *   fp32 fragments of both operands in registers and multiplies them as lo*hi + hi*lo + hi*hi on the 16-bit MFMA.
  *   Bit SAMAUDIO_X3_ATTENTION does the same for the two contractions of the self-attention.  Everything else of the context
  *   (norms, softmax, the small GEMM classes, the codec) stays exact fp32.  In
  *   libsamaudio_hip_f16.so the halves are IEEE fp16 (22 mantissa bits per operand); in libsamaudio_hip.so bfloat16 (16 bits). */
@@ -164,7 +165,7 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
 #define SAMAUDIO_X3_ATTENTION (1 << 14)
 #define SAMAUDIO_CLS_X3_CAPABLE \
   (SAMAUDIO_CLS_QKV | SAMAUDIO_CLS_WO | SAMAUDIO_CLS_CWQ | SAMAUDIO_CLS_CWO | SAMAUDIO_CLS_W13 | SAMAUDIO_CLS_W2 | SAMAUDIO_CLS_PATCH | \
-   SAMAUDIO_CLS_CKV | SAMAUDIO_X3_ATTENTION)
+   SAMAUDIO_CLS_CKV | SAMAUDIO_CLS_CODEC | SAMAUDIO_X3_ATTENTION)
 #define SAMAUDIO_CLS_F32_CAPABLE (SAMAUDIO_CLS_TIME | SAMAUDIO_CLS_OUT | SAMAUDIO_CLS_IN | SAMAUDIO_CLS_PREP | SAMAUDIO_CLS_YEMB)
 int samaudio_set_option(samaudio_ctx* ctx, int option, int value);
 

@@ -238,5 +238,10 @@ constexpr int GEMM_FLAG_W_KTM = 2048;
 // result - row stride act_ld = 3 * (N / 2), [lo | hi | hi] with hi = rn16(v), lo = rn16(v - hi) - i.e. the next GEMM's split
 // activation operand straight from the fp32 accumulators (SAMAUDIO_OPT_X3_CLASSES; kernels.hip split3_kernel is the stand-alone form)
 constexpr int GEMM_FLAG_OUT_SPLIT3 = 4096;
+// flags bit 13 (fp32 kernel of gemm.hip only): COMPENSATED 16-bit multiply of fp32 operands, split ON THE FLY - the fp32 fragments of
+// a K slab are split in registers into hi = rn16(x), lo = rn16(x - hi) and multiplied as lo*hi + hi*lo + hi*hi on the 16-bit MFMA
+// (3 x 16x16x32 instead of 8 x 16x16x4f32 per 32 k: the fp32 product to ~2^-21, 2.7x less matrix-core time; no second copy of
+// anything).  SAMAUDIO_OPT_X3_CLASSES bit SAMAUDIO_CLS_CODEC: the DAC-VAE convolutions of an fp32 context.
+constexpr int GEMM_FLAG_X3_FLY = 8192;
 
 }  // namespace sa

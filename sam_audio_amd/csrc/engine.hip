@@ -396,7 +396,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp * (fold_all ? cfg_.n_layers : 1)) : nullptr;
   // SAMAUDIO_OPT_X3_CLASSES: the split activation operand [lo | hi | hi] of the widest GEMM input (16-bit, 3 K elements per row)
   // (x3a: D-wide operands and the patcher's halo-padded rows; x3u: the SwiGLU hidden, written by the w13 launch while it reads x3a)
-  const bool x3g = !bf16_ && (x3_classes_ & ~SAMAUDIO_X3_ATTENTION);
+  const bool x3g = !bf16_ && (x3_classes_ & ~(SAMAUDIO_X3_ATTENTION | SAMAUDIO_CLS_CODEC));
   void* x3a = x3g ? b.take((size_t)rows * (T + 2) * 3 * (size_t)D * 2) : nullptr;
   void* x3u = x3g ? b.take((size_t)M * 3 * (size_t)F * 2) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
@@ -560,9 +560,9 @@ Status Engine::set_option_value(int option, int value) {
   if (option == SAMAUDIO_OPT_X3_CLASSES) {
     if (value && bf16_) return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES applies to fp32 contexts (compensated 16-bit operands under fp32 storage)");
     if (value & ~SAMAUDIO_CLS_X3_CAPABLE)
-      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: only the six big GEMM classes of the DiT layers (qkv, wo, cwq, cwo, w13, w2), patch, ckv and SAMAUDIO_X3_ATTENTION");
+      return fail(SAMAUDIO_ERR_ARG, "SAMAUDIO_OPT_X3_CLASSES: only the six big GEMM classes of the DiT layers (qkv, wo, cwq, cwo, w13, w2), patch, ckv, codec and SAMAUDIO_X3_ATTENTION");
     if (dit_ready_) SA_TRY(check_x3_weights(value));   // (before finalize(0): checked there)
-    if (((value & ~SAMAUDIO_X3_ATTENTION) != 0) != ((x3_classes_ & ~SAMAUDIO_X3_ATTENTION) != 0)) prepared_ = false;   // the scratch operand is part of the workspace plan
+    if (((value & ~(SAMAUDIO_X3_ATTENTION | SAMAUDIO_CLS_CODEC)) != 0) != ((x3_classes_ & ~(SAMAUDIO_X3_ATTENTION | SAMAUDIO_CLS_CODEC)) != 0)) prepared_ = false;   // the scratch operand is part of the workspace plan
     x3_classes_ = value;
     return Status{};
   }
@@ -644,6 +644,8 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
               [&] { return launch_gemm(p, false, st); });
   }
   if (!is16 && quant_fmt_ && (quant_classes_ & cls)) p.flags |= (quant_fmt_ << 2) | (quant_fmt_ << 4);
+  // SAMAUDIO_OPT_X3_CLASSES bit CODEC (fp32 contexts): the convolution multiplies on split operands, split in registers (gemm.hip)
+  if (!is16 && p.tag && x3(SAMAUDIO_CLS_CODEC)) p.flags |= GEMM_FLAG_X3_FLY;
   if (const char* why = gemm_check(p, is16)) return fail(SAMAUDIO_ERR_ARG, why);
   if (!prof_on_) {
     SA_HIP(launch_gemm(p, is16, st));

@@ -145,6 +145,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int nslab = p.K / BK;
   const int lr = lane & 15, lg = lane >> 4;
   const int qa = (p.flags >> 2) & 3, qw = (p.flags >> 4) & 3;  // operand rounding (fp32 kernel only, see quant16)
+  const bool x3fly = sizeof(T) == 4 && (p.flags & GEMM_FLAG_X3_FLY) != 0;   // (uniform)
   issue(0);
   for (int s = 0; s < nslab; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -152,6 +153,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     if (s + 1 < nslab) issue((s + 1) & 1);
     const char* sA = smem + (s & 1) * STAGE;
     const char* sB = sA + TILE_A;
+    if constexpr (sizeof(T) == 4) {
+      if (x3fly) {
+        // GEMM_FLAG_X3_FLY: both k-steps of the 32-element slab at once.  A lane's 8 values (k = 4 lg .. + 3 and 16 + 4 lg .. + 3) form
+        // one 16x16x32 fragment; A and W use the same lane -> k map, so the MFMA pairs equal k.  Small terms first.
+#pragma clang fp contract(off)
+        bf16x8_t ah[FM], al[FM], bh[FN], bl[FN];
+        auto split = [&](const char* base, int row, bf16x8_t& hi, bf16x8_t& lo) {
+          const int sw = (row >> 1) & 7;
+          const f32x4_t v0 = *(const f32x4_t*)(base + row * 128 + ((lg ^ sw) << 4));
+          const f32x4_t v1 = *(const f32x4_t*)(base + row * 128 + (((4 + lg) ^ sw) << 4));
+          unsigned h[4], l[4];
+          h[0] = pack_h16x2(fminf(fmaxf(v0[0], -kH16Max), kH16Max), fminf(fmaxf(v0[1], -kH16Max), kH16Max));
+          h[1] = pack_h16x2(fminf(fmaxf(v0[2], -kH16Max), kH16Max), fminf(fmaxf(v0[3], -kH16Max), kH16Max));
+          h[2] = pack_h16x2(fminf(fmaxf(v1[0], -kH16Max), kH16Max), fminf(fmaxf(v1[1], -kH16Max), kH16Max));
+          h[3] = pack_h16x2(fminf(fmaxf(v1[2], -kH16Max), kH16Max), fminf(fmaxf(v1[3], -kH16Max), kH16Max));
+          l[0] = pack_h16x2(v0[0] - h16_lo(h[0]), v0[1] - h16_hi(h[0]));
+          l[1] = pack_h16x2(v0[2] - h16_lo(h[1]), v0[3] - h16_hi(h[1]));
+          l[2] = pack_h16x2(v1[0] - h16_lo(h[2]), v1[1] - h16_hi(h[2]));
+          l[3] = pack_h16x2(v1[2] - h16_lo(h[3]), v1[3] - h16_hi(h[3]));
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+          hi = __builtin_bit_cast(bf16x8_t, (u32x4_t){h[0], h[1], h[2], h[3]});
+          lo = __builtin_bit_cast(bf16x8_t, (u32x4_t){l[0], l[1], l[2], l[3]});
+        };
+#pragma unroll
+        for (int i = 0; i < FM; ++i) split(sA, wm * WTM + i * 16 + lr, ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) split(sB, wn * WTN + j * 16 + lr, bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            acc[i][j] = SA_MFMA_16x16x32(bh[j], al[i], acc[i][j]);
+            acc[i][j] = SA_MFMA_16x16x32(bl[j], ah[i], acc[i][j]);
+            acc[i][j] = SA_MFMA_16x16x32(bh[j], ah[i], acc[i][j]);
+          }
+        continue;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       typename Mma<T>::frag_t af[FM], bfr[FN];

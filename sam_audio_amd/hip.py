@@ -92,7 +92,7 @@ ALT16_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "w13": "w13", "w2": "
 # the six big GEMM classes of the DiT layers (97 % of the flops) and the engine weight each reads
 X3_ATTENTION = 1 << 14   # samaudio.h SAMAUDIO_X3_ATTENTION: the self-attention's contractions on split operands as well
 CLS_X3_GEMMS = CLS["qkv"] | CLS["wo"] | CLS["cwq"] | CLS["cwo"] | CLS["w13"] | CLS["w2"]
-CLS_X3_DEFAULT = CLS_X3_GEMMS | CLS["patch"] | CLS["ckv"] | X3_ATTENTION
+CLS_X3_DEFAULT = CLS_X3_GEMMS | CLS["patch"] | CLS["ckv"] | CLS["codec"] | X3_ATTENTION
 X3_WEIGHTS = {"wqkv": "qkv", "wo": "wo", "c_wq": "cwq", "c_wo": "cwo", "w13": "w13", "w2": "w2"}
 QUANT_FORMATS = {"bf16": 1, "fp16": 2}
 SENTINEL_NAMES = CLASSES + ("norm", "attn")

@@ -86,6 +86,67 @@ def test_x3_gemm_is_the_fp32_product(gpu, prec, shape):
 
 
 @pytest.mark.parametrize("prec", X3)
+@pytest.mark.parametrize("shape", [(300, 96, 672, 96), (200, 192, 256, 256), (70, 1, 448, 64)])
+def test_fp32_gemm_with_operands_split_on_the_fly(gpu, prec, shape):
+    """GemmParams.flags bit 13 (common.h GEMM_FLAG_X3_FLY; SAMAUDIO_OPT_X3_CLASSES bit CODEC): the fp32 kernel of gemm.hip splits the
+    fp32 fragments of BOTH operands in registers and multiplies on the 16-bit MFMA - here as a dilated implicit convolution
+    (kc < K: the DAC-VAE's k7 convolutions, reference codec.py:65-89) with bias and Snake, against the exact-fp32 launch of the same
+    parameters and the fp64 product."""
+    M, N, K, kc = shape
+    g = torch.Generator().manual_seed(5)
+    taps, dil, halo = K // kc, 3, 40
+    x = torch.randn(M + 2 * halo, kc, generator=g) * torch.logspace(-1.5, 1, kc)[None, :]
+    w = torch.randn(N, K, generator=g) * 0.05
+    bias, alpha = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5
+    a_off = (halo - (taps // 2) * dil) * kc
+    rows = torch.stack([x[halo - (taps // 2) * dil + j * dil: halo - (taps // 2) * dil + j * dil + M] for j in range(taps)], 1).reshape(M, K)
+    ref = rows.double() @ w.double().T + bias.double()
+    lib = hip.lib(hip.operands_for(prec))
+    outs = {}
+    for flags in (0, 8192):
+        o32, oact = torch.full((M, N), float("nan"), device=gpu), torch.full((M, N), float("nan"), device=gpu)
+        xd, wd, bd, ad = x.to(gpu).contiguous(), w.to(gpu).contiguous(), bias.to(gpu), alpha.to(gpu)
+        prm = util.gemm_params(xd, wd, M, N, K, a_off=a_off, lda=kc, kc=kc, tap_stride=dil * kc, bias=bd, out_f32=o32, f32_geom=(0, N, 0),
+                               out_act=oact, act_geom=(0, N, 0), act=hip.ACT_SNAKE, act_alpha=ad, flags=flags)
+        hip.check(lib.samaudio_op_gemm(C.byref(prm), C.sizeof(prm), hip.F32, util.stream()))
+        outs[flags] = (o32.cpu(), oact.cpu())
+    e_exact = (outs[0][0] - ref.float()).abs().max().item()
+    e_fly = (outs[8192][0] - ref.float()).abs().max().item()
+    half = HALF[prec]
+    e_plain = ((rows.to(half).double() @ w.to(half).double().T + bias.double()).float() - ref.float()).abs().max().item()
+    snake = ref + torch.sin(alpha.double() * ref) ** 2 / (alpha.double() + 1e-9)
+    e_act = (outs[8192][1] - snake.float()).abs().max().item()
+    print(f"fp32 GEMM, operands split on the fly ({prec}) {shape}: max-abs err {e_fly:.3e} (exact-fp32 launch {e_exact:.3e}, plain 16-bit "
+          f"operands {e_plain:.3e}); Snake output {e_act:.3e}; |ref| <= {ref.abs().max():.2f}")
+    tol = (4e-6 if half == torch.float16 else 1e-4) * max(1.0, ref.abs().max().item())
+    assert e_fly < tol and e_act < 2 * tol and e_fly < e_plain / 20
+
+
+@pytest.mark.parametrize("prec", X3)
+def test_codec_roundtrip_in_x3_context(gpu, prec):
+    """DAC-VAE encode and decode of an x3 model (fp32 context, convolutions on operands split on the fly; decoder likewise unless
+    codec_decode='16') against the oracle (reference codec.py:65-89)."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=3)
+    hop = cfg.audio_codec.hop_length
+    wav = torch.stack([synthetic_clip(i, 20 * hop) for i in range(2)])
+    with torch.inference_mode():
+        z_ref = O.dac_encode(sd, cfg.audio_codec, wav)
+        w_ref = O.dac_decode(sd, cfg.audio_codec, z_ref).squeeze(1)
+    for dec in ("32", "16"):
+        model = SAMAudio(cfg, precision=prec, device=str(gpu), codec_decode=dec)
+        model.load_state_dict(sd, strict=False)
+        z = model.encode_audio(wav.to(gpu))
+        w = model.decode_audio(z)
+        e_z = (z.cpu() - z_ref.transpose(1, 2)).abs().max().item()
+        e_w = (w.cpu() - w_ref).abs().max().item()
+        print(f"codec in an {prec} model, decoder '{dec}': encode latent err {e_z:.3e} (|z| <= {z_ref.abs().max():.2f}), decoded waveform err "
+              f"{e_w:.3e} (|w| <= {w_ref.abs().max():.2f})")
+        assert e_z < (2e-5 if prec == "fp16x3" else 5e-4)
+        assert e_w < ((2e-5 if prec == "fp16x3" else 5e-4) if dec == "32" else 5e-3)
+
+
+@pytest.mark.parametrize("prec", X3)
 @pytest.mark.parametrize("T", [50, 250, 300])
 def test_self_attention_on_split_operands(gpu, prec, T):
     """SAMAUDIO_X3_ATTENTION: fp32 Q / K / V^T in, fp32 rows out, both contractions on hi/lo-split operands on the 16-bit MFMA -
