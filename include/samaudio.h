@@ -182,6 +182,14 @@ int samaudio_prepare(samaudio_ctx* ctx, int rows, int frames, int text_len, cons
                      const float* text, const uint8_t* text_mask, const float* video, const int64_t* anchor_ids,
                      int n_ids, const int64_t* anchor_alignment, const uint8_t* audio_pad_mask,
                      samaudio_stream stream);
+/* The same with the conditioning as separate() holds it (no concatenated / repeated copies):
+ *   latent [rows / candidates, frames, latent_channels / 2] f32: the DAC-VAE mean latent z; audio_features = (z | z)
+ *   (model.py:182-184) is never materialised - the feature GEMM reads each z row twice (two K taps, stride 0);
+ *   candidates >= 1: text / text_mask / video / anchor_ids / anchor_alignment / audio_pad_mask hold rows / candidates clips; the
+ *   per-clip conditioning is computed once and repeated sample-major for the clip's candidates (model.py:193-203) inside the engine. */
+int samaudio_prepare_latent(samaudio_ctx* ctx, int rows, int frames, int text_len, int candidates, const float* latent,
+                            const float* text, const uint8_t* text_mask, const float* video, const int64_t* anchor_ids,
+                            int n_ids, const int64_t* anchor_alignment, const uint8_t* audio_pad_mask, samaudio_stream stream);
 
 /* One ODE function evaluation = SAMAudio.forward (model.py:130-180) -> DiT.forward (transformer.py:473-524).
  *   noisy [rows, frames, 256] f32, time [n_time] f32 with n_time in {1, rows}, out [rows, frames, 256] f32 */
@@ -201,6 +209,9 @@ int samaudio_codec_encode(samaudio_ctx* ctx, const float* wav, int items, int64_
                           samaudio_stream stream);
 int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int frames, float* wav,
                           samaudio_stream stream);
+/* Decode straight from the ODE state (reference model.py:291-295 without the transposed copy): state [rows, frames, 2 * codec_dim]
+ * f32 -> wav [2 * rows, frames * hop]: waveform 2b = channels [0, codec_dim) of row block b (target), 2b + 1 the rest (residual). */
+int samaudio_codec_decode_pairs(samaudio_ctx* ctx, const float* state, int rows, int frames, float* wav, samaudio_stream stream);
 
 /* ---- reranking and span prediction ------------------------------------------ */
 

@@ -545,6 +545,10 @@ hipError_t launch_peav_cls_mask(float* h, const float* cls, const unsigned char*
   return hipSuccess;
 }
 
+hipError_t launch_repeat_items_f32(const float* src, float* dst, int items, int rep, long elems, hipStream_t) {
+  for (long r = (long)items * rep - 1; r >= 0; --r) std::memmove(dst + r * elems, src + (r / rep) * elems, (size_t)elems * 4);
+  return hipSuccess;
+}
 hipError_t launch_repeat_rows_u8(const unsigned char* src, unsigned char* dst, int rows, int rep, int T, hipStream_t) {
   for (long r = 0; r < (long)rows * rep; ++r) std::memcpy(dst + r * T, src + (r / rep) * T, (size_t)T);
   return hipSuccess;

@@ -98,6 +98,14 @@ int samaudio_prepare(samaudio_ctx* ctx, int rows, int frames, int text_len, cons
                                   anchor_alignment, audio_pad_mask, (hipStream_t)stream));
 }
 
+int samaudio_prepare_latent(samaudio_ctx* ctx, int rows, int frames, int text_len, int candidates, const float* latent,
+                            const float* text, const uint8_t* text_mask, const float* video, const int64_t* anchor_ids,
+                            int n_ids, const int64_t* anchor_alignment, const uint8_t* audio_pad_mask, samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  return ret(ctx->engine->prepare(rows, frames, text_len, latent, text, text_mask, video, anchor_ids, n_ids, anchor_alignment,
+                                  audio_pad_mask, (hipStream_t)stream, candidates, true));
+}
+
 int samaudio_forward(samaudio_ctx* ctx, const float* noisy, const float* time, int n_time, float* out,
                      samaudio_stream stream) {
   if (!ctx) return bad("null context");
@@ -120,6 +128,12 @@ int samaudio_codec_decode(samaudio_ctx* ctx, const float* latent, int items, int
                           samaudio_stream stream) {
   if (!ctx) return bad("null context");
   return ret(ctx->engine->codec_decode(latent, items, frames, wav, (hipStream_t)stream));
+}
+
+int samaudio_codec_decode_pairs(samaudio_ctx* ctx, const float* state, int rows, int frames, float* wav, samaudio_stream stream) {
+  if (!ctx) return bad("null context");
+  if (rows <= 0) return bad("codec_decode_pairs: rows");
+  return ret(ctx->engine->codec_decode(state, 2 * rows, frames, wav, (hipStream_t)stream, true));
 }
 
 void samaudio_debug_force_gemm_variant(int variant) { sa::gemm_force_variant(variant); }

@@ -54,13 +54,18 @@ class Engine {
   size_t workspace_bytes(int rows, int frames, int text_len, int codec_items, int64_t samples);
   Status set_workspace(void* p, size_t bytes);
 
+  // `candidates` > 1: every conditioning tensor holds rows / candidates clips and serves `candidates` consecutive rows each
+  // (reference model.py:193-203, sample-major); `latent_feats`: feats is the codec latent z [.., frames, latent_channels / 2] and the
+  // audio features are (z | z) (model.py:182-184) - read twice through a zero tap stride, never materialised
   Status prepare(int rows, int frames, int text_len, const float* feats, const float* text, const uint8_t* text_mask,
                  const float* video, const int64_t* anchor_ids, int n_ids, const int64_t* anchor_alignment,
-                 const uint8_t* pad_mask, hipStream_t st);
+                 const uint8_t* pad_mask, hipStream_t st, int candidates = 1, bool latent_feats = false);
   Status forward(const float* noisy, const float* time, int n_time, float* out, hipStream_t st);
   Status ode_solve(float* state, int method, const float* grid_host, int n_grid, hipStream_t st);
   Status codec_encode(const float* wav, int items, int64_t samples, float* latent, hipStream_t st);
-  Status codec_decode(const float* latent, int items, int frames, float* wav, hipStream_t st);
+  // `pairs`: latent is the ODE state [items / 2, frames, 2 * codec_dim] - item 2b = the first codec_dim channels of row b (target),
+  // 2b + 1 the second (residual): reference model.py:291-295 without the transposed copy
+  Status codec_decode(const float* latent, int items, int frames, float* wav, hipStream_t st, bool pairs = false);
 
   // Per-kernel timing with HIP events on the launch stream (bench.py's roofline leg): between begin and end
   // every GEMM launch is bracketed by an event pair; end synchronises and folds them per tile variant.

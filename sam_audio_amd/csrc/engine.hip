@@ -827,9 +827,10 @@ static void with_res(GemmParams& p, const float* r, long ld) { p.res = r; p.res_
 // ---------------------------------------------------------------------------------------------------
 Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float* text, const uint8_t* text_mask,
                        const float* video, const int64_t* anchor_ids, int n_ids, const int64_t* anchor_alignment,
-                       const uint8_t* pad_mask, hipStream_t st) {
+                       const uint8_t* pad_mask, hipStream_t st, int cand, bool latent_feats) {
   if (!dit_ready_) return fail(SAMAUDIO_ERR_STATE, "prepare: DiT weights not finalized");
   if (rows <= 0 || T <= 0 || !feats) return fail(SAMAUDIO_ERR_ARG, "prepare: bad shape");
+  if (cand < 1 || rows % cand) return fail(SAMAUDIO_ERR_ARG, "prepare: rows must be a multiple of candidates");
   if (T > cfg_.max_positions) return fail(SAMAUDIO_ERR_ARG, "prepare: more frames than RoPE positions");
   if (text && Lt <= 0) return fail(SAMAUDIO_ERR_ARG, "prepare: text_len must be positive");
   if (!text) Lt = 1;
@@ -842,10 +843,18 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   rows_ = rows; frames_ = T; text_len_ = Lt; frames_pad_ = (int)round_up(T, 64);
   const int D = cfg_.dim, C2 = cfg_.latent_channels;
   const long M = (long)rows * T, Mt = (long)rows * Lt;
+  // the conditioning is computed once per CLIP (B = rows / candidates of them) and then repeated for the clip's candidates: the
+  // per-clip results live in buffers the evaluations overwrite anyway (aligned, hp1) until the repeat kernels have read them
+  const int B = rows / cand;
+  const long Mb = (long)B * T, Mtb = (long)B * Lt;
+  float* const cond_b = cand > 1 ? d_.aligned : d_.cond;
+  float* const textp_b = cand > 1 ? d_.hp1 : d_.text_proj;
 
-  if (pad_mask) SA_HIP(hipMemcpyAsync(d_.pad_mask, pad_mask, M, hipMemcpyDeviceToDevice, st));
+  if (pad_mask && cand > 1) SA_HIP(launch_repeat_rows_u8(pad_mask, d_.pad_mask, B, cand, T, st));
+  else if (pad_mask) SA_HIP(hipMemcpyAsync(d_.pad_mask, pad_mask, M, hipMemcpyDeviceToDevice, st));
   else SA_HIP(hipMemsetAsync(d_.pad_mask, 1, M, st));
-  if (text && text_mask) SA_HIP(hipMemcpyAsync(d_.text_mask, text_mask, Mt, hipMemcpyDeviceToDevice, st));
+  if (text && text_mask && cand > 1) SA_HIP(launch_repeat_rows_u8(text_mask, d_.text_mask, B, cand, Lt, st));
+  else if (text && text_mask) SA_HIP(hipMemcpyAsync(d_.text_mask, text_mask, Mt, hipMemcpyDeviceToDevice, st));
   else SA_HIP(hipMemsetAsync(d_.text_mask, 1, Mt, st));
   // patcher conv input: halo rows stay zero for the whole solve
   SA_HIP(hipMemsetAsync(d_.gnbuf, 0, (size_t)rows * (T + 2) * D * esz_, st));
@@ -854,25 +863,29 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   const bool pf = f32c(SAMAUDIO_CLS_PREP);
   const int PREP = SAMAUDIO_CLS_PREP;
   // cond = proj_b + audio_features @ Wf^T                           (model.py:116-125, columns 512..767)
-  if (!pf) SA_HIP(launch_to_act(feats, 0, C2, 0, d_.feats, 0, bf16_, 1, M, C2, C2, 0, st));
+  // latent_feats: audio_features = (z | z) of the codec latent z [Mb, C2 / 2] (model.py:182-184): the K axis of this GEMM is two
+  // taps of C2 / 2 channels that read the SAME row (tap stride 0) - the same products in the same order as on the concatenation
+  const int fw = latent_feats ? C2 / 2 : C2;   // width of the rows `feats` holds
+  if (!pf) SA_HIP(launch_to_act(feats, 0, fw, 0, d_.feats, 0, bf16_, 1, Mb, fw, fw, 0, st));
   {
-    GemmParams p = pf ? lin(feats, C2, g32_.proj_wf, M, D, C2) : lin(d_.feats, C2, g_.proj_wf, M, D, C2);
+    GemmParams p = pf ? lin(feats, fw, g32_.proj_wf, Mb, D, C2) : lin(d_.feats, fw, g_.proj_wf, Mb, D, C2);
+    if (latent_feats) { p.kc = fw; p.tap_stride = 0; }
     p.bias = g_.proj_b;
-    out_f32(p, d_.cond, D);
+    out_f32(p, cond_b, D);
     SA_TRY(gemm(p, st, -1.0, PREP, pf));
   }
   // cond += tanh(g_v) * LayerNorm(conv1x1(video))                   (align.py:41-50; zeros if no video: Q8)
   const void* vid_op = d_.video;
   if (pf && video) vid_op = video;
-  else if (pf) { vid_op = d_.prep32; SA_HIP(hipMemsetAsync(d_.prep32, 0, (size_t)M * cfg_.video_dim * 4, st)); }
-  else if (video) SA_HIP(launch_to_act(video, 0, cfg_.video_dim, 0, d_.video, 0, bf16_, 1, M, cfg_.video_dim, cfg_.video_dim, 0, st));
-  else SA_HIP(hipMemsetAsync(d_.video, 0, (size_t)M * cfg_.video_dim * esz_, st));
+  else if (pf) { vid_op = d_.prep32; SA_HIP(hipMemsetAsync(d_.prep32, 0, (size_t)Mb * cfg_.video_dim * 4, st)); }
+  else if (video) SA_HIP(launch_to_act(video, 0, cfg_.video_dim, 0, d_.video, 0, bf16_, 1, Mb, cfg_.video_dim, cfg_.video_dim, 0, st));
+  else SA_HIP(hipMemsetAsync(d_.video, 0, (size_t)Mb * cfg_.video_dim * esz_, st));
   {
-    GemmParams p = lin(vid_op, cfg_.video_dim, pf ? (const void*)g32_.vid_w : g_.vid_w, M, D, cfg_.video_dim);
+    GemmParams p = lin(vid_op, cfg_.video_dim, pf ? (const void*)g32_.vid_w : g_.vid_w, Mb, D, cfg_.video_dim);
     p.bias = g_.vid_b;
     out_f32(p, d_.vtmp, D);
     SA_TRY(gemm(p, st, -1.0, PREP, pf));
-    SA_HIP(launch_layernorm_accum(d_.vtmp, g_.vid_ln_w, g_.vid_ln_b, g_.vid_gate, d_.cond, (int)M, D, 1e-5f, st));
+    SA_HIP(launch_layernorm_accum(d_.vtmp, g_.vid_ln_w, g_.vid_ln_b, g_.vid_gate, cond_b, (int)Mb, D, 1e-5f, st));
   }
   // cond += tanh(g_a) * proj(Emb[ids.gather(alignment)])            (model.py:54-65; tanh folded into anc_w)
   // folded cross-attention output projection: zero the probability buffer once (its K padding columns stay zero)
@@ -887,24 +900,28 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
     SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment,
-                                pf ? (void*)d_.prep32 : d_.anch, pf ? false : bf16_, rows, T, cfg_.anchor_dim,
+                                pf ? (void*)d_.prep32 : d_.anch, pf ? false : bf16_, B, T, cfg_.anchor_dim,
                                 cfg_.anchor_vocab, st));
-    GemmParams p = pf ? lin(d_.prep32, cfg_.anchor_dim, g32_.anc_w, M, D, cfg_.anchor_dim)
-                      : lin(d_.anch, cfg_.anchor_dim, g_.anc_w, M, D, cfg_.anchor_dim);
-    with_res(p, d_.cond, D);
-    out_f32(p, d_.cond, D);
+    GemmParams p = pf ? lin(d_.prep32, cfg_.anchor_dim, g32_.anc_w, Mb, D, cfg_.anchor_dim)
+                      : lin(d_.anch, cfg_.anchor_dim, g_.anc_w, Mb, D, cfg_.anchor_dim);
+    with_res(p, cond_b, D);
+    out_f32(p, cond_b, D);
     SA_TRY(gemm(p, st, -1.0, PREP, pf));
   }
   // text_proj = memory_proj(text)                                   (model.py:171)
   if (text) {
-    if (!pf) SA_HIP(launch_to_act(text, 0, cfg_.text_dim, 0, d_.text, 0, bf16_, 1, Mt, cfg_.text_dim, cfg_.text_dim, 0, st));
-    GemmParams p = pf ? lin(text, cfg_.text_dim, g32_.mem_w, Mt, D, cfg_.text_dim)
-                      : lin(d_.text, cfg_.text_dim, g_.mem_w, Mt, D, cfg_.text_dim);
+    if (!pf) SA_HIP(launch_to_act(text, 0, cfg_.text_dim, 0, d_.text, 0, bf16_, 1, Mtb, cfg_.text_dim, cfg_.text_dim, 0, st));
+    GemmParams p = pf ? lin(text, cfg_.text_dim, g32_.mem_w, Mtb, D, cfg_.text_dim)
+                      : lin(d_.text, cfg_.text_dim, g_.mem_w, Mtb, D, cfg_.text_dim);
     p.bias = g_.mem_b;
-    out_f32(p, d_.text_proj, D);
+    out_f32(p, textp_b, D);
     SA_TRY(gemm(p, st, -1.0, PREP, pf));
   } else {
-    SA_HIP(hipMemsetAsync(d_.text_proj, 0, (size_t)Mt * D * 4, st));
+    SA_HIP(hipMemsetAsync(textp_b, 0, (size_t)Mtb * D * 4, st));
+  }
+  if (cand > 1) {   // sample-major repeat of the per-clip conditioning (model.py:193-203)
+    SA_HIP(launch_repeat_items_f32(cond_b, d_.cond, B, cand, (long)T * D, st));
+    SA_HIP(launch_repeat_items_f32(textp_b, d_.text_proj, B, cand, (long)Lt * D, st));
   }
   prepared_ = true;
   return Status{};
@@ -1427,9 +1444,10 @@ Status Engine::codec_encode(const float* wav, int items, int64_t S, float* laten
   return Status{};
 }
 
-Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, hipStream_t st) {
+Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, hipStream_t st, bool pairs) {
   if (!codec_ready_) return fail(SAMAUDIO_ERR_STATE, "codec_decode: codec weights not finalized");
   if (!latent || !wav || items <= 0 || T0 <= 0) return fail(SAMAUDIO_ERR_ARG, "codec_decode: bad argument");
+  if (pairs && items % 2) return fail(SAMAUDIO_ERR_ARG, "codec_decode: the state layout holds (target, residual) pairs");
   long hop = 1;
   for (int i = 0; i < 4; ++i) hop *= cfg_.enc_rates[i];
   const int64_t S = (int64_t)T0 * hop;
@@ -1440,6 +1458,8 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
   int chunk = ws_bytes_ > fixed ? (int)((ws_bytes_ - fixed) / (per_item ? per_item : 1)) : 0;
   if (!ws_ || chunk < 1) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_decode: workspace too small");
   if (chunk > items) chunk = items;
+  if (pairs && chunk > 1) chunk &= ~1;   // a pass holds whole pairs
+  if (pairs && chunk < 2) return fail(SAMAUDIO_ERR_WORKSPACE, "codec_decode: workspace too small for one (target, residual) pair");
   prepared_ = false;
   prof_cls_ = "codec";
   long encT[5], decT[5];
@@ -1463,6 +1483,12 @@ Status Engine::codec_decode(const float* latent, int items, int T0, float* wav, 
       SA_HIP(launch_zero_halo(sb[i].act, bf16_, n, sb[i].T, sb[i].C, HALO, st));
       SA_HIP(launch_zero_halo(sb[i].tmp, bf16_, n, sb[i].T, sb[i].C, HALO, st));
     }
+    if (pairs) {   // items (2b, 2b + 1) = channels [0, CD) / [CD, 2 CD) of state row block b: two strided gathers, no transposed copy
+      const long item = (long)(T0 + 2 * HALO) * CD;
+      for (int sgn = 0; sgn < 2; ++sgn)
+        SA_HIP(launch_to_act(latent + (long)(i0 / 2) * T0 * 2 * CD, (long)T0 * 2 * CD, 2L * CD, sgn * CD, (char*)lat + (size_t)sgn * item * esz_,
+                             2 * item, bf16_, n / 2, T0, CD, CD, HALO, st));
+    } else
     SA_HIP(launch_to_act(latent + (long)i0 * T0 * CD, (long)T0 * CD, CD, 0, lat, 0, bf16_, n, T0, CD, CD, HALO, st));
     {
       GemmParams p = conv_same(lat, T0, CD, 1, 1, dec_.proj_w, CD, CL, n);  // quantizer.out_proj

@@ -191,6 +191,8 @@ hipError_t launch_peav_cls_mask(float* h, const float* cls, const unsigned char*
 // dst[b*rep + c][:] = src[b][:]
 hipError_t launch_repeat_rows_u8(const unsigned char* src, unsigned char* dst, int rows, int rep, int T,
                                  hipStream_t st);
+// dst[b*rep + c][:] = src[b][:], items of `elems` fp32 values (elems % 4 == 0)
+hipError_t launch_repeat_items_f32(const float* src, float* dst, int items, int rep, long elems, hipStream_t st);
 // masked GroupNorm(1 group) + SiLU into a halo-padded channels-last buffer; partials: B * 64 * 3 doubles
 hipError_t launch_masked_groupnorm_silu(const float* x, const float* w, const float* b, const unsigned char* mask,
                                         double* partials, void* out, bool bf16, int B, int S, int C, int halo,

@@ -44,6 +44,22 @@ hipError_t launch_repeat_rows_u8(const unsigned char* src, unsigned char* dst, i
   return hipGetLastError();
 }
 
+// dst[b*rep + c][:] = src[b][:] for items of `elems` fp32 values (elems % 4 == 0): the conditioning of a clip repeated for each
+// of its reranking candidates, sample-major (reference model.py:193-203 repeat_interleave) - inside the engine, once per separate()
+__global__ void repeat_items_f32_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int rep, long e4, long total4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const long item = i / e4;
+  dst[i] = src[(item / rep) * e4 + (i - item * e4)];
+}
+hipError_t launch_repeat_items_f32(const float* src, float* dst, int items, int rep, long elems, hipStream_t st) {
+  if (elems % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return hipErrorInvalidValue;
+  const long total4 = (long)items * rep * (elems / 4);
+  hipLaunchKernelGGL(repeat_items_f32_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, (const float4*)src, (float4*)dst,
+                     rep, elems / 4, total4);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // Masked GroupNorm(1 group) + SiLU, channels-last (hf:198-238): statistics over the VALID (frame, channel) entries of
 // a sample, affine, output of masked frames = 0 (x_norm * mask, and silu(0) = 0).  Same two-pass, fixed-order fp64

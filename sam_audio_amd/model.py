@@ -492,13 +492,19 @@ class SAMAudio:
         return z
 
     def decode_audio(self, latents: torch.Tensor, lane: Optional[_Lane] = None,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, pairs: bool = False) -> torch.Tensor:
         """latents channels-last [N, T, codebook_dim] -> [N, T*hop] (reference codec.py:86-89).  `lane`: run on that
-        lane's context (and on the current stream); `out`: a contiguous [N, T*hop] fp32 destination."""
+        lane's context (and on the current stream); `out`: a contiguous [N, T*hop] fp32 destination.
+        `pairs`: `latents` is the ODE state [rows, T, 2*codebook_dim]; waveform 2b = the first codebook_dim channels of row
+        block b (target), 2b + 1 the rest (residual) - reference model.py:291-295, gathered inside the engine instead of a
+        transposed copy."""
         if not self._has_codec:
             raise RuntimeError("audio_codec weights are not loaded")
         lat = latents.to(self.device, torch.float32).contiguous()
         items, frames, _ = lat.shape
+        if pairs:
+            assert lat.shape[2] == 2 * self.cfg.audio_codec.codebook_dim
+            items *= 2
         samples = frames * self.cfg.audio_codec.hop_length
         wav = out if out is not None else torch.empty(items, samples, device=self.device)
         assert wav.shape == (items, samples) and wav.is_contiguous() and wav.dtype == torch.float32
@@ -517,13 +523,21 @@ class SAMAudio:
                 need = self._lib.samaudio_workspace_bytes(ctx, 0, 0, 1, self._codec_chunk(items), samples)
                 assert own._workspace.numel() - (aligned - base) >= need
                 hip.check(self._lib.samaudio_set_workspace(ctx, C.c_void_p(aligned), own._workspace.numel() - (aligned - base)))
-            hip.check(self._lib.samaudio_codec_decode(ctx, hip.ptr(lat), items, frames, hip.ptr(wav),
-                                                      hip.current_stream_ptr()))
+            if pairs:
+                hip.check(self._lib.samaudio_codec_decode_pairs(ctx, hip.ptr(lat), items // 2, frames, hip.ptr(wav),
+                                                                hip.current_stream_ptr()))
+            else:
+                hip.check(self._lib.samaudio_codec_decode(ctx, hip.ptr(lat), items, frames, hip.ptr(wav),
+                                                          hip.current_stream_ptr()))
         return wav
 
     # ------------------------------------------------------------------ DiT
     def _prepare(self, audio_features, text_features, text_mask, masked_video_features, anchor_ids,
-                 anchor_alignment, audio_pad_mask, lane: Optional[_Lane] = None, anchors_validated: bool = False) -> None:
+                 anchor_alignment, audio_pad_mask, lane: Optional[_Lane] = None, anchors_validated: bool = False,
+                 candidates: int = 1, latent: bool = False) -> None:
+        """`latent`: `audio_features` is the codec latent z [B, T, codebook_dim] and every conditioning tensor holds B clips, each
+        serving `candidates` consecutive rows of the solve (samaudio_prepare_latent: (z | z) and the sample-major repeat of
+        reference model.py:182-184,193-203 happen inside the engine, nothing is concatenated or repeated here)."""
         dev = self.device
         own = lane if lane is not None else self
         feats = audio_features.to(dev, torch.float32).contiguous()
@@ -557,6 +571,13 @@ class SAMAudio:
         if audio_pad_mask is not None:
             pad = audio_pad_mask.to(dev).to(torch.uint8).contiguous()
         own._live = (feats, text, tmask, video, ids, align, pad)
+        if latent:
+            self._ensure_workspace(rows * candidates, frames, text_len, 0, 0, lane)
+            hip.check(self._lib.samaudio_prepare_latent(
+                own._ctx, rows * candidates, frames, text_len, candidates, hip.ptr(feats), hip.ptr(text), hip.ptr(tmask),
+                hip.ptr(video), hip.ptr(ids), n_ids, hip.ptr(align), hip.ptr(pad), hip.current_stream_ptr()))
+            return
+        assert candidates == 1
         self._ensure_workspace(rows, frames, text_len, 0, 0, lane)
         hip.check(self._lib.samaudio_prepare(
             own._ctx, rows, frames, text_len, hip.ptr(feats), hip.ptr(text), hip.ptr(tmask), hip.ptr(video),
@@ -598,7 +619,8 @@ class SAMAudio:
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_TAIL_SPLIT, split))
 
     def _solve_concurrent(self, noise: torch.Tensor, ode_opt: Dict[str, Any], cond: List[Optional[torch.Tensor]],
-                          groups: int, decode: bool = False, anchors_validated: bool = False):
+                          groups: int, decode: bool = False, anchors_validated: bool = False, candidates: int = 1,
+                          latent: bool = False):
         """prepare + ODE solve (+ DAC-VAE decode of target and residual when `decode`) of `groups` contiguous row groups,
         each on its own engine context and HIP stream, driven by one host thread per group (the C calls release the GIL).
         Rows are independent, so the result equals the single-stream one bit for bit.  Returns the
@@ -624,9 +646,12 @@ class SAMAudio:
 
         def work(i: int, lane: Optional[_Lane]):
             try:
-                rr = shard_range(rows, i, groups)
+                # contiguous groups of CLIPS (all candidates of a clip stay in one group: SURVEY.md section 8e)
+                cr = shard_range(rows // candidates, i, groups)
+                rr = range(cr.start * candidates, cr.stop * candidates)
                 sl = slice(rr.start, rr.stop)
-                part = [None if c is None else c[sl] for c in cond]
+                csl = slice(cr.start, cr.stop) if latent else sl   # `latent`: the conditioning is per clip
+                part = [None if c is None else c[csl] for c in cond]
                 stream = main if (lane is None or self._serial_groups) else lane.stream
                 if stream is not main:
                     # tensors allocated on the caller's stream and used on the lane's: tell the caching allocator, so that
@@ -637,14 +662,12 @@ class SAMAudio:
                         if t is not None and t.is_cuda:
                             t.record_stream(stream)
                 with torch.inference_mode(), torch.cuda.device(self.device), torch.cuda.stream(stream):
-                    self._prepare(*part, lane=lane, anchors_validated=anchors_validated)
+                    self._prepare(*part, lane=lane, anchors_validated=anchors_validated, candidates=candidates, latent=latent)
                     ctx = self._ctx if lane is None else lane._ctx
                     hip.check(self._lib.samaudio_ode_solve(ctx, hip.ptr(state[sl]), method, g, len(grid),
                                                            hip.current_stream_ptr()))
-                    if decode:   # rows (2b, 2b+1) = (target, residual) latents of clip b, channels-last
-                        n = rr.stop - rr.start
-                        lat = state[sl].reshape(n, frames, 2, C2 // 2).permute(0, 2, 1, 3).reshape(2 * n, frames, C2 // 2)
-                        self.decode_audio(lat.contiguous(), lane=lane, out=wavs[2 * rr.start: 2 * rr.stop])
+                    if decode:   # waveforms (2b, 2b+1) = (target, residual) of row b, gathered from the state inside the engine
+                        self.decode_audio(state[sl], lane=lane, out=wavs[2 * rr.start: 2 * rr.stop], pairs=True)
             except BaseException as exc:  # re-raised on the caller's thread
                 errors.append(exc)
 
@@ -695,9 +718,18 @@ class SAMAudio:
             raise RuntimeError("load_state_dict() first")
         cand = int(reranking_candidates)
         with torch.cuda.device(self.device):
+            # Nothing of torch's own arithmetic runs between the first and the last kernel of a step: the noise is drawn first
+            # (model.py:274-275: `torch.randn_like` on the model device), features = (z | z) (model.py:182-184), the sample-major
+            # repeat for the candidates (model.py:193-203) and the (target, residual) split of the state (model.py:291-295) are
+            # index arithmetic inside the engine (samaudio_prepare_latent / samaudio_codec_decode_pairs).
+            hop = self.cfg.audio_codec.hop_length
+            B, T = batch.audios.size(0), -(-batch.audios.size(-1) // hop)
+            C2 = self.cfg.transformer.out_channels
+            if noise is None:
+                noise = torch.randn(B * cand, T, C2, device=self.device)         # model.py:274-275
+            assert tuple(noise.shape) == (B * cand, T, C2), "noise must be [B*candidates, T, 256]"
             z = self.encode_audio(batch.audios)                                  # [B, T, 128]
-            feats = torch.cat([z, z], dim=2)                                     # model.py:182-184
-            B, T, C2 = feats.shape
+            assert z.shape[:2] == (B, T) and 2 * z.size(2) == C2
             text, text_mask = self._text(batch)
             video = None
             if batch.masked_video is not None:                                   # model.py:186-191
@@ -715,35 +747,28 @@ class SAMAudio:
                 if self.span_predictor is None:
                     warnings.warn("predict_spans=True ignored: no span predictor attached (model.span_predictor)")
                 else:
-                    batch = self.predict_spans(batch, feats, batch.audio_pad_mask)   # model.py:259-268
+                    batch = self.predict_spans(batch, z, batch.audio_pad_mask)   # model.py:259-268 (reads channels [0, 128))
                     if self.fix_span_order:
                         anchor_ids, anchor_alignment = batch.anchor_ids, batch.anchor_alignment
-            feats_r = self._repeat(feats, cand)
-            if noise is None:
-                noise = torch.randn_like(feats_r)                                # model.py:274-275
-            assert noise.shape == feats_r.shape, "noise must be [B*candidates, T, 256]"
-            cond = [feats_r, self._repeat(text, cand), self._repeat(text_mask, cand), self._repeat(video, cand),
-                    self._repeat(anchor_ids, cand), self._repeat(anchor_alignment, cand),
-                    self._repeat(batch.audio_pad_mask, cand)]
-            groups = min(self.streams, feats_r.size(0))
+            cond = [z, text, text_mask, video, anchor_ids, anchor_alignment, batch.audio_pad_mask]   # per clip: B items each
+            groups = min(self.streams, B)
             wavs = None
             if groups > 1:
                 cond = [None if c is None else c.to(self.device) for c in cond]
                 # each group also decodes its own rows on its stream: the codec's HBM-bound convolutions of one group run
                 # beside the other group's kernels instead of after both solves
-                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True, anchors_validated=validated)
+                latent, wavs = self._solve_concurrent(noise, ode_opt, cond, groups, decode=True, anchors_validated=validated,
+                                                      candidates=cand, latent=True)
             else:
                 self._apply_options(1)
-                self._prepare(*cond, anchors_validated=validated)
+                self._prepare(*cond, anchors_validated=validated, candidates=cand, latent=True)
                 latent = self.solve(noise, ode_opt)                              # states[-1], [Bc, T, 256]
             self.last_latent = latent
-            # [Bc, T, 2C] -> rows (2b, 2b+1) = (target, residual) latents, channels-last (model.py:291-295)
-            Bc, half = latent.size(0), C2 // 2
+            # [Bc, T, 2C] -> waveforms (2b, 2b+1) = (target, residual) of row b (model.py:291-295)
+            Bc = latent.size(0)
             if wavs is None:
-                lat = latent.reshape(Bc, T, 2, half).permute(0, 2, 1, 3).reshape(2 * Bc, T, half).contiguous()
-                wavs = self.decode_audio(lat).view(Bc, 2, -1)
+                wavs = self.decode_audio(latent, pairs=True).view(Bc, 2, -1)
             # codec.py:91-97, from the batch's host copy of the frame counts: slicing by device scalars would block on the GPU
-            hop = self.cfg.audio_codec.hop_length
             sizes = [n * hop for n in (getattr(batch, "sizes_host", None) or [int(v) for v in batch.sizes.tolist()])]
             target = self.unbatch(wavs[:, 0].view(B, cand, -1), sizes)
             residual = self.unbatch(wavs[:, 1].view(B, cand, -1), sizes)

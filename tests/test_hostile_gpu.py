@@ -28,9 +28,12 @@ SIZE = os.environ.get("SAMAUDIO_HOSTILE_SIZE", "small*")
 # 3.4e-3, mixed 3.5e-1 / 2.8e-2, bf16 2.1e-1 / 2.2e-2 on |latent| <= 14.0, |wave| <= 0.85; large* fp16 6.6e-3 / 2.7e-3, mixed 6.9e-2 /
 # 1.7e-2, bf16 6.9e-2 / 2.7e-2 on |latent| <= 13.2, |wave| <= 0.94; fp32 8.9e-5 / 8.0e-6 and 1.4e-5 / 6.9e-6).  Reading: NO 16-bit mode
 # holds 1e-3 on these statistics; IEEE fp16 operands are ten times closer than any mode with bfloat16 operands.
-BOUNDS = {"small*": {"fp32": (1e-3, 1e-3), "fp16": (6.5e-2, 7e-3), "mixed": (7e-1, 6e-2), "bf16": (4.5e-1, 4.5e-2)},
-          "large*": {"fp32": (1e-3, 1e-3), "fp16": (1.4e-2, 5.5e-3), "mixed": (1.4e-1, 3.5e-2), "bf16": (1.4e-1, 5.5e-2)}}
-BOUND = BOUNDS.get(SIZE, {"fp32": (1e-3, 1e-3), "fp16": (None, None), "mixed": (None, None), "bf16": (None, None)})
+# Round 6: precision "fp16x3" (fp32 storage, every big contraction on hi/lo-split IEEE-half operands: 3 MFMA products per multiply,
+# include/samaudio.h SAMAUDIO_OPT_X3_CLASSES) is held to the north_star's (1e-3, 1e-3) like fp32 - measured 9.8e-5 / 1.4e-5 at small*,
+# 7.0e-5 / 1.3e-5 at large* (profiles/r6_call2/): the fast mode that holds the bound on these statistics, and bench.py's headline.
+BOUNDS = {"small*": {"fp32": (1e-3, 1e-3), "fp16x3": (1e-3, 1e-3), "fp16": (6.5e-2, 7e-3), "mixed": (7e-1, 6e-2), "bf16": (4.5e-1, 4.5e-2)},
+          "large*": {"fp32": (1e-3, 1e-3), "fp16x3": (1e-3, 1e-3), "fp16": (1.4e-2, 5.5e-3), "mixed": (1.4e-1, 3.5e-2), "bf16": (1.4e-1, 5.5e-2)}}
+BOUND = BOUNDS.get(SIZE, {"fp32": (1e-3, 1e-3), "fp16x3": (1e-3, 1e-3), "fp16": (None, None), "mixed": (None, None), "bf16": (None, None)})
 FP16_MAX = 65504.0
 
 
@@ -52,11 +55,11 @@ def hostile(gpu):
     return dict(cfg=cfg, sd=sd, batch=batch, noise=noise, lat=lat_ref, wav=t_ref + r_ref)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16", "mixed", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3", "fp16", "mixed", "bf16"])
 def test_full_solve_on_hostile_weights(gpu, hostile, prec):
     model = SAMAudio(hostile["cfg"], precision=prec, device=str(gpu))
     model.load_state_dict(hostile["sd"], strict=False)
-    model.sentinel(True)
+    model.sentinel(prec != "fp16x3")   # (an x3 context has no 16-bit activation tensors to scan: its operands are split on the fly)
     res = model.separate(hostile["batch"].to(gpu), noise=hostile["noise"].to(gpu))
     rep = model.sentinel_report()
     lat_ref, wav_ref = hostile["lat"], hostile["wav"]
@@ -70,7 +73,7 @@ def test_full_solve_on_hostile_weights(gpu, hostile, prec):
     assert torch.isfinite(model.last_latent).all() and all(torch.isfinite(w).all() for w in res.target + res.residual)
     bad = {k: v["nonfinite"] for k, v in rep.items() if v["nonfinite"] > 0}
     assert not bad, f"non-finite 16-bit tensors written by: {bad}"
-    assert seen, "the sentinel saw no tensor: is it wired to the launches?"
+    assert seen or prec == "fp16x3", "the sentinel saw no tensor: is it wired to the launches?"
     if prec in ("fp16", "mixed"):   # IEEE fp16 tensors: a factor 4 of headroom below the format's largest value
         alt = {c for c in hip.CLASSES if model.alt16_classes & hip.CLS[c]}   # these write / read bfloat16 in the mixed mode
         close = {k: v["absmax"] for k, v in rep.items() if k not in alt and v["absmax"] > FP16_MAX / 4}
