@@ -840,7 +840,7 @@ def run(args):
                 # predict_spans() writes the predicted anchors into the batch (reference model.py:245, processor.py:122-123)
                 # and a batch that already has anchors skips the predictor: every step starts from the un-anchored batch
                 batch.process_anchors(None)
-                batch.anchor_ids, batch.anchor_alignment = batch.anchor_ids.to(dev), batch.anchor_alignment.to(dev)
+                batch.to(dev)   # (Batch.to keeps the host-side range guarantee of the anchor tensors; assigning them would drop it)
             return model.separate(batch, reranking_candidates=args.candidates, predict_spans=args.predict_spans)
 
         for i in range(warmup):
@@ -893,7 +893,7 @@ def run(args):
 
             def once():
                 batch.process_anchors(None)
-                batch.anchor_ids, batch.anchor_alignment = batch.anchor_ids.to(dev), batch.anchor_alignment.to(dev)
+                batch.to(dev)   # (Batch.to keeps the host-side range guarantee of the anchor tensors; assigning them would drop it)
                 model.separate(batch, reranking_candidates=args.candidates, predict_spans=spans)
 
             with warnings.catch_warnings():
@@ -1098,7 +1098,6 @@ def run(args):
                                                                          if args.share_gpu and world > 1 else ""),
                 "streams_per_gpu": n_streams, "reranking_candidates": args.candidates,
                 "predict_spans": bool(args.predict_spans), "world_size_seen": world,
-                "ode_graph_replays": model.graph_replays(),   # SAMAudio(ode_graph=...) / SAMAUDIO_ODE_GRAPH: 0 = eager launches
                 "text_encoder_in_step": ("t5-base dims (12 layers, d_model 768), random init, hash tokenizer, T5 stack on the HIP "
                                          "library (fp32), run on the descriptions inside every timed step") if args.t5 else None,
                 "visual_prompt": (f"{cfg.vision_encoder.name} tower, 250 frames x 336x336 per clip, encoded inside the step"

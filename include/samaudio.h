@@ -77,7 +77,11 @@ int samaudio_set_tensor(samaudio_ctx* ctx, const char* name, const void* data, i
 int samaudio_finalize(samaudio_ctx* ctx, int what);
 
 /* Scratch.  `codec_items`: waveforms processed per codec pass (0 = no codec use), `samples`: padded
- * samples per waveform. */
+ * samples per waveform.  Besides the activations of one evaluation the DiT part holds, in 16-bit contexts with text_len <= 16 and
+ * 128-wide heads, the folded cross-attention operands of ALL layers (rows * dim * pad64(heads * (8 | 16)) * n_layers 16-bit
+ * elements: 0.76 GB for 32 rows at the large stand-in dims, zeroed once per samaudio_prepare), and in fp32 contexts with
+ * SAMAUDIO_OPT_X3_CLASSES the split activation operands (rows * (frames + 2) * 3 * dim and rows * frames * 3 * ffn_hidden 16-bit
+ * elements).  Query it AFTER setting the options that change the plan (SAMAUDIO_OPT_X3_CLASSES). */
 size_t samaudio_workspace_bytes(samaudio_ctx* ctx, int rows, int frames, int text_len, int codec_items,
                                 int64_t samples);
 int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
@@ -121,12 +125,9 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   REPORTED by samaudio_sentinel_read with the class it came from instead of propagating silently.  Allocates 4 KiB of device
  *   memory on first use (the only allocation of the library besides the checksum trace). */
 #define SAMAUDIO_OPT_SENTINEL 7
-/*   SAMAUDIO_OPT_ODE_GRAPH (default 0): value 1 lets samaudio_ode_solve replay the launches of a solve as a HIP graph (SURVEY.md
- *   section 7 step 6).  The first solve of a shape runs eagerly, the second is captured (stream capture, thread-local mode: the row
- *   groups of two contexts capture independently) and instantiated, later ones with the same context state - workspace, shapes, grid,
- *   method, options, weights - replay it; anything else falls back to eager launches.  The state tensor travels through a buffer
- *   of the workspace so that the captured pointers stay valid.  Scheduling only: the same kernels with the same arguments. */
-#define SAMAUDIO_OPT_ODE_GRAPH 8
+/* (option 8 was SAMAUDIO_OPT_ODE_GRAPH, rounds 5: a solve's launches replayed as one HIP graph.  Bitwise equal and measured at
+ * + 0.0 ... 0.3 % - the host already runs ahead of the GPU, there is no launch gap to close - so it was removed in round 6;
+ * profiles/r5_call13/ holds the measurement, the git history the code.) */
 /*   SAMAUDIO_OPT_X3_CLASSES (fp32 contexts; value = mask of SAMAUDIO_CLS_X3_CAPABLE bits, default 0): COMPENSATED 16-bit operands -
  *   precision "fp16x3" of the host classes.  The reference computes in fp32 (README.md:48); no plain 16-bit operand format holds
  *   the 1e-3 parity bound on trained-like weight statistics.  A GEMM of a named class keeps its fp32
@@ -397,11 +398,11 @@ int samaudio_profile_begin(samaudio_ctx* ctx);
 /* SAMAUDIO_OPT_SENTINEL: synchronises `stream`, copies out absmax[SAMAUDIO_SENTINEL_SLOTS] / nonfinite[SAMAUDIO_SENTINEL_SLOTS]
  * (counts as doubles) accumulated since the last read, and resets them. */
 int samaudio_sentinel_read(samaudio_ctx* ctx, float* absmax, double* nonfinite, samaudio_stream stream);
-/* SAMAUDIO_OPT_ODE_GRAPH: how many solves of this context ran as a graph launch so far (0 = every solve was launched eagerly). */
-long samaudio_graph_replays(samaudio_ctx* ctx);
 /* Test hook: force the GEMM kernel variant (-1 automatic; 0..2 the 128-row tiles of gemm.hip; 22 = gemm8 256x256 8-phase,
  * 27 = gemm8s 128x128, 25 / 26 / 28 / 29 / 32 / 33 / 34 = the 32x32x16-family tiles, 35 = conv7h; csrc/gemm.hip
- * gemm_variant_name).  A launch the forced kernel does not cover falls back to gemm.hip's tiles. */
+ * gemm_variant_name).  A launch the forced kernel does not cover falls back to gemm.hip's tiles - except launches on
+ * K-tile-major weights or with the split-form output, which exist in the 8-phase family only: forcing anything but 22 / 27 on
+ * them is refused with SAMAUDIO_ERR_ARG and that reason (a model's own launches never leave the family). */
 void samaudio_debug_force_gemm_variant(int variant);
 /* Test hooks (csrc/kernels.h lists them; 0 = shipped behaviour): 11 = k7 convolutions as implicit GEMMs, 16 = DAC residual
  * units as two launches, 18 = fuse residual units whatever the launch size, 19 = residual-unit kernel form (1 / 3 = weight-

@@ -152,7 +152,6 @@ int samaudio_sentinel_read(samaudio_ctx* ctx, float* absmax, double* nonfinite, 
   return ret(ctx->engine->sentinel_read(absmax, nonfinite, (hipStream_t)stream));
 }
 
-long samaudio_graph_replays(samaudio_ctx* ctx) { return ctx ? ctx->engine->graph_replays() : 0; }
 
 int samaudio_profile_end(samaudio_ctx* ctx, samaudio_kernel_stat* out, int capacity, int* count) {
   if (!ctx || !count || (capacity > 0 && !out)) return bad("samaudio_profile_end: null argument");

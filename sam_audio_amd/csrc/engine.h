@@ -77,7 +77,6 @@ class Engine {
     double flops = 0, bytes = 0, ms = 0;
   };
   Status sentinel_read(float* absmax, double* nonfinite, hipStream_t st);   // SAMAUDIO_OPT_SENTINEL
-  long graph_replays() const { return graph_replays_; }   // SAMAUDIO_OPT_ODE_GRAPH
   Status profile_begin();
   Status profile_end(std::vector<KernelStat>& out);
   ~Engine();
@@ -131,25 +130,7 @@ class Engine {
   int alt_classes_ = 0;     // SAMAUDIO_OPT_ALT16_CLASSES (16-bit contexts)
   int prefetch_rows_ = 0;   // SAMAUDIO_OPT_PREFETCH_ROWS (16-bit contexts)
   int x3_classes_ = 0;      // SAMAUDIO_OPT_X3_CLASSES (fp32 contexts)
-  // SAMAUDIO_OPT_ODE_GRAPH: the launches of one solve as a HIP graph, replayed while `graph_key_` describes the context's state
-  bool graphs_ = false;
-  unsigned long long gen_ = 0;   // bumped by everything that can change what a solve launches (weights, workspace, options)
-  struct GraphKey {
-    unsigned long long gen = 0, debug = 0;
-    int method = -1, rows = 0, frames = 0, text_len = 0, fold_ltp = 0;
-    std::vector<float> grid;
-    bool operator==(const GraphKey& o) const {
-      return gen == o.gen && debug == o.debug && method == o.method && rows == o.rows && frames == o.frames && text_len == o.text_len &&
-             fold_ltp == o.fold_ltp && grid == o.grid;
-    }
-  };
-  GraphKey graph_key_, graph_seen_;   // the instantiated graph's key / the key of the last eager solve (capture on its repeat)
-  void* graph_exec_ = nullptr;        // hipGraphExec_t
-  long graph_replays_ = 0;
-  void* capture_stream_ = nullptr;    // hipStream_t: where a solve on the legacy default stream is recorded
-  Status set_option_value(int option, int value);
   Status solve_launches(float* y, int method, const float* grid, int n_grid, hipStream_t st);   // the launches of one solve
-  void drop_graph();
   bool sentinel_on_ = false;   // SAMAUDIO_OPT_SENTINEL
   float* sentinel_dev_ = nullptr;   // [SAMAUDIO_SENTINEL_SLOTS][2] slots + [kSentinelPartials][2] partials (debug_device_alloc)
   // fold the scan of a tensor into `slot` (no-op unless the sentinel is on); fmt as launch_sentinel
@@ -209,7 +190,7 @@ class Engine {
 
   // DiT workspace (assigned by plan_dit)
   struct {
-    float *ystate, *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
+    float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
         *feats, *text, *video, *anch, *probs, *ut, *x3a, *x3u;
     float *temb32, *tu32, *tsilu32, *xn32, *prep32, *mem32, *yu32, *yemb32;  // fp32 operands of the f32 classes (16-bit contexts)

@@ -141,7 +141,6 @@ Status Engine::set_tensor(const char* name, const void* p, int dtype, int ndim, 
   // (e.g. the codec set after the DiT set) leaves an already finalized set valid.
   if (tensors_.count(name)) dit_ready_ = codec_ready_ = enc_ready_ = false;
   tensors_[name] = t;
-  ++gen_;   // (a captured solve holds the old pointers)
   return Status{};
 }
 
@@ -183,7 +182,6 @@ Status Engine::need_w5(const std::string& name, int N, int K, const void** out, 
 static int kpad(int k, bool bf16) { return (int)round_up(k, bf16 ? 64 : 32); }
 
 Status Engine::finalize(int what) {
-  ++gen_;
   const int D = cfg_.dim, F = cfg_.ffn_hidden, L = cfg_.n_layers, C2 = cfg_.latent_channels;
   const int F32 = SAMAUDIO_DT_F32, AT = at_dtype_;
 #define NEEDF(field, name, ...) SA_TRY(need(name, F32, {__VA_ARGS__}, (const void**)&(field)))
@@ -367,7 +365,6 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   auto f32 = [&](long n) { return (float*)b.take((size_t)n * 4); };
   auto act = [&](long n) { return b.take((size_t)n * esz_); };
   auto& d = d_;
-  float* ystate = f32(M * C2);   // SAMAUDIO_OPT_ODE_GRAPH: the ODE state at a pointer that outlives the caller's tensor
   float* ymid = f32(M * C2); float* aligned = f32(M * D); float* cond = f32(M * D); float* h = f32(M * D);
   float* hp1 = f32(M * D); float* text_proj = f32(Mt * D); float* t_emb = f32(nt * D); float* t0 = f32(nt * 6 * D);
   float* tsin = f32(nt * D); float* vtmp = f32(M * D); float* times = f32(4096);
@@ -389,11 +386,14 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
     mem32 = f32(Mt * D); yu32 = f32(Mt * D); yemb32 = f32(Mt * D);
   }
   // folded cross-attention (bf16, Lt <= 16): probabilities [M, KP] and the per-batch operand U^T [rows][D][KP]
+  // (the condition prepare() folds under: 16-bit context, short memory, 128-wide heads, not switched off)
   const long ltp = Lt <= 8 ? 8 : 16, kp = round_up(H * ltp, 64);
-  void* probs = (bf16_ && Lt <= 16) ? act(M * kp) : nullptr;
-  // (one slice per layer: the folds of an evaluation run as one launch in front of the layer loop)
+  const bool fold = bf16_ && Lt <= 16 && D / cfg_.n_heads == 128 && !std::getenv("SAMAUDIO_NO_FOLD");
+  void* probs = fold ? act(M * kp) : nullptr;
+  // (one slice per layer: the folds of an evaluation run as one launch in front of the layer loop; debug flag 31 - one launch per
+  // layer - only ever uses the first slice)
   const bool fold_all = cfg_.n_layers <= kMaxFoldLayers;
-  void* ut = (bf16_ && Lt <= 16) ? act((long)rows * D * kp * (fold_all ? cfg_.n_layers : 1)) : nullptr;
+  void* ut = fold ? act((long)rows * D * kp * (fold_all ? cfg_.n_layers : 1)) : nullptr;
   // SAMAUDIO_OPT_X3_CLASSES: the split activation operand [lo | hi | hi] of the widest GEMM input (16-bit, 3 K elements per row)
   // (x3a: D-wide operands and the patcher's halo-padded rows; x3u: the SwiGLU hidden, written by the w13 launch while it reads x3a)
   const bool x3g = !bf16_ && (x3_classes_ & ~(SAMAUDIO_X3_ATTENTION | SAMAUDIO_CLS_CODEC));
@@ -403,7 +403,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
   if (assign) {
-    d.ystate = ystate; d.ymid = ymid; d.aligned = aligned; d.cond = cond; d.h = h; d.hp1 = hp1; d.text_proj = text_proj; d.t_emb = t_emb;
+    d.ymid = ymid; d.aligned = aligned; d.cond = cond; d.h = h; d.hp1 = hp1; d.text_proj = text_proj; d.t_emb = t_emb;
     d.t0 = t0; d.modgs = modgs; d.tsin = tsin; d.vtmp = vtmp; d.times = times; d.ybf = ybf; d.xn = xn; d.qkv = qkv; d.Q = Q; d.K = K;
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
@@ -459,7 +459,6 @@ size_t Engine::workspace_bytes(int rows, int frames, int text_len, int codec_ite
 
 Status Engine::set_workspace(void* p, size_t bytes) {
   if (!p || (reinterpret_cast<uintptr_t>(p) & 255)) return fail(SAMAUDIO_ERR_WORKSPACE, "workspace must be 256-byte aligned");
-  if ((char*)p != ws_ || bytes != ws_bytes_) ++gen_;   // (a captured solve holds pointers into the old workspace)
   ws_ = (char*)p;
   ws_bytes_ = bytes;
   prepared_ = false;
@@ -511,22 +510,6 @@ Status Engine::check_x3_weights(int classes) const {
 }
 
 Status Engine::set_option(int option, int value) {
-  const auto sig = [this] {
-    return std::make_tuple(tail_split_, f32_classes_, alt_classes_, prefetch_rows_, sentinel_on_, quant_classes_, quant_fmt_, graphs_,
-                           x3_classes_);
-  };
-  const auto before = sig();
-  const Status s = set_option_value(option, value);
-  if (sig() != before) ++gen_;   // options change which kernels a solve launches (a captured solve is dropped; setting the same
-  return s;                      // value again - SAMAudio does before every solve - keeps it)
-}
-
-Status Engine::set_option_value(int option, int value) {
-  if (option == SAMAUDIO_OPT_ODE_GRAPH) {
-    graphs_ = value != 0;
-    if (!graphs_) drop_graph();
-    return Status{};
-  }
   if (option == SAMAUDIO_OPT_TAIL_SPLIT) {
     tail_split_ = value != 0;
     return Status{};
@@ -801,8 +784,6 @@ Status Engine::profile_end(std::vector<KernelStat>& out) {
 
 Engine::~Engine() {
   for (hipEvent_t e : ev_pool_) (void)hipEventDestroy(e);
-  drop_graph();
-  if (capture_stream_) (void)hipStreamDestroy((hipStream_t)capture_stream_);
   debug_device_free(sentinel_dev_);
   if (hash_) {   // SAMAUDIO_TRACE_HASH recorder
     HashTrace* h = (HashTrace*)hash_;
@@ -1253,64 +1234,7 @@ Status Engine::ode_solve(float* y, int method, const float* grid, int n_grid, hi
   if (!y || !grid || n_grid < 2 || 2 * n_grid > 4096) return fail(SAMAUDIO_ERR_ARG, "ode_solve: bad grid");
   for (int k = 0; k + 1 < n_grid; ++k)
     if (!(grid[k + 1] > grid[k])) return fail(SAMAUDIO_ERR_ARG, "ode_solve: grid must be increasing");
-  // SAMAUDIO_OPT_ODE_GRAPH: replay / capture (never while a measurement or debugging aid brackets or inspects the launches)
-  if (graphs_ && !prof_on_ && !sentinel_on_ && !hash_on() && !trace_on()) {
-    GraphKey key;
-    key.gen = gen_; key.debug = debug_epoch(); key.method = method; key.rows = rows_; key.frames = frames_; key.text_len = text_len_; key.fold_ltp = fold_ltp_;
-    key.grid.assign(grid, grid + n_grid);
-    const size_t bytes = (size_t)rows_ * frames_ * cfg_.latent_channels * 4;
-    if (graph_exec_ && key == graph_key_) {
-      SA_HIP(hipMemcpyAsync(d_.ystate, y, bytes, hipMemcpyDeviceToDevice, st));
-      SA_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec_, st));
-      ++graph_replays_;
-      SA_HIP(hipMemcpyAsync(y, d_.ystate, bytes, hipMemcpyDeviceToDevice, st));
-      return Status{};
-    }
-    if (key == graph_seen_) {   // the second solve of this shape: capture it
-      drop_graph();
-      SA_HIP(hipMemcpyAsync(d_.ystate, y, bytes, hipMemcpyDeviceToDevice, st));
-      // the launches are recorded on a stream of the engine's own - nothing executes during capture - and the graph is launched
-      // on `st`: the legacy default stream (torch's current stream unless the caller chose one) cannot be captured, and a
-      // caller's stream may carry events the caller polls while this thread records (hipErrorCapturedEvent)
-      if (!capture_stream_ && hipStreamCreateWithFlags((hipStream_t*)&capture_stream_, hipStreamNonBlocking) != hipSuccess)
-        capture_stream_ = nullptr;
-      const hipStream_t cs = (hipStream_t)capture_stream_;
-      const bool verbose = std::getenv("SAMAUDIO_GRAPH_VERBOSE") != nullptr;
-      hipError_t e = cs ? hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) : hipErrorNotSupported;
-      if (verbose && e != hipSuccess) std::fprintf(stderr, "samaudio: graph capture refused: %s\n", hipGetErrorString(e));
-      if (e == hipSuccess) {
-        const Status s = solve_launches(d_.ystate, method, grid, n_grid, cs);
-        hipGraph_t g = nullptr;
-        e = hipStreamEndCapture(cs, &g);
-        if (verbose && (e != hipSuccess || !s.ok()))
-          std::fprintf(stderr, "samaudio: graph capture failed: %s / %s\n", hipGetErrorString(e), s.ok() ? "launches ok" : s.msg.c_str());
-        hipGraphExec_t exec = nullptr;
-        if (s.ok() && e == hipSuccess && g && (e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0)) == hipSuccess && exec) {
-          if (verbose) std::fprintf(stderr, "samaudio: solve captured as a graph\n");
-          graph_exec_ = exec;
-          graph_key_ = key;
-          (void)hipGraphDestroy(g);
-          SA_HIP(hipGraphLaunch(exec, st));
-          ++graph_replays_;
-          SA_HIP(hipMemcpyAsync(y, d_.ystate, bytes, hipMemcpyDeviceToDevice, st));
-          return Status{};
-        }
-        if (verbose && s.ok()) std::fprintf(stderr, "samaudio: graph instantiate failed: %s\n", hipGetErrorString(e));
-        if (g) (void)hipGraphDestroy(g);
-        (void)hipGetLastError();
-        if (!s.ok()) return s;
-      }
-      (void)hipGetLastError();   // capture refused (the simulator, a stream that cannot be captured): eager launches below
-    }
-    graph_seen_ = key;
-  }
   return solve_launches(y, method, grid, n_grid, st);
-}
-
-void Engine::drop_graph() {
-  if (graph_exec_) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec_);
-  graph_exec_ = nullptr;
-  graph_key_ = GraphKey{};
 }
 
 Status Engine::solve_launches(float* y, int method, const float* grid, int n_grid, hipStream_t st) {

@@ -339,6 +339,10 @@ static int gemm1_variant(const GemmParams& p) {
 // How each entry was chosen (one-box A/B per step, round 2): DESIGN.md sections 3.1 and 3.4, profiles/r2_call*/.
 int gemm_variant(const GemmParams& p, bool is_bf16) {
   const bool g2 = is_bf16 && gemm2_ok(p);
+  // (K-tile-major weights / the split-form output exist in the 8-phase family only: a FORCED variant other than 22 / 27 on such a
+  // launch is refused by gemm_check with that reason - tests/test_gemm2_gpu.py::test_ktm_weights_are_refused_outside_the_8phase_family;
+  // the policy itself never leaves the family for them, and every side operand the engine registers is 16-byte aligned by
+  // samaudio_set_tensor, so gemm2_ok cannot fail for a model's launches)
   if (g_force >= 3) {
     const bool known = g_force == 22 || (g_force >= 25 && g_force <= 29) || (g_force >= 32 && g_force < kGemmVariants);
     if (g_force == 35 && !(g2 && conv7h_ok(p))) return gemm1_variant(p);   // conv7h computes convolutions only

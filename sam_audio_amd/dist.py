@@ -61,12 +61,11 @@ def shard_batch(batch: Batch, rank: int, world: int) -> Batch:
     out.masked_video = None if batch.masked_video is None else [batch.masked_video[i] for i in rows]
     out.hop_length, out.audio_sampling_rate = batch.hop_length, batch.audio_sampling_rate
     out.text_features, out.text_mask = pick(batch.text_features), pick(batch.text_mask)
-    out.anchor_ids = pick(batch.anchor_ids)
-    out.anchor_alignment = pick(batch.anchor_alignment)[:, :frames]
+    # rows of tensors that were range-checked on the host keep that guarantee (Batch.anchor_vocab_validated)
+    out._set_anchor_tensors(pick(batch.anchor_ids), pick(batch.anchor_alignment)[:, :frames], getattr(batch, "anchor_vocab_validated", 0))
     out.anchors = None if batch.anchors is None else [batch.anchors[i] for i in rows]
     host = getattr(batch, "sizes_host", None)
     out.sizes_host = [host[i] for i in rows] if host is not None else [int(v) for v in sizes.tolist()]
-    out.anchors_validated = bool(getattr(batch, "anchors_validated", False))   # rows of tensors that were checked on the host
     return out
 
 

@@ -73,7 +73,6 @@ def dtype_code(dtype, operands: Optional[str] = None, alt_ok: bool = False) -> i
     return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_BF16}[dtype]
 ODE_EULER, ODE_MIDPOINT = 0, 1
 OPT_TAIL_SPLIT, OPT_F32_CLASSES, OPT_QUANT_CLASSES, OPT_QUANT_FORMAT, OPT_ALT16_CLASSES, OPT_PREFETCH_ROWS, OPT_SENTINEL = 1, 2, 3, 4, 5, 6, 7
-OPT_ODE_GRAPH = 8
 OPT_X3_CLASSES = 9
 SENTINEL_SLOTS = 16
 # GEMM classes of the DiT / codec (samaudio.h SAMAUDIO_CLS_*), in bit order
@@ -243,7 +242,6 @@ _PROTOS = {
     "samaudio_codec_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "samaudio_profile_begin": (C.c_int, [C.c_void_p]),
     "samaudio_sentinel_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p]),
-    "samaudio_graph_replays": (C.c_long, [C.c_void_p]),
     "samaudio_debug_force_gemm_variant": (None, [C.c_int]),
     "samaudio_debug_set_flag": (None, [C.c_int, C.c_int]),
     "samaudio_debug_poison_lds": (C.c_int, [C.c_void_p]),

@@ -108,11 +108,9 @@ class SAMAudio:
 
     def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
                  text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto",
-                 weight_layout: str = "auto", prefetch_rows: Optional[int] = None, ode_graph: Optional[bool] = None,
-                 x3_classes="auto", codec_decode: str = "auto"):
-        """`ode_graph`: replay the launches of a solve as a HIP graph from the third solve of a shape on (samaudio.h
-        SAMAUDIO_OPT_ODE_GRAPH; None = environment SAMAUDIO_ODE_GRAPH, default off).  Scheduling only.
-        `weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
+                 weight_layout: str = "auto", prefetch_rows: Optional[int] = None, x3_classes="auto",
+                 codec_decode: str = "auto"):
+        """`weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
         K-tile-major (weights.ktm_layout; a launch then streams its weights front to back), "rows" keeps them row-major;
         "auto" = DEFAULT_WEIGHT_LAYOUT.  `prefetch_rows`: evaluations of at most this many rows (batch x frames) let the CUs a
         GEMM launch leaves idle read the next GEMM's weights (samaudio.h SAMAUDIO_OPT_PREFETCH_ROWS; None =
@@ -155,7 +153,6 @@ class SAMAudio:
         if prefetch_rows is None:
             prefetch_rows = int(os.environ.get("SAMAUDIO_PREFETCH_ROWS", DEFAULT_PREFETCH_ROWS))
         self.prefetch_rows = 0 if precision == "fp32" else int(prefetch_rows)
-        self.ode_graph = bool(int(os.environ.get("SAMAUDIO_ODE_GRAPH", "0"))) if ode_graph is None else bool(ode_graph)
         self.device = torch.device(device) if device is not None else None
         self.text_encoder = text_encoder      # callable: list[str] -> (features [B,Lt,768], mask [B,Lt])
         # rerankers (reference model.py:94-95): any callable with the reference's Ranker.forward keywords that returns
@@ -322,7 +319,6 @@ class SAMAudio:
         return pe is not None and all(("model.visual." + k) in vis for k in expected_keys(pe))
 
     def _set_precision_options(self, ctx) -> None:
-        hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ODE_GRAPH, int(self.ode_graph)))
         if hip.storage_precision(self.precision) != "fp32":
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_F32_CLASSES, self.f32_classes))
             hip.check(self._lib.samaudio_set_option(ctx, hip.OPT_ALT16_CLASSES, self.alt16_classes))
@@ -398,10 +394,6 @@ class SAMAudio:
                     out[n]["absmax"] = max(out[n]["absmax"], float(mx[i]))
                     out[n]["nonfinite"] += float(bad[i])
         return out
-
-    def graph_replays(self) -> int:
-        """Solves that ran as a HIP-graph launch so far, over every engine context (`ode_graph`; 0 = all launched eagerly)."""
-        return sum(int(self._lib.samaudio_graph_replays(ctx)) for ctx in [self._ctx] + [lane._ctx for lane in self._lanes])
 
     # ------------------------------------------------------------------ measurement (bench.py)
     def profile_begin(self, serial_groups: bool = True) -> None:
@@ -742,7 +734,8 @@ class SAMAudio:
             # process_anchors rebinds new tensors, so in the reference snapshot predicted spans never reach the ODE
             # (quirk Q13).  fix_span_order=True opts into the evidently intended order.
             anchor_ids, anchor_alignment = batch.anchor_ids, batch.anchor_alignment
-            validated = bool(getattr(batch, "anchors_validated", False))   # host-built anchors: no device-side range check
+            # host-built anchors, range-checked against THIS model's anchor vocabulary: no device-side range check
+            validated = getattr(batch, "anchor_vocab_validated", 0) == self.cfg.num_anchors + 1
             if predict_spans and batch.anchors is None:
                 if self.span_predictor is None:
                     warnings.warn("predict_spans=True ignored: no span predictor attached (model.span_predictor)")

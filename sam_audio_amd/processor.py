@@ -157,23 +157,52 @@ class Batch:
             ids = torch.full((n, width), ANCHOR_VOCAB["<pad>"], dtype=torch.long)
             for i, r in enumerate(rows):
                 ids[i, : len(r)] = torch.tensor(r)
-        self.anchor_ids = ids.to(self.audios.device)
-        self.anchor_alignment = alignment.to(self.audios.device)
+        # Built here, on the host, from vocabulary tokens and slot numbers, and CHECKED here on the CPU tensors (real checks, not
+        # asserts: they survive `python -O`): every id is in [0, len(ANCHOR_VOCAB)), every alignment entry in [0, ids.size(1)).
+        # SAMAudio.separate() then skips its device-side range check - four blocking device -> host reads - provided the vocabulary
+        # the ids were checked against is the model's (`anchor_vocab_validated` == cfg.num_anchors + 1; reference model.py:61 would
+        # raise inside gather / nn.Embedding).  Rebinding either tensor by hand (the property setters) drops the guarantee; moving
+        # them with Batch.to() keeps it.
+        if int(alignment.max()) >= ids.size(1) or int(alignment.min()) < 0:
+            raise IndexError(f"anchor_alignment values must be in [0, {ids.size(1)})")
+        if int(ids.max()) >= len(ANCHOR_VOCAB) or int(ids.min()) < 0:
+            raise IndexError(f"anchor ids must be in [0, {len(ANCHOR_VOCAB)})")
+        self._set_anchor_tensors(ids.to(self.audios.device), alignment.to(self.audios.device), len(ANCHOR_VOCAB))
         self.anchors = anchors
-        # Built here, on the host, from vocabulary tokens and slot numbers: every id is in [0, len(ANCHOR_VOCAB)) and every
-        # alignment entry in [0, ids.size(1)) BY CONSTRUCTION (asserted once, on the CPU tensors) - SAMAudio.separate() then skips
-        # its device-side range check, which costs four blocking device -> host reads (reference model.py:61 would raise inside
-        # gather / nn.Embedding).  Code that assigns anchor tensors by hand must reset this to False.
-        assert int(alignment.max()) < ids.size(1) and int(alignment.min()) >= 0
-        assert int(ids.max()) < len(ANCHOR_VOCAB) and int(ids.min()) >= 0
-        self.anchors_validated = True
+
+    # anchor tensors: plain attributes for readers; assignment from outside drops the host-side range guarantee
+    def _set_anchor_tensors(self, ids, alignment, vocab_validated: int) -> None:
+        self._anchor_ids, self._anchor_alignment, self.anchor_vocab_validated = ids, alignment, int(vocab_validated)
+
+    @property
+    def anchor_ids(self):
+        return self._anchor_ids
+
+    @anchor_ids.setter
+    def anchor_ids(self, value) -> None:
+        self._anchor_ids, self.anchor_vocab_validated = value, 0
+
+    @property
+    def anchor_alignment(self):
+        return self._anchor_alignment
+
+    @anchor_alignment.setter
+    def anchor_alignment(self, value) -> None:
+        self._anchor_alignment, self.anchor_vocab_validated = value, 0
+
+    @property
+    def anchors_validated(self) -> bool:
+        """the anchor tensors are the ones process_anchors built and range-checked on the host (possibly moved by to())"""
+        return getattr(self, "anchor_vocab_validated", 0) > 0
 
     def to(self, device) -> "Batch":
-        for name in ("audios", "anchor_ids", "anchor_alignment", "sizes", "wav_sizes", "audio_pad_mask",
-                     "text_features", "text_mask"):
+        for name in ("audios", "sizes", "wav_sizes", "audio_pad_mask", "text_features", "text_mask"):
             value = getattr(self, name)
             if value is not None:
                 setattr(self, name, value.to(device))
+        # (the same values on another device: the host-side range guarantee travels with them)
+        self._set_anchor_tensors(self._anchor_ids.to(device), self._anchor_alignment.to(device),
+                                 getattr(self, "anchor_vocab_validated", 0))
         if self.masked_video is not None:
             self.masked_video = [v.to(device) for v in self.masked_video]
         return self

@@ -148,14 +148,10 @@ def test_engine_separate_pieces_on_the_emulation_match_the_oracle(emu):
     grid = (C.c_float * 3)(0.0, 0.5, 1.0)
     _check(emu, emu.samaudio_ode_solve(ctx, hip.ptr(state), hip.ODE_MIDPOINT, grid, 3, None))
     assert (state - lat_ref).abs().max() < 1e-3
-    # SAMAUDIO_OPT_ODE_GRAPH where stream capture is refused (no GPU here): every solve falls back to the eager launches
-    _check(emu, emu.samaudio_set_option(ctx, hip.OPT_ODE_GRAPH, 1))
-    for _ in range(3):
+    for _ in range(2):   # a solve is a pure function of (state, conditioning, grid): repeats are bitwise equal
         again = noise.clone().contiguous()
         _check(emu, emu.samaudio_ode_solve(ctx, hip.ptr(again), hip.ODE_MIDPOINT, grid, 3, None))
         assert torch.equal(again, state)
-    assert emu.samaudio_graph_replays(ctx) == 0
-    _check(emu, emu.samaudio_set_option(ctx, hip.OPT_ODE_GRAPH, 0))
     lat = state.reshape(B, frames, 2, 128).permute(0, 2, 1, 3).reshape(2 * B, frames, 128).contiguous()
     out = torch.empty(2 * B, samples)
     _check(emu, emu.samaudio_codec_decode(ctx, hip.ptr(lat), 2 * B, frames, hip.ptr(out), None))

@@ -137,6 +137,30 @@ def test_processor_batching_matches_reference_semantics():
     assert float(masked[0].abs().max()) == 0
 
 
+def test_anchor_range_guarantee_follows_the_tensors():
+    """Batch.process_anchors range-checks ids / alignment on the host (real checks) and records the vocabulary they were checked
+    against; SAMAudio.separate() skips its blocking device-side check only while that guarantee holds: Batch.to() and
+    dist.shard_batch keep it, assigning either tensor by hand drops it."""
+    from sam_audio_amd.dist import shard_batch
+    from sam_audio_amd.processor import ANCHOR_VOCAB
+    cfg = preset_config("tiny")
+    hop = cfg.audio_codec.hop_length
+    proc = SAMAudioProcessor.from_config(cfg)
+    clips = [torch.zeros(1, 8 * hop), torch.zeros(1, 6 * hop)]
+    batch = proc(descriptions=["a", "b"], audios=clips, anchors=[[("+", 0.0, 0.08)], [("-", 0.04, 0.12)]])
+    assert batch.anchors_validated and batch.anchor_vocab_validated == len(ANCHOR_VOCAB) == cfg.num_anchors + 1
+    assert batch.to("cpu").anchors_validated                              # moved, same values: kept
+    assert shard_batch(batch, 1, 2).anchors_validated                      # rows of checked tensors: kept
+    batch.anchor_ids = batch.anchor_ids.clone()                           # rebound by hand: dropped
+    assert not batch.anchors_validated and batch.anchor_vocab_validated == 0
+    batch.process_anchors(None)                                           # rebuilt (and re-checked) on the host: back
+    assert batch.anchors_validated
+    batch.anchor_alignment = batch.anchor_alignment + 0
+    assert not batch.anchors_validated
+    with pytest.raises(KeyError):                                         # a token outside the vocabulary never becomes an id
+        batch.process_anchors([[("?", 0.0, 0.04)], []])
+
+
 def test_product_path_has_no_cpu_fallback():
     """The host class refuses to run without a GPU instead of silently computing elsewhere."""
     from sam_audio_amd import SAMAudio
