@@ -247,7 +247,7 @@ def oracle_sample(cfg, sd_cpu, clips, text, tmask, noise, threads):
     per_clip = (t_enc + t_ode + t_dec) / R
     base = {
         "value": CLIP_SECONDS / per_clip, "unit": "s-audio/s", "cores": threads, "kind": "port",
-        "sample": (f"{R} clips x 10 s, same dims, fp32 torch oracle (restatement of the reference, pinned to its own "
+        "sample": (f"{R} clip(s) x 10 s, same dims, fp32 torch oracle (restatement of the reference, pinned to its own "
                    f"classes; the reference package itself cannot be imported on the GPU box), the whole path once: DAC "
                    f"encode {t_enc:.2f} s + 16 midpoint steps = 32 DiT evaluations {t_ode:.2f} s + DAC decode "
                    f"x{2 * R} {t_dec:.2f} s => {per_clip:.1f} s per clip"),
@@ -293,7 +293,7 @@ def hostile_check(precision, dev, threads, size="small*"):
     cfg = preset_config(size)
     sd = make_hostile(init_state_dict(cfg, seed=0, device=dev), cfg, seed=0)
     sd_cpu = {k: v.cpu() for k, v in sd.items()}
-    R = 2
+    R = 1
     hop = cfg.audio_codec.hop_length
     n = int(CLIP_SECONDS * cfg.audio_codec.sample_rate) // hop * hop
     clips = [synthetic_clip(i, n) for i in range(R)]
@@ -487,7 +487,8 @@ def other_configs(args):
     runs = [
         ("configs[1] small* 8 clips", ["--size", "small*", "--batch", "8"]),
         ("configs[2] share of one of 8 GPUs: 4 clips", ["--batch", "4"] + (["--oracle-cache", large] if large else [])),
-        ("configs[3] 8 clips x 8 candidates, span predictor + Judge", ["--batch", "8", "--candidates", "8", "--predict-spans"]),
+        ("configs[3] 8 clips x 8 candidates, span predictor + Judge", ["--batch", "8", "--candidates", "8", "--predict-spans", "--steps", "2",
+                                                                       "--verify-seconds", "1.28"]),
         ("configs[4] 4 clips, visual prompts", ["--batch", "4", "--visual"]),
     ]
     out = []
@@ -884,7 +885,7 @@ def run(args):
     breakdown = None
     if rank == 0 and (args.candidates > 1 or args.predict_spans):
         ranker, predictor = model.text_ranker, model.span_predictor
-        b_steps = max(2, min(args.steps, 4))
+        b_steps = max(1, min(args.steps - 1, 4))
 
         def run(spans, rerank):
             model.text_ranker = ranker if rerank else None
@@ -1035,7 +1036,7 @@ def run(args):
                                args.cpu_threads or usable_cores())
         log(f"parity_check (rerank): {parity}")
     elif want_cpu or want_verify:
-        R = min(2, len(my_ids))
+        R = 1   # the bounded CPU sample: ONE 10 s clip through the whole path (~50 s on 16 cores; 2 clips until round 5)
         threads = args.cpu_threads or usable_cores()
         g = torch.Generator().manual_seed(99)
         noise = torch.randn(R, n_samples // cfg.audio_codec.hop_length, tcfg.out_channels, generator=g)
