@@ -524,6 +524,16 @@ hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hip
   return hipSuccess;
 }
 
+hipError_t launch_act_flat(const float* in, long in_bstride, float* out, long out_bstride, int items, long count, int chan, int act,
+                           const float* alpha, hipStream_t) {
+  for (int b = 0; b < items; ++b)
+    for (long i = 0; i < count; ++i) {
+      const float v = in[(long)b * in_bstride + i];
+      out[(long)b * out_bstride + i] = act == ACT_SNAKE ? snake_h(v, alpha[i % chan]) : act == ACT_TANH ? std::tanh(v) : act == ACT_SILU ? silu_h(v) : v;
+    }
+  return hipSuccess;
+}
+
 hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t) {
   const size_t e = bf16 ? 2 : 4;
   for (int b = 0; b < B; ++b) {

@@ -100,6 +100,16 @@ class Engine {
   // `presplit`: the activation operand is already in its split form at that address (written by the kernel that produced it)
   Status gemm_x3(GemmParams p, const void* w3, bool ktm, hipStream_t st, int cls, const void* presplit = nullptr);
   bool x3(int cls) const { return !bf16_ && (x3_classes_ & cls) != 0; }
+  // SAMAUDIO_OPT_X3_CLASSES bit CODEC, convolutions with >= 256 output channels whose weight has a registered "<name>.x3" twin
+  // ([N, K / Cin, 3 Cin]: every Cin-block of a weight row as [W_hi | W_lo | W_hi]): the fp32 activation buffer is split row by row
+  // into a scratch operand and the launch runs on the 8-phase 16-bit kernels over K' = 3K; the activation is applied to the raw fp32
+  // result by an elementwise kernel.  Everything else of the codec multiplies on operands split in registers (GEMM_FLAG_X3_FLY).
+  struct X3CodecW { const void* w; int cin; };
+  std::map<const void*, X3CodecW> x3_codec_;
+  void* x3_codec_scratch_ = nullptr;
+  size_t x3_codec_scratch_bytes_ = 0;
+  size_t codec_x3_per_item(int64_t samples) const;
+  Status gemm_codec_x3(const GemmParams& p, const X3CodecW& w, hipStream_t st, double alg_flops);
   Status check_x3_weights(int classes) const;
   bool f32c(int cls) const { return bf16_ && (f32_classes_ & cls) != 0; }
   bool alt16(int cls) const { return bf16_ && (alt_classes_ & cls) != 0; }   // SAMAUDIO_OPT_ALT16_CLASSES (mixed mode)

@@ -181,6 +181,10 @@ hipError_t launch_to_act(const float* in, long in_bstride, long in_ld, int in_co
 // format = [lo | hi | hi] per row, hi = rn16(x), lo = rn16(x - hi); K % 8 == 0
 hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hipStream_t st);
 
+// out[b][e] = act(in[b][e]; alpha[e % chan]) for e < count (fp32, contiguous per item, in-place allowed; count, chan % 4 == 0)
+hipError_t launch_act_flat(const float* in, long in_bstride, float* out, long out_bstride, int items, long count, int chan, int act,
+                           const float* alpha, hipStream_t st);
+
 // zero the halo rows of a [B][halo + T + halo][C] buffer
 hipError_t launch_zero_halo(void* buf, bool bf16, int B, long T, int C, int halo, hipStream_t st);
 

@@ -827,6 +827,43 @@ hipError_t launch_split3(const float* x, long ldx, void* out, long M, int K, hip
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// out[b][e] = act(in[b][e]; alpha[e % chan]) over `count` contiguous fp32 values per batch item (in-place allowed): the activation
+// of a codec convolution whose multiply ran as a compensated 16-bit launch (engine.hip gemm_codec_x3) - the same snake_f / tanhf
+// expressions as the fp32 convolution kernel's epilogue (gemm.hip), applied to its raw fp32 result
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_flat_kernel(const float* __restrict__ in, long in_bstride, float* __restrict__ out,
+                                                       long out_bstride, long count, int chan, int act, const float* __restrict__ alpha) {
+  const float* ib = in + (long)blockIdx.y * in_bstride;
+  float* ob = out + (long)blockIdx.y * out_bstride;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += (long)gridDim.x * 1024) {
+    const float4 v = *(const float4*)(ib + i);
+    const int c = (int)(i % chan);
+    float4 r;
+    if (act == ACT_SNAKE) {
+      const float4 al = *(const float4*)(alpha + c);
+      r = make_float4(snake_f(v.x, al.x), snake_f(v.y, al.y), snake_f(v.z, al.z), snake_f(v.w, al.w));
+    } else if (act == ACT_TANH) {
+      r = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+    } else if (act == ACT_SILU) {
+      r = make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w));
+    } else {
+      r = v;
+    }
+    *(float4*)(ob + i) = r;
+  }
+}
+hipError_t launch_act_flat(const float* in, long in_bstride, float* out, long out_bstride, int items, long count, int chan, int act,
+                           const float* alpha, hipStream_t st) {
+  if (count % 4 || chan % 4 || in_bstride % 4 || out_bstride % 4 || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) ||
+      (act == ACT_SNAKE && (!alpha || ((uintptr_t)alpha & 15))))
+    return hipErrorInvalidValue;
+  long gx = (count / 4 + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(act_flat_kernel, dim3((unsigned)gx, items), dim3(256), 0, st, in, in_bstride, out, out_bstride, count, chan, act, alpha);
+  return hipGetLastError();
+}
+
 template <typename TA>
 __global__ void zero_halo_kernel(TA* __restrict__ buf, long T, int C, int halo) {
   const int b = blockIdx.y;

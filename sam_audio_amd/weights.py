@@ -330,6 +330,40 @@ def convert_codec(sd: Dict[str, torch.Tensor], cfg: SAMAudioConfig, act_dtype: t
     return out
 
 
+def convert_codec_x3(tensors: Dict[str, torch.Tensor], half: torch.dtype, min_out: int = 256) -> Dict[str, torch.Tensor]:
+    """The "<name>.x3" twins of the codec convolutions with >= `min_out` output channels (include/samaudio.h SAMAUDIO_OPT_X3_CLASSES,
+    class CODEC), made from the fp32 engine tensors of convert_codec: a weight row [K] = [block][Cin] becomes [block][W_hi | W_lo |
+    W_hi], shape [N, K / Cin, 3 Cin] - Cin = the channel count of one input row (a tap of a dilated convolution, a time step of a
+    strided / transposed one), so that the activation buffer split row by row into [lo | hi | hi] lines up with it."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, w in tensors.items():
+        if w.dim() != 2 or w.dtype != torch.float32 or not (name.startswith("enc.") or name.startswith("dec.")) or name.endswith(".x3"):
+            continue
+        n, k = w.shape
+        leaf = name.rsplit(".", 2)[-2:] if name.count(".") >= 2 else [name]
+        if name.endswith((".w1", ".w2")):
+            cin = n
+        elif name.endswith("down.w"):
+            cin = n // 2
+        elif name == "enc.out.w":
+            cin = k // 3
+        elif name == "dec.proj.w":
+            cin = k
+        elif name == "dec.in.w":
+            cin = k // 7
+        elif name.endswith("up.w"):
+            cin = k // 2
+        else:
+            continue
+        if n < min_out or cin % 8 or k % cin or (3 * k) % 64:
+            continue
+        blocks = w.reshape(n, k // cin, cin)
+        hi = blocks.clamp(-65504.0, 65504.0).to(half) if half == torch.float16 else blocks.to(half)
+        lo = (blocks - hi.float()).to(half)
+        out[name + ".x3"] = torch.cat([hi, lo, hi], dim=2).contiguous()
+    return out
+
+
 def split_missing_unexpected(sd_keys, cfg: SAMAudioConfig) -> Tuple[List[str], List[str]]:
     """Key bookkeeping of reference SAMAudio.load_state_dict (model.py:346-359)."""
     want = set(expected_keys(cfg))

@@ -177,7 +177,8 @@ def test_judge_at_pe_av_large_dims(gpu, prec):
     scores = m.score_candidates(ids.to(gpu), wav_in.to(gpu), wav_sep.to(gpu), cand, attention_mask=att.to(gpu),
                                 padding_mask=pad.to(gpu))
     assert scores.shape == (B, cand)
-    util.report(f"judge overall score, pe-av-large dims, {prec}", scores.reshape(-1), want[:, 0], 1e-3 if prec == "fp32" else 2e-2)
+    # 16-bit bound = 2 x the error measured on MI355X (bf16 1.7e-3 on |score| <= 0.55, profiles/r6_call5/tower_errors.log)
+    util.report(f"judge overall score, pe-av-large dims, {prec}", scores.reshape(-1), want[:, 0], 1e-3 if prec == "fp32" else 4e-3)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -205,7 +206,7 @@ def test_frame_predictor_at_pe_a_frame_large_dims(gpu, prec):
     out = fp(input_features=feats.to(gpu), padding_mask=pad.to(gpu), return_spans=True, text_pooled=pooled.to(gpu))
     scale = max(1.0, want.abs().max().item())
     util.report(f"frame logits, pe-a-frame-large dims, {prec}", out.logits.cpu() * pad, want * pad,
-                (1e-3 if prec == "fp32" else 2e-2) * scale)
+                (1e-3 if prec == "fp32" else 1.2e-2) * scale)   # bf16: 2 x measured (1.9e-1 on |logit| <= 31.7, profiles/r6_call5/)
     if prec == "fp32":   # bit-exact frame indices away from the threshold (north_star)
         margin = (want.abs() > 1e-2) | ~pad
         ids_w, al_w = O.anchors_to_ids([[("+", s, e) for s, e in r] for r in J.spans_from_logits(want, pad, 1920, 48000)],
