@@ -106,11 +106,15 @@ class _Lane:
 class SAMAudio:
     config_cls = SAMAudioConfig
 
-    def __init__(self, cfg: SAMAudioConfig, precision: str = "bf16", device: Optional[str] = None,
+    def __init__(self, cfg: SAMAudioConfig, precision: str = "fp16x3", device: Optional[str] = None,
                  text_encoder: Optional[Callable] = None, streams: int = 1, f32_classes="auto",
                  weight_layout: str = "auto", prefetch_rows: Optional[int] = None, x3_classes="auto",
                  codec_decode: str = "auto"):
-        """`weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
+        """`precision`: "fp16x3" (default: the reference computes in fp32, README.md:48 - fp32 storage and every big contraction on
+        hi/lo-split IEEE-half operands hold its results to 1e-3 on benign and trained-like weights) | "fp16" |
+        "mixed" | "bf16" (plain 16-bit GEMM operands: ~3x the throughput, inside 1e-3 on benign weights only / not at all) | "fp32"
+        (exact-fp32 MFMA) | "bf16x3".
+        `weight_layout` (16-bit precisions): "ktm" stores the weights of the five big GEMM classes of the DiT layers
         K-tile-major (weights.ktm_layout; a launch then streams its weights front to back), "rows" keeps them row-major;
         "auto" = DEFAULT_WEIGHT_LAYOUT.  `prefetch_rows`: evaluations of at most this many rows (batch x frames) let the CUs a
         GEMM launch leaves idle read the next GEMM's weights (samaudio.h SAMAUDIO_OPT_PREFETCH_ROWS; None =
@@ -228,7 +232,7 @@ class SAMAudio:
 
     @classmethod
     def from_pretrained(cls, model_id: str, map_location: str = "cpu", strict: bool = True,
-                        precision: str = "bf16", device: Optional[str] = None, **model_kwargs):
+                        precision: str = "fp16x3", device: Optional[str] = None, **model_kwargs):
         """Local directory with the reference's `config.json` + `checkpoint.pt`
         (reference base.py:17-62; hub download needs network access this build does not have)."""
         if not os.path.isdir(model_id):
