@@ -1285,6 +1285,7 @@ static int gemm8_linear_epilogue(const GemmParams& p) {
 static GemmParams with_epilogue_choice(const GemmParams& p) {
   GemmParams q = p;
   q.flags = (q.flags & ~192) | gemm8_linear_epilogue(p);
+  if (!q.raster_gm && debug_flag(35) > 0) q.raster_gm = debug_flag(35);   // (A/B) M-tiles per raster group of the 8-phase family
   return q;
 }
 

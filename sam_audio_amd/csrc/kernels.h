@@ -27,6 +27,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 33: (A/B) smallest last round, in 256x256 tiles, that is split off as a 128x128-tile tail launch (0 = shipped: 8)
 //   flag 31: 1 = the folded cross-attention operand U = Wo V of every layer in its own launch (shipped: all layers of an evaluation in
 //            one launch in front of the layer loop) - its bitwise test
+//   flag 35: (A/B) M-tiles per raster group of the 8-phase family (0 = shipped: 8; GemmParams.raster_gm)
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);

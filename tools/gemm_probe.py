@@ -20,6 +20,7 @@ dev = torch.device("cuda:0")
 for spec in (sys.argv[1:] or ["22:w13", "22:c_wq", "22:qkv", "22:w2"]):
     v, name = spec.split(":")
     m, n, k, sw = SHAPES[name]
+    k *= int(os.environ.get("PROBE_KMUL", "1"))   # 3: the K' = 3K launches of the fp16x3 mode (split operands)
     A = torch.randn(m, k, device=dev).to(torch.bfloat16)
     W = (torch.randn(n, k, device=dev) / k ** 0.5).to(torch.bfloat16)
     out = torch.empty(m, n // 2 if sw else n, device=dev, dtype=torch.bfloat16)
