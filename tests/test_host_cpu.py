@@ -161,6 +161,49 @@ def test_anchor_range_guarantee_follows_the_tensors():
         batch.process_anchors([[("?", 0.0, 0.04)], []])
 
 
+def test_split_weight_forms_of_the_x3_precisions():
+    """weights.x3_weight / convert_dit_x3 / convert_codec_x3 (include/samaudio.h SAMAUDIO_OPT_X3_CLASSES): [W_hi | W_lo | W_hi] along K
+    per input-channel block, hi + lo = W to ~2^-22, K-tile-major storage a pure permutation; precision plumbing of hip.py."""
+    from sam_audio_amd.weights import convert_codec_x3, convert_dit_x3, ktm_to_rows, x3_weight
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(96, 128, generator=g) * torch.logspace(-4, 1, 128)[None]
+    rows = x3_weight(w, torch.float16, ktm=False)
+    assert rows.shape == (96, 384) and rows.dtype == torch.float16
+    hi, lo = rows[:, :128].float(), rows[:, 128:256].float()
+    assert torch.equal(rows[:, :128], rows[:, 256:]) and torch.equal(rows[:, :128], w.half())
+    assert ((hi + lo - w).abs() <= w.abs() * 2.0 ** -21 + 2.0 ** -25).all()
+    assert torch.equal(ktm_to_rows(x3_weight(w, torch.float16, ktm=True)), rows)
+    assert torch.isfinite(x3_weight(torch.tensor([[1e5, -7e4] + [0.0] * 62]), torch.float16, ktm=False).float()).all()   # clamped, not inf
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=1)
+    dit = convert_dit(sd, cfg, torch.float32, torch.device("cpu"))
+    t = cfg.transformer
+    x3 = convert_dit_x3(dit, t.n_layers, torch.float16, hip.CLS_X3_DEFAULT)
+    D, F = t.dim, t.ffn_hidden
+    assert x3["L0.wqkv.x3"].shape == (3 * D // 64, 3 * D, 64) and x3["L0.w2.x3"].shape == (3 * F // 64, D, 64)
+    assert x3["c_wkv_all.x3"].shape == (3 * D // 64, t.n_layers * 2 * D, 64)
+    p3 = ktm_to_rows(x3["patch1.w.x3"])            # [D, 3 taps x 3D]: every tap's D columns split on its own
+    for tap in range(3):
+        blk = p3[:, tap * 3 * D:(tap + 1) * 3 * D]
+        assert torch.equal(blk[:, :D], dit["patch1.w"][:, tap * D:(tap + 1) * D].half()) and torch.equal(blk[:, :D], blk[:, 2 * D:])
+    assert set(k.rsplit(".", 2)[-2] for k in x3 if k.startswith("L0.")) == set(hip.X3_WEIGHTS)
+    assert not convert_dit_x3(dit, t.n_layers, torch.float16, hip.CLS["w2"]).keys() - {f"L{i}.w2.x3" for i in range(t.n_layers)}
+    codec = convert_codec(sd, cfg, torch.float32, torch.device("cpu"))
+    c3 = convert_codec_x3(codec, torch.float16)
+    assert c3 and all(codec[k[:-3]].shape[0] >= 256 for k in c3)            # wide convolutions only
+    for k, v in c3.items():                                                 # [N, K / Cin, 3 Cin], blocks of the fp32 weight
+        n, kk = codec[k[:-3]].shape
+        cin = v.shape[2] // 3
+        assert v.shape == (n, kk // cin, 3 * cin) and torch.equal(v[:, :, :cin], codec[k[:-3]].reshape(n, kk // cin, cin).half())
+    assert "dec.s1.r0.w1.x3" in c3 and c3["dec.s1.r0.w1.x3"].shape[2] == 3 * 384 and "dec.s3.r0.w1.x3" not in c3
+    assert hip.precision_code("fp16x3") == hip.F32 and hip.operands_for("fp16x3") == "fp16" and hip.operands_for("bf16x3") == "bf16"
+    assert hip.storage_precision("fp16x3") == "fp32" and hip.act_dtype("fp16x3") == torch.float32
+    assert hip.class_mask("attn,qkv") == hip.X3_ATTENTION | hip.CLS["qkv"]
+    with pytest.raises(ValueError):
+        hip.check_precision("fp16x3")              # the towers beside the DiT have no compensated mode
+    hip.check_precision("fp16x3", x3_ok=True)
+
+
 def test_product_path_has_no_cpu_fallback():
     """The host class refuses to run without a GPU instead of silently computing elsewhere."""
     from sam_audio_amd import SAMAudio
