@@ -140,6 +140,8 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   PATCH (the patcher's k3 convolutions: "patch1.w.x3" / "patch2.w.x3", [D, 9D] with EACH tap's D columns split into 3D) and CKV
  *   ("c_wkv_all.x3") can be switched on as well.  Class CODEC needs no second copy of anything: the fp32 convolution kernel splits the
  *   fp32 fragments of both operands in registers and multiplies them as lo*hi + hi*lo + hi*hi on the 16-bit MFMA.
+ *   With class CWO on, text memories of <= 16 tokens (128-wide heads) take the folded form of the cross-attention output projection on
+ *   compensated operands (h += P . U, U = Wo V per layer and batch item: K' = 3 * pad64(heads * (8 | 16)) instead of 3 * dim).
  *   Bit SAMAUDIO_X3_ATTENTION does the same for the two contractions of the self-attention.  Everything else of the context
  *   (norms, softmax, the small GEMM classes, the codec) stays exact fp32.  In
  *   libsamaudio_hip_f16.so the halves are IEEE fp16 (22 mantissa bits per operand); in libsamaudio_hip.so bfloat16 (16 bits). */

@@ -555,6 +555,13 @@ hipError_t launch_peav_cls_mask(float* h, const float* cls, const unsigned char*
   return hipSuccess;
 }
 
+hipError_t launch_cross_attn_probs3(const float*, const float*, const float*, long, const unsigned char*, void*, int, int, int, int, int,
+                                    int, float, hipStream_t) {
+  return hipErrorNotSupported;   // (the launcher emulation runs with SAMAUDIO_NO_FOLD: the folded kernels are not emulated)
+}
+hipError_t launch_cross_attn_fold3_layers(const float* const*, int, const float*, long, void*, int, int, int, int, int, hipStream_t) {
+  return hipErrorNotSupported;
+}
 hipError_t launch_repeat_items_f32(const float* src, float* dst, int items, int rep, long elems, hipStream_t) {
   for (long r = (long)items * rep - 1; r >= 0; --r) std::memmove(dst + r * elems, src + (r / rep) * elems, (size_t)elems * 4);
   return hipSuccess;

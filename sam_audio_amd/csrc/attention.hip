@@ -917,6 +917,181 @@ __global__ __launch_bounds__(512) void cross_attn_fold_kernel(const FoldLayers l
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Folded cross-attention of an x3 context (SAMAUDIO_OPT_X3_CLASSES class CWO, Lt <= 16, head_dim 128): the same fold as above -
+// h += P . U, U = Wo V per (layer, batch item) - with fp32 inputs and compensated operands on both sides of the K = H*LtP GEMM:
+//   cross_attn_probs3_kernel: fp32 q (raw, q-norm applied here) and fp32 k -> softmax probabilities in fp32 (one wave per (row, head),
+//     as cross_attn_kernel<float>), written as the GEMM's split activation row [P_lo | P_hi | P_hi] (3 KP 16-bit elements);
+//   cross_attn_fold3_kernel: cross_attn_fold_kernel with fp32 Wo / V split in registers, U = V_l Wo_h + V_h Wo_l + V_h Wo_h in fp32,
+//     written as the per-batch weight operand [U_hi | U_lo | U_hi] (rows of 3 KP).
+// The D-wide c_wo GEMM over K' = 3 D of the unfolded x3 path becomes one over K' = 3 KP = 576: 7.6 % of the DiT's flops gone.
+// ---------------------------------------------------------------------------------------------------
+// LTP = token slots per head (8 | 16): the scores of ALL tokens are reduced across the wave together (LTP independent butterflies in
+// flight per stage instead of one reduction after the other: the kernel is bound by the latency of its cross-lane steps)
+template <int LTP>
+__global__ __launch_bounds__(256) void cross_attn_probs3_kernel(const float* __restrict__ q, const float* __restrict__ qw,
+                                                                const float* __restrict__ kv, long kv_ld,
+                                                                const unsigned char* __restrict__ mask, bf16_t* __restrict__ P3, int KP,
+                                                                long M, int T, int Lt, int H, float eps) {
+#pragma clang fp contract(off)
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= M * H) return;
+  const int lane = threadIdx.x & 63;
+  const long m = item / H;
+  const int h = (int)(item % H);
+  const long b = m / T;
+  const int D = H * 128;
+  float q0, q1;
+  load2<float>(q + m * D + h * 128 + 2 * lane, q0, q1);
+  const float w0 = qw[2 * lane], w1 = qw[2 * lane + 1];
+  float part[LTP + 1];
+  bool live[LTP];
+#pragma unroll
+  for (int j = 0; j < LTP; ++j) {
+    live[j] = j < Lt && mask[b * Lt + (j < Lt ? j : 0)] != 0;   // wave-uniform
+    float k0 = 0.f, k1 = 0.f;
+    if (live[j]) load2<float>(kv + (b * Lt + j) * kv_ld + h * 128 + 2 * lane, k0, k1);
+    part[j] = (q0 * w0) * k0 + (q1 * w1) * k1;
+  }
+  part[LTP] = q0 * q0 + q1 * q1;   // the q-norm statistic rides along: inv is a scalar, the scores are scaled with it afterwards
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int j = 0; j <= LTP; ++j) part[j] += __shfl_xor(part[j], o, 64);
+  const float inv = rsqrtf(part[LTP] / 128.f + eps);
+  float mx = -INFINITY, mine = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < LTP; ++j) {
+    const float sj = live[j] ? part[j] * inv * 0.08838834764831845f : -INFINITY;
+    mx = fmaxf(mx, sj);
+    if (lane == j) mine = sj;
+  }
+  const float e = mine != -INFINITY ? expf(mine - mx) : 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int j = 0; j < LTP; ++j) l += live[j] ? expf(part[j] * inv * 0.08838834764831845f - mx) : 0.f;   // (every lane: no second reduction)
+  if (lane < LTP) {
+    const float p = lane < Lt ? e / l : 0.f;   // (every token masked: 0 / 0 = NaN, as the reference's softmax of an all -inf row)
+    const unsigned short hi = f2bf(fminf(fmaxf(p, -kH16Max), kH16Max));
+    const unsigned short lo = f2bf(p - bf2f(hi));
+    unsigned short* row = (unsigned short*)P3 + m * (3L * KP) + h * LTP + lane;
+    row[0] = lo;
+    row[KP] = hi;
+    row[2 * KP] = hi;
+  }
+}
+
+struct FoldLayers3 {
+  const float* wo[kMaxFoldLayers];
+};
+__global__ __launch_bounds__(512) void cross_attn_fold3_kernel(const FoldLayers3 layers, const int zsplits, const float* __restrict__ kv_all,
+                                                               long kv_ld, bf16_t* __restrict__ UT_all, int KP, int B, int Lt,
+                                                               int LtP, int H) {
+  __shared__ __attribute__((aligned(16))) unsigned short stage[2][4 * 64 * 8 * 16];  // [hi | lo][item][n][head][token <= 16]: 128 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int D = H * 128;
+  const int layer = (int)blockIdx.z / zsplits, zsplit = (int)blockIdx.z % zsplits;
+  const float* __restrict__ wo = layers.wo[layer];
+  const float* __restrict__ kv = kv_all + (long)layer * 2 * D;
+  bf16_t* __restrict__ UT = UT_all + (long)layer * B * D * 3 * KP;
+  const int h = blockIdx.y * 8 + wave;
+  const bool head_ok = h < H;
+  const int hc = head_ok ? h : H - 1;
+  const int n0 = blockIdx.x * 64;
+  bf16x8_t wfh[4][4], wfl[4][4];  // [n-fragment][k-step], hi / lo halves of the fp32 Wo fragments
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const float* src = wo + (long)(n0 + s4 * 16 + r) * D + hc * 128 + ks * 32 + g * 8;
+      uint4 hi, lo;
+      split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+      wfh[s4][ks] = __builtin_bit_cast(bf16x8_t, hi);
+      wfl[s4][ks] = __builtin_bit_cast(bf16x8_t, lo);
+    }
+  const int run = 8 * LtP;                        // elements of one (item, channel) run: this workgroup's heads
+  const int k0 = blockIdx.y * run;                // first column of the run inside a third of a U^T row
+  const int segs = run / 8;                       // 16-byte segments per run
+  const int bz = (((B + zsplits - 1) / zsplits) + 3) & ~3;
+  const int b_end = (zsplit + 1) * bz < B ? (zsplit + 1) * bz : B;
+  for (int b0 = zsplit * bz; b0 < b_end; b0 += 4) {
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      const int b = b0 + bb < B ? b0 + bb : B - 1;
+      const float* vrow = kv + ((long)b * Lt + (r < Lt ? r : 0)) * kv_ld + D + hc * 128 + g * 8;
+      bf16x8_t vh[4], vl[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        uint4 hi, lo;
+        split8(*(const float4*)(vrow + ks * 32), *(const float4*)(vrow + ks * 32 + 4), hi, lo);
+        // rows of tokens that do not exist / heads beyond H must be exact zeros (never "multiplied away": 0 x NaN)
+        if (r >= Lt || !head_ok) hi = lo = make_uint4(0u, 0u, 0u, 0u);
+        vh[ks] = __builtin_bit_cast(bf16x8_t, hi);
+        vl[ks] = __builtin_bit_cast(bf16x8_t, lo);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        f32x4_t u = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          u = SA_MFMA_16x16x32(vl[ks], wfh[s4][ks], u);
+          u = SA_MFMA_16x16x32(vh[ks], wfl[s4][ks], u);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) u = SA_MFMA_16x16x32(vh[ks], wfh[s4][ks], u);
+        if (g * 4 < LtP) {  // lane: tokens g*4 .. g*4+3 of channel s4*16 + r
+          const unsigned h01 = pack_h16x2(u[0], u[1]), h23 = pack_h16x2(u[2], u[3]);
+          const unsigned l01 = pack_h16x2(u[0] - h16_lo(h01), u[1] - h16_hi(h01)), l23 = pack_h16x2(u[2] - h16_lo(h23), u[3] - h16_hi(h23));
+          const int at = ((bb * 64 + s4 * 16 + r) * 8 + wave) * LtP + g * 4;
+          *(uint2*)(stage[0] + at) = make_uint2(h01, h23);
+          *(uint2*)(stage[1] + at) = make_uint2(l01, l23);
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * 64 * segs; idx += 512) {
+      const int seg = idx % segs, n = (idx / segs) & 63, bb = idx / (segs * 64);
+      if (b0 + bb < B && k0 + seg * 8 < KP) {
+        bf16_t* dst = UT + ((long)(b0 + bb) * D + n0 + n) * (3L * KP) + k0 + seg * 8;   // [U_hi | U_lo | U_hi]
+        const uint4 hi = *(const uint4*)(stage[0] + (bb * 64 + n) * run + seg * 8), lo = *(const uint4*)(stage[1] + (bb * 64 + n) * run + seg * 8);
+        *(uint4*)dst = hi;
+        *(uint4*)(dst + KP) = lo;
+        *(uint4*)(dst + 2 * KP) = hi;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_cross_attn_probs3(const float* q, const float* qw, const float* kv, long kv_ld, const unsigned char* mask, void* P3,
+                                    int KP, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st) {
+  if (Lt > 16 || (LtP != 8 && LtP != 16) || Lt > LtP || H * LtP > KP) return hipErrorInvalidValue;
+  const long items = (long)B * T * H;
+  if (LtP == 8)
+    hipLaunchKernelGGL(cross_attn_probs3_kernel<8>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, q, qw, kv, kv_ld, mask, (bf16_t*)P3, KP,
+                       (long)B * T, T, Lt, H, eps);
+  else
+    hipLaunchKernelGGL(cross_attn_probs3_kernel<16>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, q, qw, kv, kv_ld, mask, (bf16_t*)P3, KP,
+                       (long)B * T, T, Lt, H, eps);
+  return hipGetLastError();
+}
+hipError_t launch_cross_attn_fold3_layers(const float* const* wo, int n_layers, const float* kv_all, long kv_ld, void* UT3_all, int KP,
+                                          int B, int Lt, int LtP, int H, hipStream_t st) {
+  if (n_layers <= 0 || n_layers > kMaxFoldLayers || (LtP != 8 && LtP != 16) || Lt > LtP || H * LtP > KP) return hipErrorInvalidValue;
+  FoldLayers3 layers;
+  for (int l = 0; l < kMaxFoldLayers; ++l) layers.wo[l] = wo[l < n_layers ? l : 0];
+  const int D = H * 128;
+  const int groups = (KP + 8 * LtP - 1) / (8 * LtP);
+  const int target = B <= 16 ? 1 : 384;   // (batch splits as launch_cross_attn_fold_layers)
+  int zs = (target + (D / 64) * groups - 1) / ((D / 64) * groups);
+  const int zmax = (B + 3) / 4;
+  zs = zs < 1 ? 1 : zs > zmax ? zmax : zs;
+  hipLaunchKernelGGL(cross_attn_fold3_kernel, dim3(D / 64, groups, zs * n_layers), dim3(512), 0, st, layers, zs, kv_all, kv_ld,
+                     (bf16_t*)UT3_all, KP, B, Lt, LtP, H);
+  return hipGetLastError();
+}
+
 hipError_t launch_cross_attn_probs(const void* q, const float* qw, const void* kv, long kv_ld, const unsigned char* mask,
                                    void* P, int ldp, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st) {
   hipLaunchKernelGGL(cross_attn_probs_kernel, dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const bf16_t*)q, qw,

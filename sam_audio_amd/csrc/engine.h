@@ -153,6 +153,7 @@ class Engine {
   char* ws_ = nullptr;
   size_t ws_bytes_ = 0;
   int rows_ = 0, frames_ = 0, text_len_ = 0, frames_pad_ = 0;
+  bool fold3_ = false;   // the fold runs on compensated operands (x3 context, class CWO)
   int fold_ltp_ = 0, fold_kp_ = 0;  // folded cross-attention: tokens per head slot (8 | 16; 0 = not folded), padded K
   bool has_anchor_ = false;
 
@@ -202,7 +203,7 @@ class Engine {
   struct {
     float *ymid, *aligned, *cond, *h, *hp1, *text_proj, *t_emb, *t0, *modgs, *tsin, *vtmp, *times;
     void *ybf, *xn, *qkv, *Q, *K, *Vt, *attn, *hbf, *qc, *ca, *u, *gnbuf, *mem, *yu, *yemb, *kvc, *temb, *tu, *tsilu,
-        *feats, *text, *video, *anch, *probs, *ut, *x3a, *x3u;
+        *feats, *text, *video, *anch, *probs, *ut, *x3a, *x3u, *x3p, *ut3;
     float *temb32, *tu32, *tsilu32, *xn32, *prep32, *mem32, *yu32, *yemb32;  // fp32 operands of the f32 classes (16-bit contexts)
     unsigned char *pad_mask, *text_mask;
     double* gn_part;

@@ -412,6 +412,12 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
   const bool x3g = !bf16_ && (x3_classes_ & ~(SAMAUDIO_X3_ATTENTION | SAMAUDIO_CLS_CODEC));
   void* x3a = x3g ? b.take((size_t)rows * (T + 2) * 3 * (size_t)D * 2) : nullptr;
   void* x3u = x3g ? b.take((size_t)M * 3 * (size_t)F * 2) : nullptr;
+  // folded cross-attention on compensated operands (class CWO of an x3 context, short memory, 128-wide heads): probabilities
+  // [M][3 kp] and the per-batch operands of all layers [L][rows][D][3 kp]
+  const bool fold3 = x3g && (x3_classes_ & SAMAUDIO_CLS_CWO) && Lt <= 16 && D / cfg_.n_heads == 128 && cfg_.n_layers <= kMaxFoldLayers &&
+                     !std::getenv("SAMAUDIO_NO_FOLD");
+  void* x3p = fold3 ? b.take((size_t)M * 3 * kp * 2) : nullptr;
+  void* ut3 = fold3 ? b.take((size_t)rows * D * 3 * kp * 2 * cfg_.n_layers) : nullptr;
   unsigned char* pad_mask = (unsigned char*)b.take((size_t)M);
   unsigned char* text_mask = (unsigned char*)b.take((size_t)Mt);
   double* gn_part = (double*)b.take((size_t)rows * 64 * 2 * 8);
@@ -421,7 +427,7 @@ Status Engine::plan_dit(Bump& b, int rows, int T, int Lt, bool assign) {
     d.Vt = Vt; d.attn = attn; d.hbf = hbf; d.qc = qc; d.ca = ca; d.u = u; d.gnbuf = gnbuf; d.mem = mem; d.yu = yu;
     d.yemb = yemb; d.kvc = kvc; d.temb = temb; d.tu = tu; d.tsilu = tsilu; d.feats = feats; d.text = text;
     d.video = video; d.anch = anch; d.temb32 = temb32; d.tu32 = tu32; d.tsilu32 = tsilu32; d.xn32 = xn32; d.prep32 = prep32;
-    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.x3a = x3a; d.x3u = x3u; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
+    d.mem32 = mem32; d.yu32 = yu32; d.yemb32 = yemb32; d.probs = probs; d.ut = ut; d.x3a = x3a; d.x3u = x3u; d.x3p = x3p; d.ut3 = ut3; d.pad_mask = pad_mask; d.text_mask = text_mask; d.gn_part = gn_part;
   }
   return Status{};
 }
@@ -948,6 +954,14 @@ Status Engine::prepare(int rows, int T, int Lt, const float* feats, const float*
     // 0 * (K padding of U) must stay 0
     SA_HIP(hipMemsetAsync(d_.ut, 0, (size_t)rows * D * fold_kp_ * esz_ * (cfg_.n_layers <= kMaxFoldLayers ? cfg_.n_layers : 1), st));
   }
+  fold3_ = false;
+  if (d_.ut3 && d_.x3p) {   // x3 context: the fold on compensated operands (zero K padding of P and U, once per prepare)
+    fold3_ = true;
+    fold_ltp_ = Lt <= 8 ? 8 : 16;
+    fold_kp_ = (int)round_up((long)cfg_.n_heads * fold_ltp_, 64);
+    SA_HIP(hipMemsetAsync(d_.x3p, 0, (size_t)M * 3 * fold_kp_ * 2, st));
+    SA_HIP(hipMemsetAsync(d_.ut3, 0, (size_t)rows * D * 3 * fold_kp_ * 2 * cfg_.n_layers, st));
+  }
   has_anchor_ = anchor_ids != nullptr;
   if (anchor_ids) {
     SA_HIP(launch_anchor_gather(g_.anc_emb, (const long*)anchor_ids, n_ids, (const long*)anchor_alignment,
@@ -1114,7 +1128,14 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
   }
   trace("kvc", d_.kvc, (size_t)Mt * kv_ld, bf16_, st);
   // folded cross-attention: U_l = Wo_l V_l of EVERY layer in one launch (it depends on the text memory only, not on h)
-  const bool fold_all = fold_ltp_ && cfg_.n_layers <= kMaxFoldLayers && !debug_flag(31);   // flag 31: one launch per layer (A/B, tests)
+  const bool fold_all = fold_ltp_ && !fold3_ && cfg_.n_layers <= kMaxFoldLayers && !debug_flag(31);   // flag 31: one launch per layer (A/B, tests)
+  if (fold3_) {   // x3 context: U = Wo V of every layer on split operands, [L][rows][D][3 kp] = [U_hi | U_lo | U_hi]
+    const float* wos[kMaxFoldLayers];
+    for (int l = 0; l < cfg_.n_layers; ++l) wos[l] = (const float*)layers_[l].c_wo;
+    SA_TRY(op("cross_attn_fold3", ((double)D * D * 4 + (double)rows * D * fold_kp_ * 6 + (double)Mt * D * 4) * cfg_.n_layers, 0, st, [&] {
+      return launch_cross_attn_fold3_layers(wos, cfg_.n_layers, (const float*)d_.kvc, kv_ld, d_.ut3, fold_kp_, rows, Lt, fold_ltp_, H, st);
+    }));
+  }
   const size_t ut_layer = (size_t)rows * D * fold_kp_ * esz_;
   if (fold_all) {
     const void* wos[kMaxFoldLayers];
@@ -1205,7 +1226,23 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWQ));
     }
     const void* kv_l = (const char*)d_.kvc + (size_t)l * 2 * D * esz_;
-    if (fold_ltp_) {
+    if (fold3_) {
+      // h += P . U on compensated operands: K' = 3 kp = 576 instead of 3 D
+      SA_TRY(op("cross_attn_probs3", (MD * 4 + (double)M * fold_kp_ * 6 + (double)Mt * 2 * D * 4), 0, st, [&] {
+        return launch_cross_attn_probs3((const float*)d_.qc, w.c_q_norm, (const float*)kv_l, kv_ld, d_.text_mask, d_.x3p, fold_kp_, rows, T, Lt,
+                                        fold_ltp_, H, eps, st);
+      }));
+      const int K3 = 3 * fold_kp_;
+      GemmParams p = lin(d_.x3p, K3, (const char*)d_.ut3 + (size_t)l * rows * D * K3 * 2, T, D, K3);
+      p.nbatch = rows;
+      p.a_bstride = (long)T * K3;
+      p.w_bstride = (long)D * K3;
+      with_res(p, d_.h, D);
+      p.res_bstride = (long)T * D;
+      out_f32(p, d_.h, D);
+      p.f32_bstride = (long)T * D;
+      SA_TRY(gemm(p, st, 2.0 * M * (double)D * H * Lt, SAMAUDIO_CLS_CWO, 2));
+    } else if (fold_ltp_) {
       // h += P . U with U = Wo V folded per (batch, head, token): K = H*Lt instead of D (see attention.hip)
       SA_TRY(op("cross_attn_probs", (MD + (double)M * fold_kp_ + (double)Mt * 2 * D) * esz_, 0, st, [&] {
         return launch_cross_attn_probs(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.probs, fold_kp_, rows, T, Lt,
@@ -1228,7 +1265,9 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       trace("  ut", ut_l, (size_t)rows * D * fold_kp_, bf16_, st);
       SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_CWO));
     } else {
-      SA_HIP(launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st, hd));
+      SA_TRY(op("cross_attention", (2 * MD + (double)Mt * 2 * D) * esz_, 4.0 * M * Lt * D, st, [&] {
+        return launch_cross_attention(d_.qc, w.c_q_norm, kv_l, kv_ld, d_.text_mask, d_.ca, bf16_, rows, T, Lt, H, eps, st, hd);
+      }));
       GemmParams p = lin(d_.ca, D, w.c_wo, M, D, D);
       with_res(p, d_.h, D);
       out_f32(p, d_.h, D);

@@ -149,6 +149,12 @@ hipError_t launch_cross_attn_fold(const void* wo, const void* kv, long kv_ld, vo
 constexpr int kMaxFoldLayers = 48;
 hipError_t launch_cross_attn_fold_layers(const void* const* wo, int n_layers, const void* kv_all, long kv_ld, void* UT_all, int KP,
                                          int B, int Lt, int LtP, int H, hipStream_t st);
+// the same fold for x3 contexts (fp32 tensors in, compensated operands out; attention.hip): P3 [M, 3 KP] = [P_lo | P_hi | P_hi],
+// UT3_all [n_layers][B][D][3 KP] = [U_hi | U_lo | U_hi]; q raw fp32 [M, D] (q-norm applied here), kv fp32 with k already normalised
+hipError_t launch_cross_attn_probs3(const float* q, const float* qw, const float* kv, long kv_ld, const unsigned char* mask, void* P3,
+                                    int KP, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st);
+hipError_t launch_cross_attn_fold3_layers(const float* const* wo, int n_layers, const float* kv_all, long kv_ld, void* UT3_all, int KP,
+                                          int B, int Lt, int LtP, int H, hipStream_t st);
 // per-(row, layer, head) RMSNorm of the K halves of kv_all [rows, L*2D] (all layers' cross-attention keys at
 // once); w_all [L, 128]
 hipError_t launch_headnorm_layers(void* kv_all, const float* w_all, bool bf16, int rows, int L, int H, float eps,

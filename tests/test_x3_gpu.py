@@ -219,6 +219,31 @@ def test_separate_x3_matches_oracle(gpu, prec):
 
 
 @pytest.mark.parametrize("prec", X3)
+@pytest.mark.parametrize("text_len", [3, 12, 20])
+def test_x3_cross_attention_folds_for_short_memories_only(gpu, prec, text_len):
+    """x3 context, class CWO: text memories of <= 16 tokens take the folded form on compensated operands (h += P . U over K' = 3 * 192:
+    cross_attn_probs3 / cross_attn_fold3 kernels, 8- and 16-token head slots), longer ones the unfolded c_wo GEMM over K' = 3 D - both
+    against the oracle (reference transformer.py:382-388), with a ragged text mask."""
+    cfg = preset_config("tiny")
+    sd = init_state_dict(cfg, seed=5)
+    hop = cfg.audio_codec.hop_length
+    clips = [synthetic_clip(i, 6 * hop) for i in range(2)]
+    text, tmask = synthetic_text_features(2, text_len, ragged=True)
+    batch = SAMAudioProcessor.from_config(cfg)(descriptions=["a", "b"], audios=clips, text_features=text, text_mask=tmask)
+    noise = synthetic_noise(2, 6)
+    opt = {"method": "euler", "options": {"step_size": 0.5}}
+    with torch.inference_mode():
+        _, _, lat_ref = O.separate(sd, cfg, batch.audios, batch.sizes.long(), text, tmask, noise, method="euler", step_size=0.5,
+                                   decode=False)
+    model = SAMAudio(cfg, precision=prec, device=str(gpu))
+    model.load_state_dict(sd, strict=False)
+    model.separate(batch.to(gpu), noise=noise.to(gpu), ode_opt=opt)
+    err = (model.last_latent.cpu() - lat_ref).abs().max().item()
+    print(f"x3 cross-attention, {text_len} text tokens ({prec}): latent max-abs err {err:.3e} (|ref| <= {lat_ref.abs().max():.2f})")
+    assert err < (1e-4 if prec == "fp16x3" else 1e-3)
+
+
+@pytest.mark.parametrize("prec", X3)
 def test_x3_classes_can_be_switched_per_class_and_need_their_weights(gpu, prec):
     cfg = preset_config("tiny")
     sd = init_state_dict(cfg, seed=3)
