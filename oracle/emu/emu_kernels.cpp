@@ -562,6 +562,12 @@ hipError_t launch_cross_attn_probs3(const float*, const float*, const float*, lo
 hipError_t launch_cross_attn_fold3_layers(const float* const*, int, const float*, long, void*, int, int, int, int, int, hipStream_t) {
   return hipErrorNotSupported;
 }
+hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos, const float* rope_sin, void* Q, void* K,
+                           void* Vt, bool bf16, int B, int T, int Tp, int H, float eps, hipStream_t st, int head_dim);
+hipError_t launch_qkv_prep_f32x(const float* qkv, const float* qw, const float* kw, const float* rope_cos, const float* rope_sin, float* Q,
+                                float* K, float* Vt, int B, int T, int Tp, int H, float eps, hipStream_t st) {
+  return launch_qkv_prep(qkv, qw, kw, rope_cos, rope_sin, Q, K, Vt, false, B, T, Tp, H, eps, st, 128);
+}
 hipError_t launch_repeat_items_f32(const float* src, float* dst, int items, int rep, long elems, hipStream_t) {
   for (long r = (long)items * rep - 1; r >= 0; --r) std::memmove(dst + r * elems, src + (r / rep) * elems, (size_t)elems * 4);
   return hipSuccess;

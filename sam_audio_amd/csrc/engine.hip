@@ -1180,6 +1180,9 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
       else SA_TRY(gemm(p, st, -1.0, SAMAUDIO_CLS_QKV));
     }
     SA_TRY(op("qkv_prep", 2 * 3 * MD * esz_, 0, st, [&] {
+      if (x3(SAMAUDIO_X3_ATTENTION) && hd == 128)   // fp32 tensors, the fast access pattern (its consumer is the compensated attention)
+        return launch_qkv_prep_f32x((const float*)d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, (float*)d_.Q, (float*)d_.K,
+                                    (float*)d_.Vt, rows, T, Tp, H, eps, st);
       return launch_qkv_prep(d_.qkv, w.q_norm, w.k_norm, g_.rope_cos, g_.rope_sin, d_.Q, d_.K, d_.Vt, bf16_, rows, T, Tp, H,
                              eps, st, hd);
     }));

@@ -114,6 +114,11 @@ hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, co
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st, int head_dim = 128);   // head_dim 64 | 128 (rope tables [T, head_dim / 2])
 
+// x3 contexts, head_dim 128: the same on fp32 tensors with the 16-lane-per-row access pattern of the 16-bit fast path (row statistics
+// summed in another order than the general fp32 kernel: not the exact-fp32 parity mode's kernel)
+hipError_t launch_qkv_prep_f32x(const float* qkv, const float* qw, const float* kw, const float* rope_cos, const float* rope_sin, float* Q,
+                                float* K, float* Vt, int B, int T, int Tp, int H, float eps, hipStream_t st);
+
 // self-attention over the padded layout above; key_mask [B,T] bytes (1 = attend); out [B*T, H*128]
 hipError_t launch_self_attention(const void* Q, const void* K, const void* Vt, const unsigned char* key_mask,
                                  void* out, bool bf16, int B, int T, int Tp, int H, hipStream_t st, bool out_alt = false);

@@ -528,6 +528,90 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
   }
 }
 
+// fp32 form of the fast path above (x3 contexts: fp32 qkv rows in, fp32 Q / K / V^T out for the compensated self-attention): 16
+// lanes x 32 bytes per 128-wide head row, row statistics by 16-lane DPP reductions, V transposed through LDS.  The general fp32
+// kernel above - one wave per row, two 64-lane reductions after one another - stays the exact-fp32 parity mode's (its summation
+// order is what the fp32 golden tests were recorded with); this one ran 88 -> 4x us per launch at M = 4 000 (profiles/r6_final2/).
+__global__ __launch_bounds__(256) void qkv_prep_f32x_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
+                                                            const float* __restrict__ kw, const float* __restrict__ rc,
+                                                            const float* __restrict__ rs, float* __restrict__ Q, float* __restrict__ K,
+                                                            float* __restrict__ Vt, int T, int Tp, int H, float eps) {
+  __shared__ __attribute__((aligned(16))) float vt[64 * 132];  // [t][d], row stride 132 floats
+  const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int D = H * 128;
+  const long ld = 3L * D;
+  const int tid = threadIdx.x;
+  const int sub = tid & 15;   // 8-element chunk of the head row
+  const int rgrp = tid >> 4;  // 16 row groups
+  const long bh = (long)b * H + h;
+  float wq[8], wk[8];
+  {
+    const float4 a = *(const float4*)(qw + sub * 8), c = *(const float4*)(qw + sub * 8 + 4);
+    const float4 e = *(const float4*)(kw + sub * 8), f = *(const float4*)(kw + sub * 8 + 4);
+    wq[0] = a.x; wq[1] = a.y; wq[2] = a.z; wq[3] = a.w; wq[4] = c.x; wq[5] = c.y; wq[6] = c.z; wq[7] = c.w;
+    wk[0] = e.x; wk[1] = e.y; wk[2] = e.z; wk[3] = e.w; wk[4] = f.x; wk[5] = f.y; wk[6] = f.z; wk[7] = f.w;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int tt = it * 16 + rgrp;
+    const int t = t0 + tt;
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, k[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (t < T) {  // uniform over each 16-lane row group
+      const float* row = qkv + ((long)b * T + t) * ld + h * 128 + sub * 8;
+      const float4 q0 = *(const float4*)row, q1 = *(const float4*)(row + 4), k0 = *(const float4*)(row + D), k1 = *(const float4*)(row + D + 4);
+      v0 = *(const float4*)(row + 2 * D);
+      v1 = *(const float4*)(row + 2 * D + 4);
+      q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+      k[0] = k0.x; k[1] = k0.y; k[2] = k0.z; k[3] = k0.w; k[4] = k1.x; k[5] = k1.y; k[6] = k1.z; k[7] = k1.w;
+      float sq = 0.f, sk = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
+      sq = row16_sum(sq);
+      sk = row16_sum(sk);
+      const float iq = rsqrtf(sq / 128.f + eps), ik = rsqrtf(sk / 128.f + eps);
+      const float4 c4 = *(const float4*)(rc + (long)t * 64 + sub * 4), s4 = *(const float4*)(rs + (long)t * 64 + sub * 4);
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = q[2 * e] * iq * wq[2 * e], a1 = q[2 * e + 1] * iq * wq[2 * e + 1];
+        q[2 * e] = a0 * cc[e] - a1 * sn[e];
+        q[2 * e + 1] = a0 * sn[e] + a1 * cc[e];
+        const float b0 = k[2 * e] * ik * wk[2 * e], b1 = k[2 * e + 1] * ik * wk[2 * e + 1];
+        k[2 * e] = b0 * cc[e] - b1 * sn[e];
+        k[2 * e + 1] = b0 * sn[e] + b1 * cc[e];
+      }
+    }
+    float* qd = Q + (bh * Tp + t) * 128 + sub * 8;
+    float* kd = K + (bh * Tp + t) * 128 + sub * 8;
+    *(float4*)qd = make_float4(q[0], q[1], q[2], q[3]);
+    *(float4*)(qd + 4) = make_float4(q[4], q[5], q[6], q[7]);
+    *(float4*)kd = make_float4(k[0], k[1], k[2], k[3]);
+    *(float4*)(kd + 4) = make_float4(k[4], k[5], k[6], k[7]);
+    *(float4*)(vt + tt * 132 + sub * 8) = v0;
+    *(float4*)(vt + tt * 132 + sub * 8 + 4) = v1;
+  }
+  __syncthreads();
+  // V^T rows: thread -> (d, 8 consecutive t); 128 d x 8 chunks = 1024 items, 4 per thread
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int item = it * 256 + tid;
+    const int d = item >> 3, c = item & 7;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = vt[(c * 8 + e) * 132 + d];
+    float* dst = Vt + (bh * 128 + d) * Tp + t0 + c * 8;
+    *(float4*)dst = make_float4(x[0], x[1], x[2], x[3]);
+    *(float4*)(dst + 4) = make_float4(x[4], x[5], x[6], x[7]);
+  }
+}
+hipError_t launch_qkv_prep_f32x(const float* qkv, const float* qw, const float* kw, const float* rope_cos, const float* rope_sin, float* Q,
+                                float* K, float* Vt, int B, int T, int Tp, int H, float eps, hipStream_t st) {
+  if (Tp % 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(qkv_prep_f32x_kernel, dim3(Tp / 64, H, B), dim3(256), 0, st, qkv, qw, kw, rope_cos, rope_sin, Q, K, Vt, T, Tp, H, eps);
+  return hipGetLastError();
+}
+
 hipError_t launch_qkv_prep(const void* qkv, const float* qw, const float* kw, const float* rope_cos,
                            const float* rope_sin, void* Q, void* K, void* Vt, bool bf16, int B, int T, int Tp, int H,
                            float eps, hipStream_t st, int head_dim) {
