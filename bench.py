@@ -595,9 +595,10 @@ def traffic_of(kernel: str, split: bool = False):
         except (OSError, KeyError, ValueError):
             continue
         name = kernel.split("/")[-1]
-        if name.endswith("_x3"):   # launches over K' = 3K: their own PMC passes (profiles/r6_traffic_x3.json), never the 1x figures
-            if not fname.startswith("r6_traffic_x3"):
-                continue
+        # launches over K' = 3K have their own PMC passes (profiles/r6_traffic_x3.json): never mixed with the one-product figures
+        if name.endswith("_x3") != fname.startswith("r6_traffic_x3"):
+            continue
+        if name.endswith("_x3"):
             name = name[:-3]
         key = SYMBOLS.get(name, "")
         hit = [v for k, v in table.items() if key and k.startswith(key)]
