@@ -26,6 +26,10 @@ pytestmark = pytest.mark.gpu
 SIZE = os.environ.get("SAMAUDIO_SHAPES_SIZE", "small*")
 PREC = os.environ.get("SAMAUDIO_SHAPES_PRECISION", "fp16x3")
 SIM = os.environ.get("SAMAUDIO_EMU_DRYRUN", "") != ""
+# The 8-candidate test carries ~3 minutes of CPU oracle time (8 x 10 s rows + the Judge oracle on 16 waveforms): it runs when
+# SAMAUDIO_SLOW_TESTS=1 (tools/r6_final.sh sets it: profiles/r6_final2/gpu_tests.log, shapes_large.log), so that the default
+# `pytest -m gpu` stays near the duration of the earlier rounds' suites; the visual test (45 s) always runs.
+SLOW = os.environ.get("SAMAUDIO_SLOW_TESTS", "") not in ("", "0")
 
 
 def _model(gpu):
@@ -36,7 +40,7 @@ def _model(gpu):
     return cfg, model, {k: v.cpu() for k, v in sd.items()}
 
 
-@pytest.mark.skipif(SIM, reason="10 s clips x 8 candidates: hardware only")
+@pytest.mark.skipif(SIM or not SLOW, reason="10 s clips x 8 candidates, ~3 min of CPU oracle: hardware, SAMAUDIO_SLOW_TESTS=1")
 def test_eight_candidates_of_ten_seconds_through_spans_solve_and_judge(gpu):
     cfg, model, sd_cpu = _model(gpu)
     tower = bench.tower_precision(PREC)

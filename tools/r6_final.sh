@@ -7,6 +7,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/${R6_OUT:-r6_final}; mkdir -p $O
 export OMP_NUM_THREADS=16
+export SAMAUDIO_SLOW_TESTS=1   # tests/test_zz_benchmarked_shapes_gpu.py: the 8-candidate test too
 ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $O/smoke.log 2>&1; grep "smoke" $O/smoke.log | cut -c1-120
 ( time timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $O/bench_driver_like.log 2> $O/bench_driver_like.err; echo "bench exit=$?"
 grep -o '"value": [0-9.]*' $O/bench_driver_like.log | head -3; tail -3 $O/bench_driver_like.err | grep real
