@@ -629,7 +629,8 @@ def reference_flops(cfg, clips, text_len):
 def tower_precision(precision):
     """the towers beside the DiT (Judge, span predictor, vision tower: SURVEY.md section 8 "next" rows) have no compensated mode: beside
     an x3 DiT they run on the library's plain 16-bit operands, as they do beside an fp16 one"""
-    return {"fp16x3": "fp16", "bf16x3": "bf16"}.get(precision, precision)
+    from sam_audio_amd import hip
+    return hip.tower_precision(precision)
 
 
 X3_PRODUCTS = 3   # MFMA products per algorithmic multiply of a "_x3" launch (lo*hi + hi*lo + hi*hi)

@@ -40,6 +40,12 @@ def storage_precision(precision: str) -> str:
     return "fp32" if is_x3(precision) else precision
 
 
+def tower_precision(precision: str) -> str:
+    """The towers beside the DiT (Judge, span predictor, vision tower) have no compensated mode: beside an x3 DiT they run on the
+    library's plain 16-bit operands, as they do beside a plain 16-bit one."""
+    return {"fp16x3": "fp16", "bf16x3": "bf16"}.get(precision, precision)
+
+
 def precision_code(precision: str) -> int:
     return F32 if storage_precision(precision) == "fp32" else BF16
 

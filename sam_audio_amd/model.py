@@ -253,7 +253,7 @@ class SAMAudio:
         except FileNotFoundError as exc:
             warnings.warn(f"text encoder not attached ({exc}); pass text_features / text_mask to the processor or set "
                           "model.text_encoder")
-        model.attach_rankers(precision=hip.storage_precision(precision))
+        model.attach_rankers(precision=hip.tower_precision(precision))
         return model
 
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
@@ -273,7 +273,7 @@ class SAMAudio:
             # really carries the PE-Core tower (a text-only deployment pays nothing for it)
             from .vision_encoder import PerceptionEncoder
             self.vision_encoder = PerceptionEncoder(self.cfg.vision_encoder, device=self.device,
-                                                    precision=hip.storage_precision(self.precision))
+                                                    precision=hip.tower_precision(self.precision))
         if vis and hasattr(self.vision_encoder, "load_state_dict"):
             # The tower's key list is restated from the published PE-Core architecture (perception_models is not
             # importable offline), so it is validated for what the engine NEEDS, not for what a genuine checkpoint may carry
