@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void qkv_prep_bf16_kernel(const bf16_t* __rest
 // fp32 form of the fast path above (x3 contexts: fp32 qkv rows in, fp32 Q / K / V^T out for the compensated self-attention): 16
 // lanes x 32 bytes per 128-wide head row, row statistics by 16-lane DPP reductions, V transposed through LDS.  The general fp32
 // kernel above - one wave per row, two 64-lane reductions after one another - stays the exact-fp32 parity mode's (its summation
-// order is what the fp32 golden tests were recorded with); this one ran 88 -> 4x us per launch at M = 4 000 (profiles/r6_final2/).
+// order is what the fp32 golden tests were recorded with); this one runs 56 us per launch at M = 4 000 where the generic one took 90 (profiles/r6_final2/ -> r6_final3/).
 __global__ __launch_bounds__(256) void qkv_prep_f32x_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
                                                             const float* __restrict__ kw, const float* __restrict__ rc,
                                                             const float* __restrict__ rs, float* __restrict__ Q, float* __restrict__ K,
