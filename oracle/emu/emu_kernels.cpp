@@ -93,6 +93,18 @@ static void gemm_t(const GemmParams& p) {
       for (int n = 0; n < p.N; ++n) {
         const T* w = W + (long)n * p.K;
         float s = 0.f;
+        if constexpr (sizeof(T) == 4) {
+          if (p.flags & GEMM_FLAG_W_FLY16) {   // split weight (common.h): slab of 32 k = [4 chunks hi | 4 chunks lo], chunk c = k in {4c.., 16+4c..}
+            const bf16_t* h = (const bf16_t*)w;
+            for (int k = 0; k < p.K; ++k) {
+              const int kk = k % 32, pos = (kk % 16 / 4) * 8 + (kk / 16) * 4 + kk % 4;
+              const bf16_t* slab = h + (long)(k / 32) * 64;
+              s += arow[k] * (HE<bf16_t>::ld(slab + pos) + HE<bf16_t>::ld(slab + 32 + pos));
+            }
+            acc[n] = s;
+            continue;
+          }
+        }
         if (ktm)
           for (int k = 0; k < p.K; ++k) s += arow[k] * HE<T>::ld(W + ((long)(k / 64) * p.N + n) * 64 + k % 64);
         else

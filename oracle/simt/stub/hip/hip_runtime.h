@@ -207,6 +207,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   std::memcpy(&r, x + (size_t)from * 8, 4);
   return r;
 }
+// v_med3_f32
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 // v_permlane16_swap_b32: the odd 16-lane rows of `vdst` swap with the even rows of `src` (lane l of an odd row <-> lane
 // l - 16); returns {new vdst, new src}.  Every lane of the wave takes part (as on the hardware: EXEC-masked lanes read
 // garbage there).

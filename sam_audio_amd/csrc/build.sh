@@ -19,6 +19,7 @@ build_one() {  # $1 = object dir, $2 = extra flags, $3 = output
       # gemm2.hip / gemm8.hip: the fully unrolled 4x4-fragment epilogues exceed clang's default pragma-unroll budget; without
       # the full unroll the accumulator array is indexed dynamically and lands in scratch memory.
       if [ $f = gemm2 ] || [ $f = gemm8 ]; then EXTRA="-mllvm -pragma-unroll-threshold=262144 -Wno-inline-asm"; fi
+      if [ $f = gemm ]; then EXTRA="-mllvm -pragma-unroll-threshold=262144 -Wno-inline-asm"; fi   # (gemm.hip: the 128 x 128 instantiations kept their accumulators in scratch memory without it - round 6, profiles/r6_call13/)
       hipcc $FLAGS $extra_all $EXTRA -c $f.hip -o $dir/$f.o &
       pids+=($!)
     fi

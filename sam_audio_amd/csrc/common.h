@@ -243,5 +243,12 @@ constexpr int GEMM_FLAG_OUT_SPLIT3 = 4096;
 // (3 x 16x16x32 instead of 8 x 16x16x4f32 per 32 k: the fp32 product to ~2^-21, 2.7x less matrix-core time; no second copy of
 // anything).  SAMAUDIO_OPT_X3_CLASSES bit SAMAUDIO_CLS_CODEC: the DAC-VAE convolutions of an fp32 context.
 constexpr int GEMM_FLAG_X3_FLY = 8192;
+// flags bit 14 (with bit 13 only): W is the launch's weight ALREADY SPLIT, in the layout the on-the-fly kernel's fragment reads want -
+// same size and row stride as the fp32 matrix; the 128 bytes of a row's 32-k slab hold eight 16-byte chunks: chunk c < 4 = the hi
+// halves of k = 4c .. 4c+3 and 16+4c .. 16+4c+3 (one lane's operand of a 16x16x32 MFMA), chunk 4 + c = their lo halves
+// (weights.py codec_fly16 makes it; the same hi / lo bits the kernel would compute from the fp32 weight, so the results are the same
+// bits).  Weights are constants: splitting them once per model instead of once per tile and slab takes the split of W out of the
+// K loop, which for the narrow DAC-VAE stages (N = 64 .. 192) is most of its vector-ALU work.
+constexpr int GEMM_FLAG_W_FLY16 = 16384;
 
 }  // namespace sa

@@ -106,6 +106,7 @@ class Engine {
   // result by an elementwise kernel.  Everything else of the codec multiplies on operands split in registers (GEMM_FLAG_X3_FLY).
   struct X3CodecW { const void* w; int cin; };
   std::map<const void*, X3CodecW> x3_codec_;
+  std::map<const void*, const void*> fly_codec_;   // fp32 codec weight -> its "<name>.fly" twin (GEMM_FLAG_W_FLY16)
   void* x3_codec_scratch_ = nullptr;
   size_t x3_codec_scratch_bytes_ = 0;
   size_t codec_x3_per_item(int64_t samples) const;

@@ -340,6 +340,19 @@ Status Engine::finalize(int what) {
         if (t.shape[0] != base->shape[0] || t.shape[1] * cin != base->shape[1] || cin % 8) continue;
         x3_codec_[base->p] = X3CodecW{t.p, (int)cin};
       }
+    // ... and "<name>.fly" twins (weights.py convert_codec_fly16): the narrow convolutions' weights already split, in the layout the
+    // fp32 kernel's on-the-fly multiply reads (common.h GEMM_FLAG_W_FLY16)
+    fly_codec_.clear();
+    if (!bf16_)
+      for (const auto& kv : tensors_) {
+        const std::string& name = kv.first;
+        if (name.size() < 5 || name.compare(name.size() - 4, 4, ".fly") != 0 || (name.rfind("enc.", 0) != 0 && name.rfind("dec.", 0) != 0)) continue;
+        const TensorRef* base = find(name.substr(0, name.size() - 4));
+        const TensorRef& t = kv.second;
+        if (!base || base->shape.size() != 2 || t.dtype != SAMAUDIO_DT_BF16 || t.shape.size() != 2) continue;
+        if (t.shape[0] != base->shape[0] || t.shape[1] != 2 * base->shape[1] || base->shape[1] % 32) continue;
+        fly_codec_[base->p] = t.p;
+      }
     if (what == 2) return Status{};  // encoder only: the Judge's DACVAEEncoder (reference codec.py:42-78)
     // decoder
     NEEDW(dec_.proj_w, "dec.proj.w", CL, CD);
@@ -677,7 +690,13 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
   }
   if (!is16 && quant_fmt_ && (quant_classes_ & cls)) p.flags |= (quant_fmt_ << 2) | (quant_fmt_ << 4);
   // SAMAUDIO_OPT_X3_CLASSES bit CODEC (fp32 contexts): the convolution multiplies on split operands, split in registers (gemm.hip)
-  if (!is16 && p.tag && x3(SAMAUDIO_CLS_CODEC)) p.flags |= GEMM_FLAG_X3_FLY;
+  if (!is16 && p.tag && x3(SAMAUDIO_CLS_CODEC)) {
+    p.flags |= GEMM_FLAG_X3_FLY;
+    if (!p.w_bstride && !fly_codec_.empty()) {
+      const auto it = fly_codec_.find(p.W);
+      if (it != fly_codec_.end()) { p.W = it->second; p.flags |= GEMM_FLAG_W_FLY16; }
+    }
+  }
   if (const char* why = gemm_check(p, is16)) return fail(SAMAUDIO_ERR_ARG, why);
   if (!prof_on_) {
     SA_HIP(launch_gemm(p, is16, st));

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace sa {
 
 typedef h16x8_t bf16x8_t;  // 8 x 16-bit operand words (bf16, or fp16 with -DSA_OPERAND_FP16: common.h)
@@ -67,8 +69,29 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM_, int WN_>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+// FLY (fp32 only): the instantiation serves GEMM_FLAG_X3_FLY | GEMM_FLAG_W_FLY16 launches and nothing else (the wide tiles of the
+// narrow DAC-VAE stages, fly_variant below) - no exact-fp32 path, no split of W in the K loop.
+// NS (FLY only): stages of the slab ring.  2 = the loop of every other instantiation (compiler-visible DMA, vmcnt(0) + one barrier
+// per slab: one slab in flight while one is multiplied); 3 = two slabs in flight - the DMA issued as inline assembly (dma16x), retired
+// by counted s_waitcnt vmcnt, one bare s_barrier per slab.
+template <int N> __device__ __forceinline__ void wait_vm_fly() {   // literal counts: the simulator reads the number from the text
+  static_assert(N == 0 || (N >= 5 && N <= 8) || N == 11 || N == 12, "add the literal");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+// the direct-to-LDS load as inline assembly (as gemm8.hip dma16v): invisible to the compiler, which would otherwise put vmcnt(0) in
+// front of every barrier; M0 = LDS base, one wait state between the M0 write and the load
+__device__ __forceinline__ void dma16x(const void* gsrc, size_t lds_wave_addr) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA1
+}
+template <typename T, int BM, int BN, int WM_, int WN_, bool FLY = false, int NS = 2>
+__global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(const GemmParams p) {   // (two waves per SIMD: two workgroups per CU)
   constexpr int NW = WM_ * WN_;
   static_assert(NW == 4, "4 waves per workgroup");
   constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -78,7 +101,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave per slab
   static_assert(BM % 32 == 0 && BN % 32 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
   constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  static_assert(NS == 2 || (FLY && NS == 3), "ring depth");
+  __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,9 +150,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     char* sA = smem + stage * STAGE;
     char* sB = sA + TILE_A;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) dma16(a_rows[i] + a_tap + a_in, sA + (wave + 4 * i) * 1024);
+    for (int i = 0; i < AI; ++i) {
+      if constexpr (NS == 3) dma16x(a_rows[i] + a_tap + a_in, (size_t)(__attribute__((address_space(3))) char*)(sA + (wave + 4 * i) * 1024));
+      else dma16(a_rows[i] + a_tap + a_in, sA + (wave + 4 * i) * 1024);
+    }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (wave + 4 * i) * 1024);
+    for (int i = 0; i < BI; ++i) {
+      if constexpr (NS == 3) dma16x(w_rows[i], (size_t)(__attribute__((address_space(3))) char*)(sB + (wave + 4 * i) * 1024));
+      else dma16(w_rows[i], sB + (wave + 4 * i) * 1024);
+    }
     // advance to the next slab
     a_in += BK;
     while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
@@ -145,7 +175,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const int nslab = p.K / BK;
   const int lr = lane & 15, lg = lane >> 4;
   const int qa = (p.flags >> 2) & 3, qw = (p.flags >> 4) & 3;  // operand rounding (fp32 kernel only, see quant16)
-  const bool x3fly = sizeof(T) == 4 && (p.flags & GEMM_FLAG_X3_FLY) != 0;   // (uniform)
+  const bool x3fly = FLY || (sizeof(T) == 4 && (p.flags & GEMM_FLAG_X3_FLY) != 0);   // (uniform)
+  const bool wfly = FLY || (p.flags & GEMM_FLAG_W_FLY16) != 0;                         // (uniform) W arrives split: common.h
+  // one 32-k slab of an X3_FLY launch (stage image sA | sB)
+  auto fly_slab = [&](const char* sA, const char* sB) {
+        // GEMM_FLAG_X3_FLY: both k-steps of the 32-element slab at once.  A lane's 8 values (k = 4 lg .. + 3 and 16 + 4 lg .. + 3) form
+        // one 16x16x32 fragment; A and W use the same lane -> k map, so the MFMA pairs equal k.  Small terms first.
+#pragma clang fp contract(off)
+        bf16x8_t ah[FM], al[FM], bh[FN], bl[FN];
+        auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -kH16Max, kH16Max); };   // (one instruction; finite x: fmin(fmax()))
+        auto split = [&](const char* base, int row, bf16x8_t& hi, bf16x8_t& lo) {
+          const int sw = (row >> 1) & 7;
+          const f32x4_t v0 = *(const f32x4_t*)(base + row * 128 + ((lg ^ sw) << 4));
+          const f32x4_t v1 = *(const f32x4_t*)(base + row * 128 + (((4 + lg) ^ sw) << 4));
+          unsigned h[4], l[4];
+          h[0] = pack_h16x2(cl(v0[0]), cl(v0[1]));
+          h[1] = pack_h16x2(cl(v0[2]), cl(v0[3]));
+          h[2] = pack_h16x2(cl(v1[0]), cl(v1[1]));
+          h[3] = pack_h16x2(cl(v1[2]), cl(v1[3]));
+          l[0] = pack_h16x2(v0[0] - h16_lo(h[0]), v0[1] - h16_hi(h[0]));
+          l[1] = pack_h16x2(v0[2] - h16_lo(h[1]), v0[3] - h16_hi(h[1]));
+          l[2] = pack_h16x2(v1[0] - h16_lo(h[2]), v1[1] - h16_hi(h[2]));
+          l[3] = pack_h16x2(v1[2] - h16_lo(h[3]), v1[3] - h16_hi(h[3]));
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+          hi = __builtin_bit_cast(bf16x8_t, (u32x4_t){h[0], h[1], h[2], h[3]});
+          lo = __builtin_bit_cast(bf16x8_t, (u32x4_t){l[0], l[1], l[2], l[3]});
+        };
+        if (wfly) {   // GEMM_FLAG_W_FLY16: chunk lg of the row's slab IS the lane's hi operand, chunk 4 + lg its lo operand
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int row = wn * WTN + j * 16 + lr, sw = (row >> 1) & 7;
+            bh[j] = *(const bf16x8_t*)(sB + row * 128 + ((lg ^ sw) << 4));
+            bl[j] = *(const bf16x8_t*)(sB + row * 128 + (((4 + lg) ^ sw) << 4));
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) split(sB, wn * WTN + j * 16 + lr, bh[j], bl[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) split(sA, wm * WTM + i * 16 + lr, ah[i], al[i]);
+        // term-major: FM x FN independent accumulators between two MFMAs on the same one (per element the order stays lo.hi, hi.lo, hi.hi)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = SA_MFMA_16x16x32(bh[j], al[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = SA_MFMA_16x16x32(bl[j], ah[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) acc[i][j] = SA_MFMA_16x16x32(bh[j], ah[i], acc[i][j]);
+  };
+  if constexpr (NS == 3) {   // (FLY) two slabs in flight
+    issue(0);
+    if (nslab > 1) issue(1);
+    for (int s = 0; s < nslab; ++s) {
+      if (s + 1 < nslab) wait_vm_fly<AI + BI>();   // slab s landed, slab s + 1 may be in flight
+      else wait_vm_fly<0>();
+      __builtin_amdgcn_s_barrier();   // ... for every wave; the reads of slab s - 1 (the stage slab s + 2 goes to) are complete
+      if (s + 2 < nslab) issue((s + 2) % 3);
+      const char* sA = smem + (s % 3) * STAGE;
+      fly_slab(sA, sA + TILE_A);
+    }
+  } else {
   issue(0);
   for (int s = 0; s < nslab; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -155,42 +249,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const char* sB = sA + TILE_A;
     if constexpr (sizeof(T) == 4) {
       if (x3fly) {
-        // GEMM_FLAG_X3_FLY: both k-steps of the 32-element slab at once.  A lane's 8 values (k = 4 lg .. + 3 and 16 + 4 lg .. + 3) form
-        // one 16x16x32 fragment; A and W use the same lane -> k map, so the MFMA pairs equal k.  Small terms first.
-#pragma clang fp contract(off)
-        bf16x8_t ah[FM], al[FM], bh[FN], bl[FN];
-        auto split = [&](const char* base, int row, bf16x8_t& hi, bf16x8_t& lo) {
-          const int sw = (row >> 1) & 7;
-          const f32x4_t v0 = *(const f32x4_t*)(base + row * 128 + ((lg ^ sw) << 4));
-          const f32x4_t v1 = *(const f32x4_t*)(base + row * 128 + (((4 + lg) ^ sw) << 4));
-          unsigned h[4], l[4];
-          h[0] = pack_h16x2(fminf(fmaxf(v0[0], -kH16Max), kH16Max), fminf(fmaxf(v0[1], -kH16Max), kH16Max));
-          h[1] = pack_h16x2(fminf(fmaxf(v0[2], -kH16Max), kH16Max), fminf(fmaxf(v0[3], -kH16Max), kH16Max));
-          h[2] = pack_h16x2(fminf(fmaxf(v1[0], -kH16Max), kH16Max), fminf(fmaxf(v1[1], -kH16Max), kH16Max));
-          h[3] = pack_h16x2(fminf(fmaxf(v1[2], -kH16Max), kH16Max), fminf(fmaxf(v1[3], -kH16Max), kH16Max));
-          l[0] = pack_h16x2(v0[0] - h16_lo(h[0]), v0[1] - h16_hi(h[0]));
-          l[1] = pack_h16x2(v0[2] - h16_lo(h[1]), v0[3] - h16_hi(h[1]));
-          l[2] = pack_h16x2(v1[0] - h16_lo(h[2]), v1[1] - h16_hi(h[2]));
-          l[3] = pack_h16x2(v1[2] - h16_lo(h[3]), v1[3] - h16_hi(h[3]));
-          typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-          hi = __builtin_bit_cast(bf16x8_t, (u32x4_t){h[0], h[1], h[2], h[3]});
-          lo = __builtin_bit_cast(bf16x8_t, (u32x4_t){l[0], l[1], l[2], l[3]});
-        };
-#pragma unroll
-        for (int i = 0; i < FM; ++i) split(sA, wm * WTM + i * 16 + lr, ah[i], al[i]);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) split(sB, wn * WTN + j * 16 + lr, bh[j], bl[j]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            acc[i][j] = SA_MFMA_16x16x32(bh[j], al[i], acc[i][j]);
-            acc[i][j] = SA_MFMA_16x16x32(bl[j], ah[i], acc[i][j]);
-            acc[i][j] = SA_MFMA_16x16x32(bh[j], ah[i], acc[i][j]);
-          }
+        fly_slab(sA, sB);
         continue;
       }
     }
+    if constexpr (!FLY) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       typename Mma<T>::frag_t af[FM], bfr[FN];
@@ -220,7 +283,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = Mma<T>::run(bfr[j], af[i], acc[i][j]);   // swapped: see the epilogue
     }
+    }   // !FLY
   }
+  }   // NS
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // The operands go into the MFMA swapped (W fragment first): per fragment D = (A W^T)^T, i.e. a lane holds row m = lane & 15
@@ -245,6 +310,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     else if (p.act == ACT_GELU_TANH) a = gelu_tanh_f(v);
     return v;
   };
+  if constexpr (sizeof(T) == 4) {
+    // LEAN form (fp32 launches whose operands allow 16-byte accesses throughout: every DAC-VAE convolution of an fp32 context except
+    // the windowed transposed ones): ALL loads of the epilogue - bias / Snake alpha per column block, the residual rows - are
+    // requested before the first store.  The loop below loads, waits and stores per 16 x 16 fragment, and vmcnt retires in order: a load
+    // issued behind a store is waited for together with that store's round trip to L2 - FM x FN round trips in series per tile,
+    // measured as 32 us per 128 x 96 tile against 0.5 us per K slab (profiles/r6_call13/fly_probe.log: a k1 convolution, three slabs
+    // per tile, ran at 1.4 TB/s of its 1.47 GB).  Same expressions in the same order: the same bits.
+    auto al16 = [](const void* q, long a, long b2, long c) { return (((size_t)q) & 15) == 0 && !((a | b2 | c) & 3); };
+    const bool lean = !p.swiglu && !p.gate && !p.chan_mod && !p.c_ld_rel && !(p.N & 3) && (!p.bias || al16(p.bias, 0, 0, 0)) &&
+                      (p.act != ACT_SNAKE || al16(p.act_alpha, 0, 0, 0)) && (!p.res || al16(p.res, p.res_off, p.res_ld, p.res_bstride)) &&
+                      (!p.out_f32 || al16(p.out_f32, p.f32_off, p.f32_ld, p.f32_bstride)) &&
+                      (!p.out_act || al16(p.out_act, p.act_off, p.act_ld, p.act_bstride));
+    if (lean && (p.act == ACT_NONE || p.act == ACT_SNAKE)) {
+      // accumulators -> LDS (the K loop's stages are free after one barrier): rows of BN floats, 16-byte chunks XOR-swizzled with the
+      // row.  Then a ROLLED loop: a wave instruction covers 64 / (BN / 4) whole rows - full cache lines per load and store - and
+      // its body exists once (unrolled over the FM x FN fragments with the activation chain of finish() inlined per element, the
+      // epilogue is ~50 000 instructions per instantiation, walked once per tile from a cold instruction cache: the 26 us per
+      // 128 x 96 tile that profiles/r6_call14/fly_probe.log shows in front of its 21 us of K loop).
+      constexpr int CPR = BN / 4, RPI = 64 / CPR, WR = BM / 4, NIT = (WR + RPI - 1) / RPI;   // chunks per row, rows per wave instruction, rows per wave
+      static_assert(BN % 32 == 0 && BM * BN * 4 <= NS * STAGE, "epilogue staging area");
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int row = wm * WTM + i * 16 + lr, c = wn * (WTN / 4) + j * 4 + lg;
+          *(f32x4_t*)(smem + row * (BN * 4) + ((c ^ (row & 7)) << 4)) = acc[i][j];
+        }
+      __syncthreads();
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = lane % CPR, rsub = lane / CPR;
+      const bool lane_on = rsub < RPI;
+      const int n = n0 + c * 4;
+      const int ncl = n < p.N ? n : p.N - 4;   // clamped address for the loads of columns past N (stores masked)
+      const float4 bb = p.bias ? *(const float4*)(p.bias + ncl) : z;
+      const float4 sa = p.act == ACT_SNAKE ? *(const float4*)(p.act_alpha + ncl) : z;
+      const float* const res0 = p.res ? p.res + p.res_off + (long)b * p.res_bstride + ncl : nullptr;
+      float* const f320 = p.out_f32 ? p.out_f32 + p.f32_off + (long)b * p.f32_bstride + n : nullptr;
+      float* const act0 = p.out_act ? (float*)p.out_act + p.act_off + (long)b * p.act_bstride + n : nullptr;
+      const int rw = wave * WR;   // this wave's rows of the tile
+      auto body = [&](auto SNAKE) {
+        // finish() without the gate and with the activation known (same expressions, same order)
+        auto fin = [&](float v, const float bias, const float res, const float sal, float& a) -> float {
+          v += bias;
+          v *= p.alpha;
+          v += res;
+          a = decltype(SNAKE)::value ? snake_f(v, sal) : v;
+          return v;
+        };
+        auto res_of = [&](int it) {
+          const int m = m0 + rw + it * RPI + rsub;
+          return res0 ? *(const float4*)(res0 + (long)(m < p.M ? m : p.M - 1) * p.res_ld) : z;
+        };
+        float4 rr = res_of(0);
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+          const float4 rn = it + 1 < NIT ? res_of(it + 1) : z;   // requested ahead of this iteration's stores (vmcnt retires in order)
+          const int rl = it * RPI + rsub, row = rw + (rl < WR ? rl : 0), m = m0 + row;
+          const float4 sv = *(const float4*)(smem + row * (BN * 4) + ((c ^ (row & 7)) << 4));
+          float a0, a1, a2, a3;
+          const float v0 = fin(sv.x, bb.x, rr.x, sa.x, a0), v1 = fin(sv.y, bb.y, rr.y, sa.y, a1), v2 = fin(sv.z, bb.z, rr.z, sa.z, a2),
+                      v3 = fin(sv.w, bb.w, rr.w, sa.w, a3);
+          if (lane_on && rl < WR && m < p.M && n < p.N) {
+            if (f320) *(float4*)(f320 + (long)m * p.f32_ld) = p.f32_act ? make_float4(a0, a1, a2, a3) : make_float4(v0, v1, v2, v3);
+            if (act0) *(float4*)(act0 + (long)m * p.act_ld) = make_float4(a0, a1, a2, a3);
+          }
+          rr = rn;
+        }
+      };
+      if (p.act == ACT_SNAKE) body(std::true_type{});
+      else body(std::false_type{});
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int m = m0 + wm * WTM + i * 16 + lr;
@@ -337,8 +476,21 @@ static int gemm1_variant(const GemmParams& p) {
 //   32x32x16 family: 25 / 26 (128x128, 64x128 BK 64), 28 (256x64), 29 / 32 / 33 / 34 (BK 32 multi-workgroup tiles),
 //                    35 = conv7h - the DAC-VAE stages with 64 .. 192 channels.
 // How each entry was chosen (one-box A/B per step, round 2): DESIGN.md sections 3.1 and 3.4, profiles/r2_call*/.
+// GEMM_FLAG_X3_FLY | GEMM_FLAG_W_FLY16 launches (the DAC-VAE stages with < 256 channels in an fp32 context): 4 x 1 waves, each 32
+// rows x the whole tile width.  In the K loop a wave then splits only ITS OWN two activation fragments (2 x 28 vector-ALU
+// instructions per 32-k slab) and multiplies them with every column fragment of the tile: 36 MFMAs per slab at N = 96 where the
+// 128 x 32 tile of gemm1_variant had 12 MFMAs behind the split of two activation AND two weight fragments, three times per row block
+// (one workgroup per 32 columns).  128 x 96 for N = 96 / 192, 128 x 128 for N = 128, 128 x 64 / 128 x 32 below.  Same k order per
+// output element as every tile of this file.
+static int fly_variant(const GemmParams& p) {
+  if (p.N <= 32) return 39;
+  if (p.N <= 64) return 38;
+  if (p.N % 96 == 0 || p.N <= 96) return 36;
+  return 37;
+}
 int gemm_variant(const GemmParams& p, bool is_bf16) {
   const bool g2 = is_bf16 && gemm2_ok(p);
+  if (!is_bf16 && g_force < 0 && (p.flags & GEMM_FLAG_W_FLY16) && debug_flag(36) != 1) return fly_variant(p);   // flag 36 = 1 (A/B): the old tiles
   // (K-tile-major weights / the split-form output exist in the 8-phase family only: a FORCED variant other than 22 / 27 on such a
   // launch is refused by gemm_check with that reason - tests/test_gemm2_gpu.py::test_ktm_weights_are_refused_outside_the_8phase_family;
   // the policy itself never leaves the family for them, and every side operand the engine registers is 16-byte aligned by
@@ -382,6 +534,10 @@ int gemm_variant(const GemmParams& p, bool is_bf16) {
 }
 const char* gemm_variant_name(int v, bool is_bf16) {
   if (v < 0 || v >= kGemmVariants) return "";
+  if (v >= 36) {
+    static const char* fly[4] = {"gemm_f32x3_128x96", "gemm_f32x3_128x128", "gemm_f32x3_128x64", "gemm_f32x3_128x32"};
+    return is_bf16 ? "" : fly[v - 36];
+  }
   if (v < 3) {
     static const char* base[2][3] = {{"gemm_f32_128x128", "gemm_f32_128x64", "gemm_f32_128x32"},
                                      {"gemm_bf16_128x128", "gemm_bf16_128x64", "gemm_bf16_128x32"}};
@@ -441,6 +597,27 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st) {
     return e != hipSuccess ? e : launch_gemm8_split(p, full, 1, st);
   }
   const int v = gemm_variant(p, is_bf16);
+  if (v >= 36) {   // fly_variant (fp32 operands, weights already split)
+    const auto go = [&](auto kern, int bm, int bn) {
+      const long tiles = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch;
+      hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), 0, st, p);
+      return hipGetLastError();
+    };
+    const int ring = debug_flag(36);   // (A/B) 2 = three-stage slab ring, 3 = the same on 256-row tiles at N % 96 == 0
+    if (ring == 3 && v == 36) return go(gemm_kernel<float, 256, 96, 4, 1, true, 3>, 256, 96);
+    if (ring >= 2) switch (v) {
+      case 36: return go(gemm_kernel<float, 128, 96, 4, 1, true, 3>, 128, 96);
+      case 37: return go(gemm_kernel<float, 128, 128, 4, 1, true, 3>, 128, 128);
+      case 38: return go(gemm_kernel<float, 128, 64, 4, 1, true, 3>, 128, 64);
+      default: return go(gemm_kernel<float, 128, 32, 4, 1, true, 3>, 128, 32);
+    }
+    switch (v) {
+      case 36: return go(gemm_kernel<float, 128, 96, 4, 1, true>, 128, 96);
+      case 37: return go(gemm_kernel<float, 128, 128, 4, 1, true>, 128, 128);
+      case 38: return go(gemm_kernel<float, 128, 64, 4, 1, true>, 128, 64);
+      default: return go(gemm_kernel<float, 128, 32, 4, 1, true>, 128, 32);
+    }
+  }
   if (v >= 3) return launch_gemm2(p, v - 3, st);
   return is_bf16 ? launch_t<bf16_t>(p, v, st) : launch_t<float>(p, v, st);
 }
@@ -454,6 +631,8 @@ const char* gemm_check(const GemmParams& p, bool is_bf16) {
     return "gemm: A strides/offsets must be 16-byte aligned";
   if (p.swiglu && (p.N % 32)) return "gemm: swiglu needs N % 32 == 0";
   if (p.gate && p.rows_per_gate <= 0) return "gemm: rows_per_gate";
+  if ((p.flags & GEMM_FLAG_W_FLY16) && (is_bf16 || !(p.flags & GEMM_FLAG_X3_FLY)))
+    return "gemm: split-weight layout (flags bit 14): fp32 launches with operands split on the fly (bit 13) only";
   if (p.flags & (512 | 1024)) {   // mixed mode: alt-format output / operands exist in the 8-phase family only
     if (!is_bf16 || !gemm2_ok(p) || !gemm8_alt_ok(p)) return "gemm: alt 16-bit format: plain 16-bit launches with a lean epilogue only";
     const int v = gemm_variant(p, is_bf16);

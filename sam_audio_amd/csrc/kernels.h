@@ -28,6 +28,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 31: 1 = the folded cross-attention operand U = Wo V of every layer in its own launch (shipped: all layers of an evaluation in
 //            one launch in front of the layer loop) - its bitwise test
 //   flag 35: (A/B) M-tiles per raster group of the 8-phase family (0 = shipped: 8; GemmParams.raster_gm)
+//   flag 36: (A/B, tests) split-weight launches of the fp32 kernel (GEMM_FLAG_W_FLY16) on the tiles of gemm1_variant instead of fly_variant's
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
@@ -46,7 +47,7 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st);
 const char* gemm_check(const GemmParams& p, bool is_bf16);
 int gemm_variant(const GemmParams& p, bool is_bf16);       // which kernel / tile shape launch_gemm picks
 const char* gemm_variant_name(int variant, bool is_bf16);
-constexpr int kGemmVariants = 36;  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
+constexpr int kGemmVariants = 40;  // 36 .. 39 = the fp32 kernel's 4 x 1-wave tiles of split-weight launches (gemm.hip fly_variant);  // 35 = conv7h (k7 convolution, halo tile resident in LDS; conv7h_ok launches only)  // 0..2 gemm.hip tiles, 3.. = 3 + gemm2.hip variant; 25 / 26 = 128x128 / 64x128 tiles for small M
                                    // (32x32x16 family); 27 = gemm8s, the 128x128 tile of the 16x16x32 (8-phase) family;
                                    // 28 = 256x64 tile of the 32x32x16 family for 64-channel convolutions
 // gemm2.hip: 256-row-tile bf16 kernels (variants 3.. in gemm_variant's numbering are gemm2 variants 0..)

@@ -20,7 +20,8 @@ import torch
 from . import hip
 from .config import SAMAudioConfig
 from .processor import Batch
-from .weights import F32_SOURCE_KEYS, convert_codec, convert_dit, convert_dit_f32, convert_codec_x3, convert_dit_x3, split_missing_unexpected
+from .weights import (F32_SOURCE_KEYS, convert_codec, convert_codec_fly16, convert_codec_x3, convert_dit, convert_dit_f32, convert_dit_x3,
+                      split_missing_unexpected)
 
 DFLT_ODE_OPT = {"method": "midpoint", "options": {"step_size": 2 / 32}}  # reference model.py:22
 # Layout of the five big DiT weight matrices and the next-weights prefetch of few-row launches (SAMAudio.__init__; DESIGN.md
@@ -307,6 +308,8 @@ class SAMAudio:
                 self._register(codec)
                 if self.x3_classes & hip.CLS["codec"]:   # the wide convolutions' split twins (8-phase 16-bit launches over K' = 3K)
                     self._register(convert_codec_x3(codec, hip.half_dtype(self.precision)))
+                    # ... and the narrow ones' weights split once, for the fp32 kernel that splits its activations on the fly
+                    self._register(convert_codec_fly16(codec, hip.half_dtype(self.precision)))
                 self._has_codec = True
                 if self.codec_decode == "16":
                     self._codec16_tensors = convert_codec(state_dict, self.cfg, hip.half_dtype(self.precision), self.device)

@@ -364,6 +364,44 @@ def convert_codec_x3(tensors: Dict[str, torch.Tensor], half: torch.dtype, min_ou
     return out
 
 
+def fly16_weight(w: torch.Tensor, half: torch.dtype) -> torch.Tensor:
+    """An fp32 GEMM weight [N, K] (K % 32 == 0) in the split layout of GemmParams.flags bit 14 (csrc/common.h GEMM_FLAG_W_FLY16):
+    per row and 32-k slab, 128 bytes = 4 chunks of hi halves + 4 chunks of lo halves, chunk c = k in {4c .. 4c+3, 16+4c .. 16+4c+3} -
+    one lane's operand of a 16x16x32 MFMA.  hi = rn16(clamp(w)), lo = rn16(w - hi): the bits gemm.hip's register split computes.
+    Returned as a 16-bit tensor [N, 2K] (the byte size and row stride of the fp32 matrix)."""
+    n, k = w.shape
+    assert w.dtype == torch.float32 and k % 32 == 0
+    hi = w.clamp(-65504.0, 65504.0).to(half) if half == torch.float16 else w.to(half)
+    lo = (w - hi.float()).to(half)
+    # k = 16 j + 4 c + e  ->  [slab][c][j][e]
+    parts = [t.reshape(n, k // 32, 2, 4, 4).permute(0, 1, 3, 2, 4).reshape(n, k // 32, 32) for t in (hi, lo)]
+    return torch.cat(parts, dim=2).reshape(n, 2 * k).contiguous()
+
+
+def fly16_to_f32(t: torch.Tensor) -> torch.Tensor:
+    """Inverse of fly16_weight up to the split (hi + lo as fp32): tests."""
+    n, k2 = t.shape
+    k = k2 // 2
+    b = t.reshape(n, k // 32, 2, 4, 2, 4).float()          # [slab][hi|lo][c][j][e]
+    v = b[:, :, 0] + b[:, :, 1]
+    return v.permute(0, 1, 3, 2, 4).reshape(n, k)
+
+
+def convert_codec_fly16(tensors: Dict[str, torch.Tensor], half: torch.dtype, max_out: int = 256) -> Dict[str, torch.Tensor]:
+    """The "<name>.fly" twins of the codec convolutions with < `max_out` output channels - the ones convert_codec_x3 leaves to the
+    fp32 kernel with operands split on the fly (SAMAUDIO_OPT_X3_CLASSES bit CODEC): their weights split ONCE, in the layout that
+    kernel's fragment reads want (fly16_weight), so that its K loop splits activations only."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, w in tensors.items():
+        if w.dim() != 2 or w.dtype != torch.float32 or not (name.startswith("enc.") or name.startswith("dec.")) or name.endswith((".x3", ".fly")):
+            continue
+        n, k = w.shape
+        if n >= max_out or k % 32 or not name.endswith(".w") and not name.endswith((".w1", ".w2")):
+            continue
+        out[name + ".fly"] = fly16_weight(w, half)
+    return out
+
+
 def split_missing_unexpected(sd_keys, cfg: SAMAudioConfig) -> Tuple[List[str], List[str]]:
     """Key bookkeeping of reference SAMAudio.load_state_dict (model.py:346-359)."""
     want = set(expected_keys(cfg))

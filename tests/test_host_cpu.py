@@ -196,6 +196,18 @@ def test_split_weight_forms_of_the_x3_precisions():
         cin = v.shape[2] // 3
         assert v.shape == (n, kk // cin, 3 * cin) and torch.equal(v[:, :, :cin], codec[k[:-3]].reshape(n, kk // cin, cin).half())
     assert "dec.s1.r0.w1.x3" in c3 and c3["dec.s1.r0.w1.x3"].shape[2] == 3 * 384 and "dec.s3.r0.w1.x3" not in c3
+    # the narrow convolutions: "<name>.fly" twins, the weight split once in the fragment layout of GemmParams.flags bit 14
+    from sam_audio_amd.weights import convert_codec_fly16, fly16_to_f32, fly16_weight
+    fly = convert_codec_fly16(codec, torch.float16)
+    assert fly and not ({k[:-4] for k in fly} & {k[:-3] for k in c3}) and "dec.s3.r0.w1.fly" in fly
+    assert {k[:-4] for k in fly} | {k[:-3] for k in c3} == {k for k, v in codec.items() if v.dim() == 2 and v.shape[1] % 32 == 0}
+    for k, v in fly.items():
+        wb = codec[k[:-4]]
+        assert v.dtype == torch.float16 and v.shape == (wb.shape[0], 2 * wb.shape[1])
+        assert ((fly16_to_f32(v) - wb).abs() <= wb.abs() * 2.0 ** -21 + 2.0 ** -25).all()
+    one = fly16_weight(torch.arange(64, dtype=torch.float32)[None] + 1, torch.float16)   # slab 0 of row 0: chunk c = k in {4c.., 16+4c..}
+    assert one[0, :8].tolist() == [1, 2, 3, 4, 17, 18, 19, 20] and one[0, 8:16].tolist() == [5, 6, 7, 8, 21, 22, 23, 24]
+    assert one[0, 32:64].abs().max() == 0 and one[0, 64:72].tolist() == [33, 34, 35, 36, 49, 50, 51, 52]
     assert hip.precision_code("fp16x3") == hip.F32 and hip.operands_for("fp16x3") == "fp16" and hip.operands_for("bf16x3") == "bf16"
     assert hip.storage_precision("fp16x3") == "fp32" and hip.act_dtype("fp16x3") == torch.float32
     assert hip.class_mask("attn,qkv") == hip.X3_ATTENTION | hip.CLS["qkv"]

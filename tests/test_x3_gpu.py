@@ -16,7 +16,7 @@ import torch
 from oracle import samaudio_oracle as O
 from sam_audio_amd import SAMAudio, SAMAudioProcessor, hip, preset_config
 from sam_audio_amd.synthetic import init_state_dict, make_hostile, synthetic_clip, synthetic_noise, synthetic_text_features
-from sam_audio_amd.weights import ktm_to_rows, x3_weight
+from sam_audio_amd.weights import fly16_to_f32, fly16_weight, ktm_to_rows, x3_weight
 from tests import util
 
 pytestmark = pytest.mark.gpu
@@ -86,7 +86,7 @@ def test_x3_gemm_is_the_fp32_product(gpu, prec, shape):
 
 
 @pytest.mark.parametrize("prec", X3)
-@pytest.mark.parametrize("shape", [(300, 96, 672, 96), (200, 192, 256, 256), (70, 1, 448, 64)])
+@pytest.mark.parametrize("shape", [(300, 96, 672, 96), (200, 192, 256, 256), (70, 1, 448, 64), (150, 128, 448, 64), (140, 64, 448, 64)])
 def test_fp32_gemm_with_operands_split_on_the_fly(gpu, prec, shape):
     """GemmParams.flags bit 13 (common.h GEMM_FLAG_X3_FLY; SAMAUDIO_OPT_X3_CLASSES bit CODEC): the fp32 kernel of gemm.hip splits the
     fp32 fragments of BOTH operands in registers and multiplies on the 16-bit MFMA - here as a dilated implicit convolution
@@ -103,19 +103,32 @@ def test_fp32_gemm_with_operands_split_on_the_fly(gpu, prec, shape):
     ref = rows.double() @ w.double().T + bias.double()
     lib = hip.lib(hip.operands_for(prec))
     outs = {}
-    for flags in (0, 8192):
+    wfly = fly16_weight(w, HALF[prec]).to(gpu)   # flags bit 14: the weight already split, in the kernel's fragment layout
+    assert torch.equal(fly16_to_f32(wfly.cpu()), w.to(HALF[prec]).float() + (w - w.to(HALF[prec]).float()).to(HALF[prec]).float())
+    # (flags, debug flag 36): exact fp32 | both operands split in registers | the split weight on the 4 x 1-wave tiles (shipped) | on the
+    # tiles of the plain policy | on the three-stage ring | on its 256-row tile
+    cases = {"exact": (0, 0), "fly": (8192, 0), "twin": (8192 | 16384, 0), "twin_old_tiles": (8192 | 16384, 1), "twin_ring3": (8192 | 16384, 2),
+             "twin_ring3_256": (8192 | 16384, 3)}
+    for name, (flags, dbg) in cases.items():
         o32, oact = torch.full((M, N), float("nan"), device=gpu), torch.full((M, N), float("nan"), device=gpu)
-        xd, wd, bd, ad = x.to(gpu).contiguous(), w.to(gpu).contiguous(), bias.to(gpu), alpha.to(gpu)
+        xd, wd, bd, ad = x.to(gpu).contiguous(), (wfly if flags & 16384 else w.to(gpu).contiguous()), bias.to(gpu), alpha.to(gpu)
         prm = util.gemm_params(xd, wd, M, N, K, a_off=a_off, lda=kc, kc=kc, tap_stride=dil * kc, bias=bd, out_f32=o32, f32_geom=(0, N, 0),
                                out_act=oact, act_geom=(0, N, 0), act=hip.ACT_SNAKE, act_alpha=ad, flags=flags)
-        hip.check(lib.samaudio_op_gemm(C.byref(prm), C.sizeof(prm), hip.F32, util.stream()))
-        outs[flags] = (o32.cpu(), oact.cpu())
-    e_exact = (outs[0][0] - ref.float()).abs().max().item()
-    e_fly = (outs[8192][0] - ref.float()).abs().max().item()
+        lib.samaudio_debug_set_flag(36, dbg)
+        try:
+            hip.check(lib.samaudio_op_gemm(C.byref(prm), C.sizeof(prm), hip.F32, util.stream()))
+            outs[name] = (o32.cpu(), oact.cpu())
+        finally:
+            lib.samaudio_debug_set_flag(36, 0)
+    for name in cases:
+        if name.startswith("twin"):
+            assert torch.equal(outs[name][0], outs["fly"][0]) and torch.equal(outs[name][1], outs["fly"][1]), f"{name}: same bits as the register split"
+    e_exact = (outs["exact"][0] - ref.float()).abs().max().item()
+    e_fly = (outs["fly"][0] - ref.float()).abs().max().item()
     half = HALF[prec]
     e_plain = ((rows.to(half).double() @ w.to(half).double().T + bias.double()).float() - ref.float()).abs().max().item()
     snake = ref + torch.sin(alpha.double() * ref) ** 2 / (alpha.double() + 1e-9)
-    e_act = (outs[8192][1] - snake.float()).abs().max().item()
+    e_act = (outs["fly"][1] - snake.float()).abs().max().item()
     print(f"fp32 GEMM, operands split on the fly ({prec}) {shape}: max-abs err {e_fly:.3e} (exact-fp32 launch {e_exact:.3e}, plain 16-bit "
           f"operands {e_plain:.3e}); Snake output {e_act:.3e}; |ref| <= {ref.abs().max():.2f}")
     tol = (4e-6 if half == torch.float16 else 1e-4) * max(1.0, ref.abs().max().item())
