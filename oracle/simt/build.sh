@@ -37,13 +37,6 @@ for f in gemm gemm2 gemm8 kernels attention peav_kernels vit_kernels t5_kernels 
       grep -q "(void)lds;" $OUT/gemm2_simt.hip || { echo "gemm2.hip: dma16a asm statement not found"; exit 1; }
       src=$OUT/gemm2_simt.hip
     fi
-    if [ $f = gemm ]; then
-      # gemm.hip's inline-assembly DMA (dma16x, the three-stage ring of the split-weight tiles) becomes the builtin the stub emulates
-      sed 's|^.*// SIMT-DMA1$|  simt::dma_asm = true; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); simt::dma_asm = false; (void)lds;|' $src > $OUT/gemm_simt.hip
-      grep -q "(void)lds;" $OUT/gemm_simt.hip || { echo "gemm.hip: dma16x asm statement not found"; exit 1; }
-      EXTRA="-I $SRC"
-      src=$OUT/gemm_simt.hip
-    fi
     if [ $f = gemm8 ]; then
       # gemm8.hip's scalar-base DMA (dma16s: inline assembly with operands) becomes the builtin the stub emulates
       sed 's|^.*// SIMT-DMA8$|  simt::dma_asm = true; __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)sbase + voff), (__attribute__((address_space(3))) void*)lds_wave_addr, 16, 0, 0); simt::dma_asm = false; (void)lds;|' $src > $OUT/gemm8_simt.hip

@@ -71,27 +71,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
 
 // FLY (fp32 only): the instantiation serves GEMM_FLAG_X3_FLY | GEMM_FLAG_W_FLY16 launches and nothing else (the wide tiles of the
 // narrow DAC-VAE stages, fly_variant below) - no exact-fp32 path, no split of W in the K loop.
-// NS (FLY only): stages of the slab ring.  2 = the loop of every other instantiation (compiler-visible DMA, vmcnt(0) + one barrier
-// per slab: one slab in flight while one is multiplied); 3 = two slabs in flight - the DMA issued as inline assembly (dma16x), retired
-// by counted s_waitcnt vmcnt, one bare s_barrier per slab.
-template <int N> __device__ __forceinline__ void wait_vm_fly() {   // literal counts: the simulator reads the number from the text
-  static_assert(N == 0 || (N >= 5 && N <= 8) || N == 11 || N == 12, "add the literal");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-}
-// the direct-to-LDS load as inline assembly (as gemm8.hip dma16v): invisible to the compiler, which would otherwise put vmcnt(0) in
-// front of every barrier; M0 = LDS base, one wait state between the M0 write and the load
-__device__ __forceinline__ void dma16x(const void* gsrc, size_t lds_wave_addr) {
-  const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)lds_wave_addr);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds), "v"(gsrc) : "memory", "m0");  // SIMT-DMA1
-}
-template <typename T, int BM, int BN, int WM_, int WN_, bool FLY = false, int NS = 2>
-__global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(const GemmParams p) {   // (two waves per SIMD: two workgroups per CU)
+// (Measured and removed, round 6: a three-stage ring of the FLY tiles - two slabs in flight, the DMA as inline assembly with counted
+// vmcnt - is 84 KB of LDS at 128 x 96, one workgroup per CU instead of two, and ran 1.35x SLOWER than this loop on the k7 shapes, on
+// 128- and on 256-row tiles; profiles/r6_call15/fly_probe.log, columns ring3 / ring3 256.)
+template <typename T, int BM, int BN, int WM_, int WN_, bool FLY = false>
+__global__ __launch_bounds__(256, (FLY ? 2 : 1)) void gemm_kernel(const GemmParams p) {   // (two waves per SIMD: two workgroups per CU)
   constexpr int NW = WM_ * WN_;
   static_assert(NW == 4, "4 waves per workgroup");
   constexpr int CH = 16 / (int)sizeof(T);   // elements per 16-byte chunk
@@ -101,7 +85,7 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
   constexpr int AI = BM / 32, BI = BN / 32;  // DMA instructions per wave per slab
   static_assert(BM % 32 == 0 && BN % 32 == 0 && WTM % 16 == 0 && WTN % 16 == 0, "tile shape");
   constexpr int TILE_A = BM * 128, TILE_B = BN * 128, STAGE = TILE_A + TILE_B;
-  static_assert(NS == 2 || (FLY && NS == 3), "ring depth");
+  constexpr int NS = 2;   // stages: one slab in flight while one is multiplied
   __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
 
   const int tid = threadIdx.x;
@@ -141,6 +125,9 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
       w_rows[i] = W + (long)n * p.K + chunk * CH;
     }
   }
+  // (Measured without effect and removed, round 6: a first-touch pass - every thread requesting up to six of the 128-byte lines of the
+  // tile's activation rows with ordinary loads in front of the K loop, so that the slabs of the first tap find them in L2: k7 at 96
+  // channels 1.057 ms with, 0.980 without; end to end 89.17 s-audio/s both ways; profiles/r6_call17/.)
   // running position of this lane's chunk inside the (tap, offset) structure of A's k axis
   int a_in = chunk * CH;   // offset inside the current tap segment
   long a_tap = 0;          // element offset of the current tap
@@ -150,15 +137,9 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
     char* sA = smem + stage * STAGE;
     char* sB = sA + TILE_A;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      if constexpr (NS == 3) dma16x(a_rows[i] + a_tap + a_in, (size_t)(__attribute__((address_space(3))) char*)(sA + (wave + 4 * i) * 1024));
-      else dma16(a_rows[i] + a_tap + a_in, sA + (wave + 4 * i) * 1024);
-    }
+    for (int i = 0; i < AI; ++i) dma16(a_rows[i] + a_tap + a_in, sA + (wave + 4 * i) * 1024);
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      if constexpr (NS == 3) dma16x(w_rows[i], (size_t)(__attribute__((address_space(3))) char*)(sB + (wave + 4 * i) * 1024));
-      else dma16(w_rows[i], sB + (wave + 4 * i) * 1024);
-    }
+    for (int i = 0; i < BI; ++i) dma16(w_rows[i], sB + (wave + 4 * i) * 1024);
     // advance to the next slab
     a_in += BK;
     while (a_in >= p.kc) { a_in -= p.kc; a_tap += p.tap_stride; }
@@ -228,18 +209,6 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
 #pragma unroll
           for (int j = 0; j < FN; ++j) acc[i][j] = SA_MFMA_16x16x32(bh[j], ah[i], acc[i][j]);
   };
-  if constexpr (NS == 3) {   // (FLY) two slabs in flight
-    issue(0);
-    if (nslab > 1) issue(1);
-    for (int s = 0; s < nslab; ++s) {
-      if (s + 1 < nslab) wait_vm_fly<AI + BI>();   // slab s landed, slab s + 1 may be in flight
-      else wait_vm_fly<0>();
-      __builtin_amdgcn_s_barrier();   // ... for every wave; the reads of slab s - 1 (the stage slab s + 2 goes to) are complete
-      if (s + 2 < nslab) issue((s + 2) % 3);
-      const char* sA = smem + (s % 3) * STAGE;
-      fly_slab(sA, sA + TILE_A);
-    }
-  } else {
   issue(0);
   for (int s = 0; s < nslab; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -285,7 +254,6 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
     }
     }   // !FLY
   }
-  }   // NS
 
   // ---- epilogue ---------------------------------------------------------------------------------
   // The operands go into the MFMA swapped (W fragment first): per fragment D = (A W^T)^T, i.e. a lane holds row m = lane & 15
@@ -311,12 +279,14 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
     return v;
   };
   if constexpr (sizeof(T) == 4) {
-    // LEAN form (fp32 launches whose operands allow 16-byte accesses throughout: every DAC-VAE convolution of an fp32 context except
-    // the windowed transposed ones): ALL loads of the epilogue - bias / Snake alpha per column block, the residual rows - are
-    // requested before the first store.  The loop below loads, waits and stores per 16 x 16 fragment, and vmcnt retires in order: a load
-    // issued behind a store is waited for together with that store's round trip to L2 - FM x FN round trips in series per tile,
-    // measured as 32 us per 128 x 96 tile against 0.5 us per K slab (profiles/r6_call13/fly_probe.log: a k1 convolution, three slabs
-    // per tile, ran at 1.4 TB/s of its 1.47 GB).  Same expressions in the same order: the same bits.
+    // LEAN form: fp32 launches whose operands allow 16-byte accesses throughout and whose activation is none or Snake - every
+    // DAC-VAE convolution of an fp32 context except the windowed transposed ones and the final tanh; the input projections of the DiT.
+    // The general loop below is unrolled over the FM x FN fragments with the seven-way activation chain of finish() inlined per
+    // element: ~50 000 instructions per instantiation, walked once per tile from a cold instruction cache, each fragment's loads
+    // issued behind the previous fragment's stores (vmcnt retires in order: the load is waited for together with the store's round
+    // trip).  Measured per 128 x 96 tile: 26 - 32 us of epilogue in front of 21 us of K loop; a k1 convolution - three slabs per tile -
+    // ran at 1.4 TB/s of its 1.47 GB (profiles/r6_call13/, r6_call14/fly_probe.log).  With the form below the same launch runs at
+    // 3.3 TB/s and the k7 convolutions 1.5 - 2x faster (r6_call15/).  Same expressions in the same order: the same bits.
     auto al16 = [](const void* q, long a, long b2, long c) { return (((size_t)q) & 15) == 0 && !((a | b2 | c) & 3); };
     const bool lean = !p.swiglu && !p.gate && !p.chan_mod && !p.c_ld_rel && !(p.N & 3) && (!p.bias || al16(p.bias, 0, 0, 0)) &&
                       (p.act != ACT_SNAKE || al16(p.act_alpha, 0, 0, 0)) && (!p.res || al16(p.res, p.res_off, p.res_ld, p.res_bstride)) &&
@@ -324,10 +294,8 @@ __global__ __launch_bounds__(256, (FLY && NS == 2 ? 2 : 1)) void gemm_kernel(con
                       (!p.out_act || al16(p.out_act, p.act_off, p.act_ld, p.act_bstride));
     if (lean && (p.act == ACT_NONE || p.act == ACT_SNAKE)) {
       // accumulators -> LDS (the K loop's stages are free after one barrier): rows of BN floats, 16-byte chunks XOR-swizzled with the
-      // row.  Then a ROLLED loop: a wave instruction covers 64 / (BN / 4) whole rows - full cache lines per load and store - and
-      // its body exists once (unrolled over the FM x FN fragments with the activation chain of finish() inlined per element, the
-      // epilogue is ~50 000 instructions per instantiation, walked once per tile from a cold instruction cache: the 26 us per
-      // 128 x 96 tile that profiles/r6_call14/fly_probe.log shows in front of its 21 us of K loop).
+      // row.  Then a ROLLED loop whose body exists once: a wave instruction covers 64 / (BN / 4) whole rows - full cache lines per
+      // load and store -, the residual row of iteration it + 1 is requested before the stores of iteration it.
       constexpr int CPR = BN / 4, RPI = 64 / CPR, WR = BM / 4, NIT = (WR + RPI - 1) / RPI;   // chunks per row, rows per wave instruction, rows per wave
       static_assert(BN % 32 == 0 && BM * BN * 4 <= NS * STAGE, "epilogue staging area");
       __syncthreads();
@@ -603,14 +571,6 @@ hipError_t launch_gemm(const GemmParams& p, bool is_bf16, hipStream_t st) {
       hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), 0, st, p);
       return hipGetLastError();
     };
-    const int ring = debug_flag(36);   // (A/B) 2 = three-stage slab ring, 3 = the same on 256-row tiles at N % 96 == 0
-    if (ring == 3 && v == 36) return go(gemm_kernel<float, 256, 96, 4, 1, true, 3>, 256, 96);
-    if (ring >= 2) switch (v) {
-      case 36: return go(gemm_kernel<float, 128, 96, 4, 1, true, 3>, 128, 96);
-      case 37: return go(gemm_kernel<float, 128, 128, 4, 1, true, 3>, 128, 128);
-      case 38: return go(gemm_kernel<float, 128, 64, 4, 1, true, 3>, 128, 64);
-      default: return go(gemm_kernel<float, 128, 32, 4, 1, true, 3>, 128, 32);
-    }
     switch (v) {
       case 36: return go(gemm_kernel<float, 128, 96, 4, 1, true>, 128, 96);
       case 37: return go(gemm_kernel<float, 128, 128, 4, 1, true>, 128, 128);

@@ -28,7 +28,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 31: 1 = the folded cross-attention operand U = Wo V of every layer in its own launch (shipped: all layers of an evaluation in
 //            one launch in front of the layer loop) - its bitwise test
 //   flag 35: (A/B) M-tiles per raster group of the 8-phase family (0 = shipped: 8; GemmParams.raster_gm)
-//   flag 36: (A/B, tests) split-weight launches of the fp32 kernel (GEMM_FLAG_W_FLY16) on the tiles of gemm1_variant instead of fly_variant's
+//   flag 36: 1 = (A/B, tests) split-weight launches of the fp32 kernel (GEMM_FLAG_W_FLY16) on the tiles of gemm1_variant instead of fly_variant's
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);

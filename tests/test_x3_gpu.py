@@ -106,9 +106,8 @@ def test_fp32_gemm_with_operands_split_on_the_fly(gpu, prec, shape):
     wfly = fly16_weight(w, HALF[prec]).to(gpu)   # flags bit 14: the weight already split, in the kernel's fragment layout
     assert torch.equal(fly16_to_f32(wfly.cpu()), w.to(HALF[prec]).float() + (w - w.to(HALF[prec]).float()).to(HALF[prec]).float())
     # (flags, debug flag 36): exact fp32 | both operands split in registers | the split weight on the 4 x 1-wave tiles (shipped) | on the
-    # tiles of the plain policy | on the three-stage ring | on its 256-row tile
-    cases = {"exact": (0, 0), "fly": (8192, 0), "twin": (8192 | 16384, 0), "twin_old_tiles": (8192 | 16384, 1), "twin_ring3": (8192 | 16384, 2),
-             "twin_ring3_256": (8192 | 16384, 3)}
+    # tiles of the plain policy
+    cases = {"exact": (0, 0), "fly": (8192, 0), "twin": (8192 | 16384, 0), "twin_old_tiles": (8192 | 16384, 1)}
     for name, (flags, dbg) in cases.items():
         o32, oact = torch.full((M, N), float("nan"), device=gpu), torch.full((M, N), float("nan"), device=gpu)
         xd, wd, bd, ad = x.to(gpu).contiguous(), (wfly if flags & 16384 else w.to(gpu).contiguous()), bias.to(gpu), alpha.to(gpu)

@@ -2,7 +2,7 @@
 """Times the fp32 kernel's compensated launches (GemmParams.flags bits 13 / 14, gemm.hip) on the shapes of the DAC-VAE stages with
 < 256 channels, one launch per shape and form, with torch events on the launch stream.
 usage: [PROBE_ROWS=1920000] python tools/fly_probe.py        forms: register split of both operands on the plain tiles | split weight
-on the plain tiles | split weight on the 4 x 1-wave tiles | three-stage ring | three-stage ring on 256 rows"""
+on the plain tiles | split weight on the 4 x 1-wave tiles"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,7 @@ lib = hip.lib("fp16")
 SHAPES = [("k7 96ch d1", 96, 672, 96, 1), ("k7 96ch d9", 96, 672, 96, 9), ("k1 96ch", 96, 96, 96, 1), ("k7 192ch d3", 192, 1344, 192, 3),
           ("k1 192ch", 192, 192, 192, 1), ("up 192->2x96", 192, 384, 384, 1), ("k7 128ch d1", 128, 896, 128, 1), ("k7 64ch d1", 64, 448, 64, 1),
           ("k7 96->1", 1, 672, 96, 1)]
-FORMS = [("fly", 8192, 0), ("twin old tiles", 8192 | 16384, 1), ("twin 4x1", 8192 | 16384, 0), ("ring3", 8192 | 16384, 2), ("ring3 256", 8192 | 16384, 3)]
+FORMS = [("fly", 8192, 0), ("twin old tiles", 8192 | 16384, 1), ("twin 4x1", 8192 | 16384, 0)]
 for name, N, K, kc, dil in SHAPES:
     rows = M // 2 if N == 192 and kc == 192 else M    # the 192-channel stage runs at half the sample rate
     taps, halo = K // kc, 32
