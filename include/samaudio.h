@@ -138,8 +138,12 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   class's weights registered in that split form under "<name>.x3" - 16-bit, [N, 3K] row-major or [3K/64, N, 64] K-tile-major
  *   (sam_audio_amd/weights.py x3_weight) - for L<i>.wqkv, wo, c_wq, c_wo, w13, w2; checked like the ".f32" copies above.  Classes
  *   PATCH (the patcher's k3 convolutions: "patch1.w.x3" / "patch2.w.x3", [D, 9D] with EACH tap's D columns split into 3D) and CKV
- *   ("c_wkv_all.x3") can be switched on as well.  Class CODEC needs no second copy of anything: the fp32 convolution kernel splits the
- *   fp32 fragments of both operands in registers and multiplies them as lo*hi + hi*lo + hi*hi on the 16-bit MFMA.
+ *   ("c_wkv_all.x3") can be switched on as well.  Class CODEC works without a second copy of anything: the fp32 convolution kernel splits
+ *   the fp32 fragments of both operands in registers and multiplies them as lo*hi + hi*lo + hi*hi on the 16-bit MFMA.  Optional twins make
+ *   it faster: "<name>.x3" ([N, K / Cin, 3 Cin], weights.py convert_codec_x3) sends a convolution with >= 256 output channels through the
+ *   16-bit 8-phase kernels over K' = 3K; "<name>.fly" (16-bit, [N, 2K]: the weight split ONCE in the fragment layout of the fp32 kernel,
+ *   csrc/common.h GEMM_FLAG_W_FLY16, weights.py convert_codec_fly16) takes the split of the weight out of that kernel's K loop.  Same
+ *   bits with or without them.
  *   With class CWO on, text memories of <= 16 tokens (128-wide heads) take the folded form of the cross-attention output projection on
  *   compensated operands (h += P . U, U = Wo V per layer and batch item: K' = 3 * pad64(heads * (8 | 16)) instead of 3 * dim).
  *   Bit SAMAUDIO_X3_ATTENTION does the same for the two contractions of the self-attention.  Everything else of the context

@@ -340,30 +340,47 @@ __global__ __launch_bounds__(NW * 64) void self_attn_x3_kernel(const float* __re
   char* Pw = Ps + wave * 2048;
   constexpr int PL = NW * 2048;   // offset of the lo image of P
 
+  // the fp32 K / V^T values of a key tile travel global -> registers -> (split) -> LDS; the NEXT tile's values are requested right
+  // after this tile's went into LDS, so that their latency runs underneath this tile's MFMAs and softmax (round 6: the loads used to
+  // sit between the two barriers at the top of the tile, exposed once per tile with one workgroup per CU)
+  constexpr int NIT = HD / (8 * NW);
+  float4 kreg[NIT][2], vreg[NIT][2];
+  auto request = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 64 * NW * it;
+      const float* ksrc = K + (bh * Tp + kt + idx / CH) * HD + (idx % CH) * 8;
+      kreg[it][0] = *(const float4*)ksrc;
+      kreg[it][1] = *(const float4*)(ksrc + 4);
+      const float* vsrc = Vt + (bh * HD + (idx >> 3)) * Tp + kt + (idx & 7) * 8;
+      vreg[it][0] = *(const float4*)vsrc;
+      vreg[it][1] = *(const float4*)(vsrc + 4);
+    }
+  };
+  request(0);
   for (int kt = 0; kt < Tp; kt += 64) {
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < HD / (8 * NW); ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int idx = tid + 64 * NW * it;
       {
         const int row = idx / CH, c = idx % CH;
-        const float* src = K + (bh * Tp + kt + row) * HD + c * 8;
         uint4 hi, lo;
-        split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+        split8(kreg[it][0], kreg[it][1], hi, lo);
         const int off = row * (HD * 2) + ((c ^ (row & (CH - 1))) << 4);
         *(uint4*)(Ks + off) = hi;
         *(uint4*)(Ks + KB + off) = lo;
       }
       {
         const int d = idx >> 3, c = idx & 7;
-        const float* src = Vt + (bh * HD + d) * Tp + kt + c * 8;
         uint4 hi, lo;
-        split8(*(const float4*)src, *(const float4*)(src + 4), hi, lo);
+        split8(vreg[it][0], vreg[it][1], hi, lo);
         const int off = d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
         *(uint4*)(Vs + off) = hi;
         *(uint4*)(Vs + KB + off) = lo;
       }
     }
+    if (kt + 64 < Tp) request(kt + 64);
     __syncthreads();
     f32x4_t s[4];
 #pragma unroll
@@ -926,58 +943,85 @@ __global__ __launch_bounds__(512) void cross_attn_fold_kernel(const FoldLayers l
 //     written as the per-batch weight operand [U_hi | U_lo | U_hi] (rows of 3 KP).
 // The D-wide c_wo GEMM over K' = 3 D of the unfolded x3 path becomes one over K' = 3 KP = 576: 7.6 % of the DiT's flops gone.
 // ---------------------------------------------------------------------------------------------------
-// LTP = token slots per head (8 | 16): the scores of ALL tokens are reduced across the wave together (LTP independent butterflies in
-// flight per stage instead of one reduction after the other: the kernel is bound by the latency of its cross-lane steps)
+// LTP = token slots per head (8 | 16).  One wave = 16 rows of one clip x one head, the scores S = (q w) K^T on the 16-bit MFMA over
+// split operands (q_l K_h + q_h K_l + q_h K_h, four k-steps of 32: 12 MFMAs), as every other contraction of the mode.  The form it
+// replaces (rounds 6, first half: one wave per (row, head), fp32 products, nine butterfly reductions of six ds_bpermute steps each) was
+// bound by the latency of its 54 cross-lane steps: 68 us per launch at 4 000 rows for 45 MB of q (profiles/r6_final3/).  Lane
+// (lr, lg) holds the operands' k = 32 ks + 8 lg .. + 7 of row / token lr and, after the MFMAs, the scores of row lr and tokens
+// 4 lg .. 4 lg + 3; the row statistic of the q-norm and the softmax need two exchanges across lg each.
 template <int LTP>
 __global__ __launch_bounds__(256) void cross_attn_probs3_kernel(const float* __restrict__ q, const float* __restrict__ qw,
                                                                 const float* __restrict__ kv, long kv_ld,
                                                                 const unsigned char* __restrict__ mask, bf16_t* __restrict__ P3, int KP,
                                                                 long M, int T, int Lt, int H, float eps) {
 #pragma clang fp contract(off)
-  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= M * H) return;
-  const int lane = threadIdx.x & 63;
-  const long m = item / H;
+  const int tblks = (T + 15) >> 4;                                  // row blocks per clip (a block never spans two clips: K differs)
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);      // (clip, row block, head)
+  const long B = M / T;
+  if (item >= B * tblks * H) return;
+  const int lane = threadIdx.x & 63, lr = lane & 15, lg = lane >> 4;
   const int h = (int)(item % H);
-  const long b = m / T;
+  const long bt = item / H;
+  const long b = bt / tblks;
+  const int t = (int)(bt % tblks) * 16 + lr;
+  const bool row_ok = t < T;
+  const long m = b * T + (row_ok ? t : T - 1);
   const int D = H * 128;
-  float q0, q1;
-  load2<float>(q + m * D + h * 128 + 2 * lane, q0, q1);
-  const float w0 = qw[2 * lane], w1 = qw[2 * lane + 1];
-  float part[LTP + 1];
-  bool live[LTP];
+  const bool tok_ok = lr < Lt && mask[b * Lt + (lr < Lt ? lr : 0)] != 0;   // this lane's K row (token lr) takes part
+  const float* qrow = q + m * D + h * 128 + lg * 8;
+  const float* krow = kv + (b * Lt + (lr < Lt ? lr : 0)) * kv_ld + h * 128 + lg * 8;
+  const float* wrow = qw + lg * 8;
+  auto cl = [](float x) { return __builtin_amdgcn_fmed3f(x, -kH16Max, kH16Max); };
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
 #pragma unroll
-  for (int j = 0; j < LTP; ++j) {
-    live[j] = j < Lt && mask[b * Lt + (j < Lt ? j : 0)] != 0;   // wave-uniform
-    float k0 = 0.f, k1 = 0.f;
-    if (live[j]) load2<float>(kv + (b * Lt + j) * kv_ld + h * 128 + 2 * lane, k0, k1);
-    part[j] = (q0 * w0) * k0 + (q1 * w1) * k1;
+  for (int ks = 0; ks < 4; ++ks) {
+    const float4 qa = *(const float4*)(qrow + ks * 32), qb = *(const float4*)(qrow + ks * 32 + 4);
+    const float4 wa = *(const float4*)(wrow + ks * 32), wb = *(const float4*)(wrow + ks * 32 + 4);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 ka = tok_ok ? *(const float4*)(krow + ks * 32) : z, kb = tok_ok ? *(const float4*)(krow + ks * 32 + 4) : z;
+    ss += qa.x * qa.x + qa.y * qa.y + qa.z * qa.z + qa.w * qa.w + qb.x * qb.x + qb.y * qb.y + qb.z * qb.z + qb.w * qb.w;
+    uint4 qh, ql, kh, kl;
+    split8(make_float4(cl(qa.x * wa.x), cl(qa.y * wa.y), cl(qa.z * wa.z), cl(qa.w * wa.w)),
+           make_float4(cl(qb.x * wb.x), cl(qb.y * wb.y), cl(qb.z * wb.z), cl(qb.w * wb.w)), qh, ql);
+    split8(make_float4(cl(ka.x), cl(ka.y), cl(ka.z), cl(ka.w)), make_float4(cl(kb.x), cl(kb.y), cl(kb.z), cl(kb.w)), kh, kl);
+    const bf16x8_t Qh = __builtin_bit_cast(bf16x8_t, qh), Ql = __builtin_bit_cast(bf16x8_t, ql);
+    const bf16x8_t Kh = __builtin_bit_cast(bf16x8_t, kh), Kl = __builtin_bit_cast(bf16x8_t, kl);
+    acc = SA_MFMA_16x16x32(Kh, Ql, acc);   // (tokens as the first operand: a lane then owns 4 consecutive tokens of ITS row)
+    acc = SA_MFMA_16x16x32(Kl, Qh, acc);
+    acc = SA_MFMA_16x16x32(Kh, Qh, acc);
   }
-  part[LTP] = q0 * q0 + q1 * q1;   // the q-norm statistic rides along: inv is a scalar, the scores are scaled with it afterwards
+  ss += __shfl_xor(ss, 16, 64);
+  ss += __shfl_xor(ss, 32, 64);
+  const float inv = rsqrtf(ss / 128.f + eps);
+  float sc[4], mx = -INFINITY;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int j = 0; j <= LTP; ++j) part[j] += __shfl_xor(part[j], o, 64);
-  const float inv = rsqrtf(part[LTP] / 128.f + eps);
-  float mx = -INFINITY, mine = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < LTP; ++j) {
-    const float sj = live[j] ? part[j] * inv * 0.08838834764831845f : -INFINITY;
-    mx = fmaxf(mx, sj);
-    if (lane == j) mine = sj;
+  for (int e = 0; e < 4; ++e) {
+    const int j = 4 * lg + e;
+    const bool live = j < Lt && mask[b * Lt + (j < Lt ? j : 0)] != 0;
+    sc[e] = live ? acc[e] * inv * 0.08838834764831845f : -INFINITY;
+    mx = fmaxf(mx, sc[e]);
   }
-  const float e = mine != -INFINITY ? expf(mine - mx) : 0.f;
-  float l = 0.f;
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float ex[4], l = 0.f;
 #pragma unroll
-  for (int j = 0; j < LTP; ++j) l += live[j] ? expf(part[j] * inv * 0.08838834764831845f - mx) : 0.f;   // (every lane: no second reduction)
-  if (lane < LTP) {
-    const float p = lane < Lt ? e / l : 0.f;   // (every token masked: 0 / 0 = NaN, as the reference's softmax of an all -inf row)
-    const unsigned short hi = f2bf(fminf(fmaxf(p, -kH16Max), kH16Max));
-    const unsigned short lo = f2bf(p - bf2f(hi));
-    unsigned short* row = (unsigned short*)P3 + m * (3L * KP) + h * LTP + lane;
-    row[0] = lo;
-    row[KP] = hi;
-    row[2 * KP] = hi;
+  for (int e = 0; e < 4; ++e) {
+    ex[e] = sc[e] != -INFINITY ? expf(sc[e] - mx) : 0.f;
+    l += ex[e];
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (row_ok && 4 * lg < LTP) {
+    float pr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pr[e] = 4 * lg + e < Lt ? ex[e] / l : 0.f;   // (every token masked: 0 / 0 = NaN, as the reference's softmax of an all -inf row)
+    const unsigned h0 = pack_h16x2(cl(pr[0]), cl(pr[1])), h1 = pack_h16x2(cl(pr[2]), cl(pr[3]));
+    const unsigned l0 = pack_h16x2(pr[0] - h16_lo(h0), pr[1] - h16_hi(h0)), l1 = pack_h16x2(pr[2] - h16_lo(h1), pr[3] - h16_hi(h1));
+    unsigned short* row = (unsigned short*)P3 + m * (3L * KP) + h * LTP + 4 * lg;
+    *(uint2*)row = make_uint2(l0, l1);
+    *(uint2*)(row + KP) = make_uint2(h0, h1);
+    *(uint2*)(row + 2 * KP) = make_uint2(h0, h1);
   }
 }
 
@@ -1067,7 +1111,7 @@ __global__ __launch_bounds__(512) void cross_attn_fold3_kernel(const FoldLayers3
 hipError_t launch_cross_attn_probs3(const float* q, const float* qw, const float* kv, long kv_ld, const unsigned char* mask, void* P3,
                                     int KP, int B, int T, int Lt, int LtP, int H, float eps, hipStream_t st) {
   if (Lt > 16 || (LtP != 8 && LtP != 16) || Lt > LtP || H * LtP > KP) return hipErrorInvalidValue;
-  const long items = (long)B * T * H;
+  const long items = (long)B * ((T + 15) / 16) * H;   // one wave per (clip, 16-row block, head)
   if (LtP == 8)
     hipLaunchKernelGGL(cross_attn_probs3_kernel<8>, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, q, qw, kv, kv_ld, mask, (bf16_t*)P3, KP,
                        (long)B * T, T, Lt, H, eps);

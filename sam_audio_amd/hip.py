@@ -220,7 +220,7 @@ class _Handle:
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
 
-        def call(*args, _fn=fn, _self=self):
+        def call(*args, _fn=fn, _self=self, _tls=_tls):   # (_tls bound here: a destructor at interpreter exit finds the module's globals gone)
             _tls.last = _self
             return _fn(*args)
         object.__setattr__(self, name, call)
