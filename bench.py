@@ -450,19 +450,25 @@ def parity_rerank(model, cfg, sd_cpu, proc, dev, precision, judge_sd_cpu, second
                                pj["padding_mask"].repeat_interleave(cand, 0))[:, 0].reshape(1, cand)
         t_judge = time.perf_counter() - t0
     pick_hip, pick_ref = int(scores_hip.argmax(dim=1)), int(J.rerank_select(want)[0])
-    chosen = wav_ref[pick_ref, 0, :n]
     e_lat, e_score = _max_err(lat, lat_ref), _max_err(scores_hip, want)
-    e_wav = _max_err(res.target[0], chosen) if pick_hip == pick_ref else None
+    # The selection is compared at the Judge's own resolution: the two paths pick the same candidate, or the HIP pick is - by the
+    # ORACLE's scores - within twice the measured score error of the oracle's best (with random-init weights the eight candidates of a
+    # clip score within 2e-4 of each other at large* dims, as far apart as the 16-bit Judge is accurate: profiles/r6_final4/).  The
+    # waveform is that of the HIP pick against the oracle's waveform of the SAME candidate.
+    margin = float(want[0, pick_ref] - want[0, pick_hip])
+    consistent = pick_hip == pick_ref or margin <= 2.0 * e_score
+    e_wav = _max_err(res.target[0], wav_ref[pick_hip, 0, :n])
     return {
         "precision": precision, "rows": cand, "clip_seconds": round(T * codec.hop_length / codec.sample_rate, 3),
         "what": f"configs[3]: 1 clip x {cand} candidates - DAC encode -> full 16-step solve of every candidate -> decode -> Judge "
                 "scores -> argmax; HIP path (HIP Judge as text_ranker) vs the oracle (separate(candidates) + oracle Judge on the "
                 "oracle's candidates); max-abs",
-        "tolerance": 1e-3, "within_tolerance": bool(e_lat <= 1e-3 and pick_hip == pick_ref and (e_wav is None or e_wav <= 1e-3)),
+        "tolerance": 1e-3, "within_tolerance": bool(e_lat <= 1e-3 and consistent and e_wav <= 1e-3),
         "ode_latent_err": e_lat, "ode_latent_ref_max": float(lat_ref.abs().max()),
         "judge_overall_scores_hip": [round(float(v), 5) for v in scores_hip[0]],
         "judge_overall_scores_oracle": [round(float(v), 5) for v in want[0]],
         "judge_score_err": e_score, "argmax_hip": pick_hip, "argmax_oracle": pick_ref, "argmax_equal": pick_hip == pick_ref,
+        "argmax_margin_oracle": margin, "argmax_consistent": bool(consistent),
         "selected_waveform_err": e_wav, "oracle_seconds": {"separate": round(t_sep, 1), "judge": round(t_judge, 1)},
     }
 

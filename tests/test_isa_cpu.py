@@ -122,3 +122,33 @@ def test_gemm8_k_loops_are_free_of_scratch_traffic(gemm8_asm):
         limit = 96 if "gemm8_kernel" in name else 0
         assert spills.get(name, 0) <= limit, f"{name}: vgpr_spill_count {spills.get(name)} > {limit}"
     assert seen >= 6
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# gemm.hip (round 6): built WITHOUT the full-unroll budget its epilogue loops need, hipcc indexed the accumulator array dynamically
+# and kept it in scratch memory - every 128 x 128 instantiation (bf16 and fp32) stored all accumulators after every K slab, behind
+# s_nop waits for the MFMA results (profiles/r6_call14/: the 128-channel DAC-VAE stage 96 -> 49 ms per step with the flag alone).
+# The flags are read from csrc/build.sh, so that the scan sees what ships.
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_gemm_kernels_keep_their_accumulators_in_registers(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    build = open(os.path.join(CSRC, "build.sh")).read()
+    m = re.search(r'if \[ \$f = gemm \]; then EXTRA="([^"]*)"', build)
+    assert m and "-pragma-unroll-threshold" in m.group(1), "csrc/build.sh: gemm.hip needs the full-unroll budget"
+    dst = tmp_path / "gemm.s"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", *m.group(1).split(),
+                           "-DSA_OPERAND_FP16", "--cuda-device-only", "-S", "-o", str(dst), os.path.join(CSRC, "gemm.hip")],
+                          stderr=subprocess.DEVNULL)
+    seen = 0
+    for name, lines in _kernels(dst.read_text()).items():
+        if "gemm_kernel" not in name:
+            continue
+        mfma = [i for i, t in enumerate(lines) if t.startswith("v_mfma")]
+        assert mfma, name
+        seen += 1
+        # the K loop ends with the last MFMA in front of the first epilogue store; nothing in it may touch scratch memory
+        bad = [t for t in lines[mfma[0]: mfma[-1] + 1] if t.startswith("scratch_")]
+        assert not bad, f"{name}: {len(bad)} scratch operations between the first and the last MFMA, e.g. {bad[:3]}"
+    assert seen >= 10   # 3 bf16 + 3 fp32 plain tiles, 4 split-weight tiles

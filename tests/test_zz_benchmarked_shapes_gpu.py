@@ -5,7 +5,8 @@ candidates of 1.28 s; configs[4]: 2.56 s clips).  Here the same comparisons run 
 
 * configs[3]: 1 clip x 8 candidates x 10 s through DAC encode -> the 16-step solve of every candidate -> decode -> the Judge's
   scores -> argmax (reference model.py:297-330, model/judge.py:90-132, ranking/judge.py:21-42) against the oracles: candidate
-  latents <= 1e-3, the same argmax, the selected waveform <= 1e-3, scores within the stated bound;
+  latents <= 1e-3, the same argmax (or a tie at the Judge's resolution: bench.parity_rerank), the selected waveform <= 1e-3,
+  scores within the stated bound;
 * configs[4]: 2 clips x 10 s with a full 250-frame masked video each through the PE-Core tower + the visually conditioned solve
   (reference model.py:186-191, vision_encoder.py:47-113): tower features vs the CPU tower oracle, latent and waveform <= 1e-3.
 
@@ -49,12 +50,15 @@ def test_eight_candidates_of_ten_seconds_through_spans_solve_and_judge(gpu):
     proc = SAMAudioProcessor.from_config(cfg)
     out = bench.parity_rerank(model, cfg, sd_cpu, proc, gpu, PREC, judge_sd_cpu, 10.0, 8, bench.usable_cores(), cand=8)
     print(f"configs[3] at its benchmarked shape ({SIZE}, {PREC} DiT, {tower} Judge): latent {out['ode_latent_err']:.3e} (|ref| <= "
-          f"{out['ode_latent_ref_max']:.2f}), Judge scores {out['judge_score_err']:.3e}, argmax {out['argmax_hip']} / {out['argmax_oracle']}, "
+          f"{out['ode_latent_ref_max']:.2f}), Judge scores {out['judge_score_err']:.3e}, argmax {out['argmax_hip']} / {out['argmax_oracle']} (margin by the oracle's scores {out['argmax_margin_oracle']:.2e}), "
           f"selected waveform {out['selected_waveform_err']}; oracle {out['oracle_seconds']}")
     assert out["rows"] == 8 and out["clip_seconds"] == 10.0
     assert out["ode_latent_err"] <= 1e-3
-    assert out["argmax_equal"], (out["judge_overall_scores_hip"], out["judge_overall_scores_oracle"])
-    assert out["selected_waveform_err"] is not None and out["selected_waveform_err"] <= 1e-3
+    # the same pick, or - by the oracle's own scores - a pick within twice the measured score error of the oracle's best (random-init
+    # candidates score within 2e-4 of each other at large* dims: bench.parity_rerank); the waveform is the HIP pick's against the
+    # oracle's waveform of that candidate
+    assert out["argmax_consistent"], (out["argmax_margin_oracle"], out["judge_overall_scores_hip"], out["judge_overall_scores_oracle"])
+    assert out["selected_waveform_err"] <= 1e-3
     # the Judge itself runs on plain 16-bit operands: 2 x the error measured on MI355X (profiles/r6_final/)
     assert out["judge_score_err"] <= 2e-3
 
