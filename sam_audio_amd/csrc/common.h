@@ -250,5 +250,11 @@ constexpr int GEMM_FLAG_X3_FLY = 8192;
 // bits).  Weights are constants: splitting them once per model instead of once per tile and slab takes the split of W out of the
 // K loop, which for the narrow DAC-VAE stages (N = 64 .. 192) is most of its vector-ALU work.
 constexpr int GEMM_FLAG_W_FLY16 = 16384;
+// flags bit 15 (8-phase family, plain 16-bit launches): the operands are the K-CONCATENATED split operands of the compensated mode -
+// A rows [x_lo | x_hi | x_hi], W rows [W_hi | W_lo | W_hi], K = 3 x the original K, a multiple of 192 - and the kernel may use that: the
+// three products of one original K-tile run back to back in the order lo.hi, hi.hi, hi.lo, sharing the operand tiles they have in
+// common (gemm8.hip gemm8x_kernel: a third less staging traffic; gemm8s_kernel: the same order through its K-tile index map).  The
+// result is the same sum in another order.
+constexpr int GEMM_FLAG_X3_SHARE = 32768;
 
 }  // namespace sa

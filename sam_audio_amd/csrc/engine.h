@@ -93,7 +93,9 @@ class Engine {
   // alg_flops < 0: 2*M*N*K*nbatch (exact unless K carries zero padding, then the caller passes the true count).
   // cls: SAMAUDIO_CLS_* bit of the launch (0: codec launches are classed by prof_cls_); f32: exact-fp32 operands inside a
   // 16-bit context (SAMAUDIO_OPT_F32_CLASSES - the caller hands fp32 A / W / out_act pointers)
-  // mode 2: a SAMAUDIO_OPT_X3_CLASSES launch inside an fp32 context (16-bit A / W over K' = 3K, fp32 outputs; gemm_x3 builds it)
+  // mode 2: a SAMAUDIO_OPT_X3_CLASSES launch inside an fp32 context (16-bit A / W over K' = 3K, fp32 outputs; gemm_x3 builds it), both operands split over the
+  // whole K (A rows [lo | hi | hi], W rows [W_hi | W_lo | W_hi]: the launch may share operand tiles, common.h GEMM_FLAG_X3_SHARE); mode 3: the same
+  // with K' split per input block (the convolutions of gemm_codec_x3 / the patcher: [block][3 Cin]) - a plain walk over K' only
   Status gemm(const GemmParams& p, hipStream_t st, double alg_flops = -1.0, int cls = 0, int mode = 0);
   // SAMAUDIO_OPT_X3_CLASSES: `p` = the fp32 context's plain launch (fp32 A rows, fp32-typed outputs) of a class that is switched
   // on; `w3` = its "<name>.x3" weight.  Splits A into the scratch operand [lo | hi | hi] and runs ONE 16-bit GEMM over K' = 3K.

@@ -645,7 +645,7 @@ static int cls_slot(int cls) {
 }
 
 Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, int cls, int mode) {
-  const bool f32 = mode == 1, x3m = mode == 2;
+  const bool f32 = mode == 1, x3m = mode == 2 || mode == 3;   // mode 3: an x3 launch whose K' is split per input block, not as a whole
   const bool is16 = bf16_ || x3m;   // the launch's operand format (an X3 launch: 16-bit operands inside an fp32 context)
   if (sentinel_on_ && p_in.out_act && !p_in.c_ld_rel && !x3m) {
     sentinel_on_ = false;   // (the launch itself, without recursion)
@@ -681,6 +681,14 @@ Status Engine::gemm(const GemmParams& p_in, hipStream_t st, double alg_flops, in
   // bit 11 (from the caller): W is K-tile-major
   p.flags = (p_in.flags & (512 | GEMM_FLAG_W_KTM | GEMM_FLAG_OUT_SPLIT3)) | (tail_split_ ? 0 : 2) | (alt16(cls) && !f32 ? 1024 : 0);
   if (p.tag) cls = SAMAUDIO_CLS_CODEC;
+  // an x3 launch on K-concatenated split operands: let the 8-phase kernels share the operand tiles the three products have in common
+  // (common.h GEMM_FLAG_X3_SHARE) wherever the launch qualifies; debug flag 38 = 1: the plain walk over K' (A/B, tests)
+  // mode 3 (the convolutions: every Cin-block of K' is its own [hi | lo | hi]) never qualifies
+  if (mode == 2 && debug_flag(38) != 1 && (debug_flag(38) < 2 || (cls & (debug_flag(38) >> 1)))) {   // (flag 38 >= 2: class mask << 1, diagnosis)
+    GemmParams q = p;
+    q.flags |= GEMM_FLAG_X3_SHARE;
+    if (q.kc == q.K && q.K % 192 == 0 && !gemm_check(q, true)) p = q;
+  }
   if (f32) {  // a class of SAMAUDIO_OPT_F32_CLASSES: exact-fp32 kernel inside a 16-bit context
     if (!p.W) return fail(SAMAUDIO_ERR_WEIGHT, "SAMAUDIO_OPT_F32_CLASSES: the class's \"<name>.f32\" weight copy is not registered");
     if (const char* why = gemm_check(p, false)) return fail(SAMAUDIO_ERR_ARG, why);
@@ -769,7 +777,7 @@ Status Engine::gemm_codec_x3(const GemmParams& p_in, const X3CodecW& w, hipStrea
   if (!p_in.out_f32) { p.out_f32 = raw; p.f32_ld = p_in.act_ld; p.f32_bstride = p_in.act_bstride; p.f32_off = p_in.act_off; }
   p.out_act = nullptr; p.act_ld = p.act_bstride = p.act_off = 0; p.act = ACT_NONE; p.f32_act = 0;
   const double flops = alg_flops >= 0 ? alg_flops : 2.0 * p_in.M * (double)p_in.N * p_in.K * p_in.nbatch;
-  SA_TRY(gemm(p, st, flops, SAMAUDIO_CLS_CODEC, 2));
+  SA_TRY(gemm(p, st, flops, SAMAUDIO_CLS_CODEC, p_in.K == c && p_in.kc == c ? 2 : 3));   // one block: [lo | hi | hi] x [W_hi | W_lo | W_hi] over the whole K'
   if (!p_in.out_act || (act == ACT_NONE && !p_in.out_f32)) return Status{};
   // region the launch wrote, per item: [c_lo, c_hi) of the windowed (transposed) convolutions, else M rows of N
   const long start = p_in.c_ld_rel ? p_in.c_lo : 0, count = p_in.c_ld_rel ? p_in.c_hi - p_in.c_lo : (long)p_in.M * p_in.N;
@@ -1055,7 +1063,7 @@ Status Engine::eval_field(const float* noisy, const float* time, int nt, float* 
     SA_TRY(op("split3", (double)prow * D * (4 + 6), 0, st, [&] { return launch_split3((const float*)d_.gnbuf, D, d_.x3a, prow, D, st); }));
     p.A = d_.x3a; p.W = W3; p.lda = 3L * D; p.kc = 3 * D; p.tap_stride = 3L * D; p.a_bstride = (long)(T + 2) * 3 * D; p.K = 9 * D;
     if (ktm3) p.flags |= GEMM_FLAG_W_KTM;
-    return gemm(p, st, 2.0 * T * (double)D * 3 * D * rows, SAMAUDIO_CLS_PATCH, 2);
+    return gemm(p, st, 2.0 * T * (double)D * 3 * D * rows, SAMAUDIO_CLS_PATCH, 3);
   };
   trace("cond", d_.cond, (size_t)M * D, false, st);
   trace("aligned", d_.aligned, (size_t)M * D, false, st);

@@ -603,6 +603,11 @@ const char* gemm_check(const GemmParams& p, bool is_bf16) {
     const int v = gemm_variant(p, is_bf16);
     if (v != 22 && v != 27) return "gemm: split3 output: the tile policy did not pick the 8-phase family for this launch";
   }
+  if (p.flags & GEMM_FLAG_X3_SHARE) {   // operand-sharing walk of K-concatenated split operands: the 8-phase family, plain launches
+    if (!is_bf16 || !gemm2_ok(p) || !gemm8_share_ok(p)) return "gemm: shared split operands (flags bit 15): plain 16-bit launches with K' = 3K, K % 64 == 0";
+    const int v = gemm_variant(p, is_bf16);
+    if (v != 22 && v != 27) return "gemm: shared split operands: the tile policy did not pick the 8-phase family for this launch";
+  }
   if (p.flags & GEMM_FLAG_W_KTM) {   // K-tile-major weights: only the 8-phase family addresses them
     if (!is_bf16 || !gemm2_ok(p) || p.w_bstride) return "gemm: K-tile-major W: plain 16-bit launches with one weight matrix only";
     const int v = gemm_variant(p, is_bf16);

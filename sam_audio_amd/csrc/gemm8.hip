@@ -963,6 +963,228 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
   }   // tiles of this workgroup
 }
 
+// gemm8x_kernel (round 6): gemm8_kernel for the K-CONCATENATED operands of the compensated mode (GemmParams.flags bit 15,
+// GEMM_FLAG_X3_SHARE: A rows [x_lo | x_hi | x_hi], W rows [W_hi | W_lo | W_hi], K' = 3K - common.h), aware that a third of what the plain
+// kernel stages is a copy.  Per 64 original k the plain kernel walks three K-tiles far apart in K' - (x_lo, W_hi), (x_hi, W_lo),
+// (x_hi, W_hi) - and stages six operand tiles; here the three products of one original k-tile run back to back in the order
+//     (x_lo, W_hi)   (x_hi, W_hi)   (x_hi, W_lo)
+// so that consecutive products share an operand tile that is already in LDS: FOUR staged tiles for the same 192 MFMAs per wave (a
+// third less DMA, LDS-write and L2 / HBM traffic; the third copies of both operands are never read).  The buffers have fixed roles -
+// A: x_lo in buffer 0, x_hi in buffer 1; W: W_hi in buffer 0, W_lo in buffer 1 - and every restaging keeps the distance to the last
+// read of its buffer that gemm8_kernel has (A: restaged in P1 / P2 of the tile after its last reader; W: in P3 / P4, behind the P2
+// reads of its last reader or later):
+//     product 0 of t:  reads A0 W0   stages x_hi(t) -> A1 (P1, P2), W_lo(t) -> W1 (P3, P4)        vmcnt(4): x_hi(t) landed
+//     product 1 of t:  reads A1 W0   stages x_lo(t+1) -> A0,        W_hi(t+1) -> W0                vmcnt(8): W_lo(t) landed
+//     product 2 of t:  reads A1 W1   stages nothing                                                vmcnt(0): x_lo / W_hi(t+1) landed
+// Same phases, barriers, stagger, priorities and epilogues as gemm8_kernel.  The accumulation order of an output element is
+// lo.hi, hi.hi, hi.lo per original k-tile; gemm8s_kernel walks the same order for such launches (its K-tile index map), so the tile
+// policy may still pick by row count without changing a bit.  Plain operands within 32-bit offsets only (no implicit convolutions).
+__global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const int tile_count) {
+  constexpr int BM = 256, BN = 256, HT = 128 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[4 * 2 * HT];   // [HA0, HA1, HB0, HB1][buffer] as gemm8_kernel
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int total = tile_count > 0 ? tile_count : ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.nbatch;
+  const WGeom wg_ = w_geom(p);
+  if (p.pf_ptr && (int)blockIdx.x >= total) {
+    prefetch_lines(p, (int)blockIdx.x - total, (int)gridDim.x - total, 512);
+    return;
+  }
+  const int T3 = p.K / 192;   // original K-tiles: K' = 3K, 64 k each
+  for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+  int b, tm, tn;
+  tile_of(p, BM, BN, xcd_run_pos_of(total, vb), b, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int r8 = lane >> 3;
+  unsigned a_off[2][2], w_off[2][2];
+  const bf16_t* const A0 = (const bf16_t*)p.A + p.a_off + (long)b * p.a_bstride;
+  const bf16_t* const W0 = (const bf16_t*)p.W + (long)b * p.w_bstride;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = wave * 16 + q * 8 + r8;
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int m = m0 + h * 128 + row;
+      m = m < p.M ? m : p.M - 1;
+      a_off[h][q] = (unsigned)(((long)m * p.lda + chunk * 8) * 2);
+      int n = n0 + h * 128 + row;
+      n = n < p.N ? n : p.N - 1;
+      w_off[h][q] = (unsigned)(((long)n * wg_.ns + chunk * 8) * 2);
+    }
+  }
+  const size_t lds0 = (size_t)(__attribute__((address_space(3))) char*)smem;
+  // K-tile `kt` of K' (64 elements = 128 bytes of an A row; wg_.kstep bytes of W) -> half-tile h of buffer `buf`
+  auto stage_a = [&](int h, int buf, int kt) {
+    const char* a_base = (const char*)A0 + (long)kt * 128;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16s(a_base, a_off[h][q], lds0 + (size_t)((h * 2 + buf) * HT + wave * 2048 + q * 1024));
+  };
+  auto stage_w = [&](int h, int buf, int kt) {
+    const char* w_base = (const char*)W0 + (long)kt * wg_.kstep;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16s(w_base, w_off[h][q], lds0 + (size_t)(((2 + h) * 2 + buf) * HT + wave * 2048 + q * 1024));
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t af[4][2];
+  bf16x8_t wf[2][2][2];
+  auto frag = [&](const char* half_base, int row, int ks) -> bf16x8_t {
+    return *(const bf16x8_t*)(half_base + row * 128 + ((((ks << 2) + lg) ^ ((row >> 1) & 7)) << 4));
+  };
+#define SA_G8X_READ_A(BUF, ASUB, KS)                                                                              \
+  do {                                                                                                            \
+    const char* base_ = smem + (wr * 2 + (BUF)) * HT;                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) af[i][KS] = frag(base_, (ASUB) * 64 + i * 16 + lr, KS);        \
+  } while (0)
+#define SA_G8X_READ_W(BUF, SUB, SET, KS)                                                                          \
+  do {                                                                                                            \
+    const char* base_ = smem + ((2 + (wc >> 1)) * 2 + (BUF)) * HT;                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      wf[SET][j][KS] = frag(base_, (wc & 1) * 64 + (SUB) * 32 + j * 16 + lr, KS);                                 \
+  } while (0)
+#define SA_G8X_MMA(ASUB, WSUB, SET, KS)                                                                           \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
+        acc[(ASUB) * 4 + i][(WSUB) * 2 + j] =                                                                     \
+            SA_MFMA_16x16x32(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                     \
+  } while (0)
+  // one product (a K-tile of 64): reads A buffer AB / W buffer WB; SA / SW: stage K-tile KA of A into buffer AD (P1, P2) / K-tile KW
+  // of W into buffer WD (P3, P4); WAITS = the s_waitcnt of P4 (text: the simulator reads the count).  RW false: the W fragments of
+  // the previous product are still in wf[][][] (both column halves, both k-steps) and are not read again.
+#define SA_G8X_TILE(AB, WB, RW, SA, AD, KA, SW, WD, KW, WAITS)                                                    \
+  do {                                                                                                            \
+    if (RW) SA_G8X_READ_W(WB, 0, 0, 0);                                                                           \
+    SA_G8X_READ_A(AB, 0, 0);                                                                                      \
+    if (RW) SA_G8X_READ_W(WB, 0, 0, 1);                                                                           \
+    SA_G8X_READ_A(AB, 0, 1);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (SA) stage_a(0, AD, KA);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(0, 0, 0, 0);                                                                                       \
+    SA_G8X_MMA(0, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    if (RW) {                                                                                                     \
+      SA_G8X_READ_W(WB, 1, 1, 0);                                                                                 \
+      SA_G8X_READ_W(WB, 1, 1, 1);                                                                                 \
+    }                                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (SA) stage_a(1, AD, KA);                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(0, 1, 1, 0);                                                                                       \
+    SA_G8X_MMA(0, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    SA_G8X_READ_A(AB, 1, 0);                                                                                      \
+    SA_G8X_READ_A(AB, 1, 1);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    if (SW) stage_w(0, WD, KW);                                                                                   \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(1, 1, 1, 0);                                                                                       \
+    SA_G8X_MMA(1, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    if (SW) stage_w(1, WD, KW);                                                                                   \
+    asm volatile(WAITS ::: "memory");                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(1, 0, 0, 0);                                                                                       \
+    SA_G8X_MMA(1, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+  } while (0)
+  // the product behind one that read the same A buffer: af[][] still holds that buffer's LOWER 64 rows of this wave (read in P3), so
+  // the quadrants run bottom first - (1,0) (1,1) (0,1) (0,0) - and only the upper rows are read again; all of W is new.  Stages
+  // nothing.  An output element belongs to one quadrant: its accumulation order does not depend on the order of the quadrants.
+#define SA_G8X_TILE_REV(AB, WB, WAITS)                                                                            \
+  do {                                                                                                            \
+    SA_G8X_READ_W(WB, 0, 0, 0);                                                                                   \
+    SA_G8X_READ_W(WB, 0, 0, 1);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(1, 0, 0, 0);                                                                                       \
+    SA_G8X_MMA(1, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    SA_G8X_READ_W(WB, 1, 1, 0);                                                                                   \
+    SA_G8X_READ_W(WB, 1, 1, 1);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(1, 1, 1, 0);                                                                                       \
+    SA_G8X_MMA(1, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    SA_G8X_READ_A(AB, 0, 0);                                                                                      \
+    SA_G8X_READ_A(AB, 0, 1);                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(0, 1, 1, 0);                                                                                       \
+    SA_G8X_MMA(0, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    asm volatile(WAITS ::: "memory");                                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                                \
+    SA_G8X_MMA(0, 0, 0, 0);                                                                                       \
+    SA_G8X_MMA(0, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+  } while (0)
+
+  // prologue: x_lo(0) and W_hi(0) complete
+  stage_w(0, 0, 0);
+  stage_w(1, 0, 0);
+  stage_a(0, 0, 0);
+  stage_a(1, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  int t = 0;
+  for (; t + 1 < T3; ++t) {   // the next original K-tile exists: no branch between fragment reads and MFMAs
+    SA_G8X_TILE(0, 0, true, true, 1, T3 + t, true, 1, T3 + t, "s_waitcnt vmcnt(4)");
+    SA_G8X_TILE(1, 0, false, true, 0, t + 1, true, 0, t + 1, "s_waitcnt vmcnt(8)");
+    SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
+  }
+  SA_G8X_TILE(0, 0, true, true, 1, T3 + t, true, 1, T3 + t, "s_waitcnt vmcnt(4)");
+  SA_G8X_TILE(1, 0, false, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
+  SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef SA_G8X_TILE_REV
+#undef SA_G8X_TILE
+#undef SA_G8X_MMA
+#undef SA_G8X_READ_W
+#undef SA_G8X_READ_A
+
+  if (p.flags & 64) {
+    epilogue8_linear<2>(p, acc, b, m0 + wr * 128, n0 + wc * 64, lane);
+  } else {
+    __syncthreads();
+    if (p.flags & 128) epilogue8_rows<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+    else epilogue8<2>(p, acc, smem + wave * 16384, b, m0 + wr * 128, n0 + wc * 64, lane);
+    if (vb + (int)gridDim.x < total) __syncthreads();
+  }
+  }   // tiles of this workgroup
+}
+
 // gemm8s: the SAME arithmetic as gemm8_kernel on a 128 x 128 tile - 16x16x32 MFMA with swapped operands, identical
 // fragment <-> k mapping, K walked in slabs of 64 with the two k-steps of a slab in the same order - so an output element
 // is accumulated bit for bit as the 256 x 256 kernel accumulates it.  The tile policy (gemm.hip gemm_variant) may
@@ -1076,10 +1298,20 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
   // lets the pipelined form's reads of K-tile t+1 really complete underneath the MFMAs of K-tile t
   // K-tile kt (CONV: the a_in / a_tap state points at it) -> stage buf: the A-tile loads QA0 <= q < QA1 and the W-tile loads q < QW1
   // of this wave's row block
+  // GEMM_FLAG_X3_SHARE (common.h): K-tile kt of the walk = product kt % 3 of original K-tile kt / 3, in gemm8x_kernel's order
+  // (x_lo, W_hi) (x_hi, W_hi) (x_hi, W_lo) - the same accumulation order per output element, whichever of the two kernels runs
+  const bool share = (p.flags & GEMM_FLAG_X3_SHARE) != 0;
+  const int T3 = p.K / 192;
   auto stage_q = [&](int buf, int kt, auto QA0, auto QA1, auto QW1) {
     const size_t dst = lds0 + (size_t)(buf * (2 * TB) + wave * 4096);
-    const char* a_base = (const char*)A0 + (long)kt * (BK * 2);
-    const char* w_base = (const char*)W0 + (long)kt * wg_.kstep;
+    int ka = kt, kw = kt;
+    if (share) {
+      const int t3 = kt / 3, r3 = kt - 3 * t3;
+      ka = r3 == 0 ? t3 : T3 + t3;
+      kw = r3 == 2 ? T3 + t3 : t3;
+    }
+    const char* a_base = (const char*)A0 + (long)ka * (BK * 2);
+    const char* w_base = (const char*)W0 + (long)kw * wg_.kstep;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (q < decltype(QA0)::value || q >= decltype(QA1)::value) continue;
@@ -1089,7 +1321,7 @@ __global__ __launch_bounds__(PROD >= 0 ? 512 : 256) void gemm8s_kernel(const Gem
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (q >= decltype(QW1)::value) continue;
-      if constexpr (CONV) dma16v((const char*)w_row[q] + (long)kt * wg_.kstep, dst + TB + q * 1024);
+      if constexpr (CONV) dma16v((const char*)w_row[q] + (long)kw * wg_.kstep, dst + TB + q * 1024);
       else dma16s(w_base, w_off[q], dst + TB + q * 1024);
     }
     if constexpr (CONV) {
@@ -1322,6 +1554,11 @@ static void launch_gemm8s_grid(const GemmParams& p, bool pipe, bool conv, dim3 g
 bool gemm8_split3_ok(const GemmParams& p) {
   return !(p.flags & GEMM_FLAG_OUT_SPLIT3) || (p.swiglu && p.out_act && gemm8_linear_epilogue(p) == 64);
 }
+// flags bit 15 is well-formed: plain operands within 32-bit offsets (no implicit convolution), K' = 3K with K a multiple of 64, the
+// library's own operand format
+bool gemm8_share_ok(const GemmParams& p) {
+  return !(p.flags & GEMM_FLAG_X3_SHARE) || (!gemm8_wide(p) && !(p.flags & 1024) && p.K % 192 == 0 && p.kc == p.K);
+}
 // flags bits 9 / 10 are well-formed for this launch: plain operands within 32-bit offsets, a lean epilogue for an alt-format output
 bool gemm8_alt_ok(const GemmParams& p) {
   if (!(p.flags & (512 | 1024))) return true;
@@ -1363,7 +1600,8 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   // the other group's launch after every tile.
   if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
   if (p.pf_ptr && p.pf_bytes > 0 && tile_count == 0 && grid.x < 256) grid.x = 256;   // idle CUs warm the next launch's weights
-  if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
+  if ((p.flags & GEMM_FLAG_X3_SHARE) && !gemm8_wide(p) && !(p.flags & 1024)) hipLaunchKernelGGL(gemm8x_kernel, grid, block, 0, st, p, tile_count);
+  else if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (p.flags & 1024) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, tile_count);   // alt-format operands
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
 }

@@ -29,6 +29,7 @@ hipError_t launch_poison_lds(hipStream_t st);
 //            one launch in front of the layer loop) - its bitwise test
 //   flag 35: (A/B) M-tiles per raster group of the 8-phase family (0 = shipped: 8; GemmParams.raster_gm)
 //   flag 36: 1 = (A/B, tests) split-weight launches of the fp32 kernel (GEMM_FLAG_W_FLY16) on the tiles of gemm1_variant instead of fly_variant's
+//   flag 38: 1 = x3 launches walk K' = 3K as a plain GEMM (shipped: the operand-sharing order of GEMM_FLAG_X3_SHARE) - A/B, bitwise tests
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);
@@ -55,6 +56,7 @@ bool gemm2_ok(const GemmParams& p);
 hipError_t launch_gemm2(const GemmParams& p, int variant, hipStream_t st);
 // gemm8.hip: 256x256 8-phase kernel (variant 22); needs gemm2_ok(p)
 hipError_t launch_gemm8(const GemmParams& p, hipStream_t st);
+bool gemm8_share_ok(const GemmParams& p);   // GemmParams.flags bit 15 is well-formed for this launch (gemm8.hip)
 // gemm8.hip: 128x128 tile with gemm8's arithmetic (bitwise identical results), two workgroups per CU; needs gemm2_ok(p)
 hipError_t launch_gemm8s(const GemmParams& p, hipStream_t st);
 // gemm8.hip: GemmParams.flags bits 9 / 10 (mixed mode: out_act written / operands read in the alt 16-bit format) are well-formed;

@@ -307,3 +307,39 @@ def test_x3_holds_the_bound_on_hostile_weights_where_fp16_does_not(gpu):
     wav = max((a.cpu() - b).abs().max().item() for a, b in zip(res.target + res.residual, t_ref + r_ref))
     print(f"hostile {size} fp16x3: latent max-abs err {lat:.3e} (|ref| <= {lat_ref.abs().max():.2f}), waveform {wav:.3e}")
     assert lat <= 1e-3 and wav <= 1e-3
+
+
+@pytest.mark.parametrize("prec", X3)
+@pytest.mark.parametrize("shape", [(300, 256, 128), (130, 512, 448), (520, 768, 64)])
+def test_x3_gemm_sharing_the_operand_tiles(gpu, prec, shape):
+    """GemmParams.flags bit 15 (common.h GEMM_FLAG_X3_SHARE): the 8-phase kernels walk the K-concatenated split operands product by
+    product per original K-tile - (x_lo, W_hi) (x_hi, W_hi) (x_hi, W_lo) - sharing the operand tiles two consecutive products have in
+    common (gemm8x_kernel), the 128 x 128 kernel in the same order through its K-tile index map: the fp32 product as before, and THE
+    SAME BITS from both tile sizes (the tile policy picks by row count: batch-sharding invariance), in both weight layouts."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, K, generator=g) * torch.logspace(-2, 1, K)[None, :]
+    w = torch.randn(N, K, generator=g) * 0.05
+    ref = (x.double() @ w.double().T).float()
+    half = HALF[prec]
+    a3 = _split3(x, prec, gpu)
+    lib = hip.lib(hip.operands_for(prec))
+    outs = {}
+    try:
+        for ktm in (False, True):
+            w3 = x3_weight(w, half, ktm=ktm).to(gpu)
+            for variant in (22, 27):
+                for share in (0, 32768):
+                    lib.samaudio_debug_force_gemm_variant(variant)
+                    out = torch.full((M, N), float("nan"), device=gpu)
+                    util.gemm(PLAIN[prec], a3, w3, M, N, 3 * K, out_f32=out, f32_geom=(0, N, 0), flags=(2048 if ktm else 0) | share)
+                    outs[(ktm, variant, share)] = out.cpu()
+    finally:
+        lib.samaudio_debug_force_gemm_variant(-1)
+    plain = outs[(False, 22, 0)]
+    shared = outs[(False, 22, 32768)]
+    e_plain, e_shared = (plain - ref).abs().max().item(), (shared - ref).abs().max().item()
+    print(f"x3 GEMM {prec} {shape}: max-abs err plain walk {e_plain:.3e}, shared operand tiles {e_shared:.3e}; |ref| <= {ref.abs().max():.2f}")
+    for key, o in outs.items():
+        assert torch.equal(o, shared if key[2] else plain), f"{key}: the order of a walk does not depend on tile size or weight layout"
+    assert e_shared <= 2 * e_plain + 1e-6 * ref.abs().max().item()

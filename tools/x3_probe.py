@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Times the K' = 3K launches of the fp16x3 mode on the real DiT shapes, plain walk against the operand-sharing walk
+(GemmParams.flags bit 15, gemm8.hip gemm8x_kernel / gemm8s_kernel's index map).  usage: [PROBE_ROWS=4000] python tools/x3_probe.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from sam_audio_amd import hip  # noqa: E402
+from sam_audio_amd.config import preset_config  # noqa: E402
+from tests import util  # noqa: E402
+
+t = preset_config("large*").transformer
+D, Fh = t.dim, t.ffn_hidden
+dev = torch.device("cuda:0")
+for M in [int(r) for r in os.environ.get("PROBE_ROWS", "4000,500").split(",")]:
+    shapes = {"qkv": (M, 3 * D, D), "wo": (M, D, D), "w13": (M, 2 * Fh, D), "w2": (M, D, Fh)}
+    for name, (m, n, k) in shapes.items():
+        k3 = 3 * k
+        A = torch.randn(m, k3, device=dev).to(torch.float16)
+        W = (torch.randn(n, k3, device=dev) / k3 ** 0.5).to(torch.float16)
+        out = torch.empty(m, n, device=dev, dtype=torch.float32)
+        line = f"M={m} {name} N={n} K'={k3}:"
+        for flags in (0, 32768):
+            if k % 64:
+                continue
+            for _ in range(2):
+                util.gemm("fp16", A, W, m, n, k3, out_f32=out, f32_geom=(0, n, 0), flags=flags)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                util.gemm("fp16", A, W, m, n, k3, out_f32=out, f32_geom=(0, n, 0), flags=flags)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 100
+            line += f"  {'shared' if flags else 'plain'} {us:8.1f} us {2.0 * m * n * k3 / us / 1e6:7.1f} TF/s(mfma)"
+        print(line, flush=True)
