@@ -23,6 +23,7 @@ for M in [int(r) for r in os.environ.get("PROBE_ROWS", "4000,500").split(",")]:
         W = (torch.randn(n, k3, device=dev) / k3 ** 0.5).to(torch.float16)
         out = torch.empty(m, n, device=dev, dtype=torch.float32)
         line = f"M={m} {name} N={n} K'={k3}:"
+        keep = {}
         for flags in (0, 32768):
             if k % 64:
                 continue
@@ -36,5 +37,8 @@ for M in [int(r) for r in os.environ.get("PROBE_ROWS", "4000,500").split(",")]:
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100
+            keep[flags] = out.clone()
             line += f"  {'shared' if flags else 'plain'} {us:8.1f} us {2.0 * m * n * k3 / us / 1e6:7.1f} TF/s(mfma)"
+        if len(keep) == 2:   # another order of the same sum: fp32 rounding apart (a race or a missed wait shows as O(1))
+            line += f"  |shared - plain| <= {(keep[0] - keep[32768]).abs().max().item():.2e} (|out| <= {keep[0].abs().max().item():.1f})"
         print(line, flush=True)
