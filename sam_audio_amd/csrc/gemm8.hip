@@ -979,10 +979,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // Same phases, barriers, stagger, priorities and epilogues as gemm8_kernel.  The accumulation order of an output element is
 // lo.hi, hi.hi, hi.lo per original k-tile; gemm8s_kernel walks the same order for such launches (its K-tile index map), so the tile
 // policy may still pick by row count without changing a bit.  Plain operands within 32-bit offsets only (no implicit convolutions).
-// RS: fragments two consecutive products have in common stay in registers (false = A/B, debug flag 39).  PH2 (needs RS): a product runs as
-// TWO phases of 32 MFMAs per wave instead of four of 16 - half the barriers per MFMA; the operand buffers keep their distances: a
-// half-tile is restaged only once its reader group has consumed its last fragments of it in MFMAs (see SA_G8X_TILE2)
-template <bool RS, bool PH2>
+// RS: fragments two consecutive products have in common stay in registers (false = A/B, debug flag 39).  A two-phase form of the products
+// (32 MFMAs per wave and phase, half the barriers) was built and measured in round 6: no gain on the timed step (profiles/r6_call23).
+template <bool RS>
 __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, HT = 128 * 128;
   __shared__ __attribute__((aligned(16))) char smem[4 * 2 * HT];   // [HA0, HA1, HB0, HB1][buffer] as gemm8_kernel
@@ -1153,85 +1152,6 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
     __builtin_amdgcn_s_barrier();                                                                                 \
   } while (0)
 
-  // two-phase forms.  Phase A: the upper 64 rows of the wave against all 64 columns, phase B the lower rows; the product's vmcnt wait sits in
-  // front of phase B's FIRST barrier: group 0 leaves the product's last barrier when group 1 leaves that one, i.e. has waited for its share
-  // of the half-tiles group 0 reads next (behind the MFMAs of phase B it would not have: the simulator's late-DMA mode shows it).  STA / STB: what phase A / B stage, as statements.
-  // Restaging and its readers (group g = waves with wr == g read A half-tile g; group 1 runs one barrier behind group 0, so when
-  // group 0 is in phase A of a product, group 1 is in the MFMAs of phase B of the product before it and has consumed every fragment
-  // it read there): product 0 stages x_hi(t) -> A buffer 1 (A) and W_lo(t) -> W buffer 1 (B), both last read in product 2 of t - 1;
-  // product 1 stages W_hi(t+1) -> W buffer 0 (last read in phase A of product 0) and half-tile 0 of x_lo(t+1) -> A buffer 0 (read by
-  // group 0 only, consumed) in phase A, half-tile 1 of it (group 1's, last read in its phase B of product 0, consumed once group 0
-  // is in phase B of product 1) in phase B.  DMA issue order per wave = the four-phase form's: the same vmcnt counts.
-#define SA_G8X_TILE2(AB, WB, RW, STA, STB, WAITS)                                                                 \
-  do {                                                                                                            \
-    if (RW) {                                                                                                     \
-      SA_G8X_READ_W(WB, 0, 0, 0);                                                                                 \
-      SA_G8X_READ_W(WB, 0, 0, 1);                                                                                 \
-    }                                                                                                             \
-    SA_G8X_READ_A(AB, 0, 0);                                                                                      \
-    SA_G8X_READ_A(AB, 0, 1);                                                                                      \
-    if (RW) {                                                                                                     \
-      SA_G8X_READ_W(WB, 1, 1, 0);                                                                                 \
-      SA_G8X_READ_W(WB, 1, 1, 1);                                                                                 \
-    }                                                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    STA;                                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
-    SA_G8X_MMA(0, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA(0, 0, 0, 1);                                                                                       \
-    SA_G8X_MMA(0, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA(0, 1, 1, 1);                                                                                       \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-    SA_G8X_READ_A(AB, 1, 0);                                                                                      \
-    SA_G8X_READ_A(AB, 1, 1);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    STB;                                                                                                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
-    asm volatile(WAITS ::: "memory");                                                                             \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
-    SA_G8X_MMA(1, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA(1, 1, 1, 1);                                                                                       \
-    SA_G8X_MMA(1, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA(1, 0, 0, 1);                                                                                       \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-  } while (0)
-  // the product behind one that read the same A buffer (af[][] holds its lower rows): lower rows first, all of W new, stages nothing
-#define SA_G8X_TILE2_REV(AB, WB, WAITS)                                                                           \
-  do {                                                                                                            \
-    SA_G8X_READ_W(WB, 0, 0, 0);                                                                                   \
-    SA_G8X_READ_W(WB, 0, 0, 1);                                                                                   \
-    SA_G8X_READ_W(WB, 1, 1, 0);                                                                                   \
-    SA_G8X_READ_W(WB, 1, 1, 1);                                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
-    SA_G8X_MMA(1, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA(1, 0, 0, 1);                                                                                       \
-    SA_G8X_MMA(1, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA(1, 1, 1, 1);                                                                                       \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-    SA_G8X_READ_A(AB, 0, 0);                                                                                      \
-    SA_G8X_READ_A(AB, 0, 1);                                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
-    asm volatile(WAITS ::: "memory");                                                                             \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-    __builtin_amdgcn_s_setprio(1);                                                                                \
-    SA_G8X_MMA(0, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA(0, 1, 1, 1);                                                                                       \
-    SA_G8X_MMA(0, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA(0, 0, 0, 1);                                                                                       \
-    __builtin_amdgcn_s_setprio(0);                                                                                \
-    __builtin_amdgcn_s_barrier();                                                                                 \
-  } while (0)
-
   // prologue: x_lo(0) and W_hi(0) complete
   stage_w(0, 0, 0);
   stage_w(1, 0, 0);
@@ -1242,17 +1162,6 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
   if (wr == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
   __builtin_amdgcn_s_waitcnt(0xC07F);
   int t = 0;
-  if constexpr (PH2) {
-    static_assert(RS || !PH2, "the two-phase form keeps the shared fragments in registers");
-    for (; t + 1 < T3; ++t) {
-      SA_G8X_TILE2(0, 0, true, (stage_a(0, 1, T3 + t), stage_a(1, 1, T3 + t)), (stage_w(0, 1, T3 + t), stage_w(1, 1, T3 + t)), "s_waitcnt vmcnt(4)");
-      SA_G8X_TILE2(1, 0, false, (stage_w(0, 0, t + 1), stage_w(1, 0, t + 1), stage_a(0, 0, t + 1)), stage_a(1, 0, t + 1), "s_waitcnt vmcnt(8)");
-      SA_G8X_TILE2_REV(1, 1, "s_waitcnt vmcnt(0)");
-    }
-    SA_G8X_TILE2(0, 0, true, (stage_a(0, 1, T3 + t), stage_a(1, 1, T3 + t)), (stage_w(0, 1, T3 + t), stage_w(1, 1, T3 + t)), "s_waitcnt vmcnt(4)");
-    SA_G8X_TILE2(1, 0, false, (void)0, (void)0, "s_waitcnt vmcnt(0)");
-    SA_G8X_TILE2_REV(1, 1, "s_waitcnt vmcnt(0)");
-  } else {
   for (; t + 1 < T3; ++t) {   // the next original K-tile exists: no branch between fragment reads and MFMAs
     SA_G8X_TILE(0, 0, true, true, 1, T3 + t, true, 1, T3 + t, "s_waitcnt vmcnt(4)");
     SA_G8X_TILE(1, 0, !RS, true, 0, t + 1, true, 0, t + 1, "s_waitcnt vmcnt(8)");
@@ -1263,10 +1172,7 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
   SA_G8X_TILE(1, 0, !RS, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
   if constexpr (RS) SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
   else SA_G8X_TILE(1, 1, true, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
-  }
   if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef SA_G8X_TILE2_REV
-#undef SA_G8X_TILE2
 #undef SA_G8X_TILE_REV
 #undef SA_G8X_TILE
 #undef SA_G8X_MMA
@@ -1700,9 +1606,8 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
   if (p.pf_ptr && p.pf_bytes > 0 && tile_count == 0 && grid.x < 256) grid.x = 256;   // idle CUs warm the next launch's weights
   if ((p.flags & GEMM_FLAG_X3_SHARE) && !gemm8_wide(p) && !(p.flags & 1024)) {
-    if (debug_flag(39) == 1) hipLaunchKernelGGL((gemm8x_kernel<false, false>), grid, block, 0, st, p, tile_count);
-    else if (debug_flag(39) == 3) hipLaunchKernelGGL((gemm8x_kernel<true, true>), grid, block, 0, st, p, tile_count);
-    else hipLaunchKernelGGL((gemm8x_kernel<true, false>), grid, block, 0, st, p, tile_count);
+    if (debug_flag(39) == 1) hipLaunchKernelGGL((gemm8x_kernel<false>), grid, block, 0, st, p, tile_count);
+    else hipLaunchKernelGGL((gemm8x_kernel<true>), grid, block, 0, st, p, tile_count);
   }
   else if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (p.flags & 1024) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, tile_count);   // alt-format operands

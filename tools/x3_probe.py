@@ -19,8 +19,11 @@ for M in [int(r) for r in os.environ.get("PROBE_ROWS", "4000,500").split(",")]:
     shapes = {"qkv": (M, 3 * D, D), "wo": (M, D, D), "w13": (M, 2 * Fh, D), "w2": (M, D, Fh)}
     for name, (m, n, k) in shapes.items():
         k3 = 3 * k
-        A = torch.randn(m, k3, device=dev).to(torch.float16)
-        W = (torch.randn(n, k3, device=dev) / k3 ** 0.5).to(torch.float16)
+        x, w = torch.randn(m, k, device=dev), torch.randn(n, k, device=dev) / k ** 0.5   # the split forms of sam_audio_amd.weights.x3_weight
+        xh, wh = x.half(), w.half()
+        A = torch.cat([(x - xh.float()).half(), xh, xh], dim=1).contiguous()
+        W = torch.cat([wh, (w - wh.float()).half(), wh], dim=1).contiguous()
+        del x, w, xh, wh
         out = torch.empty(m, n, device=dev, dtype=torch.float32)
         line = f"M={m} {name} N={n} K'={k3}:"
         keep = {}
