@@ -588,6 +588,8 @@ SYMBOLS = {
                                                                    # bf16-operand instantiation of the mixed mode)
     "gemm8_bf16_256x256_8phase_conv": "sa::gemm8_kernel<true",     # implicit convolutions (patcher, wide codec stages)
     "gemm8s_bf16_128x128": "sa::gemm8s_kernel<",
+    # the K' = 3K launches of the compensated mode on K-concatenated operands: the operand-sharing kernel (common.h GEMM_FLAG_X3_SHARE)
+    "gemm8_bf16_256x256_8phase_x3": "sa::gemm8x_kernel",
 }
 
 
@@ -604,10 +606,11 @@ def traffic_of(kernel: str, split: bool = False):
         # launches over K' = 3K have their own PMC passes (profiles/r6_traffic_x3.json): never mixed with the one-product figures
         if name.endswith("_x3") != fname.startswith("r6_traffic_x3"):
             continue
-        if name.endswith("_x3"):
-            name = name[:-3]
         key = SYMBOLS.get(name, "")
         hit = [v for k, v in table.items() if key and k.startswith(key)]
+        if not hit and name.endswith("_x3"):   # (the convolutions and every x3 launch of a table older than gemm8x_kernel: gemm8_kernel itself)
+            key = SYMBOLS.get(name[:-3], "")
+            hit = [v for k, v in table.items() if key and k.startswith(key)]
         if hit:   # several instantiations of the symbol: the one with the most launches is the one the roofline is about
             best = max(hit, key=lambda v: v.get("launches", 0))
             return round(best["traffic_bytes_per_launch"]), f"HBM bytes per launch, rocprofv3 PMC passes (profiles/{fname})"

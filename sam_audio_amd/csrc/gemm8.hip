@@ -979,9 +979,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // Same phases, barriers, stagger, priorities and epilogues as gemm8_kernel.  The accumulation order of an output element is
 // lo.hi, hi.hi, hi.lo per original k-tile; gemm8s_kernel walks the same order for such launches (its K-tile index map), so the tile
 // policy may still pick by row count without changing a bit.  Plain operands within 32-bit offsets only (no implicit convolutions).
-// RS: fragments two consecutive products have in common stay in registers (false = A/B, debug flag 39).  A two-phase form of the products
-// (32 MFMAs per wave and phase, half the barriers) was built and measured in round 6: no gain on the timed step (profiles/r6_call23).
-template <bool RS>
+// Fragments two consecutive products have in common stay in registers (A/B against reading every fragment of every product from LDS:
+// +2-3 % per launch, profiles/r6_call22).  A two-phase form of the products (32 MFMAs per wave and phase, half the barriers) was built
+// and measured in round 6: no gain on the timed step (profiles/r6_call23).
 __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, HT = 128 * 128;
   __shared__ __attribute__((aligned(16))) char smem[4 * 2 * HT];   // [HA0, HA1, HB0, HB1][buffer] as gemm8_kernel
@@ -1164,14 +1164,12 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
   int t = 0;
   for (; t + 1 < T3; ++t) {   // the next original K-tile exists: no branch between fragment reads and MFMAs
     SA_G8X_TILE(0, 0, true, true, 1, T3 + t, true, 1, T3 + t, "s_waitcnt vmcnt(4)");
-    SA_G8X_TILE(1, 0, !RS, true, 0, t + 1, true, 0, t + 1, "s_waitcnt vmcnt(8)");
-    if constexpr (RS) SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
-    else SA_G8X_TILE(1, 1, true, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
+    SA_G8X_TILE(1, 0, false, true, 0, t + 1, true, 0, t + 1, "s_waitcnt vmcnt(8)");
+    SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
   }
   SA_G8X_TILE(0, 0, true, true, 1, T3 + t, true, 1, T3 + t, "s_waitcnt vmcnt(4)");
-  SA_G8X_TILE(1, 0, !RS, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
-  if constexpr (RS) SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
-  else SA_G8X_TILE(1, 1, true, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
+  SA_G8X_TILE(1, 0, false, false, 0, 0, false, 0, 0, "s_waitcnt vmcnt(0)");
+  SA_G8X_TILE_REV(1, 1, "s_waitcnt vmcnt(0)");
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef SA_G8X_TILE_REV
 #undef SA_G8X_TILE
@@ -1605,10 +1603,7 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   // the other group's launch after every tile.
   if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
   if (p.pf_ptr && p.pf_bytes > 0 && tile_count == 0 && grid.x < 256) grid.x = 256;   // idle CUs warm the next launch's weights
-  if ((p.flags & GEMM_FLAG_X3_SHARE) && !gemm8_wide(p) && !(p.flags & 1024)) {
-    if (debug_flag(39) == 1) hipLaunchKernelGGL((gemm8x_kernel<false>), grid, block, 0, st, p, tile_count);
-    else hipLaunchKernelGGL((gemm8x_kernel<true>), grid, block, 0, st, p, tile_count);
-  }
+  if ((p.flags & GEMM_FLAG_X3_SHARE) && !gemm8_wide(p) && !(p.flags & 1024)) hipLaunchKernelGGL(gemm8x_kernel, grid, block, 0, st, p, tile_count);
   else if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (p.flags & 1024) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, tile_count);   // alt-format operands
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);

@@ -30,7 +30,6 @@ hipError_t launch_poison_lds(hipStream_t st);
 //   flag 35: (A/B) M-tiles per raster group of the 8-phase family (0 = shipped: 8; GemmParams.raster_gm)
 //   flag 36: 1 = (A/B, tests) split-weight launches of the fp32 kernel (GEMM_FLAG_W_FLY16) on the tiles of gemm1_variant instead of fly_variant's
 //   flag 38: 1 = x3 launches walk K' = 3K as a plain GEMM (shipped: the operand-sharing order of GEMM_FLAG_X3_SHARE) - A/B, bitwise tests
-//   flag 39: 1 = (A/B) gemm8x_kernel reads every fragment of every product from LDS (shipped: the fragments two consecutive products share stay in registers)
 //   flag 30: (A/B) number of 256x256 tiles from which the policy uses gemm8 instead of gemm8s (0 = shipped: 128)
 //   flag 25: only in the ablation build (tools/build_abl.sh): selects an ablation of the round-3 8-phase loop
 void set_debug_flag(int flag, int value);

@@ -110,7 +110,7 @@ def test_gemm8_k_loops_are_free_of_scratch_traffic(gemm8_asm):
     kernels, spills = gemm8_asm
     seen = 0
     for name, lines in kernels.items():
-        if "gemm8_kernel" not in name and "gemm8s_kernel" not in name:
+        if "gemm8_kernel" not in name and "gemm8s_kernel" not in name and "gemm8x_kernel" not in name:   # (gemm8x: the x3 mode's dominant kernel)
             continue
         mfma = [i for i, t in enumerate(lines) if t.startswith("v_mfma")]
         assert mfma, name
@@ -119,9 +119,9 @@ def test_gemm8_k_loops_are_free_of_scratch_traffic(gemm8_asm):
         bad = [t for t in region if t.startswith("scratch_") or t.startswith("buffer_load") or t.startswith("buffer_store")]
         assert not bad, f"{name}: {len(bad)} scratch / buffer operations between the first and the last MFMA, e.g. {bad[:3]}"
         # the pipelined / plain 128x128 forms must not spill at all; the 256x256 kernel's prologue / epilogue spills are tracked
-        limit = 96 if "gemm8_kernel" in name else 0
+        limit = 96 if ("gemm8_kernel" in name or "gemm8x_kernel" in name) else 0
         assert spills.get(name, 0) <= limit, f"{name}: vgpr_spill_count {spills.get(name)} > {limit}"
-    assert seen >= 6
+    assert seen >= 8 and any("gemm8x_kernel" in n for n in kernels)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
