@@ -981,7 +981,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // policy may still pick by row count without changing a bit.  Plain operands within 32-bit offsets only (no implicit convolutions).
 // Fragments two consecutive products have in common stay in registers (A/B against reading every fragment of every product from LDS:
 // +2-3 % per launch, profiles/r6_call22).  A two-phase form of the products (32 MFMAs per wave and phase, half the barriers) was built
-// and measured in round 6: no gain on the timed step (profiles/r6_call23).
+// and measured in round 6: no gain on the timed step (profiles/r6_call23); so was requesting x_hi a phase and a half earlier (4 - 5
+// phases in front of its vmcnt(4) instead of 2 - 3; profiles/r6_call24: no gain) - the loop does not wait for its loads.
 __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, HT = 128 * 128;
   __shared__ __attribute__((aligned(16))) char smem[4 * 2 * HT];   // [HA0, HA1, HB0, HB1][buffer] as gemm8_kernel

@@ -25,6 +25,8 @@ for spec in (sys.argv[1:] or ["22:w13", "22:c_wq", "22:qkv", "22:w2"]):
     W = (torch.randn(n, k, device=dev) / k ** 0.5).to(torch.bfloat16)
     out = torch.empty(m, n // 2 if sw else n, device=dev, dtype=torch.bfloat16)
     hip.lib().samaudio_debug_force_gemm_variant(int(v))
+    # PROBE_FLAGS=32768 with PROBE_KMUL=3: the operand-sharing walk of the headline mode (GemmParams.flags bit 15: gemm8x_kernel; random
+    # operands are fine for counters - the walk reads the first two thirds of every row)
     for _ in range(3):
-        util.gemm("bf16", A, W, m, n, k, swiglu=sw, out_act=out, act_geom=(0, out.shape[1], 0))
+        util.gemm("bf16", A, W, m, n, k, swiglu=sw, out_act=out, act_geom=(0, out.shape[1], 0), flags=int(os.environ.get("PROBE_FLAGS", "0")))
     torch.cuda.synchronize()
