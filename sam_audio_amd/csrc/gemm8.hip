@@ -982,8 +982,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const GemmParams p, const in
 // Fragments two consecutive products have in common stay in registers (A/B against reading every fragment of every product from LDS:
 // +2-3 % per launch, profiles/r6_call22).  A two-phase form of the products (32 MFMAs per wave and phase, half the barriers) was built
 // and measured in round 6: no gain on the timed step (profiles/r6_call23); so was requesting x_hi a phase and a half earlier (4 - 5
-// phases in front of its vmcnt(4) instead of 2 - 3; profiles/r6_call24: no gain) - the loop does not wait for its loads.
-template <int TAIL>   // MFMAs of a phase issued behind its closing barrier (SA_G8X_MMA_PART; A/B: debug flag 39 = TAIL)
+// phases in front of its vmcnt(4) instead of 2 - 3; profiles/r6_call24: no gain) - the loop does not wait for its loads - and issuing the
+// last 2 / 4 MFMAs of a phase behind its closing barrier (the wave arrives early, the other group's MFMAs queue behind its own:
+// profiles/r6_call25, 5 % SLOWER - the strict alternation of the two groups is what the loop lives on).
 __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const int tile_count) {
   constexpr int BM = 256, BN = 256, HT = 128 * 128;
   __shared__ __attribute__((aligned(16))) char smem[4 * 2 * HT];   // [HA0, HA1, HB0, HB1][buffer] as gemm8_kernel
@@ -1063,17 +1064,6 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
         acc[(ASUB) * 4 + i][(WSUB) * 2 + j] =                                                                     \
             SA_MFMA_16x16x32(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                     \
   } while (0)
-  // MFMAs n = j * 4 + i in [LO, HI) of SA_G8X_MMA: TAIL > 0 issues the last TAIL MFMAs of a phase BEHIND the phase's closing barrier - the
-  // wave arrives at the barrier while its last MFMAs are still to run, the other group's first MFMAs queue behind them instead of behind
-  // the barrier's release.  MFMAs touch registers only: every LDS read and DMA keeps its side of every barrier.
-#define SA_G8X_MMA_PART(ASUB, WSUB, SET, KS, LO, HI)                                                              \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                               \
-        if (j * 4 + i >= (LO) && j * 4 + i < (HI))                                                                \
-          acc[(ASUB) * 4 + i][(WSUB) * 2 + j] =                                                                   \
-              SA_MFMA_16x16x32(wf[SET][j][KS], af[i][KS], acc[(ASUB) * 4 + i][(WSUB) * 2 + j]);                   \
-  } while (0)
   // one product (a K-tile of 64): reads A buffer AB / W buffer WB; SA / SW: stage K-tile KA of A into buffer AD (P1, P2) / K-tile KW
   // of W into buffer WD (P3, P4); WAITS = the s_waitcnt of P4 (text: the simulator reads the count).  RW false: the W fragments of
   // the previous product are still in wf[][][] (both column halves, both k-steps) and are not read again.
@@ -1088,13 +1078,9 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(0, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA_PART(0, 0, 0, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(0, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(0, 0, 0, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
     if (RW) {                                                                                                     \
       SA_G8X_READ_W(WB, 1, 1, 0);                                                                                 \
       SA_G8X_READ_W(WB, 1, 1, 1);                                                                                 \
@@ -1105,13 +1091,9 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(0, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA_PART(0, 1, 1, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(0, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(0, 1, 1, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
     SA_G8X_READ_A(AB, 1, 0);                                                                                      \
     SA_G8X_READ_A(AB, 1, 1);                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
@@ -1119,25 +1101,17 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(1, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA_PART(1, 1, 1, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(1, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(1, 1, 1, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
     if (SW) stage_w(1, WD, KW);                                                                                   \
     asm volatile(WAITS ::: "memory");                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(1, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA_PART(1, 0, 0, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(1, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(1, 0, 0, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
   // the product behind one that read the same A buffer: af[][] still holds that buffer's LOWER 64 rows of this wave (read in P3), so
   // the quadrants run bottom first - (1,0) (1,1) (0,1) (0,0) - and only the upper rows are read again; all of W is new.  Stages
@@ -1150,13 +1124,9 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(1, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA_PART(1, 0, 0, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(1, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(1, 0, 0, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
     SA_G8X_READ_W(WB, 1, 1, 0);                                                                                   \
     SA_G8X_READ_W(WB, 1, 1, 1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
@@ -1164,37 +1134,25 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(1, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA_PART(1, 1, 1, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(1, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(1, 1, 1, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
     SA_G8X_READ_A(AB, 0, 0);                                                                                      \
     SA_G8X_READ_A(AB, 0, 1);                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                            \
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(0, 1, 1, 0);                                                                                       \
-    SA_G8X_MMA_PART(0, 1, 1, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(0, 1, 1, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(0, 1, 1, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
     asm volatile(WAITS ::: "memory");                                                                             \
     __builtin_amdgcn_s_barrier();                                                                                 \
     __builtin_amdgcn_s_setprio(1);                                                                                \
     SA_G8X_MMA(0, 0, 0, 0);                                                                                       \
-    SA_G8X_MMA_PART(0, 0, 0, 1, 0, 8 - TAIL);                                                                     \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    if (!TAIL) __builtin_amdgcn_s_setprio(0);                                                                     \
+    SA_G8X_MMA(0, 0, 0, 1);                                                                                       \
+    __builtin_amdgcn_s_setprio(0);                                                                                \
     __builtin_amdgcn_s_barrier();                                                                                 \
-    if (TAIL) __builtin_amdgcn_sched_barrier(0);                                                                  \
-    SA_G8X_MMA_PART(0, 0, 0, 1, 8 - TAIL, 8);                                                                     \
-    if (TAIL) __builtin_amdgcn_s_setprio(0);                                                                      \
   } while (0)
 
   // prologue: x_lo(0) and W_hi(0) complete
@@ -1218,7 +1176,6 @@ __global__ __launch_bounds__(512) void gemm8x_kernel(const GemmParams p, const i
   if (wr == 0) __builtin_amdgcn_s_barrier();
 #undef SA_G8X_TILE_REV
 #undef SA_G8X_TILE
-#undef SA_G8X_MMA_PART
 #undef SA_G8X_MMA
 #undef SA_G8X_READ_W
 #undef SA_G8X_READ_A
@@ -1649,11 +1606,7 @@ static void launch_gemm8_tiles(const GemmParams& p, dim3 grid, int tile_count, h
   // the other group's launch after every tile.
   if (debug_flag(26) != 1 && grid.x > 256) grid.x = 256;
   if (p.pf_ptr && p.pf_bytes > 0 && tile_count == 0 && grid.x < 256) grid.x = 256;   // idle CUs warm the next launch's weights
-  if ((p.flags & GEMM_FLAG_X3_SHARE) && !gemm8_wide(p) && !(p.flags & 1024)) {
-    if (debug_flag(39) == 2) hipLaunchKernelGGL((gemm8x_kernel<2>), grid, block, 0, st, p, tile_count);
-    else if (debug_flag(39) == 4) hipLaunchKernelGGL((gemm8x_kernel<4>), grid, block, 0, st, p, tile_count);
-    else hipLaunchKernelGGL((gemm8x_kernel<0>), grid, block, 0, st, p, tile_count);
-  }
+  if ((p.flags & GEMM_FLAG_X3_SHARE) && !gemm8_wide(p) && !(p.flags & 1024)) hipLaunchKernelGGL(gemm8x_kernel, grid, block, 0, st, p, tile_count);
   else if (gemm8_wide(p)) hipLaunchKernelGGL((gemm8_kernel<true>), grid, block, 0, st, p, tile_count);
   else if (p.flags & 1024) hipLaunchKernelGGL((gemm8_kernel<false, true>), grid, block, 0, st, p, tile_count);   // alt-format operands
   else hipLaunchKernelGGL((gemm8_kernel<false>), grid, block, 0, st, p, tile_count);
