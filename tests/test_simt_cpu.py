@@ -94,3 +94,22 @@ def test_modernbert_text_tower_on_the_simulator():
     kernel code."""
     out = _run(["tests/test_mbert_gpu.py"], 600)
     assert " passed" in out and "failed" not in out
+
+
+def test_operand_sharing_x3_kernel_with_dma_landing_as_late_as_the_isa_allows():
+    """gemm8x_kernel (round 6: the 8-phase kernel that shares operand tiles and fragments between the three products of the compensated
+    mode's K-concatenated operands, GemmParams.flags bit 15) against the plain walk and - bit for bit - against gemm8s_kernel's walk of
+    the same order, in both weight layouts, with every DMA landing only when its hand-counted wait retires it (vmcnt(4) / vmcnt(8) /
+    vmcnt(0) per product: a wait placed behind the wrong barrier in an experimental two-phase form failed exactly here)."""
+    env_extra = {"SAMAUDIO_SIMT_DMA": "late"}
+    old = {k: os.environ.get(k) for k in env_extra}
+    os.environ.update(env_extra)
+    try:
+        out = _run(["tests/test_x3_gpu.py", "-k", "sharing_the_operand_tiles"], 600)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert "3 passed" in out and "failed" not in out
