@@ -134,7 +134,8 @@ int samaudio_set_workspace(samaudio_ctx* ctx, void* workspace, size_t bytes);
  *   activation operand and fp32 outputs, but multiplies on the 16-bit MFMA: each operand is split into hi = rn16(x) and
  *   lo = rn16(x - hi), the activation row becomes [lo | hi | hi] (3K elements, written by a streaming kernel on the launch stream)
  *   and the weight row [W_hi | W_lo | W_hi], so that ONE launch of the library's 16-bit GEMM over K' = 3K accumulates
- *   x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32 - the fp32 product to ~2^-21 relative for three times the MFMA work.  Needs the
+ *   x_lo W_hi + x_hi W_lo + x_hi W_hi in fp32 - the fp32 product to ~2^-21 relative for three times the MFMA work (the 8-phase kernels
+ *   know the layout and stage / read what the three products share once: csrc/gemm8.hip gemm8x_kernel).  Needs the
  *   class's weights registered in that split form under "<name>.x3" - 16-bit, [N, 3K] row-major or [3K/64, N, 64] K-tile-major
  *   (sam_audio_amd/weights.py x3_weight) - for L<i>.wqkv, wo, c_wq, c_wo, w13, w2; checked like the ".f32" copies above.  Classes
  *   PATCH (the patcher's k3 convolutions: "patch1.w.x3" / "patch2.w.x3", [D, 9D] with EACH tap's D columns split into 3D) and CKV
